@@ -1,0 +1,36 @@
+"""signaloperators.jl_amd — MI355X-native sink engine behind the SignalOperators.jl
+operator API (hot path only)."""
+from .units import s, ms, Hz, kHz, frames, kframes, dB, rad, deg, Quantity  # noqa: F401
+from .signals import (  # noqa: F401
+    ErrorException, inflen, isinf, nframes, nchannels, framerate, sampletype, duration, pipe,
+    Signal, Until, After, Window, Pad, Extend, cycle, mirror, lastframe, zero, one,
+    Append, Prepend, Mix, Amplify, AddChannel, SelectChannel, OperateOn, Operate,
+    RampOn, RampOff, Ramp, FadeTo, sinramp, identity, randn,
+    Filt, Normpower, Lowpass, Highpass, Bandpass, Bandstop, Butterworth, Chebyshev1,
+    ToFramerate, ToChannels, ToEltype, Format, Uniform,
+    ArraySig, NumberSig, FuncSig, CutApply, PaddedSignal, AppendSignals, RampSignal,
+    MapSignal, FilteredSignal, NormedSignal, FilterFn, RawFilterFn, ResamplerFn,
+)
+from numpy import sin, cos  # noqa: F401  (Signal(sin), Signal(cos))
+from .engine import sink, sink_into, Plan, Array, process_sink_params, _eager  # noqa: F401
+from .lowering import lower, design_iir, design_resample  # noqa: F401
+
+until = _eager(Until)
+after = _eager(After)
+window = _eager(Window)
+append = _eager(Append)
+prepend = _eager(Prepend)
+mix = _eager(Mix)
+amplify = _eager(Amplify)
+addchannel = _eager(AddChannel)
+selectchannel = _eager(SelectChannel)
+operate = _eager(OperateOn)
+rampon = _eager(RampOn)
+rampoff = _eager(RampOff)
+ramp = _eager(Ramp)
+fadeto = _eager(FadeTo)
+normpower = _eager(Normpower)
+toframerate = _eager(ToFramerate)
+tochannels = _eager(ToChannels)
+toeltype = _eager(ToEltype)
+format = _eager(Format)

@@ -1,0 +1,40 @@
+"""Builds libsigops.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = ["kernels.hip", "planner.cpp", "design.cpp", "capi.cpp"]
+OUT = os.path.join(HERE, "libsigops.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = SRCS + ["kernels.h", "plan.h", "sigops_internal.h", "../../include/sigops.h", "build.py"]
+    return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SRCS:
+        o = os.path.join(HERE, s.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+               "-Wno-unused-function", "-x", "hip", "-c", os.path.join(HERE, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,128 @@
+// extern "C" surface of libsigops (include/sigops.h).
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sigops.h"
+#include "plan.h"
+
+namespace {
+thread_local std::string g_err;
+int set_err(int status, const std::string& msg) {
+    g_err = msg;
+    return status;
+}
+}  // namespace
+
+struct so_plan {
+    so::Plan* p;
+};
+
+extern "C" {
+
+int32_t so_abi_version(void) { return SO_ABI_VERSION; }
+
+const char* so_last_error(void) { return g_err.c_str(); }
+
+int32_t so_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t so_plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root,
+                       const so_out_desc_t* out, int32_t device, so_plan_t** plan) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_create: null plan pointer");
+    *plan = nullptr;
+    int status = SO_OK;
+    std::string err;
+    so::Plan* p = so::plan_create(nodes, n_nodes, root, out, device, status, err);
+    if (!p) return set_err(status, err);
+    *plan = new so_plan{p};
+    return SO_OK;
+}
+
+int64_t so_plan_nframes(const so_plan_t* plan) {
+    return plan ? so::plan_nframes(plan->p) : SO_LEN_MISSING;
+}
+
+int32_t so_plan_execute(so_plan_t* plan, void* out, void* hip_stream) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_execute: null plan");
+    std::string err;
+    int st = so::plan_execute(plan->p, out, hip_stream, err);
+    if (st != SO_OK) return set_err(st, err);
+    return SO_OK;
+}
+
+int32_t so_plan_set_array(so_plan_t* plan, int32_t node_index, const void* data) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_set_array: null plan");
+    std::string err;
+    int st = so::plan_set_array(plan->p, node_index, data, err);
+    if (st != SO_OK) return set_err(st, err);
+    return SO_OK;
+}
+
+int32_t so_plan_stats(const so_plan_t* plan, so_stats_t* stats) {
+    if (!plan || !stats) return set_err(SO_ERR_INVALID, "so_plan_stats: null argument");
+    so::plan_stats(plan->p, stats);
+    return SO_OK;
+}
+
+int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_set_profiling: null plan");
+    so::plan_set_profiling(plan->p, enable != 0);
+    return SO_OK;
+}
+
+void so_plan_destroy(so_plan_t* plan) {
+    if (!plan) return;
+    so::plan_destroy(plan->p);
+    delete plan;
+}
+
+int32_t so_design_iir(int32_t type, double f1, double f2, double fs, int32_t method,
+                      int32_t order, double ripple_db, double* sos, int32_t sos_capacity,
+                      int32_t* nsections, double* gain) {
+    std::vector<double> s;
+    double g = 1.0;
+    std::string err;
+    int st = so::design_iir(type, f1, f2, fs, method, order, ripple_db, s, g, err);
+    if (st != SO_OK) return set_err(st, err);
+    if (!sos || !nsections || !gain || (int)s.size() > sos_capacity)
+        return set_err(SO_ERR_INVALID, "so_design_iir: output buffer too small");
+    std::memcpy(sos, s.data(), s.size() * sizeof(double));
+    *nsections = (int32_t)(s.size() / 6);
+    *gain = g;
+    return SO_OK;
+}
+
+static int32_t copy_taps(const std::vector<double>& h, double* out, int32_t capacity, int32_t* hlen) {
+    if (!hlen) return set_err(SO_ERR_INVALID, "null hlen");
+    *hlen = (int32_t)h.size();
+    if (!out) return SO_OK;
+    if ((int)h.size() > capacity) return set_err(SO_ERR_INVALID, "tap buffer too small");
+    std::memcpy(out, h.data(), h.size() * sizeof(double));
+    return SO_OK;
+}
+
+int32_t so_design_resample_rational(int64_t num, int64_t den, double* h, int32_t capacity,
+                                    int32_t* hlen) {
+    std::vector<double> t;
+    std::string err;
+    int st = so::design_resample_rational(num, den, t, err);
+    if (st != SO_OK) return set_err(st, err);
+    return copy_taps(t, h, capacity, hlen);
+}
+
+int32_t so_design_resample_arbitrary(double rate, int32_t nphi, double* h, int32_t capacity,
+                                     int32_t* hlen) {
+    std::vector<double> t;
+    std::string err;
+    int st = so::design_resample_arbitrary(rate, nphi, t, err);
+    if (st != SO_OK) return set_err(st, err);
+    return copy_taps(t, h, capacity, hlen);
+}
+
+}  // extern "C"

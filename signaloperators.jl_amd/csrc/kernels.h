@@ -1,0 +1,17 @@
+// Host-callable launchers of the HIP kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "sigops_internal.h"
+
+namespace so {
+void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, const DOp* d_ops,
+                      const DLeaf* d_leaves, OutView out, hipStream_t st);
+// returns number of kernel launches
+int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
+               const SosGeom& g, const SosCoefs& cf, hipStream_t st);
+void launch_resample(const void* x, void* y, const double* pfb, const double* dpfb,
+                     const RsGeom& g, hipStream_t st);
+void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
+                int nparts, double* rms, hipStream_t st);
+}  // namespace so

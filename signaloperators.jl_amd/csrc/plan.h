@@ -1,0 +1,26 @@
+// Host-side planner interface (internal).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sigops.h"
+
+namespace so {
+
+int design_iir(int type, double f1, double f2, double fs, int method, int order, double ripple,
+               std::vector<double>& sos, double& gain, std::string& err);
+int design_resample_rational(int64_t num, int64_t den, std::vector<double>& h, std::string& err);
+int design_resample_arbitrary(double rate, int nphi, std::vector<double>& h, std::string& err);
+
+struct Plan;
+Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
+                  int32_t device, int& status, std::string& err);
+int plan_execute(Plan* p, void* out, void* stream, std::string& err);
+int plan_set_array(Plan* p, int32_t node_index, const void* data, std::string& err);
+int64_t plan_nframes(const Plan* p);
+void plan_stats(const Plan* p, so_stats_t* st);
+void plan_set_profiling(Plan* p, bool on);
+void plan_destroy(Plan* p);
+
+}  // namespace so

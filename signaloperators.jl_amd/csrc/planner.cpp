@@ -1,0 +1,1544 @@
+// Planner: turns the flattened operator tree (include/sigops.h) into a short list
+// of device steps.  This replaces the per-node `nextblock` state machines of the
+// reference (src/cutting.jl:154-210, src/padding.jl:200-235, src/appending.jl:82-110,
+// src/ramps.jl:45-119, src/mapsignal.jl:194-244, src/filters.jl:169-262) by a single
+// host-side pass using the closed-form semantics of every node:
+//
+//   lower(node, rectangle, index-map) -> pieces {rectangle, expression}
+//
+// Index-only nodes (Until/After/Pad/Extend/Append/Ramp regions, channel maps) never
+// reach the device: they become piece boundaries and leaf index offsets.  Stateful
+// nodes (Filt IIR, resampler, Normpower) become *stages* with device buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+#include "sigops_internal.h"
+
+namespace so {
+
+namespace {
+
+struct PlanError {
+    int status;
+    std::string msg;
+};
+[[noreturn]] void fail(int status, const std::string& msg) { throw PlanError{status, msg}; }
+
+#define HIPCHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            fail(SO_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+// ---- lengths (reference src/inflen.jl, src/signal.jl:28-37, src/numbers.jl:5-9) ----
+enum { LK_FIN, LK_INF, LK_EXT, LK_NUMEXT };
+struct Len {
+    int k;
+    int64_t n;
+};
+constexpr int64_t BIG = (int64_t)1 << 62;
+inline bool isinf_(Len l) { return l.k != LK_FIN; }
+inline int64_t clean(Len l) { return l.k == LK_FIN ? l.n : BIG; }
+
+inline int promote(int a, int b) {
+    if (a == SO_F64 || b == SO_F64) return SO_F64;
+    if (a == SO_F32 || b == SO_F32) return SO_F32;
+    return SO_I64;
+}
+inline int float_of(int t) { return t == SO_I64 ? SO_F64 : t; }
+inline double roundto(int t, double v) { return t == SO_F32 ? (double)(float)v : v; }
+inline size_t dsize(int t) { return t == SO_F32 ? 4 : 8; }
+
+struct Node {
+    so_node_t nd;
+    std::vector<int> kids;
+    Len len;
+    int dtype, nch;
+    double fs;
+};
+
+// ---- expressions -------------------------------------------------------------
+enum { E_CONST, E_LOAD, E_SCALAR, E_FUNC, E_RAMP, E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_ROUND32, E_RETYPE };
+struct Expr {
+    int op;
+    int dtype;
+    int a = -1, b = -1;
+    DLeaf leaf{};
+    int array_node = -1;  // E_LOAD of an ARRAY node (for so_plan_set_array)
+    bool mono = true, heavy = false;
+};
+struct Map {
+    int sf;
+    int64_t df;
+    int sc;
+    int64_t dc;
+};
+struct Rect {
+    int64_t a, b;
+    int c0, c1;
+};
+struct Piece {
+    Rect r;
+    int e;
+};
+
+struct Buf {
+    int64_t frames = 0, pitch = 0;
+    int nch = 0, dtype = SO_F64;
+    size_t bytes = 0;
+    void* d = nullptr;
+    bool external = false;  // aliases a user/device leaf pointer
+};
+
+enum { ST_SOS, ST_RESAMPLE, ST_NORM };
+struct Stage {
+    int kind, node;
+    int64_t need = 0;  // output frames [0,need)
+    bool processed = false;
+    int out_buf = -1, in_buf = -1, aux_buf = -1;
+    // input source (after processing): either a materialised buffer or a direct view
+    const void* in_ptr = nullptr;  // direct device pointer (nullptr -> in_buf)
+    int in_array_node = -1;
+    int64_t in_offset = 0;  // elements (direct)
+    int64_t in_pitch = 0, in_frames = 0;
+    int pw_step = -1;  // pointwise step materialising the input
+    // SOS
+    std::vector<SosCoefs> groups;
+    SosGeom sg{};
+    int mpow_buf = -1, v_buf = -1, s0_buf = -1;
+    std::vector<std::vector<double>> mpow_host;  // per group
+    // resample
+    RsGeom rg{};
+    int pfb_buf = -1, dpfb_buf = -1;
+    std::vector<double> pfb_host, dpfb_host;
+    // norm
+    int partial_buf = -1, rms_buf = -1;
+    int nparts = 0;
+};
+
+struct PwStep {
+    int piece0 = 0, npieces = 0;
+    int64_t nblocks = 0;
+    int out_buf = -1;  // -1: final output
+    int64_t bytes = 0;
+};
+
+struct Step {
+    int kind;  // 0 pointwise, 1 stage kernel
+    int idx;
+    std::string name;
+    int64_t bytes = 0;
+    double ms = 0;
+    int launches = 0;
+};
+
+struct HostLeaf {
+    int node;
+    const void* src;
+    size_t bytes;
+    int buf;
+};
+
+}  // namespace
+
+struct Plan {
+    int device = 0;
+    std::vector<Node> nodes;
+    int root = -1;
+    so_out_desc_t out{};
+    std::vector<Expr> exprs;
+    std::vector<Buf> bufs;
+    std::map<int, int> stage_of_node;
+    std::vector<Stage> stages;
+    std::vector<PwStep> pw;
+    std::vector<Step> steps;
+    std::vector<DPiece> pieces;
+    std::vector<DOp> ops;
+    std::vector<DLeaf> leaves;
+    std::vector<int> leaf_array_node;  // per leaf: ARRAY node or -1
+    std::vector<HostLeaf> host_leaves;
+    std::map<int, int> array_buf;  // ARRAY node -> buf id (host arrays: device copy)
+    std::map<int, const void*> array_ptr;  // current data pointer per ARRAY node
+    DPiece* d_pieces = nullptr;
+    DOp* d_ops = nullptr;
+    DLeaf* d_leaves = nullptr;
+    int out_stage_buf = -1;  // device staging for a host result
+    std::vector<char> host_tmp;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    so_stats_t stats{};
+    int64_t algo_bytes = 0;
+    std::map<int, bool> array_counted;
+
+    // ---- helpers ---------------------------------------------------------
+    int add_expr(const Expr& e) {
+        exprs.push_back(e);
+        return (int)exprs.size() - 1;
+    }
+    int new_buf(int64_t frames, int nch, int dtype) {
+        Buf b;
+        b.frames = frames;
+        b.pitch = (frames + 63) / 64 * 64;
+        if (b.pitch == 0) b.pitch = 64;
+        b.nch = nch;
+        b.dtype = dtype;
+        b.bytes = (size_t)b.pitch * (size_t)std::max(nch, 1) * dsize(dtype);
+        bufs.push_back(b);
+        return (int)bufs.size() - 1;
+    }
+    int raw_buf(size_t bytes) {
+        Buf b;
+        b.bytes = std::max<size_t>(bytes, 8);
+        b.dtype = SO_F64;
+        bufs.push_back(b);
+        return (int)bufs.size() - 1;
+    }
+
+    int mk_const(double v, int dtype) {
+        Expr e;
+        e.op = E_CONST;
+        e.dtype = dtype;
+        e.leaf.v0 = v;
+        e.leaf.buf = -1;
+        return add_expr(e);
+    }
+    int mk_un(int op, int a, int dtype) {
+        Expr e;
+        e.op = op;
+        e.dtype = dtype;
+        e.a = a;
+        e.mono = exprs[a].mono;
+        e.heavy = exprs[a].heavy;
+        return add_expr(e);
+    }
+    bool is_const(int e, double v) const { return exprs[e].op == E_CONST && exprs[e].leaf.v0 == v; }
+    int mk_bin(int op, int a, int b) {
+        int ta = exprs[a].dtype, tb = exprs[b].dtype;
+        int t = promote(ta, tb);
+        if (op == E_DIV && t == SO_I64) t = SO_F64;
+        // x*1 == x exactly (ramp flat regions, reference src/ramps.jl:56-59)
+        if (op == E_MUL && is_const(b, 1.0)) return t == ta ? a : mk_un(E_RETYPE, a, t);
+        if (op == E_MUL && is_const(a, 1.0)) return t == tb ? b : mk_un(E_RETYPE, b, t);
+        if (exprs[a].op == E_CONST && exprs[b].op == E_CONST) {
+            double x = exprs[a].leaf.v0, y = exprs[b].leaf.v0, r;
+            switch (op) {
+            case E_ADD: r = x + y; break;
+            case E_SUB: r = x - y; break;
+            case E_MUL: r = x * y; break;
+            default: r = x / y;
+            }
+            return mk_const(roundto(t, r), t);
+        }
+        Expr e;
+        e.op = op;
+        e.dtype = t;
+        e.a = a;
+        e.b = b;
+        e.mono = exprs[a].mono && exprs[b].mono;
+        e.heavy = exprs[a].heavy || exprs[b].heavy;
+        return add_expr(e);
+    }
+
+    // ---- model -----------------------------------------------------------
+    void build_nodes(const so_node_t* in, int n);
+    Len map_maxlen(Len x, Len y) const {
+        if (x.k == LK_NUMEXT && y.k == LK_NUMEXT) return x;
+        if (x.k == LK_INF || y.k == LK_INF) return Len{LK_INF, 0};
+        int64_t a = x.k == LK_NUMEXT ? 0 : x.n, b = y.k == LK_NUMEXT ? 0 : y.n;
+        return Len{LK_FIN, std::max(a, b)};
+    }
+
+    // ---- lowering --------------------------------------------------------
+    std::vector<Piece> lower(int ni, Rect r, Map m);
+    std::vector<Piece> lower_padded(int ni, int padkind, double padvalue, const double* padvec,
+                                    Rect r, Map m, bool always_pad);
+    std::vector<Piece> pad_pieces(int child, int padkind, double padvalue, const double* padvec,
+                                  Rect r, Map m);
+    std::vector<Piece> combine(const std::vector<std::vector<Piece>>& kids, Rect r, int op,
+                               int force_dtype);
+    int stage_for(int ni, int kind);
+    void use_stage(Stage& S, const Rect& r, const Map& m);
+    void process_stage(int sid);
+    int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
+    void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
+             bool allow_hoist);
+    int depth(int e) const;
+    int add_leaf(const Expr& e);
+    void count_array(int ni);
+    void finalize();
+    void release();
+};
+
+// ===========================================================================
+void Plan::build_nodes(const so_node_t* in, int n) {
+    nodes.resize(n);
+    for (int i = 0; i < n; ++i) {
+        Node& N = nodes[i];
+        N.nd = in[i];
+        const so_node_t& nd = in[i];
+        if (nd.n_children < 0 || (nd.n_children > 0 && !nd.children))
+            fail(SO_ERR_INVALID, "node " + std::to_string(i) + ": bad children");
+        for (int j = 0; j < nd.n_children; ++j) {
+            int c = nd.children[j];
+            if (c < 0 || c >= i) fail(SO_ERR_INVALID, "node table must be in post-order (children before parents)");
+            N.kids.push_back(c);
+        }
+        N.dtype = nd.dtype;
+        N.nch = nd.nch;
+        N.fs = nd.fs;
+        auto kid = [&](int j) -> Node& {
+            if ((int)N.kids.size() <= j) fail(SO_ERR_INVALID, "node " + std::to_string(i) + ": missing child");
+            return nodes[N.kids[j]];
+        };
+        switch (nd.kind) {
+        case SO_NODE_ARRAY:
+            if (nd.dtype != SO_F32 && nd.dtype != SO_F64)
+                fail(SO_ERR_UNSUPPORTED, "array leaves must be Float32 or Float64");
+            if (nd.l0 < 0 || nd.nch < 1) fail(SO_ERR_INVALID, "bad array shape");
+            if (nd.l0 > 0 && !nd.p0) fail(SO_ERR_INVALID, "array leaf without data");
+            N.len = Len{LK_FIN, nd.l0};
+            array_ptr[i] = nd.p0;
+            break;
+        case SO_NODE_CONST:
+            N.len = Len{LK_NUMEXT, 0};
+            N.nch = 1;
+            N.dtype = nd.i0;
+            break;
+        case SO_NODE_FUNC:
+            if (!(nd.fs > 0)) fail(SO_ERR_LENGTH, "Unknown frame rate: function signals need a frame rate");
+            N.len = Len{LK_INF, 0};
+            N.nch = 1;
+            N.dtype = SO_F64;
+            break;
+        case SO_NODE_UNTIL: {  // reference src/cutting.jl:130
+            Node& c = kid(0);
+            int64_t L = std::max<int64_t>(0, nd.l0);
+            N.len = isinf_(c.len) ? Len{LK_FIN, L} : Len{LK_FIN, std::min(c.len.n, L)};
+            N.nch = c.nch;
+            N.dtype = c.dtype;
+            break;
+        }
+        case SO_NODE_AFTER: {  // reference src/cutting.jl:134,174-181
+            Node& c = kid(0);
+            if (isinf_(c.len)) N.len = c.len;
+            else {
+                if (nd.l0 > c.len.n)
+                    fail(SO_ERR_LENGTH, "Signal is too short to skip " + std::to_string(nd.l0) + " frames");
+                N.len = Len{LK_FIN, std::min(std::max<int64_t>(c.len.n - nd.l0, 0), c.len.n)};
+            }
+            N.nch = c.nch;
+            N.dtype = c.dtype;
+            break;
+        }
+        case SO_NODE_PAD: {  // reference src/padding.jl:13-14
+            Node& c = kid(0);
+            N.len = nd.i1 ? Len{LK_EXT, clean(c.len)} : Len{LK_INF, 0};
+            N.nch = c.nch;
+            N.dtype = c.dtype;
+            if (nd.i0 == SO_PAD_VECTOR && !nd.p0) fail(SO_ERR_INVALID, "vector padding without values");
+            if ((nd.i0 == SO_PAD_CYCLE || nd.i0 == SO_PAD_MIRROR) && c.nd.kind != SO_NODE_ARRAY)
+                fail(SO_ERR_INVALID, "Attemped to specify an indexing pad function for a signal which is not known to support `getindex`.");
+            break;
+        }
+        case SO_NODE_APPEND: {  // reference src/appending.jl:59-76
+            if (N.kids.empty()) fail(SO_ERR_INVALID, "Append without signals");
+            int64_t tot = 0;
+            bool inf = false;
+            for (size_t j = 0; j < N.kids.size(); ++j) {
+                Node& c = nodes[N.kids[j]];
+                if (c.nch != kid(0).nch) fail(SO_ERR_CHANNELS, "Append: children must be Uniform in channels");
+                if (isinf_(c.len)) {
+                    if (j + 1 < N.kids.size()) fail(SO_ERR_LENGTH, "Cannot Append to the end of an infinite signal");
+                    inf = true;
+                } else tot += c.len.n;
+            }
+            N.len = inf ? Len{LK_INF, 0} : Len{LK_FIN, tot};
+            N.nch = kid(0).nch;
+            break;
+        }
+        case SO_NODE_RAMP: {
+            Node& c = kid(0);
+            N.len = c.len;
+            N.nch = c.nch;
+            N.dtype = float_of(c.dtype);
+            if (nd.l0 < 1) fail(SO_ERR_INVALID, "ramp length must be >= 1 frame");
+            break;
+        }
+        case SO_NODE_MAP: {
+            if (N.kids.empty()) fail(SO_ERR_INVALID, "MapSignal without signals");
+            Len l = kid(0).len;
+            for (size_t j = 1; j < N.kids.size(); ++j) l = map_maxlen(l, nodes[N.kids[j]].len);
+            N.len = l;
+            int fn = nd.i0;
+            int t = kid(0).dtype;
+            for (size_t j = 1; j < N.kids.size(); ++j) t = promote(t, nodes[N.kids[j]].dtype);
+            if (fn == SO_MAP_DIV && t == SO_I64) t = SO_F64;
+            if (fn == SO_MAP_TOELTYPE) t = nd.i3;
+            N.dtype = t;
+            if (nd.i1) {  // bychannel: Uniform(channels=true) already applied by the host
+                for (int k : N.kids)
+                    if (nodes[k].nch != kid(0).nch)
+                        fail(SO_ERR_CHANNELS, "OperateOn: children must be Uniform in channels (host applies ToChannels)");
+                N.nch = kid(0).nch;
+            } else {
+                switch (fn) {
+                case SO_MAP_TUPLECAT: {
+                    int s = 0;
+                    for (int k : N.kids) s += nodes[k].nch;
+                    N.nch = s;
+                    break;
+                }
+                case SO_MAP_GETCHAN:
+                    if (nd.i3 < 1 || nd.i3 > kid(0).nch) fail(SO_ERR_CHANNELS, "SelectChannel: channel out of range");
+                    N.nch = 1;
+                    break;
+                case SO_MAP_AS1CHANNEL: N.nch = 1; break;
+                case SO_MAP_ASNCHANNELS:
+                    if (kid(0).nch != 1) fail(SO_ERR_CHANNELS, "No rule to convert signal with " + std::to_string(kid(0).nch) + " channels to a signal with " + std::to_string(nd.i3) + " channels.");
+                    N.nch = nd.i3;
+                    break;
+                case SO_MAP_REVERSECH: N.nch = kid(0).nch; break;
+                default: fail(SO_ERR_UNSUPPORTED, "cross-channel map function is not lowerable");
+                }
+            }
+            break;
+        }
+        case SO_NODE_FILT_SOS: {
+            Node& c = kid(0);
+            N.len = c.len;
+            N.nch = c.nch;
+            N.dtype = float_of(c.dtype);
+            if (nd.i0 < 1 || !nd.p0) fail(SO_ERR_INVALID, "Filt without second-order sections");
+            break;
+        }
+        case SO_NODE_RESAMPLE: {  // reference src/filters.jl:165
+            Node& c = kid(0);
+            if (!(c.fs > 0) || !(nd.fs > 0)) fail(SO_ERR_LENGTH, "resampling needs known frame rates");
+            if (isinf_(c.len)) N.len = c.len.k == LK_EXT ? Len{LK_INF, 0} : c.len;
+            else N.len = Len{LK_FIN, (int64_t)std::ceil((double)c.len.n * nd.fs / c.fs)};
+            N.nch = c.nch;
+            N.dtype = float_of(c.dtype);
+            if (!nd.p0 || nd.i2 < 1) fail(SO_ERR_INVALID, "resampler without taps");
+            if ((nd.i2 & 1) == 0) fail(SO_ERR_UNSUPPORTED, "resample_filter taps must have odd length");
+            break;
+        }
+        case SO_NODE_NORMPOWER: {
+            Node& c = kid(0);
+            N.len = c.len;
+            N.nch = c.nch;
+            N.dtype = float_of(c.dtype);
+            break;
+        }
+        default: fail(SO_ERR_INVALID, "unknown node kind " + std::to_string(nd.kind));
+        }
+        if (N.dtype == SO_I64 && nd.kind != SO_NODE_CONST && nd.kind != SO_NODE_UNTIL &&
+            nd.kind != SO_NODE_AFTER && nd.kind != SO_NODE_PAD && nd.kind != SO_NODE_APPEND &&
+            nd.kind != SO_NODE_MAP)
+            fail(SO_ERR_UNSUPPORTED, "integer sample types are not lowered (SURVEY.md §8(b))");
+        // cross-check against what the host computed (catches glue bugs early)
+        if (nd.nframes != SO_LEN_UNCHECKED) {
+            int64_t mine = isinf_(N.len) ? SO_LEN_INF : N.len.n;
+            if (nd.nframes != SO_LEN_MISSING && nd.nframes != mine)
+                fail(SO_ERR_INVALID, "node " + std::to_string(i) + " (kind " + std::to_string(nd.kind) + "): host nframes " + std::to_string(nd.nframes) + " != planner " + std::to_string(mine));
+        }
+        if (nd.nch != N.nch && nd.kind != SO_NODE_CONST && nd.kind != SO_NODE_FUNC)
+            fail(SO_ERR_CHANNELS, "node " + std::to_string(i) + ": host nchannels " + std::to_string(nd.nch) + " != planner " + std::to_string(N.nch));
+        if (nd.dtype != N.dtype && nd.kind != SO_NODE_CONST)
+            fail(SO_ERR_INVALID, "node " + std::to_string(i) + ": host sampletype " + std::to_string(nd.dtype) + " != planner " + std::to_string(N.dtype));
+    }
+}
+
+// ---------------------------------------------------------------------------
+void Plan::count_array(int ni) {
+    if (array_counted[ni]) return;
+    array_counted[ni] = true;
+    const so_node_t& nd = nodes[ni].nd;
+    algo_bytes += nd.l0 * (int64_t)nd.nch * (int64_t)dsize(nd.dtype);
+}
+
+int Plan::stage_for(int ni, int kind) {
+    auto it = stage_of_node.find(ni);
+    if (it != stage_of_node.end()) return it->second;
+    Stage S;
+    S.kind = kind;
+    S.node = ni;
+    stages.push_back(S);
+    stage_of_node[ni] = (int)stages.size() - 1;
+    return (int)stages.size() - 1;
+}
+
+void Plan::use_stage(Stage& S, const Rect& r, const Map& m) {
+    int64_t hi = m.sf ? r.b + m.df : m.df + 1;
+    if (S.processed && hi > S.need) fail(SO_ERR_RUNTIME, "internal: stage need raised after processing");
+    S.need = std::max(S.need, hi);
+}
+
+static DLeaf mk_leafmap(const Map& m) {
+    DLeaf L{};
+    L.sf = m.sf;
+    L.df = m.df;
+    L.sc = m.sc;
+    L.dc = m.dc;
+    L.buf = -1;
+    L.mode = LM_PLAIN;
+    return L;
+}
+
+std::vector<Piece> Plan::pad_pieces(int child, int padkind, double padvalue, const double* padvec,
+                                    Rect r, Map m) {
+    Node& C = nodes[child];
+    int T = C.dtype;
+    std::vector<Piece> out;
+    if (r.a >= r.b) return out;
+    switch (padkind) {
+    case SO_PAD_VALUE: out.push_back({r, mk_const(roundto(T, padvalue), T)}); break;
+    case SO_PAD_ZERO: out.push_back({r, mk_const(0.0, T)}); break;
+    case SO_PAD_ONE: out.push_back({r, mk_const(1.0, T)}); break;
+    case SO_PAD_VECTOR: {
+        // per-channel constants: one piece per channel (channel counts of padded
+        // vectors are tiny in practice)
+        for (int c = r.c0; c < r.c1; ++c) {
+            int64_t cn = (int64_t)m.sc * c + m.dc;
+            out.push_back({Rect{r.a, r.b, c, c + 1}, mk_const(roundto(T, padvec[cn]), T)});
+            if (m.sc == 0) {
+                out.back().r.c1 = r.c1;
+                break;
+            }
+        }
+        break;
+    }
+    case SO_PAD_LASTFRAME: {
+        if (isinf_(C.len) || C.len.n == 0)
+            fail(SO_ERR_LENGTH, "Signal is length zero; there is no last frame to pad with.");
+        out = lower(child, r, Map{0, C.len.n - 1, m.sc, m.dc});
+        break;
+    }
+    case SO_PAD_CYCLE:
+    case SO_PAD_MIRROR: {
+        if (C.nd.kind != SO_NODE_ARRAY)
+            fail(SO_ERR_INVALID, "Attemped to specify an indexing pad function for a signal which is not known to support `getindex`.");
+        if (C.len.n == 0) fail(SO_ERR_LENGTH, "cannot index an empty array");
+        Expr e;
+        e.op = E_LOAD;
+        e.dtype = C.dtype;
+        e.leaf = mk_leafmap(m);
+        e.leaf.mode = padkind == SO_PAD_CYCLE ? LM_CYCLE : LM_MIRROR;
+        e.leaf.modn = C.len.n;
+        e.leaf.fstride = C.nd.s0;
+        e.leaf.cstride = C.nd.s1;
+        e.leaf.dtype = C.dtype;
+        e.array_node = child;
+        e.mono = (m.sc == 0);
+        count_array(child);
+        out.push_back({r, add_expr(e)});
+        break;
+    }
+    default: fail(SO_ERR_INVALID, "unknown padding kind");
+    }
+    return out;
+}
+
+// child extended with padding past its end (Pad / Extend / MapSignal's
+// Extend.(signals,padding), reference src/mapsignal.jl:26, src/padding.jl:97-101)
+std::vector<Piece> Plan::lower_padded(int ni, int padkind, double padvalue, const double* padvec,
+                                      Rect r, Map m, bool always_pad) {
+    Node& C = nodes[ni];
+    if (isinf_(C.len) && !always_pad) return lower(ni, r, m);
+    if (isinf_(C.len)) return lower(ni, r, m);
+    int64_t Nc = C.len.n;
+    std::vector<Piece> out;
+    if (m.sf == 0) {
+        if (m.df < Nc) return lower(ni, r, m);
+        return pad_pieces(ni, padkind, padvalue, padvec, r, m);
+    }
+    int64_t s = std::min(std::max(Nc - m.df, r.a), r.b);
+    if (s > r.a) out = lower(ni, Rect{r.a, s, r.c0, r.c1}, m);
+    if (s < r.b) {
+        auto p = pad_pieces(ni, padkind, padvalue, padvec, Rect{s, r.b, r.c0, r.c1}, m);
+        out.insert(out.end(), p.begin(), p.end());
+    }
+    return out;
+}
+
+// intersect the children's piece partitions of `r` and fold `op` left to right
+std::vector<Piece> Plan::combine(const std::vector<std::vector<Piece>>& kids, Rect r, int op,
+                                 int force_dtype) {
+    std::vector<int64_t> fb{r.a, r.b};
+    std::vector<int> cb{r.c0, r.c1};
+    for (auto& ps : kids)
+        for (auto& p : ps) {
+            fb.push_back(p.r.a);
+            fb.push_back(p.r.b);
+            cb.push_back(p.r.c0);
+            cb.push_back(p.r.c1);
+        }
+    std::sort(fb.begin(), fb.end());
+    fb.erase(std::unique(fb.begin(), fb.end()), fb.end());
+    std::sort(cb.begin(), cb.end());
+    cb.erase(std::unique(cb.begin(), cb.end()), cb.end());
+    std::vector<Piece> out;
+    for (size_t ci = 0; ci + 1 < cb.size(); ++ci)
+        for (size_t fi = 0; fi + 1 < fb.size(); ++fi) {
+            Rect cell{fb[fi], fb[fi + 1], cb[ci], cb[ci + 1]};
+            if (cell.a < r.a || cell.b > r.b || cell.c0 < r.c0 || cell.c1 > r.c1) continue;
+            int acc = -1;
+            for (auto& ps : kids) {
+                int e = -1;
+                for (auto& p : ps)
+                    if (p.r.a <= cell.a && cell.b <= p.r.b && p.r.c0 <= cell.c0 && cell.c1 <= p.r.c1) {
+                        e = p.e;
+                        break;
+                    }
+                if (e < 0) fail(SO_ERR_RUNTIME, "internal: child pieces do not cover the cell");
+                acc = acc < 0 ? e : mk_bin(op, acc, e);
+            }
+            (void)force_dtype;
+            // merge with the previous piece along frames when the expression is identical
+            out.push_back({cell, acc});
+        }
+    return out;
+}
+
+std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
+    std::vector<Piece> out;
+    if (r.a >= r.b || r.c0 >= r.c1) return out;
+    Node& N = nodes[ni];
+    const so_node_t& nd = N.nd;
+    switch (nd.kind) {
+    case SO_NODE_ARRAY: {
+        Expr e;
+        e.op = E_LOAD;
+        e.dtype = N.dtype;
+        e.leaf = mk_leafmap(m);
+        e.leaf.fstride = nd.s0;
+        e.leaf.cstride = nd.s1;
+        e.leaf.dtype = N.dtype;
+        e.array_node = ni;
+        e.mono = (m.sc == 0);
+        count_array(ni);
+        out.push_back({r, add_expr(e)});
+        return out;
+    }
+    case SO_NODE_CONST: out.push_back({r, mk_const(nd.d0, nd.i0)}); return out;
+    case SO_NODE_FUNC: {
+        Expr e;
+        e.op = E_FUNC;
+        e.dtype = SO_F64;
+        e.leaf = mk_leafmap(m);
+        e.leaf.mode = nd.i0;
+        e.leaf.flag = nd.i1;
+        e.leaf.v0 = nd.d0;
+        e.leaf.v1 = nd.d1;
+        e.leaf.v2 = nd.fs;
+        e.heavy = true;
+        out.push_back({r, add_expr(e)});
+        return out;
+    }
+    case SO_NODE_UNTIL: return lower(N.kids[0], r, m);
+    case SO_NODE_AFTER: return lower(N.kids[0], r, Map{m.sf, m.df + std::max<int64_t>(0, nd.l0), m.sc, m.dc});
+    case SO_NODE_PAD:
+        return lower_padded(N.kids[0], nd.i0, nd.d0, (const double*)nd.p0, r, m, true);
+    case SO_NODE_APPEND: {  // reference src/appending.jl:92-110
+        int64_t off = 0;
+        for (size_t k = 0; k < N.kids.size(); ++k) {
+            Node& C = nodes[N.kids[k]];
+            int64_t end = isinf_(C.len) ? BIG : off + C.len.n;
+            if (m.sf == 0) {
+                if (m.df >= off && m.df < end) return lower(N.kids[k], r, Map{0, m.df - off, m.sc, m.dc});
+            } else {
+                int64_t a = std::max(r.a, off - m.df), b = std::min(r.b, end == BIG ? r.b : end - m.df);
+                if (a < b) {
+                    auto p = lower(N.kids[k], Rect{a, b, r.c0, r.c1}, Map{1, m.df - off, m.sc, m.dc});
+                    out.insert(out.end(), p.begin(), p.end());
+                }
+            }
+            off = end;
+        }
+        return out;
+    }
+    case SO_NODE_RAMP: {  // reference src/ramps.jl:56-119
+        int64_t Ntot = clean(N.len), R = nd.l0;
+        int onedt = float_of(nodes[N.kids[0]].dtype);
+        auto ramp_expr = [&]() {
+            Expr e;
+            e.op = E_RAMP;
+            e.dtype = SO_F64;
+            e.leaf = mk_leafmap(m);
+            e.leaf.mode = nd.i1;
+            e.leaf.flag = nd.i0;
+            e.leaf.v0 = (double)R;
+            e.leaf.modn = nd.i0 ? Ntot - R : 0;
+            e.heavy = true;
+            return add_expr(e);
+        };
+        int64_t B;  // boundary in node frames: [0,B) first region, [B,inf) second
+        if (nd.i0 == 0) B = R;
+        else {
+            if (Ntot >= BIG) B = BIG;
+            else {
+                B = Ntot - R;
+                if (B < 0) fail(SO_ERR_UNSUPPORTED, "RampOff longer than the signal is undefined in the reference (src/ramps.jl:79-80)");
+            }
+        }
+        auto region = [&](Rect rr, bool first) {
+            bool is_ramp = (nd.i0 == 0) ? first : !first;
+            out.push_back({rr, is_ramp ? ramp_expr() : mk_const(1.0, onedt)});
+        };
+        if (m.sf == 0) {
+            region(r, m.df < B);
+            return out;
+        }
+        int64_t s = B >= BIG ? r.b : std::min(std::max(B - m.df, r.a), r.b);
+        if (s > r.a) region(Rect{r.a, s, r.c0, r.c1}, true);
+        if (s < r.b) region(Rect{s, r.b, r.c0, r.c1}, false);
+        return out;
+    }
+    case SO_NODE_MAP: {
+        int fn = nd.i0;
+        const double* pv = nullptr;
+        switch (fn) {
+        case SO_MAP_ADD:
+        case SO_MAP_MUL:
+        case SO_MAP_SUB:
+        case SO_MAP_DIV: {
+            std::vector<std::vector<Piece>> ks;
+            for (int k : N.kids) ks.push_back(lower_padded(k, nd.i2, nd.d0, pv, r, m, false));
+            if (N.kids.size() == 1) {
+                if (fn != SO_MAP_SUB) return ks[0];
+                for (auto& p : ks[0]) out.push_back({p.r, mk_un(E_NEG, p.e, exprs[p.e].dtype)});
+                return out;
+            }
+            int op = fn == SO_MAP_ADD ? E_ADD : fn == SO_MAP_MUL ? E_MUL : fn == SO_MAP_SUB ? E_SUB : E_DIV;
+            return combine(ks, r, op, -1);
+        }
+        case SO_MAP_TOELTYPE: {
+            auto ps = lower_padded(N.kids[0], nd.i2, nd.d0, pv, r, m, false);
+            for (auto& p : ps) {
+                int t = exprs[p.e].dtype;
+                int e = p.e;
+                if (nd.i3 == SO_F32 && t != SO_F32) e = mk_un(E_ROUND32, e, SO_F32);
+                else if (nd.i3 != t) e = mk_un(E_RETYPE, e, nd.i3);
+                out.push_back({p.r, e});
+            }
+            return out;
+        }
+        case SO_MAP_TUPLECAT: {  // reference src/mapsignal.jl:361-362
+            int off = 0;
+            for (int k : N.kids) {
+                int nc = nodes[k].nch;
+                if (m.sc == 0) {
+                    if (m.dc >= off && m.dc < off + nc)
+                        return lower_padded(k, nd.i2, nd.d0, pv, r, Map{m.sf, m.df, 0, m.dc - off}, false);
+                } else {
+                    // node channel cn = sc*c + dc must lie in [off, off+nc)
+                    int c_lo, c_hi;
+                    if (m.sc > 0) {
+                        c_lo = (int)std::max<int64_t>(r.c0, off - m.dc);
+                        c_hi = (int)std::min<int64_t>(r.c1, off + nc - m.dc);
+                    } else {
+                        // cn = dc - c  in [off, off+nc)  =>  c in (dc-off-nc, dc-off]
+                        c_lo = (int)std::max<int64_t>(r.c0, m.dc - off - nc + 1);
+                        c_hi = (int)std::min<int64_t>(r.c1, m.dc - off + 1);
+                    }
+                    if (c_lo < c_hi) {
+                        auto p = lower_padded(k, nd.i2, nd.d0, pv, Rect{r.a, r.b, c_lo, c_hi},
+                                              Map{m.sf, m.df, m.sc, m.dc - off}, false);
+                        out.insert(out.end(), p.begin(), p.end());
+                    }
+                }
+                off += nc;
+            }
+            return out;
+        }
+        case SO_MAP_GETCHAN:
+            return lower_padded(N.kids[0], nd.i2, nd.d0, pv, r, Map{m.sf, m.df, 0, nd.i3 - 1}, false);
+        case SO_MAP_ASNCHANNELS:
+            return lower_padded(N.kids[0], nd.i2, nd.d0, pv, r, Map{m.sf, m.df, 0, 0}, false);
+        case SO_MAP_REVERSECH: {
+            int nc = nodes[N.kids[0]].nch;
+            return lower_padded(N.kids[0], nd.i2, nd.d0, pv, r,
+                                Map{m.sf, m.df, -m.sc, (int64_t)nc - 1 - m.dc}, false);
+        }
+        case SO_MAP_AS1CHANNEL: {  // sum(x) over channels, reference src/reformatting.jl:156
+            int nc = nodes[N.kids[0]].nch;
+            if (nc > 64) fail(SO_ERR_UNSUPPORTED, "ToChannels(x,1) over more than 64 channels is not lowered yet");
+            std::vector<std::vector<Piece>> ks;
+            for (int c = 0; c < nc; ++c)
+                ks.push_back(lower_padded(N.kids[0], nd.i2, nd.d0, pv, r, Map{m.sf, m.df, 0, c}, false));
+            if (nc == 1) return ks[0];
+            return combine(ks, r, E_ADD, -1);
+        }
+        }
+        fail(SO_ERR_UNSUPPORTED, "map function not lowerable");
+    }
+    case SO_NODE_FILT_SOS:
+    case SO_NODE_RESAMPLE:
+    case SO_NODE_NORMPOWER: {
+        int kind = nd.kind == SO_NODE_FILT_SOS ? ST_SOS : nd.kind == SO_NODE_RESAMPLE ? ST_RESAMPLE : ST_NORM;
+        int sid = stage_for(ni, kind);
+        if (kind == ST_NORM) {
+            if (isinf_(N.len))
+                fail(SO_ERR_LENGTH, "Cannot normalize an infinite-length signal. Please use `Until` to take a prefix of the signal");
+            stages[sid].need = N.len.n;
+        } else {
+            use_stage(stages[sid], r, m);
+        }
+        if (stages[sid].out_buf < 0) {
+            stages[sid].out_buf = new_buf(0, N.nch, N.dtype);  // sized in finalize()
+            if (kind == ST_NORM) stages[sid].rms_buf = raw_buf(8);
+        }
+        Expr e;
+        e.op = E_LOAD;
+        e.dtype = N.dtype;
+        e.leaf = mk_leafmap(m);
+        e.leaf.fstride = 1;
+        e.leaf.cstride = -1;  // = pitch of the buffer, patched in finalize()
+        e.leaf.dtype = N.dtype;
+        e.leaf.buf = stages[sid].out_buf;
+        e.mono = (m.sc == 0);
+        int le = add_expr(e);
+        if (kind == ST_NORM) {  // vals ./= rms   (reference src/filters.jl:304-305)
+            Expr s;
+            s.op = E_SCALAR;
+            s.dtype = SO_F64;
+            s.leaf.buf = stages[sid].rms_buf;
+            int se = add_expr(s);
+            Expr d;
+            d.op = E_DIV;
+            d.dtype = N.dtype;  // stored back into the Float32/Float64 `vals`
+            d.a = le;
+            d.b = se;
+            d.mono = exprs[le].mono;
+            le = add_expr(d);
+        }
+        out.push_back({r, le});
+        return out;
+    }
+    }
+    fail(SO_ERR_INVALID, "unknown node kind");
+}
+
+// ---------------------------------------------------------------------------
+int Plan::depth(int ei) const {
+    const Expr& e = exprs[ei];
+    switch (e.op) {
+    case E_CONST:
+    case E_LOAD:
+    case E_SCALAR:
+    case E_FUNC:
+    case E_RAMP: return 1;
+    case E_NEG:
+    case E_ROUND32:
+    case E_RETYPE: return depth(e.a);
+    default: return std::max(depth(e.a), depth(e.b) + 1);
+    }
+}
+
+int Plan::add_leaf(const Expr& e) {
+    leaves.push_back(e.leaf);
+    leaf_array_node.push_back(e.op == E_LOAD ? e.array_node : -1);
+    return (int)leaves.size() - 1;
+}
+
+void Plan::gen(int ei, std::vector<DOp>& code, std::map<int, int>& hoisted,
+               std::vector<DOp>& fcode, bool allow_hoist) {
+    const Expr e = exprs[ei];
+    if (allow_hoist && e.mono && e.heavy) {
+        auto it = hoisted.find(ei);
+        if (it == hoisted.end() && (int)hoisted.size() < kMaxFrameSlots) {
+            std::map<int, int> none;
+            gen(ei, fcode, none, fcode, false);
+            int slot = (int)hoisted.size();
+            fcode.push_back(DOp{OP_STOREF, slot});
+            hoisted[ei] = slot;
+            it = hoisted.find(ei);
+        }
+        if (it != hoisted.end()) {
+            code.push_back(DOp{OP_LOADF, it->second});
+            return;
+        }
+    }
+    switch (e.op) {
+    case E_CONST: code.push_back(DOp{OP_CONST, add_leaf(e)}); return;
+    case E_LOAD: code.push_back(DOp{OP_LOAD, add_leaf(e)}); return;
+    case E_SCALAR: code.push_back(DOp{OP_SCALAR, add_leaf(e)}); return;
+    case E_FUNC: code.push_back(DOp{OP_FUNC, add_leaf(e)}); return;
+    case E_RAMP: code.push_back(DOp{OP_RAMP, add_leaf(e)}); return;
+    case E_RETYPE: gen(e.a, code, hoisted, fcode, allow_hoist); return;
+    case E_NEG:
+        gen(e.a, code, hoisted, fcode, allow_hoist);
+        code.push_back(DOp{OP_NEG, 0});
+        return;
+    case E_ROUND32:
+        gen(e.a, code, hoisted, fcode, allow_hoist);
+        code.push_back(DOp{OP_ROUND32, 0});
+        return;
+    default: {
+        gen(e.a, code, hoisted, fcode, allow_hoist);
+        gen(e.b, code, hoisted, fcode, allow_hoist);
+        int oc = e.op == E_ADD ? OP_ADD : e.op == E_SUB ? OP_SUB : e.op == E_MUL ? OP_MUL : OP_DIV;
+        code.push_back(DOp{oc, 0});
+        if (e.dtype == SO_F32) code.push_back(DOp{OP_ROUND32, 0});  // Julia Float32 arithmetic
+        return;
+    }
+    }
+}
+
+// compile pieces into one pointwise launch writing `out_buf` (or the final output)
+int Plan::emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype) {
+    PwStep st;
+    st.piece0 = (int)pieces.size();
+    st.out_buf = out_buf;
+    int64_t blk = 0;
+    constexpr int E = 2;
+    for (auto& p : ps) {
+        if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
+        if (depth(p.e) > kStackDepth)
+            fail(SO_ERR_UNSUPPORTED, "expression too deep for the fused pointwise kernel (stack depth > 4)");
+        std::vector<DOp> code, fcode;
+        std::map<int, int> hoisted;
+        int nchp = p.r.c1 - p.r.c0;
+        gen(p.e, code, hoisted, fcode, nchp > 1);
+        DPiece d{};
+        d.a = p.r.a;
+        d.b = p.r.b;
+        d.c0 = p.r.c0;
+        d.c1 = p.r.c1;
+        d.frame_pc = (int)ops.size();
+        d.frame_len = (int)fcode.size();
+        ops.insert(ops.end(), fcode.begin(), fcode.end());
+        d.samp_pc = (int)ops.size();
+        d.samp_len = (int)code.size();
+        ops.insert(ops.end(), code.begin(), code.end());
+        d.nblk_f = (d.b - d.a + kBlock * E - 1) / (kBlock * E);
+        // channel chunking: keep all channels in one workgroup unless the piece is
+        // too short to fill the machine along frames
+        int chc = nchp;
+        if (d.nblk_f < 2048 && nchp > 1) {
+            int64_t want = (2048 + d.nblk_f - 1) / d.nblk_f;
+            chc = (int)std::max<int64_t>(1, nchp / std::min<int64_t>(want, nchp));
+        }
+        d.chc = chc;
+        int nbc = (nchp + chc - 1) / chc;
+        d.block0 = blk;
+        blk += d.nblk_f * nbc;
+        pieces.push_back(d);
+        st.bytes += (d.b - d.a) * (int64_t)nchp * (int64_t)dsize(out_dtype);
+    }
+    st.npieces = (int)pieces.size() - st.piece0;
+    st.nblocks = blk;
+    pw.push_back(st);
+    return (int)pw.size() - 1;
+}
+
+// ---------------------------------------------------------------------------
+// small dense matrices for the SOS state propagation
+using Mat = std::vector<double>;
+static Mat matmul(const Mat& a, const Mat& b, int D) {
+    Mat c((size_t)D * D, 0.0);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            double v = a[(size_t)i * D + k];
+            if (v == 0.0) continue;
+            for (int j = 0; j < D; ++j) c[(size_t)i * D + j] += v * b[(size_t)k * D + j];
+        }
+    return c;
+}
+static double maxabs(const Mat& a) {
+    double m = 0;
+    for (double v : a) m = std::max(m, std::fabs(v));
+    return m;
+}
+static Mat ident(int D) {
+    Mat m((size_t)D * D, 0.0);
+    for (int i = 0; i < D; ++i) m[(size_t)i * D + i] = 1.0;
+    return m;
+}
+// one zero-input DF2T step applied to each unit state: columns of the state matrix A
+static Mat sos_state_matrix(const SosCoefs& cf) {
+    int ns = cf.nsec, D = 2 * ns;
+    Mat A((size_t)D * D, 0.0);
+    for (int col = 0; col < D; ++col) {
+        std::vector<double> s(D, 0.0);
+        s[col] = 1.0;
+        double y = 0.0;
+        for (int f = 0; f < ns; ++f) {
+            double xi = y;
+            y = s[2 * f] + cf.b0[f] * xi;
+            s[2 * f] = s[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
+            s[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
+        }
+        for (int r = 0; r < D; ++r) A[(size_t)r * D + col] = s[r];
+    }
+    return A;
+}
+static Mat matpow(Mat A, int64_t e, int D) {
+    Mat R = ident(D);
+    while (e > 0) {
+        if (e & 1) R = matmul(R, A, D);
+        e >>= 1;
+        if (e) A = matmul(A, A, D);
+    }
+    return R;
+}
+
+void Plan::process_stage(int sid) {
+    // NOTE: `stages` may grow while lowering the child; re-take references after.
+    int ni = stages[sid].node;
+    Node& N = nodes[ni];
+    const so_node_t& nd = N.nd;
+    int child = N.kids[0];
+    Node& C = nodes[child];
+    int64_t need = stages[sid].need;
+    stages[sid].processed = true;
+    if (need <= 0) return;
+
+    int64_t in_frames = need;
+    if (stages[sid].kind == ST_RESAMPLE) {
+        RsGeom g{};
+        g.arbitrary = nd.i0 == SO_RS_ARBITRARY;
+        int hlen = nd.i2;
+        g.nphi = g.arbitrary ? nd.i1 : (int)nd.l0;
+        if (g.nphi < 1) fail(SO_ERR_INVALID, "resampler: bad phase count");
+        g.L = nd.l0;
+        g.M = nd.l1;
+        if (!g.arbitrary && (g.L < 1 || g.M < 1)) fail(SO_ERR_INVALID, "resampler: bad ratio");
+        g.delta = g.arbitrary ? (double)g.nphi / nd.d0 : 0.0;
+        g.c0 = (double)(hlen - 1) / 2.0;
+        g.c0i = (hlen - 1) / 2;
+        g.taps = (hlen + g.nphi - 1) / g.nphi;
+        g.nch = N.nch;
+        g.m0 = 0;
+        g.n_out = need;
+        // newest input of the last needed output
+        int64_t jl;
+        if (g.arbitrary) {
+            double q = g.c0 + (double)(need - 1) * g.delta;
+            jl = (int64_t)std::floor(q) / g.nphi;
+        } else jl = (g.c0i + (need - 1) * g.M) / g.L;
+        int64_t nin = jl + 2;  // +1 slack: host rounding of q may differ from the device's at ties
+        if (!isinf_(C.len)) nin = std::min(nin, C.len.n);
+        g.n_in = nin;
+        in_frames = nin;
+        // polyphase tables: pfb[p][k] = h[p + nphi*k]; dpfb from dh = [diff(h);0]
+        const double* h = (const double*)nd.p0;
+        stages[sid].pfb_host.assign((size_t)g.nphi * g.taps, 0.0);
+        stages[sid].dpfb_host.assign((size_t)g.nphi * g.taps, 0.0);
+        for (int p = 0; p < g.nphi; ++p)
+            for (int k = 0; k < g.taps; ++k) {
+                int64_t hi = p + (int64_t)g.nphi * k;
+                stages[sid].pfb_host[(size_t)p * g.taps + k] = hi < hlen ? h[hi] : 0.0;
+                stages[sid].dpfb_host[(size_t)p * g.taps + k] = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+            }
+        stages[sid].pfb_buf = raw_buf(stages[sid].pfb_host.size() * 8);
+        stages[sid].dpfb_buf = raw_buf(stages[sid].dpfb_host.size() * 8);
+        g.in_dtype = g.out_dtype = N.dtype;
+        stages[sid].rg = g;
+    } else if (stages[sid].kind == ST_SOS) {
+        if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
+        int nsec = nd.i0;
+        const double* sos = (const double*)nd.p0;
+        std::vector<SosCoefs> groups;
+        for (int s0 = 0; s0 < nsec; s0 += kMaxSec) {
+            SosCoefs cf{};
+            cf.nsec = std::min(kMaxSec, nsec - s0);
+            for (int f = 0; f < cf.nsec; ++f) {
+                const double* b = sos + 6 * (s0 + f);
+                if (b[3] != 1.0) fail(SO_ERR_INVALID, "SOS rows must be normalised (a0 == 1)");
+                cf.b0[f] = b[0];
+                cf.b1[f] = b[1];
+                cf.b2[f] = b[2];
+                cf.a1[f] = b[4];
+                cf.a2[f] = b[5];
+            }
+            cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
+            groups.push_back(cf);
+        }
+        // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
+        SosGeom g{};
+        g.n = need;
+        g.nch = N.nch;
+        const double tol = std::ldexp(1.0, -70);
+        int64_t target = 262144 / std::max(1, N.nch);
+        int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
+        int64_t L = (need + nchunks - 1) / nchunks;
+        L = (L + 31) / 32 * 32;
+        std::vector<std::vector<double>> mp;
+        int K = 1;
+        int64_t W = BIG;
+        for (;;) {
+            nchunks = (need + L - 1) / L;
+            mp.clear();
+            K = 1;
+            W = 0;
+            if (nchunks <= 1) break;
+            bool ok = true;
+            for (auto& cf : groups) {
+                int D = 2 * cf.nsec;
+                Mat A = sos_state_matrix(cf);
+                // W: first power of two with ||A^W|| < tol (pass-1 warm-up length)
+                Mat P = A;
+                int64_t w = 1;
+                while (maxabs(P) >= tol && w < ((int64_t)1 << 40)) {
+                    P = matmul(P, P, D);
+                    w <<= 1;
+                }
+                W = std::max(W, w);
+                Mat M = matpow(A, L, D);
+                std::vector<double> pw_((size_t)D * D, 0.0);
+                Mat cur = ident(D);
+                std::vector<double> all;
+                int k = 0;
+                for (;;) {
+                    all.insert(all.end(), cur.begin(), cur.end());
+                    ++k;
+                    cur = matmul(cur, M, D);
+                    if (maxabs(cur) < tol) break;
+                    if (k >= 64) {
+                        ok = false;
+                        break;
+                    }
+                }
+                if (!ok) break;
+                K = std::max(K, k);
+                mp.push_back(all);
+            }
+            if (ok) break;
+            L *= 2;  // slower-decaying filter: fewer, longer chunks
+        }
+        // every group is scanned with the same K (pad shorter tables with zeros)
+        for (size_t gi = 0; gi < mp.size(); ++gi) {
+            int D = 2 * groups[gi].nsec;
+            mp[gi].resize((size_t)K * D * D, 0.0);
+        }
+        g.chunk = L;
+        g.nchunks = (int)nchunks;
+        g.warm = W;
+        g.kterms = K;
+        g.in_dtype = g.out_dtype = N.dtype;
+        stages[sid].groups = groups;
+        stages[sid].mpow_host = mp;
+        if (nchunks > 1) {
+            size_t msz = 0;
+            for (auto& v : mp) msz = std::max(msz, v.size());
+            stages[sid].mpow_buf = raw_buf(msz * 8 * groups.size());
+            stages[sid].v_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
+            stages[sid].s0_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
+        }
+        stages[sid].sg = g;
+    } else {  // ST_NORM
+        in_frames = need;
+        int64_t total = need * N.nch;
+        int nparts = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + kBlock * 8 - 1) / (kBlock * 8)));
+        stages[sid].nparts = nparts;
+        stages[sid].partial_buf = raw_buf((size_t)nparts * 8);
+    }
+
+    // lower the child over the frames this stage consumes
+    std::vector<Piece> ps;
+    if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, 0, 1, 0});
+    Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
+    S.in_frames = in_frames;
+    int in_dtype = S.kind == ST_NORM ? N.dtype : C.dtype;
+    if (S.kind != ST_NORM && float_of(C.dtype) != N.dtype) fail(SO_ERR_INVALID, "filter dtype mismatch");
+    if (S.kind != ST_NORM && C.dtype == SO_I64) in_dtype = SO_F64;
+    // direct source: a single plain contiguous load of the right type
+    bool direct = false;
+    if (S.kind != ST_NORM && ps.size() == 1) {
+        const Expr& e = exprs[ps[0].e];
+        if (e.op == E_LOAD && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 && e.leaf.sc == 1 &&
+            e.leaf.fstride == 1 && e.leaf.dtype == in_dtype && e.leaf.df >= 0 && e.leaf.dc >= 0 &&
+            (e.leaf.cstride > 0 || e.leaf.cstride == -1 || N.nch == 1)) {
+            direct = true;
+            S.in_array_node = e.array_node;
+            S.in_buf = e.leaf.buf;  // stage buffer or -1 (array)
+            S.in_offset = e.leaf.df;
+            S.in_pitch = e.leaf.cstride;  // -1: pitch of in_buf
+            if (e.array_node >= 0) {
+                // element offset = df*fstride + dc*cstride
+                S.in_offset = e.leaf.df + e.leaf.dc * std::max<int64_t>(e.leaf.cstride, 0);
+            } else {
+                if (e.leaf.dc != 0) direct = false;
+            }
+        }
+    }
+    if (S.kind == ST_NORM) {
+        // materialise the child straight into `vals` (the stage's own output buffer)
+        S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
+        S.in_buf = S.out_buf;
+        S.in_pitch = -1;
+    } else if (!direct) {
+        S.in_buf = new_buf(in_frames, N.nch, in_dtype);
+        S.in_pitch = -1;
+        S.in_array_node = -1;
+        S.in_offset = 0;
+        S.pw_step = emit_pointwise(ps, S.in_buf, in_dtype);
+    }
+}
+
+// ---------------------------------------------------------------------------
+void Plan::finalize() {
+    // size stage output buffers now that every need is known
+    for (auto& S : stages) {
+        if (S.out_buf >= 0) {
+            Buf& b = bufs[S.out_buf];
+            b.frames = S.need;
+            b.pitch = std::max<int64_t>(64, (S.need + 63) / 64 * 64);
+            b.bytes = (size_t)b.pitch * (size_t)std::max(b.nch, 1) * dsize(b.dtype);
+        }
+    }
+    // host array leaves get a device copy
+    for (size_t i = 0; i < leaves.size(); ++i) {
+        int an = leaf_array_node[i];
+        if (an < 0) continue;
+        const so_node_t& nd = nodes[an].nd;
+        if (nd.i0) continue;  // device-resident
+        if (!array_buf.count(an)) {
+            if (nd.s0 < 0 || nd.s1 < 0) fail(SO_ERR_UNSUPPORTED, "negative strides on host arrays are not supported");
+            size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
+            int b = raw_buf(extent * dsize(nd.dtype));
+            array_buf[an] = b;
+            host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
+        }
+    }
+    for (auto& S : stages)
+        if (S.in_array_node >= 0 && !nodes[S.in_array_node].nd.i0 && !array_buf.count(S.in_array_node)) {
+            const so_node_t& nd = nodes[S.in_array_node].nd;
+            size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
+            int b = raw_buf(extent * dsize(nd.dtype));
+            array_buf[S.in_array_node] = b;
+            host_leaves.push_back(HostLeaf{S.in_array_node, nd.p0, extent * dsize(nd.dtype), b});
+        }
+    if (!out.is_device && out.nframes > 0) {
+        Buf b;
+        b.frames = out.nframes;
+        b.pitch = out.nframes;
+        b.nch = out.nch;
+        b.dtype = out.dtype;
+        b.bytes = (size_t)out.nframes * out.nch * dsize(out.dtype);
+        bufs.push_back(b);
+        out_stage_buf = (int)bufs.size() - 1;
+    }
+    // allocate
+    int64_t scratch = 0;
+    for (auto& b : bufs) {
+        if (b.external) continue;
+        HIPCHECK(hipMalloc(&b.d, std::max<size_t>(b.bytes, 64)));
+        scratch += (int64_t)b.bytes;
+    }
+    stats.scratch_bytes = scratch;
+    // patch leaves
+    for (size_t i = 0; i < leaves.size(); ++i) {
+        DLeaf& L = leaves[i];
+        int an = leaf_array_node[i];
+        if (an >= 0) {
+            L.base = nodes[an].nd.i0 ? array_ptr[an] : bufs[array_buf[an]].d;
+        } else if (L.buf >= 0) {
+            L.base = bufs[L.buf].d;
+            if (L.cstride == -1) L.cstride = bufs[L.buf].pitch;
+        }
+    }
+    // upload tables
+    if (!pieces.empty()) {
+        HIPCHECK(hipMalloc(&d_pieces, pieces.size() * sizeof(DPiece)));
+        HIPCHECK(hipMemcpy(d_pieces, pieces.data(), pieces.size() * sizeof(DPiece), hipMemcpyHostToDevice));
+    }
+    if (!ops.empty()) {
+        HIPCHECK(hipMalloc(&d_ops, ops.size() * sizeof(DOp)));
+        HIPCHECK(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DOp), hipMemcpyHostToDevice));
+    }
+    if (!leaves.empty()) {
+        HIPCHECK(hipMalloc(&d_leaves, leaves.size() * sizeof(DLeaf)));
+        HIPCHECK(hipMemcpy(d_leaves, leaves.data(), leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice));
+    }
+    for (auto& S : stages) {
+        if (S.need <= 0) continue;
+        if (S.kind == ST_RESAMPLE) {
+            HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+        } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
+            size_t msz = 0;
+            for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
+            for (size_t gi = 0; gi < S.mpow_host.size(); ++gi)
+                HIPCHECK(hipMemcpy((char*)bufs[S.mpow_buf].d + gi * msz * 8, S.mpow_host[gi].data(),
+                                   S.mpow_host[gi].size() * 8, hipMemcpyHostToDevice));
+        }
+    }
+    // step list: stages in increasing node order (children first), then the root program
+    std::vector<int> order;
+    for (size_t i = 0; i < stages.size(); ++i)
+        if (stages[i].need > 0) order.push_back((int)i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
+    for (int sid : order) {
+        Stage& S = stages[sid];
+        if (S.pw_step >= 0) {
+            Step st{0, S.pw_step, "k_pointwise", pw[S.pw_step].bytes};
+            steps.push_back(st);
+        }
+        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? "k_resample" : "k_sumsq";
+        Step st{1, sid, nm, 0};
+        int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
+        if (S.kind == ST_SOS) st.bytes = 2 * S.need * S.sg.nch * esz;
+        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
+        else st.bytes = S.need * nodes[S.node].nch * esz;
+        steps.push_back(st);
+    }
+    stats.n_stages = (int)order.size() + 1;
+    stats.algorithmic_bytes = algo_bytes + out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
+    int64_t h2d = 0;
+    for (auto& h : host_leaves) h2d += (int64_t)h.bytes;
+    stats.h2d_bytes = h2d;
+    stats.d2h_bytes = out.is_device ? 0 : out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
+}
+
+void Plan::release() {
+    for (auto& b : bufs)
+        if (b.d && !b.external) hipFree(b.d);
+    bufs.clear();
+    if (d_pieces) hipFree(d_pieces);
+    if (d_ops) hipFree(d_ops);
+    if (d_leaves) hipFree(d_leaves);
+    for (auto e : events) hipEventDestroy(e);
+    events.clear();
+}
+
+// ===========================================================================
+Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
+                  int32_t device, int& status, std::string& err) {
+    std::unique_ptr<Plan> P(new Plan());
+    try {
+        if (!nodes || n_nodes < 1 || root < 0 || root >= n_nodes || !out)
+            fail(SO_ERR_INVALID, "so_plan_create: bad arguments");
+        if (out->dtype != SO_F32 && out->dtype != SO_F64)
+            fail(SO_ERR_UNSUPPORTED, "result eltype must be Float32 or Float64");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+            fail(SO_ERR_NODEVICE, "no HIP device visible: the sink engine has no CPU path");
+        if (device < 0 || device >= ndev) fail(SO_ERR_INVALID, "bad device ordinal");
+        P->device = device;
+        HIPCHECK(hipSetDevice(device));
+        P->out = *out;
+        P->root = root;
+        P->build_nodes(nodes, n_nodes);
+        Node& R = P->nodes[root];
+        // sink! length check, reference src/sink.jl:161-163
+        if (clean(R.len) < out->nframes)
+            fail(SO_ERR_LENGTH, "Signal is too short to fill buffer of length " + std::to_string(out->nframes) + ".");
+        if (R.nch != out->nch)
+            fail(SO_ERR_CHANNELS, "signal has " + std::to_string(R.nch) + " channels, buffer has " + std::to_string(out->nch) + " (the host applies ToChannels, reference src/sink.jl:164)");
+        std::vector<Piece> rootp;
+        if (out->nframes > 0) rootp = P->lower(root, Rect{0, out->nframes, 0, out->nch}, Map{1, 0, 1, 0});
+        // stages: largest node index first (all users of a stage have larger indices)
+        for (;;) {
+            int best = -1;
+            for (size_t i = 0; i < P->stages.size(); ++i)
+                if (!P->stages[i].processed && (best < 0 || P->stages[i].node > P->stages[best].node))
+                    best = (int)i;
+            if (best < 0) break;
+            P->process_stage(best);
+        }
+        int rootstep = P->emit_pointwise(rootp, -1, out->dtype);
+        P->finalize();
+        Step st{0, rootstep, "k_pointwise", P->pw[rootstep].bytes};
+        P->steps.push_back(st);
+    } catch (const PlanError& e) {
+        status = e.status;
+        err = e.msg;
+        P->release();
+        return nullptr;
+    }
+    status = SO_OK;
+    return P.release();
+}
+
+int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
+    try {
+        HIPCHECK(hipSetDevice(P->device));
+        hipStream_t st = (hipStream_t)stream;
+        if (P->out.nframes > 0 && !outp) fail(SO_ERR_INVALID, "so_plan_execute: null output");
+        for (auto& h : P->host_leaves)
+            if (h.bytes) HIPCHECK(hipMemcpyAsync(P->bufs[h.buf].d, P->array_ptr[h.node], h.bytes, hipMemcpyHostToDevice, st));
+        if (P->profiling && P->events.size() < 2 * P->steps.size()) {
+            while (P->events.size() < 2 * P->steps.size()) {
+                hipEvent_t e;
+                HIPCHECK(hipEventCreate(&e));
+                P->events.push_back(e);
+            }
+        }
+        int launches = 0;
+        for (size_t si = 0; si < P->steps.size(); ++si) {
+            Step& s = P->steps[si];
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si], st));
+            if (s.kind == 0) {
+                PwStep& w = P->pw[s.idx];
+                OutView ov{};
+                if (w.out_buf >= 0) {
+                    Buf& b = P->bufs[w.out_buf];
+                    ov.base = b.d;
+                    ov.fstride = 1;
+                    ov.cstride = b.pitch;
+                    ov.dtype = b.dtype;
+                } else if (P->out.is_device) {
+                    ov.base = outp;
+                    ov.fstride = P->out.frame_stride;
+                    ov.cstride = P->out.chan_stride;
+                    ov.dtype = P->out.dtype;
+                } else {
+                    Buf& b = P->bufs[P->out_stage_buf];
+                    ov.base = b.d;
+                    ov.fstride = 1;
+                    ov.cstride = b.pitch;
+                    ov.dtype = b.dtype;
+                }
+                if (w.nblocks > 0) {
+                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, st);
+                    s.launches = 1;
+                    launches++;
+                }
+            } else {
+                Stage& S = P->stages[s.idx];
+                Node& N = P->nodes[S.node];
+                size_t esz = dsize(N.dtype);
+                const char* inp;
+                int64_t in_pitch;
+                if (S.in_array_node >= 0) {
+                    const so_node_t& nd = P->nodes[S.in_array_node].nd;
+                    const char* base = nd.i0 ? (const char*)P->array_ptr[S.in_array_node]
+                                             : (const char*)P->bufs[P->array_buf[S.in_array_node]].d;
+                    inp = base + (size_t)S.in_offset * esz;
+                    in_pitch = N.nch == 1 ? 0 : S.in_pitch;
+                } else {
+                    Buf& b = P->bufs[S.in_buf];
+                    inp = (const char*)b.d + (size_t)S.in_offset * esz;
+                    in_pitch = b.pitch;
+                }
+                Buf& ob = P->bufs[S.out_buf];
+                if (S.kind == ST_SOS) {
+                    SosGeom g = S.sg;
+                    g.in_pitch = in_pitch;
+                    g.out_pitch = ob.pitch;
+                    size_t msz = 0;
+                    for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
+                    int nl = 0;
+                    for (size_t gi = 0; gi < S.groups.size(); ++gi) {
+                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
+                        SosGeom gg = g;
+                        if (gi > 0) gg.in_pitch = ob.pitch;
+                        // frames beyond the child's end are zero (Pad(x.signal,zero), reference
+                        // src/filters.jl:240): the materialised input covers them; a direct
+                        // source always has in_frames == need
+                        nl += launch_sos(x, ob.d, S.v_buf >= 0 ? (double*)P->bufs[S.v_buf].d : nullptr,
+                                         S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr,
+                                         S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
+                                         gg, S.groups[gi], st);
+                    }
+                    s.launches = nl;
+                    launches += nl;
+                } else if (S.kind == ST_RESAMPLE) {
+                    RsGeom g = S.rg;
+                    g.in_pitch = in_pitch;
+                    g.out_pitch = ob.pitch;
+                    launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
+                                    (const double*)P->bufs[S.dpfb_buf].d, g, st);
+                    s.launches = 1;
+                    launches++;
+                } else {
+                    launch_rms(ob.d, N.dtype, S.need, N.nch, ob.pitch, (double*)P->bufs[S.partial_buf].d,
+                               S.nparts, (double*)P->bufs[S.rms_buf].d, st);
+                    s.launches = 2;
+                    launches += 2;
+                }
+            }
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si + 1], st));
+        }
+        HIPCHECK(hipGetLastError());
+        P->stats.n_launches = launches;
+        if (!P->out.is_device && P->out.nframes > 0) {
+            Buf& b = P->bufs[P->out_stage_buf];
+            size_t esz = dsize(P->out.dtype);
+            bool planar = P->out.frame_stride == 1 && (P->out.nch == 1 || P->out.chan_stride == P->out.nframes);
+            if (planar) {
+                HIPCHECK(hipMemcpyAsync(outp, b.d, b.bytes, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            } else {
+                P->host_tmp.resize(b.bytes);
+                HIPCHECK(hipMemcpyAsync(P->host_tmp.data(), b.d, b.bytes, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                for (int c = 0; c < P->out.nch; ++c)
+                    for (int64_t f = 0; f < P->out.nframes; ++f)
+                        std::memcpy((char*)outp + (size_t)(f * P->out.frame_stride + c * P->out.chan_stride) * esz,
+                                    P->host_tmp.data() + (size_t)(c * P->out.nframes + f) * esz, esz);
+            }
+        } else if (!P->host_leaves.empty() || P->profiling) {
+            HIPCHECK(hipStreamSynchronize(st));
+        }
+        if (P->profiling) {
+            HIPCHECK(hipStreamSynchronize(st));
+            double total = 0, best = -1;
+            for (size_t si = 0; si < P->steps.size(); ++si) {
+                float ms = 0;
+                HIPCHECK(hipEventElapsedTime(&ms, P->events[2 * si], P->events[2 * si + 1]));
+                P->steps[si].ms = ms;
+                total += ms;
+                if (ms > best) {
+                    best = ms;
+                    P->stats.dominant_kernel_ms = ms;
+                    P->stats.dominant_kernel_bytes = P->steps[si].bytes;
+                    std::snprintf(P->stats.dominant_kernel, sizeof P->stats.dominant_kernel, "%s", P->steps[si].name.c_str());
+                }
+            }
+            P->stats.last_exec_ms = total;
+        }
+    } catch (const PlanError& e) {
+        err = e.msg;
+        return e.status;
+    }
+    return SO_OK;
+}
+
+int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& err) {
+    if (node_index < 0 || node_index >= (int)P->nodes.size() || P->nodes[node_index].nd.kind != SO_NODE_ARRAY) {
+        err = "so_plan_set_array: not an ARRAY node";
+        return SO_ERR_INVALID;
+    }
+    P->array_ptr[node_index] = data;
+    if (P->nodes[node_index].nd.i0) {  // device leaf: patch the leaf table
+        bool changed = false;
+        for (size_t i = 0; i < P->leaves.size(); ++i)
+            if (P->leaf_array_node[i] == node_index) {
+                P->leaves[i].base = data;
+                changed = true;
+            }
+        if (changed && P->d_leaves)
+            if (hipMemcpy(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice) != hipSuccess) {
+                err = "so_plan_set_array: leaf upload failed";
+                return SO_ERR_RUNTIME;
+            }
+    }
+    return SO_OK;
+}
+
+int64_t plan_nframes(const Plan* P) {
+    const Node& R = P->nodes[P->root];
+    return isinf_(R.len) ? SO_LEN_INF : R.len.n;
+}
+void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
+void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
+void plan_destroy(Plan* P) {
+    if (!P) return;
+    hipSetDevice(P->device);
+    P->release();
+    delete P;
+}
+
+}  // namespace so

@@ -1,0 +1,114 @@
+// Internal structures shared by the planner (host) and the HIP kernels (device).
+// Not part of the C-ABI (include/sigops.h).
+#pragma once
+#include <cstdint>
+
+namespace so {
+
+// ---------------------------------------------------------------------------
+// Fused pointwise programs.  A *piece* is a rectangle [a,b) x [c0,c1) of one
+// stage's output inside which the value is a straight-line expression (every
+// Until/After/Pad/Append/Ramp boundary has been resolved on the host into piece
+// boundaries, reference src/cutting.jl, src/padding.jl, src/appending.jl,
+// src/ramps.jl state machines).  The expression is compiled to postfix code for
+// a 4-deep register stack machine; channel-independent sub-expressions
+// (generators, ramps: reference src/functions.jl:53-60, src/ramps.jl:60-72) are
+// hoisted into a per-frame program and evaluated once per frame.
+enum OpCode : int32_t {
+    OP_CONST = 0,   // push leaf.v0
+    OP_LOAD = 1,    // push array element
+    OP_SCALAR = 2,  // push *(const double*)leaf.base (device scalar, e.g. rms)
+    OP_FUNC = 3,    // push SignalFunction value
+    OP_RAMP = 4,    // push ramp gain
+    OP_ADD = 5,
+    OP_SUB = 6,
+    OP_MUL = 7,
+    OP_DIV = 8,
+    OP_NEG = 9,
+    OP_ROUND32 = 10,  // round top of stack to Float32 (Julia Float32 arithmetic)
+    OP_STOREF = 11,   // pop -> frame slot arg
+    OP_LOADF = 12     // push frame slot arg
+};
+
+enum LeafMode : int32_t { LM_PLAIN = 0, LM_CYCLE = 1, LM_MIRROR = 2 };
+
+struct DOp {
+    int32_t code;
+    int32_t arg;
+};
+
+struct DLeaf {
+    const void* base;
+    int64_t fstride, cstride;  // elements
+    int64_t df, dc;            // idx_f = sf*n + df ; idx_c = sc*c + dc
+    int64_t modn;              // CYCLE / MIRROR length ; RAMP: M (start of :off ramp)
+    double v0, v1, v2;         // CONST: value | FUNC: omega, phi, fs | RAMP: R
+    int32_t sf, sc;
+    int32_t dtype;  // SO_F32 / SO_F64 of `base`
+    int32_t mode;   // LeafMode | FUNC: so_fn_t | RAMP: so_rampfn_t
+    int32_t flag;   // FUNC: has_omega | RAMP: direction (0 on, 1 off)
+    int32_t buf;    // >=0: `base` is patched from plan buffer `buf` after allocation
+};
+
+constexpr int kBlock = 256;
+constexpr int kMaxFrameSlots = 4;
+constexpr int kStackDepth = 4;
+
+struct DPiece {
+    int64_t a, b;  // frames [a,b) in stage-output coordinates
+    int32_t c0, c1;
+    int32_t frame_pc, frame_len;
+    int32_t samp_pc, samp_len;
+    int64_t block0;  // first workgroup of this piece
+    int64_t nblk_f;  // workgroups along frames
+    int32_t chc;     // channels per workgroup
+    int32_t pad;
+};
+
+struct OutView {
+    void* base;
+    int64_t fstride, cstride;  // elements
+    int32_t dtype;
+    int32_t pad;
+};
+
+// ---------------------------------------------------------------------------
+// Second-order-sections IIR (DSP.jl DF2T `filt!`; call site
+// reference src/filters.jl:252-255).  Up to kMaxSec sections per launch.
+constexpr int kMaxSec = 8;
+struct SosCoefs {
+    double b0[kMaxSec], b1[kMaxSec], b2[kMaxSec], a1[kMaxSec], a2[kMaxSec];
+    double gain;
+    int32_t nsec;
+    int32_t pad;
+};
+
+struct SosGeom {
+    int64_t n;       // frames to produce
+    int64_t chunk;   // L: frames per chunk
+    int64_t warm;    // W: pass-1 only filters the last min(L,W) frames of a chunk
+    int32_t nchunks;
+    int32_t nch;
+    int32_t kterms;  // K: terms of the truncated power sum in pass 2
+    int32_t in_dtype, out_dtype;
+    int32_t pad;
+    int64_t in_pitch, out_pitch;  // elements between channels
+};
+
+// ---------------------------------------------------------------------------
+// Polyphase FIR resampler (DSP.jl FIRRational/FIRInterpolator/FIRDecimator/
+// FIRArbitrary kernels; call site reference
+// src/filters.jl:252-255 with ResamplerFn, src/reformatting.jl:92-98).
+struct RsGeom {
+    int64_t n_in, n_out;
+    int64_t m0;          // first output index produced (outputs m0 .. m0+n_out)
+    int64_t L, M;        // rational
+    double delta, c0;    // arbitrary: q_m = c0 + m*delta  (two roundings)
+    int64_t c0i;         // rational: q_m = c0i + m*M
+    int32_t arbitrary;
+    int32_t nphi, taps, nch;
+    int32_t in_dtype, out_dtype;
+    int64_t in_pitch, out_pitch;
+};
+
+}  // namespace so

@@ -1,0 +1,161 @@
+"""`sink` / `sink!` for the HIP engine: the Python analogue of the Julia method
+`sink!(result::HIPSink, x, ::IsSignal)` described in INTEGRATION.md.  Mirrors
+reference src/sink.jl:28-168 for type resolution, length checks and ToChannels;
+the block loop (src/sink.jl:225-260) is replaced by so_plan_create/so_plan_execute.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from . import signals as S
+from .lowering import lower, _DT
+
+Array = np.ndarray
+
+
+def process_sink_params(x):  # src/sink.jl:94-99
+    x = S._assignal(x)
+    n = S.nframes(x)
+    if n is None:
+        S.error("Unknown number of frames in signal.")
+    if S.isknowninf(n):
+        S.error("Cannot store infinite signal.")
+    return x
+
+
+def _timeslice(x):
+    """DataCut path: sink of Until/After over raw arrays is an aliasing view
+    (reference src/sink.jl:65-69, src/cutting.jl:193-214)"""
+    if isinstance(x, S.ArraySig):
+        return x.data
+    d = _timeslice(x.signal)
+    n = d.shape[0]
+    L = x.resolvelen()
+    if x.kind == "until":
+        return d[: min(max(L, 0), n)]
+    return d[min(max(L, 0), n):]
+
+
+def _is_datacut(x):
+    if isinstance(x, S.ArraySig):
+        return True
+    return isinstance(x, S.CutApply) and x.evaltrait == "data" and _is_datacut(x.signal)
+
+
+def _root_is_plain_array(x):
+    if isinstance(x, S.ArraySig):
+        return x.fs is None
+    kids = getattr(x, "children", ())
+    arrs = [c for c in kids]
+    return bool(arrs) and all(_root_is_plain_array(c) for c in arrs if not isinstance(c, (S.NumberSig, S.FuncSig))) \
+        and any(not isinstance(c, (S.NumberSig, S.FuncSig)) for c in arrs)
+
+
+class Plan:
+    """RAII wrapper of so_plan_t"""
+
+    def __init__(self, x, result_shape, result_dtype, strides, is_device, device=0, rng=None):
+        self.lowered = lower(x, nframes_out=result_shape[0], rng=rng)
+        self.desc = K.so_out_desc_t(dtype=_DT[np.dtype(result_dtype)], nch=result_shape[1],
+                                    nframes=result_shape[0], frame_stride=strides[0],
+                                    chan_stride=strides[1], is_device=1 if is_device else 0)
+        self.handle = C.c_void_p()
+        L = K.lib()
+        st = L.so_plan_create(self.lowered.nodes, self.lowered.n, self.lowered.root,
+                              C.byref(self.desc), device, C.byref(self.handle))
+        if st != 0:
+            raise S.ErrorException(K.last_error())
+
+    def execute(self, out_ptr, stream=None):
+        st = K.lib().so_plan_execute(self.handle, C.c_void_p(out_ptr), C.c_void_p(stream or 0))
+        if st != 0:
+            raise S.ErrorException(K.last_error())
+
+    def set_profiling(self, on=True):
+        K.lib().so_plan_set_profiling(self.handle, 1 if on else 0)
+
+    def stats(self):
+        s = K.so_stats_t()
+        K.lib().so_plan_stats(self.handle, C.byref(s))
+        return {f[0]: (getattr(s, f[0]).decode() if f[0] == "dominant_kernel" else getattr(s, f[0]))
+                for f in K.so_stats_t._fields_}
+
+    def close(self):
+        if self.handle:
+            K.lib().so_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _result_fields(result):
+    if S._is_torch(result):
+        shape = tuple(result.shape)
+        st = result.stride()
+        if len(shape) == 1:
+            shape, st = (shape[0], 1), (st[0], 0)
+        dt = {"torch.float32": S.F32, "torch.float64": S.F64}[str(result.dtype)]
+        return shape, dt, st, result.is_cuda, result.data_ptr()
+    shape = result.shape
+    item = result.itemsize
+    if result.ndim == 1:
+        return (shape[0], 1), result.dtype, (result.strides[0] // item or 1, 0), False, result.ctypes.data
+    return shape, result.dtype, (result.strides[0] // item or 1, result.strides[1] // item), False, \
+        result.ctypes.data
+
+
+def sink_into(result, x, *, device=0, rng=None, stream=None):
+    """sink!(result,x): write size(result,1) frames of x (reference src/sink.jl:154-168)"""
+    x = S._assignal(x)
+    shape, dt, strides, is_dev, ptr = _result_fields(result)
+    n = S.nframes(x)
+    if n is not None and not S.isknowninf(n) and n < shape[0]:
+        S.error(f"Signal is too short to fill buffer of length {shape[0]}.")
+    x = S.ToChannels(x, shape[1])
+    plan = Plan(x, shape, dt, strides, is_dev, device=device, rng=rng)
+    try:
+        plan.execute(ptr, stream)
+    finally:
+        plan.close()
+    return result
+
+
+def sink(x, to=None, *, device=0, rng=None):
+    """sink(x[,to]) (reference src/sink.jl:28-37,64-92).  `to` may be None (type from
+    the tree's root data), `Array`/np.ndarray, `tuple`, or "torch" (device-resident
+    torch tensor, column-major)."""
+    x = process_sink_params(x)
+    if to is None:
+        to = Array if _root_is_plain_array(x) else tuple
+    if _is_datacut(x) and to is Array:
+        # aliasing view, reference src/sink.jl:65-69: only when the sink type equals the
+        # type of the underlying data (a Tuple sink of a view is copied through sink!)
+        return _timeslice(x)
+    n = S.nframes(x)
+    dt = x.dtype
+    if dt == S.I64:
+        S.error("the HIP engine sinks Float32/Float64 signals only (SURVEY.md §8(b)); "
+                "integer signals take the stock CPU sink")
+    if to == "torch":
+        import torch
+
+        tdt = torch.float32 if dt == S.F32 else torch.float64
+        res = torch.empty((x.nch, n), dtype=tdt, device=f"cuda:{device}").t()
+        sink_into(res, x, device=device, rng=rng)
+        return res, x.fs
+    res = np.empty((n, x.nch), dtype=dt, order="F")  # initsink src/sink.jl:115-119
+    sink_into(res, x, device=device, rng=rng)
+    return res if to is Array else (res, x.fs)
+
+
+# eager lower-case forms (reference: mix(xs...) = sink(Mix(xs...)) etc.)
+def _eager(op):
+    def f(*a, **k):
+        return sink(op(*a, **k))
+
+    return f

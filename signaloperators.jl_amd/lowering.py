@@ -1,0 +1,324 @@
+"""Flatten a lazy operator tree (signals.py) into the `so_node_t` table of
+include/sigops.h.  This is what the Julia glue (julia/SignalOperatorsHIP.jl) does on
+the reference side before its `ccall`.  The same table is consumed by the HIP engine
+(product) and, in tests only, by the CPU oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as K
+from . import signals as S
+from . import units as U
+
+_DT = {S.F32: K.SO_F32, S.F64: K.SO_F64, S.I64: K.SO_I64}
+
+
+def _len_code(n):
+    if n is None:
+        return K.SO_LEN_MISSING
+    if S.isknowninf(n):
+        return K.SO_LEN_INF
+    return int(n)
+
+
+def design_iir(fn, fs):
+    """FilterFn(fs): digitalfilter(design(args...,fs=fs),method) -> SOS
+    (reference src/filters.jl:10-11,94) through the library's design entry point."""
+    L = K.lib()
+    method = fn.method
+    order = method[1]
+    ripple = method[2] if len(method) > 2 else 0.0
+    cap = 6 * (2 * order + 2)
+    sos = (C.c_double * cap)()
+    nsec = C.c_int32(0)
+    gain = C.c_double(0)
+    f1 = fn.args[0]
+    f2 = fn.args[1] if len(fn.args) > 1 else 0.0
+    st = L.so_design_iir(K.FILT[fn.design], f1, f2, fs, K.METHOD[method[0]], order, ripple,
+                         sos, cap, C.byref(nsec), C.byref(gain))
+    if st != 0:
+        S.error(K.last_error())
+    return np.array(sos[: 6 * nsec.value], dtype=np.float64).reshape(-1, 6), gain.value
+
+
+def design_resample(ratio):
+    """resample_filter(ratio) (reference src/reformatting.jl:93)"""
+    L = K.lib()
+    n = C.c_int32(0)
+    if isinstance(ratio, tuple):
+        L.so_design_resample_rational(ratio[0], ratio[1], None, 0, C.byref(n))
+        h = (C.c_double * n.value)()
+        st = L.so_design_resample_rational(ratio[0], ratio[1], h, n.value, C.byref(n))
+    else:
+        L.so_design_resample_arbitrary(float(ratio), 32, None, 0, C.byref(n))
+        h = (C.c_double * n.value)()
+        st = L.so_design_resample_arbitrary(float(ratio), 32, h, n.value, C.byref(n))
+    if st != 0:
+        S.error(K.last_error())
+    return np.array(h[:], dtype=np.float64)
+
+
+def _pad_fields(pad, nch):
+    """usepad resolution, reference src/padding.jl:150-192"""
+    if pad is S.zero:
+        return K.PAD["zero"], 0.0, None
+    if pad is S.one:
+        return K.PAD["one"], 0.0, None
+    if pad is S.lastframe:
+        return K.PAD["lastframe"], 0.0, None
+    if pad is S.cycle:
+        return K.PAD["cycle"], 0.0, None
+    if pad is S.mirror:
+        return K.PAD["mirror"], 0.0, None
+    if isinstance(pad, (bool, int, float, np.integer, np.floating)):
+        return K.PAD["value"], float(pad), None
+    if isinstance(pad, (tuple, list, np.ndarray)):
+        v = np.ascontiguousarray(np.asarray(pad, dtype=np.float64).reshape(-1))
+        if v.size != nch:
+            S.error("padding vector length must equal the channel count")
+        return K.PAD["vector"], 0.0, v
+    if callable(pad):
+        import inspect
+
+        try:
+            nargs = len(inspect.signature(pad).parameters)
+        except (TypeError, ValueError):
+            nargs = -1
+        if nargs not in (1, 3):
+            S.error(f"Pad function ({pad}) must take 1 or 3 arguments. Refer to `Pad` documentation.")
+        S.error("Pad: opaque padding closures cannot be lowered to the HIP engine")
+    S.error(f"unsupported padding {pad!r}")
+
+
+class Lowered:
+    def __init__(self):
+        self.rows = []  # python dicts, converted at the end
+        self.keep = []  # keep-alive for ctypes / numpy buffers
+        self.memo = {}
+        self.array_nodes = []  # (index, ArraySig)
+        self.nodes = None
+        self.root = -1
+
+    def add(self, **kw):
+        self.rows.append(kw)
+        return len(self.rows) - 1
+
+    def finish(self, root):
+        n = len(self.rows)
+        arr = (K.so_node_t * n)()
+        for i, r in enumerate(self.rows):
+            nd = arr[i]
+            kids = r.pop("children", ())
+            for k, v in r.items():
+                setattr(nd, k, v)
+            nd.n_children = len(kids)
+            if kids:
+                ck = (C.c_int32 * len(kids))(*kids)
+                self.keep.append(ck)
+                nd.children = C.cast(ck, C.POINTER(C.c_int32))
+        self.nodes = arr
+        self.root = root
+        self.n = n
+        return self
+
+
+def _array_fields(x):
+    d = x.data
+    if S._is_torch(d):
+        ptr = d.data_ptr()
+        st = d.stride()
+        is_dev = 1 if d.is_cuda else 0
+        fstride = st[0]
+        cstride = st[1] if len(st) > 1 else 0
+    else:
+        ptr = d.ctypes.data
+        item = d.itemsize
+        fstride = d.strides[0] // item if d.shape[0] > 1 or d.strides[0] else 1
+        cstride = (d.strides[1] // item) if d.ndim > 1 else 0
+        is_dev = 0
+    return ptr, fstride, cstride, is_dev
+
+
+def _demand(x, n, out):
+    """how many frames of every randn leaf a sink of n frames evaluates"""
+    if n is None or n <= 0:
+        return
+    if isinstance(x, S.FuncSig):
+        if x.fn == S.RANDN:
+            out[id(x)] = max(out.get(id(x), 0), n)
+        return
+    if isinstance(x, (S.ArraySig, S.NumberSig, S.RampSignal)):
+        return
+
+    def capped(c, m):
+        cl = S.nframes(c)
+        if cl is None or S.isknowninf(cl):
+            return m
+        return min(m, cl)
+
+    if isinstance(x, S.CutApply):
+        L = x.resolvelen() or 0
+        _demand(x.signal, capped(x.signal, min(n, max(0, L)) if x.kind == "until" else n + max(0, L)), out)
+    elif isinstance(x, S.PaddedSignal):
+        _demand(x.signal, capped(x.signal, n), out)
+    elif isinstance(x, S.AppendSignals):
+        rem = n
+        for c in x.signals:
+            cl = S.nframes(c)
+            m = rem if (cl is None or S.isknowninf(cl)) else min(rem, cl)
+            _demand(c, m, out)
+            rem -= m
+            if rem <= 0:
+                break
+    elif isinstance(x, S.MapSignal):
+        for c in x.signals:
+            _demand(c, capped(c, n), out)
+    elif isinstance(x, S.FilteredSignal):
+        if isinstance(x.fn, S.ResamplerFn):
+            r = x.fn.ratio
+            r = r[0] / r[1] if isinstance(r, tuple) else r
+            m = int(math.ceil(n / r)) + 8
+        else:
+            m = n
+        _demand(x.signal, capped(x.signal, m), out)
+    elif isinstance(x, S.NormedSignal):
+        _demand(x.signal, S.nframes(x.signal), out)
+
+
+def lower(x, nframes_out=None, rng=None):
+    x = S._assignal(x)
+    lw = Lowered()
+    need = {}
+    if nframes_out is None:
+        nf = S.nframes(x)
+        nframes_out = None if (nf is None or S.isknowninf(nf)) else nf
+    _demand(x, nframes_out, need)
+
+    def fs_of(s):
+        return float("nan") if s.fs is None else float(s.fs)
+
+    def common(s, kind):
+        return dict(kind=kind, dtype=_DT[s.dtype], nch=s.nch, nframes=_len_code(S.nframes(s)),
+                    fs=fs_of(s))
+
+    def rec(s):
+        key = id(s)
+        if key in lw.memo and not (isinstance(s, S.FuncSig) and s.fn == S.RANDN):
+            return lw.memo[key]
+        lw.keep.append(s)
+        if isinstance(s, S.ArraySig):
+            if s.dtype == S.I64:
+                S.error("the HIP engine lowers Float32/Float64 arrays only (SURVEY.md §8(b))")
+            ptr, fst, cst, dev = _array_fields(s)
+            r = common(s, K.NODE_ARRAY)
+            r.update(p0=ptr, l0=s.n, i0=dev, s0=fst, s1=cst)
+            idx = lw.add(**r)
+            lw.array_nodes.append((idx, s))
+        elif isinstance(s, S.NumberSig):
+            r = common(s, K.NODE_CONST)
+            r.update(d0=float(s.val), i0=_DT[s.dtype], nch=1)
+            idx = lw.add(**r)
+        elif isinstance(s, S.FuncSig):
+            if s.fn == S.RANDN:
+                # randn leaves are host-materialised (SURVEY.md §7 hard part 7): one
+                # N(0,1) draw per evaluated frame, in increasing frame order
+                n = need.get(id(s), 0)
+                g = s.rng if s.rng is not None else (rng if rng is not None else np.random.default_rng())
+                data = np.asfortranarray(g.standard_normal((max(n, 0), 1)))
+                a = S.ArraySig(data, s.fs)
+                lw.keep.append(a)
+                r = common(a, K.NODE_ARRAY)
+                r["nframes"] = K.SO_LEN_UNCHECKED
+                r.update(p0=data.ctypes.data, l0=a.n, i0=0, s0=1, s1=a.n)
+                inner = lw.add(**r)
+                # the leaf is infinite in the reference: pad is never reached because
+                # demand analysis sized the array; keep lengths consistent with Pad
+                r2 = dict(kind=K.NODE_PAD, dtype=K.SO_F64, nch=1, nframes=K.SO_LEN_INF, fs=fs_of(s),
+                          i0=K.PAD["zero"], i1=0, children=(inner,))
+                idx = lw.add(**r2)
+            else:
+                if s.fs is None:
+                    S.error("Unknown frame rate: function signals need a frame rate before `sink` "
+                            "(use ToFramerate)")
+                r = common(s, K.NODE_FUNC)
+                r.update(i0=K.FN[s.fn], i1=0 if s.omega is None else 1,
+                         d0=0.0 if s.omega is None else float(s.omega), d1=s.phi, nch=1)
+                idx = lw.add(**r)
+        elif isinstance(s, S.CutApply):
+            c = rec(s.signal)
+            L = s.resolvelen()
+            if L is None:
+                S.error("Unknown number of frames in signal.")
+            r = common(s, K.NODE_UNTIL if s.kind == "until" else K.NODE_AFTER)
+            r.update(l0=int(L), children=(c,))
+            idx = lw.add(**r)
+        elif isinstance(s, S.PaddedSignal):
+            c = rec(s.signal)
+            kind, val, vec = _pad_fields(s.pad, s.nch)
+            r = common(s, K.NODE_PAD)
+            r.update(i0=kind, i1=1 if s.extending else 0, d0=val, children=(c,))
+            if vec is not None:
+                lw.keep.append(vec)
+                r["p0"] = vec.ctypes.data
+            idx = lw.add(**r)
+        elif isinstance(s, S.AppendSignals):
+            kids = tuple(rec(c) for c in s.signals)
+            r = common(s, K.NODE_APPEND)
+            r.update(children=kids)
+            idx = lw.add(**r)
+        elif isinstance(s, S.RampSignal):
+            c = rec(s.signal)
+            R = s.resolvelen()
+            if R is None:
+                S.error("Unknown number of frames in signal.")
+            r = common(s, K.NODE_RAMP)
+            r.update(i0=0 if s.direction == "on" else 1, i1=K.RAMPFN[s.fn], l0=int(R), children=(c,))
+            idx = lw.add(**r)
+        elif isinstance(s, S.MapSignal):
+            kids = tuple(rec(c) for c in s.signals)
+            pk, pv, _ = _pad_fields(s.padding, s.nch)
+            r = common(s, K.NODE_MAP)
+            extra = s.extra
+            if s.fn == S.TOELTYPE:
+                extra = _DT[np.dtype(s.extra)]
+            r.update(i0=K.MAPFN[s.fn], i1=1 if s.bychannel else 0, i2=pk, d0=pv, i3=int(extra),
+                     children=kids)
+            idx = lw.add(**r)
+        elif isinstance(s, S.FilteredSignal):
+            c = rec(s.signal)
+            if isinstance(s.fn, S.ResamplerFn):
+                ratio = s.fn.ratio
+                h = design_resample(ratio)
+                lw.keep.append(h)
+                r = common(s, K.NODE_RESAMPLE)
+                r.update(p0=h.ctypes.data, i2=int(h.size), i3=s.blocksize, children=(c,))
+                if isinstance(ratio, tuple):
+                    r.update(i0=K.RS_RATIONAL, i1=int(ratio[0]), l0=int(ratio[0]), l1=int(ratio[1]))
+                else:
+                    r.update(i0=K.RS_ARBITRARY, i1=32, d0=float(ratio))
+            else:
+                if s.fs is None:
+                    S.error("Unknown frame rate: Filt needs a frame rate before `sink`")
+                if isinstance(s.fn, S.RawFilterFn):
+                    sos, gain = s.fn.sos, s.fn.gain
+                else:
+                    sos, gain = design_iir(s.fn, s.fs)  # FilterFn(fs): designed at sink time
+                sos = np.ascontiguousarray(sos, dtype=np.float64)
+                lw.keep.append(sos)
+                r = common(s, K.NODE_FILT_SOS)
+                r.update(i0=int(sos.shape[0]), p0=sos.ctypes.data, d0=float(gain), i1=s.blocksize,
+                         children=(c,))
+            idx = lw.add(**r)
+        elif isinstance(s, S.NormedSignal):
+            c = rec(s.signal)
+            r = common(s, K.NODE_NORMPOWER)
+            r.update(children=(c,))
+            idx = lw.add(**r)
+        else:
+            S.error(f"Value is not a signal: {s!r}")
+        lw.memo[key] = idx
+        return idx
+
+    root = rec(x)
+    return lw.finish(root)

@@ -1,0 +1,63 @@
+"""Test-side loader of the CPU oracle (oracle/libsigops_oracle.so).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may use the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import sigops_amd as so
+from sigops_amd import _capi as K
+from sigops_amd import signals as S
+from sigops_amd.lowering import lower, _DT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libsigops_oracle.so")
+_lib = None
+
+
+def oracle_lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_SO)
+        L.so_oracle_sink.restype = C.c_int32
+        L.so_oracle_sink.argtypes = [C.POINTER(K.so_node_t), C.c_int32, C.c_int32,
+                                     C.POINTER(K.so_out_desc_t), C.c_void_p, C.c_int32]
+        L.so_oracle_nframes.restype = C.c_int64
+        L.so_oracle_nframes.argtypes = [C.POINTER(K.so_node_t), C.c_int32, C.c_int32]
+        L.so_oracle_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def oracle_sink_lowered(lw, nframes, nch, dtype, blocksize=0):
+    res = np.empty((nframes, nch), dtype=dtype, order="F")
+    desc = K.so_out_desc_t(dtype=_DT[np.dtype(dtype)], nch=nch, nframes=nframes, frame_stride=1,
+                           chan_stride=max(nframes, 1), is_device=0)
+    st = oracle_lib().so_oracle_sink(lw.nodes, lw.n, lw.root, C.byref(desc),
+                                     res.ctypes.data_as(C.c_void_p), blocksize)
+    if st != 0:
+        raise S.ErrorException(oracle_lib().so_oracle_last_error().decode())
+    return res
+
+
+def oracle_sink(x, nframes=None, blocksize=0, rng=None, dtype=None):
+    """CPU oracle analogue of sink(x, Array) (always evaluates; no DataCut view)."""
+    x = so.process_sink_params(x) if nframes is None else S._assignal(x)
+    n = S.nframes(x) if nframes is None else nframes
+    if dtype is None:
+        dtype = S.float_type(x.dtype)
+    lw = lower(x, nframes_out=n, rng=rng)
+    return oracle_sink_lowered(lw, n, x.nch, dtype, blocksize)
+
+
+def oracle_nframes(x):
+    lw = lower(S._assignal(x))
+    return oracle_lib().so_oracle_nframes(lw.nodes, lw.n, lw.root)
+
+
+def relerr(a, b):
+    """norm-wise relative error, Julia isapprox semantics (runtests.jl:356)"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
