@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the sink hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on):
+    Signal(noise[26 460 000 x 8], 44.1 kHz) |> Amplify(Signal(sin, ω=5Hz)) |> Until(600s)
+        |> ToFramerate(48 kHz) |> sink          
+A step is one `so_plan_execute` of that tree with the noise leaf and the result both
+resident in HBM.  N>1: one process per GPU, each rank sinks its own independent signal
+(batched independent signals shard with no data-path collective => weak scaling).
+
+One JSON line is printed by rank 0 (see the driver contract in the task statement), with
+two extra objects: "roofline" (dominant kernel vs the HBM roofline, hipEvent-timed inside
+the library on the stream the kernels run on) and "cpu_baseline" (the CPU oracle — a port of
+the reference's block-pull engine — timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_tree(so, noise, seconds):
+    return (so.Signal(noise, 44.1 * so.kHz) | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz))
+            | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz))
+
+
+def cpu_baseline(so, seconds, nch, dtype):
+    """Oracle (port of the reference's single-threaded block-pull engine) on a bounded
+    sample of the same workload.  Only this leg of bench.py touches oracle/."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bridge import oracle_sink
+
+    n_in = int(round(seconds * 44100))
+    rng = np.random.default_rng(1983)
+    noise = np.asfortranarray(rng.standard_normal((n_in, nch)).astype(dtype))
+    x = build_tree(so, noise, seconds)
+    t0 = time.perf_counter()
+    y = oracle_sink(x)
+    dt = time.perf_counter() - t0
+    return {"value": y.shape[0] / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{seconds:g} s of the same 8-ch 44.1->48 kHz pipeline "
+                      f"({y.shape[0]} output frames) on 1 thread; blocksize 4096",
+            "seconds": dt, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=600.0, help="signal duration (600 = full config)")
+    ap.add_argument("--channels", type=int, default=8)
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
+    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+                    help="signal seconds for the bounded CPU-oracle sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        ge.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.barrier()
+    import sigops_amd as so
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the sink engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    ndt = np.float64 if args.dtype == "f64" else np.float32
+    esz = 8 if args.dtype == "f64" else 4
+    nch = args.channels
+    n_in = int(round(args.seconds * 44100))
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1983 + rank)
+    noise_t = torch.randn((nch, n_in), dtype=tdt, device=dev, generator=gen)
+    noise = noise_t.t()  # [n_in x nch], column-major like Julia's Array (time fastest)
+    x = build_tree(so, noise, args.seconds)
+    n_out = so.nframes(x)
+    out_t = torch.empty((nch, n_out), dtype=tdt, device=dev)
+    out = out_t.t()
+    xs = so.ToChannels(x, nch)
+
+    t0 = time.perf_counter()
+    plan = so.Plan(xs, (n_out, nch), ndt, (out.stride(0), out.stride(1)), True, device=local_rank)
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    stream = torch.cuda.current_stream().cuda_stream
+    optr = out.data_ptr()
+
+    for _ in range(args.warmup):
+        plan.execute(optr, stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.execute(optr, stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-level timing (hipEvents inside the library, same stream), averaged over K steps
+    plan.set_profiling(True)
+    kms, kbytes, kname, tot_ms = [], 0, "", []
+    for _ in range(max(3, min(args.steps, 10))):
+        plan.execute(optr, stream)
+        st = plan.stats()
+        kms.append(st["dominant_kernel_ms"])
+        tot_ms.append(st["last_exec_ms"])
+        kbytes, kname = st["dominant_kernel_bytes"], st["dominant_kernel"]
+    plan.set_profiling(False)
+    st = plan.stats()
+    checksum = float(out_t[:, :: max(1, n_out // 4096)].double().abs().sum().item())
+
+    if rank == 0:
+        k_avg_ms = sum(kms) / len(kms)
+        achieved = kbytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        algo = st["algorithmic_bytes"]
+        ms_per_step = elapsed / args.steps * 1e3
+        res = {
+            "metric": "frames/sec sink() 44.1kHz 8ch Mix+Filt+Resample; achieved HBM GB/s",
+            "value": world * n_out * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "config3: Signal(noise[%d x %d],44.1kHz) |> Amplify(sin 5Hz) |> Until(%gs) "
+                                   "|> ToFramerate(48kHz) |> sink (device-resident leaf and result)"
+                                   % (n_in, nch, args.seconds),
+                       "in_frames": n_in, "out_frames": n_out, "channels": nch,
+                       "parallelism": f"{world} independent signals, one per GPU, no collective",
+                       "plan_create_ms": plan_ms, "launches_per_step": st["n_launches"],
+                       "stages": st["n_stages"], "scratch_bytes": st["scratch_bytes"],
+                       "checksum": checksum},
+            "hbm_GBps_whole_sink": algo / (ms_per_step * 1e-3) / 1e9,
+            "algorithmic_bytes_per_step": algo,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "kernel_ms": k_avg_ms, "kernel_algorithmic_bytes": kbytes,
+                         "all_kernels_ms": sum(tot_ms) / len(tot_ms)},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            res["cpu_baseline"] = cpu_baseline(so, args.cpu_seconds, nch, ndt)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    plan.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

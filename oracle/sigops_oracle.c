@@ -30,6 +30,11 @@
  *        whose newest input lies in it (DSP.outputlength can over-count by 1-2).
  *        SO_ORACLE_PHASE_ACCUMULATE=1 in the environment switches to the
  *        accumulator for divergence measurements.
+ *        When both frame rates are integers (e.g. 44100 -> 48000) the rate is the exact
+ *        rational L/M = fs_out/fs_in (reduced) and the positions are evaluated in exact
+ *        integer arithmetic, q_m = c0 + m*Nphi*M/L, which is what DSP.jl's accumulator
+ *        approximates; this fixes the tie cases (alpha == 0) that floating-point
+ *        accumulation resolves by accumulated rounding error.
  *   C-2  NormedSignal honours its block offset (intended semantics).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
@@ -180,15 +185,6 @@ static Len map_maxlen(Len x, Len y) {
     return len_fin(imax(a, b));
 }
 
-static int map_result_dtype(const so_node_t* nd, OSig** kids, int nk) {
-    int fn = nd->i0;
-    if (fn == SO_MAP_TOELTYPE) return nd->i3;
-    int t = kids[0]->dtype;
-    for (int j = 1; j < nk; ++j) t = promote(t, kids[j]->dtype);
-    if (fn == SO_MAP_DIV && t == SO_I64) t = SO_F64;
-    return t;
-}
-
 static OSig* build(const so_node_t* nodes, int32_t n_nodes, int32_t idx) {
     if (idx < 0 || idx >= n_nodes) fail(SO_ERR_INVALID, "oracle: bad node index %d", idx);
     const so_node_t* nd = &nodes[idx];
@@ -280,6 +276,8 @@ typedef struct {
     double* pfb;  /* [nphi][taps], pfb[p*taps+k] = h[p + nphi*k] (k = tap age) */
     double* dpfb;
     double rate, delta;
+    int exact;     /* arbitrary kernel with integer frame rates: exact rational positions */
+    int64_t eL, eM;
     double c0;     /* (hlen-1)/2 : fine-grid position of output 0 */
     int64_t m;     /* next output index (closed form) */
     /* accumulator mode (DSP.jl FIRArbitrary.update) */
@@ -289,7 +287,16 @@ typedef struct {
     int64_t consumed; /* inputs consumed so far */
 } Fir;
 
-static void fir_init(Fir* f, const so_node_t* nd) {
+static int64_t gcd64(int64_t a, int64_t b) {
+    while (b) {
+        int64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+static void fir_init(Fir* f, const so_node_t* nd, double fs_in) {
     memset(f, 0, sizeof *f);
     f->arbitrary = (nd->i0 == SO_RS_ARBITRARY);
     f->hlen = nd->i2;
@@ -298,6 +305,17 @@ static void fir_init(Fir* f, const so_node_t* nd) {
         f->nphi = nd->i1;
         f->rate = nd->d0;
         f->delta = (double)f->nphi / f->rate; /* FIRArbitrary: Δ = Nϕ/rate */
+        double fo = nd->fs, fi = fs_in;
+        if (fo == floor(fo) && fi == floor(fi) && fo >= 1 && fi >= 1 && fo < 2147483648.0 &&
+            fi < 2147483648.0 && fo / fi == f->rate && !g_phase_accumulate) {
+            int64_t g = gcd64((int64_t)fo, (int64_t)fi);
+            int64_t L = (int64_t)fo / g, M = (int64_t)fi / g;
+            if (L <= 8192 && M <= 1048576) {
+                f->exact = 1;
+                f->eL = L;
+                f->eM = M;
+            }
+        }
     } else {
         f->L = nd->l0;
         f->M = nd->l1;
@@ -329,7 +347,13 @@ static void fir_init(Fir* f, const so_node_t* nd) {
 
 /* closed-form position of output m: j = newest input (0-based), p = phase, alpha */
 static void fir_pos(const Fir* f, int64_t m, int64_t* j, int* p, double* alpha) {
-    if (f->arbitrary) {
+    if (f->arbitrary && f->exact) {
+        int64_t N = m * ((int64_t)f->nphi * f->eM);
+        int64_t qi = (int64_t)f->c0 + N / f->eL;
+        *alpha = (double)(N % f->eL) / (double)f->eL;
+        *j = qi / f->nphi;
+        *p = (int)(qi % f->nphi);
+    } else if (f->arbitrary) {
         double t = (double)m * f->delta;
         double q = f->c0 + t;
         double fl = floor(q);
@@ -480,15 +504,6 @@ static OState* mkstate(OSig* s) {
     for (int j = 0; j < s->nkids; ++j) st->kids[j] = mkstate(s->kids[j]);
     return st;
 }
-static void reset_state(OState* st) { /* fresh block chain for the same signal */
-    OSig* s = st->s;
-    OState** kids = st->kids;
-    memset(st, 0, sizeof *st);
-    st->s = s;
-    st->kids = kids;
-    for (int j = 0; j < s->nkids; ++j) reset_state(kids[j]);
-}
-
 static int nextblock(OState* st, int64_t maxlen, int skip);
 static int frame(OState* st, int64_t i, double* out); /* returns value dtype */
 
@@ -763,7 +778,7 @@ static int nextblock(OState* st, int64_t maxlen, int skip) {
             st->available_output = 0;
             if (is_rs) {
                 st->firs = (Fir*)xalloc(sizeof(Fir) * (size_t)nch);
-                for (int ch = 0; ch < nch; ++ch) fir_init(&st->firs[ch], nd); /* per channel: :205 */
+                for (int ch = 0; ch < nch; ++ch) fir_init(&st->firs[ch], nd, s->kids[0]->fs); /* per channel: :205 */
                 double ratio = st->firs[0].arbitrary ? st->firs[0].rate : (double)nd->l0 / (double)nd->l1;
                 /* init_length :185-199 */
                 int64_t n = (int64_t)trunc(fmax(1.0, (double)imin(total, st->blocksize) / ratio));

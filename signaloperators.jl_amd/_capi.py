@@ -65,6 +65,20 @@ def lib():
         raise EngineMissing(
             f"{LIB_PATH} not built: run `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). The HIP engine has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 with the same
+    # SONAME as /opt/rocm's.  If ours were loaded first, a later `import torch` would bind
+    # to it and fail ("No HIP GPUs are available"); so when torch is installed, load its
+    # copy first and let libsigops resolve against it.
+    try:
+        import importlib.util as _ilu
+
+        _spec = _ilu.find_spec("torch")
+        if _spec is not None and _spec.origin:
+            _hip = os.path.join(os.path.dirname(_spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(_hip):
+                C.CDLL(_hip, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     L.so_abi_version.restype = C.c_int32
     L.so_last_error.restype = C.c_char_p

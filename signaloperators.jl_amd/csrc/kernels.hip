@@ -366,7 +366,13 @@ int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow
 // operations (no FMA contraction) or pure int64.
 __device__ __forceinline__ void rs_pos(const RsGeom& g, int64_t m, int64_t& j, int& p,
                                        double& alpha) {
-    if (g.arbitrary) {
+    if (g.arbitrary && g.exact) {
+        const int64_t N = m * ((int64_t)g.nphi * g.M);
+        const int64_t qi = g.c0i + N / g.L;
+        alpha = __ddiv_rn((double)(N % g.L), (double)g.L);
+        j = qi / g.nphi;
+        p = (int)(qi % g.nphi);
+    } else if (g.arbitrary) {
         const double t = __dmul_rn((double)m, g.delta);
         const double q = __dadd_rn(g.c0, t);
         const double fl = floor(q);
@@ -419,6 +425,153 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
     else
         hipLaunchKernelGGL((k_resample<double>), grid, dim3(kBlock), 0, st, (const double*)x, pfb,
                            dpfb, g, (double*)y);
+}
+
+// K3p: periodic polyphase resampler (rational L/M).  Workgroup = 256 threads = 4 waves;
+// tile = pt periods x ct channels = 64 rows, staged once in LDS as fp64 (coalesced
+// global reads, 3 % halo).  Lane = row.  Each wave walks its share of the period's output
+// groups; per group the RM x kw tap table is wave-uniform (scalar loads -> SGPR FMA
+// operands) and every ds_read_b64 of an input sample feeds RM fp64 FMAs, so neither LDS
+// bandwidth nor tap traffic limits the kernel: HBM streaming does.
+//   tab  [ngroups][kw][RM]  combined taps h + alpha*dh, oldest input first, zero padded
+//   jend [ngroups]          newest input of the group's window, relative to the period base
+template <typename T, int RM>
+__global__ __launch_bounds__(1024) void k_resample_periodic(const T* __restrict__ x,
+                                                              const double* __restrict__ tab,
+                                                              const int* __restrict__ jend,
+                                                              RsPeriodic g, T* __restrict__ y,
+                                                              const DPiece* __restrict__ pieces,
+                                                              int npieces,
+                                                              const DOp* __restrict__ ops,
+                                                              const DLeaf* __restrict__ leaves) {
+    extern __shared__ double lds[];
+    const int64_t P0 = (int64_t)blockIdx.x * g.pt;
+    const int c0 = blockIdx.y * g.ct;
+    const int64_t xbase = P0 * g.M + g.jlo;  // global input index of LDS slot 0 (can be < 0)
+    if (npieces == 0) {
+        // plain planar source
+        for (int c = 0; c < g.ct; ++c) {
+            const T* xp = x + (int64_t)(c0 + c) * g.in_pitch;
+            double* lp = lds + c * g.lds_pitch;
+            for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
+                const int64_t gi = xbase + i;
+                lp[i] = (gi >= 0 && gi < g.n_in) ? (double)xp[gi] : 0.0;  // zero padding
+            }
+        }
+    } else {
+        // fused source: the child's pointwise program (mapsignal / ramps / cuts /
+        // generators) is evaluated straight into the LDS tile; the intermediate never
+        // touches HBM.  Pieces are walked one at a time so control flow stays wave-uniform.
+        const int64_t lo = xbase > 0 ? xbase : 0;
+        const int64_t hi = xbase + g.tile_len < g.n_in ? xbase + g.tile_len : g.n_in;
+        for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
+            const int64_t gi = xbase + i;
+            if (gi < 0 || gi >= g.n_in)
+                for (int c = 0; c < g.ct; ++c) lds[c * g.lds_pitch + i] = 0.0;
+        }
+        int a = 0, b = npieces - 1;
+        while (a < b) {  // first piece whose end is beyond lo (pieces are sorted by frame)
+            int mid = (a + b) >> 1;
+            if (pieces[mid].b > lo) b = mid;
+            else a = mid + 1;
+        }
+        for (int pi = a; pi < npieces && pieces[pi].a < hi; ++pi) {
+            const DPiece P = pieces[pi];
+            const int64_t fa = P.a > lo ? P.a : lo;
+            const int64_t fb = P.b < hi ? P.b : hi;
+            for (int64_t gi = fa + threadIdx.x; gi < fb; gi += blockDim.x) {
+                int64_t n[1] = {gi};
+                double F[kMaxFrameSlots][1];
+                double v[1];
+#pragma unroll
+                for (int k = 0; k < kMaxFrameSlots; ++k) F[k][0] = 0.0;
+                if (P.frame_len > 0) run_program<1>(ops, P.frame_pc, P.frame_len, leaves, n, c0, F, v);
+                const int slot = (int)(gi - xbase);
+                for (int c = 0; c < g.ct; ++c) {
+                    run_program<1>(ops, P.samp_pc, P.samp_len, leaves, n, c0 + c, F, v);
+                    // the reference stores the child into a buffer of the child's sample
+                    // type before filtering (src/filters.jl:207,244)
+                    lds[c * g.lds_pitch + slot] = sizeof(T) == 4 ? (double)(float)v[0] : v[0];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pl = lane % g.pt, cl = lane / g.pt;
+    const int64_t period = P0 + pl;
+    const int rowbase = cl * g.lds_pitch + pl * (int)g.M - g.jlo - (g.kw - 1);
+    T* yp = y + (int64_t)(c0 + cl) * g.out_pitch + period * g.L;
+    const int64_t mbase = period * g.L;
+    const int nwaves = blockDim.x >> 6;
+    const int gper = (g.ngroups + nwaves - 1) / nwaves;
+    const int gbeg = wave * gper;
+    const int gend = min(g.ngroups, gbeg + gper);
+    for (int gi = gbeg; gi < gend; ++gi) {
+        const double* __restrict__ tg = tab + (size_t)gi * g.kw * RM;
+        const double* __restrict__ xr = lds + (rowbase + jend[gi]);
+        double acc[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) acc[r] = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < g.kw; ++k) {
+            const double xv = xr[k];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[r] = fma(tg[k * RM + r], xv, acc[r]);
+        }
+        const int r0 = gi * RM;
+        if (period < g.nperiods) {
+            if (g.vec_ok && r0 + RM <= g.L && mbase + r0 + RM <= g.n_out) {
+                if constexpr (sizeof(T) == 8) {
+#pragma unroll
+                    for (int r = 0; r < RM; r += 2) {
+                        double2 v;
+                        v.x = acc[r];
+                        v.y = acc[r + 1];
+                        *reinterpret_cast<double2*>(yp + r0 + r) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RM; r += 4) {
+                        float4 v;
+                        v.x = (float)acc[r];
+                        v.y = (float)acc[r + 1];
+                        v.z = (float)acc[r + 2];
+                        v.w = (float)acc[r + 3];
+                        *reinterpret_cast<float4*>(yp + r0 + r) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+                    if (r0 + r < g.L && mbase + r0 + r < g.n_out) yp[r0 + r] = (T)acc[r];
+            }
+        }
+    }
+}
+
+void launch_resample_periodic(const void* x, void* y, const double* tab, const int* jend,
+                              const RsPeriodic& g, int dtype, const DPiece* pieces, int npieces,
+                              const DOp* ops, const DLeaf* leaves, hipStream_t st) {
+    if (g.n_out <= 0) return;
+    constexpr int RM = 8;
+    dim3 grid((unsigned)((g.nperiods + g.pt - 1) / g.pt), (unsigned)(g.nch / g.ct));
+    size_t lds = (size_t)g.ct * g.lds_pitch * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<double, RM>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<float, RM>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (dtype == SO_F32)
+        hipLaunchKernelGGL((k_resample_periodic<float, RM>), grid, dim3(64 * g.nwaves), lds, st,
+                           (const float*)x, tab, jend, g, (float*)y, pieces, npieces, ops, leaves);
+    else
+        hipLaunchKernelGGL((k_resample_periodic<double, RM>), grid, dim3(64 * g.nwaves), lds, st,
+                           (const double*)x, tab, jend, g, (double*)y, pieces, npieces, ops, leaves);
 }
 
 // ---------------------------------------------------------------------------

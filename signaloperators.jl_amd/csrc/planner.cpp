@@ -112,6 +112,7 @@ struct Stage {
     int64_t in_offset = 0;  // elements (direct)
     int64_t in_pitch = 0, in_frames = 0;
     int pw_step = -1;  // pointwise step materialising the input
+    int fused_pw = -1; // pointwise program evaluated inside the stage kernel's staging loop
     // SOS
     std::vector<SosCoefs> groups;
     SosGeom sg{};
@@ -121,6 +122,11 @@ struct Stage {
     RsGeom rg{};
     int pfb_buf = -1, dpfb_buf = -1;
     std::vector<double> pfb_host, dpfb_host;
+    bool periodic = false;
+    RsPeriodic rp{};
+    int tab_buf = -1, jend_buf = -1;
+    std::vector<double> tab_host;
+    std::vector<int> jend_host;
     // norm
     int partial_buf = -1, rms_buf = -1;
     int nparts = 0;
@@ -173,6 +179,7 @@ struct Plan {
     DOp* d_ops = nullptr;
     DLeaf* d_leaves = nullptr;
     int out_stage_buf = -1;  // device staging for a host result
+    int alias_stage = -1;    // stage whose kernel writes the final output directly
     std::vector<char> host_tmp;
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -1020,9 +1027,31 @@ void Plan::process_stage(int sid) {
         g.nch = N.nch;
         g.m0 = 0;
         g.n_out = need;
+        if (g.arbitrary) {
+            // integer frame rates: the rate is the exact rational fs_out/fs_in
+            double fo = nd.fs, fi = C.fs;
+            if (fo == std::floor(fo) && fi == std::floor(fi) && fo >= 1 && fi >= 1 &&
+                fo < 2147483648.0 && fi < 2147483648.0 && fo / fi == nd.d0) {
+                int64_t a = (int64_t)fo, b = (int64_t)fi;
+                while (b) {
+                    int64_t t = a % b;
+                    a = b;
+                    b = t;
+                }
+                int64_t Lx = (int64_t)fo / a, Mx = (int64_t)fi / a;
+                if (Lx <= 8192 && Mx <= 1048576) {
+                    g.exact = 1;
+                    g.L = Lx;
+                    g.M = Mx;
+                }
+            }
+        }
         // newest input of the last needed output
         int64_t jl;
-        if (g.arbitrary) {
+        if (g.arbitrary && g.exact) {
+            int64_t Nn = (need - 1) * ((int64_t)g.nphi * g.M);
+            jl = (g.c0i + Nn / g.L) / g.nphi;
+        } else if (g.arbitrary) {
             double q = g.c0 + (double)(need - 1) * g.delta;
             jl = (int64_t)std::floor(q) / g.nphi;
         } else jl = (g.c0i + (need - 1) * g.M) / g.L;
@@ -1044,6 +1073,97 @@ void Plan::process_stage(int sid) {
         stages[sid].dpfb_buf = raw_buf(stages[sid].dpfb_host.size() * 8);
         g.in_dtype = g.out_dtype = N.dtype;
         stages[sid].rg = g;
+        // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
+        if ((!g.arbitrary || g.exact) && need >= 2048) {
+            constexpr int RM = 8;
+            const int64_t Lb = g.L, Mb = g.M;
+            int ct = 1;
+            for (int c : {8, 4, 2})
+                if (N.nch % c == 0) {
+                    ct = c;
+                    break;
+                }
+            const int pt = 64 / ct;
+            int64_t t = std::max<int64_t>(1, 1100 / (pt * Mb));
+            if (Lb * t > 4096) t = std::max<int64_t>(1, 4096 / Lb);
+            const int64_t Ls = Lb * t, Ms = Mb * t;
+            auto pos = [&](int64_t r, int64_t& j, int& p, double& alpha) {
+                int64_t qi;
+                if (g.arbitrary) {
+                    int64_t Nn = r * ((int64_t)g.nphi * Mb);
+                    qi = g.c0i + Nn / Lb;
+                    alpha = (double)(Nn % Lb) / (double)Lb;
+                } else {
+                    qi = g.c0i + r * Mb;
+                    alpha = 0.0;
+                }
+                j = qi / g.nphi;
+                p = (int)(qi % g.nphi);
+            };
+            std::vector<int64_t> jr(Ls);
+            std::vector<int> pr(Ls);
+            std::vector<double> ar(Ls);
+            for (int64_t r = 0; r < Ls; ++r) pos(r, jr[r], pr[r], ar[r]);
+            const int ngroups = (int)((Ls + RM - 1) / RM);
+            int64_t maxspan = 0;
+            std::vector<int> jend(ngroups);
+            for (int gi = 0; gi < ngroups; ++gi) {
+                int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
+                jend[gi] = (int)jr[r1 - 1];
+                maxspan = std::max(maxspan, jr[r1 - 1] - jr[r0]);
+            }
+            const int kw = g.taps + (int)maxspan;
+            const int jlo = jend[0] - (kw - 1);
+            const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
+            int64_t pitch = (tile_len + 1) | 1;  // odd pitch: spreads channels over LDS banks
+            size_t lds_bytes = (size_t)ct * pitch * 8;
+            size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
+            if (lds_bytes <= 79 * 1024 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
+                const double* h = (const double*)nd.p0;
+                std::vector<double> tab((size_t)ngroups * kw * RM, 0.0);
+                for (int gi = 0; gi < ngroups; ++gi) {
+                    int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
+                    for (int64_t r = r0; r < r1; ++r)
+                        for (int kk = 0; kk < kw; ++kk) {
+                            int64_t rel = jend[gi] - (kw - 1) + kk;  // input index of slot kk
+                            int64_t age = jr[r] - rel;               // tap age for output r
+                            if (age < 0 || age >= g.taps) continue;
+                            int64_t hi = pr[r] + (int64_t)g.nphi * age;
+                            double hv = hi < hlen ? h[hi] : 0.0;
+                            double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                            tab[((size_t)gi * kw + kk) * RM + (r - r0)] = hv + ar[r] * dv;
+                        }
+                }
+                RsPeriodic rp{};
+                rp.n_in = g.n_in;
+                rp.n_out = need;
+                rp.L = Ls;
+                rp.M = Ms;
+                rp.nperiods = (need + Ls - 1) / Ls;
+                rp.pt = pt;
+                rp.ct = ct;
+                rp.ngroups = ngroups;
+                rp.kw = kw;
+                rp.tile_len = (int)tile_len;
+                rp.lds_pitch = (int)pitch;
+                rp.jlo = jlo;
+                rp.nch = N.nch;
+                // waves per workgroup: a divisor of the group count keeps the waves balanced;
+                // 2 workgroups/CU x up to 16 waves hide the scalar tap-load latency
+                rp.nwaves = 8;
+                for (int w = 16; w >= 4; --w)
+                    if (ngroups % w == 0) {
+                        rp.nwaves = w;
+                        break;
+                    }
+                stages[sid].periodic = true;
+                stages[sid].rp = rp;
+                stages[sid].tab_host = tab;
+                stages[sid].jend_host = jend;
+                stages[sid].tab_buf = raw_buf(tab.size() * 8);
+                stages[sid].jend_buf = raw_buf(jend.size() * 4);
+            }
+        }
     } else if (stages[sid].kind == ST_SOS) {
         if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
         int nsec = nd.i0;
@@ -1177,6 +1297,13 @@ void Plan::process_stage(int sid) {
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
+    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic &&
+               std::all_of(ps.begin(), ps.end(), [&](const Piece& p) { return p.r.c0 == 0 && p.r.c1 == N.nch; })) {
+        // fuse the child's program into the kernel's LDS staging (no intermediate in HBM)
+        std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
+        S.fused_pw = emit_pointwise(ps, -3, in_dtype);
+        S.in_buf = -1;
+        S.in_array_node = -1;
     } else if (!direct) {
         S.in_buf = new_buf(in_frames, N.nch, in_dtype);
         S.in_pitch = -1;
@@ -1189,7 +1316,13 @@ void Plan::process_stage(int sid) {
 // ---------------------------------------------------------------------------
 void Plan::finalize() {
     // size stage output buffers now that every need is known
-    for (auto& S : stages) {
+    for (size_t si = 0; si < stages.size(); ++si) {
+        Stage& S = stages[si];
+        if (S.out_buf >= 0 && (int)si == alias_stage) {
+            bufs[S.out_buf].external = true;  // the kernel writes the final output directly
+            bufs[S.out_buf].bytes = 0;
+            continue;
+        }
         if (S.out_buf >= 0) {
             Buf& b = bufs[S.out_buf];
             b.frames = S.need;
@@ -1266,6 +1399,10 @@ void Plan::finalize() {
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.periodic) {
+                HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
+            }
         } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
             size_t msz = 0;
             for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
@@ -1285,7 +1422,7 @@ void Plan::finalize() {
             Step st{0, S.pw_step, "k_pointwise", pw[S.pw_step].bytes};
             steps.push_back(st);
         }
-        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? "k_resample" : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS) st.bytes = 2 * S.need * S.sg.nch * esz;
@@ -1303,12 +1440,12 @@ void Plan::finalize() {
 
 void Plan::release() {
     for (auto& b : bufs)
-        if (b.d && !b.external) hipFree(b.d);
+        if (b.d && !b.external) (void)hipFree(b.d);
     bufs.clear();
-    if (d_pieces) hipFree(d_pieces);
-    if (d_ops) hipFree(d_ops);
-    if (d_leaves) hipFree(d_leaves);
-    for (auto e : events) hipEventDestroy(e);
+    if (d_pieces) (void)hipFree(d_pieces);
+    if (d_ops) (void)hipFree(d_ops);
+    if (d_leaves) (void)hipFree(d_leaves);
+    for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
 }
 
@@ -1347,10 +1484,31 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             if (best < 0) break;
             P->process_stage(best);
         }
-        int rootstep = P->emit_pointwise(rootp, -1, out->dtype);
+        // If the root is nothing but a full plain read of one stage's output, let that
+        // stage's kernel write the sink buffer itself (saves a read+write pass).
+        if (rootp.size() == 1 && (out->frame_stride == 1 || !out->is_device)) {
+            const Expr& e = P->exprs[rootp[0].e];
+            if (e.op == E_LOAD && e.leaf.buf >= 0 && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 &&
+                e.leaf.df == 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && e.leaf.dtype == out->dtype) {
+                for (size_t i = 0; i < P->stages.size(); ++i)
+                    if (P->stages[i].out_buf == e.leaf.buf && P->stages[i].kind != ST_NORM &&
+                        P->stages[i].need == out->nframes)
+                        P->alias_stage = (int)i;
+                if (P->alias_stage >= 0)
+                    for (auto& L : P->leaves)  // any other consumer of that buffer forbids aliasing
+                        if (L.buf == e.leaf.buf) P->alias_stage = -1;
+                if (P->alias_stage >= 0)
+                    for (auto& S : P->stages)
+                        if (S.in_buf == e.leaf.buf) P->alias_stage = -1;
+            }
+        }
+        int rootstep = -1;
+        if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
         P->finalize();
-        Step st{0, rootstep, "k_pointwise", P->pw[rootstep].bytes};
-        P->steps.push_back(st);
+        if (rootstep >= 0) {
+            Step st{0, rootstep, "k_pointwise", P->pw[rootstep].bytes};
+            P->steps.push_back(st);
+        }
     } catch (const PlanError& e) {
         status = e.status;
         err = e.msg;
@@ -1382,7 +1540,9 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
             if (s.kind == 0) {
                 PwStep& w = P->pw[s.idx];
                 OutView ov{};
-                if (w.out_buf >= 0) {
+                if (w.nblocks <= 0) {
+                    // empty rectangle (zero-frame sink): nothing to launch
+                } else if (w.out_buf >= 0) {
                     Buf& b = P->bufs[w.out_buf];
                     ov.base = b.d;
                     ov.fstride = 1;
@@ -1411,7 +1571,10 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                 size_t esz = dsize(N.dtype);
                 const char* inp;
                 int64_t in_pitch;
-                if (S.in_array_node >= 0) {
+                if (S.fused_pw >= 0) {
+                    inp = nullptr;
+                    in_pitch = 0;
+                } else if (S.in_array_node >= 0) {
                     const so_node_t& nd = P->nodes[S.in_array_node].nd;
                     const char* base = nd.i0 ? (const char*)P->array_ptr[S.in_array_node]
                                              : (const char*)P->bufs[P->array_buf[S.in_array_node]].d;
@@ -1422,7 +1585,16 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                     inp = (const char*)b.d + (size_t)S.in_offset * esz;
                     in_pitch = b.pitch;
                 }
-                Buf& ob = P->bufs[S.out_buf];
+                Buf ob = P->bufs[S.out_buf];
+                if (s.idx == P->alias_stage) {  // write the sink buffer directly
+                    if (P->out.is_device) {
+                        ob.d = outp;
+                        ob.pitch = N.nch == 1 ? std::max<int64_t>(P->out.chan_stride, S.need) : P->out.chan_stride;
+                    } else {
+                        ob.d = P->bufs[P->out_stage_buf].d;
+                        ob.pitch = P->bufs[P->out_stage_buf].pitch;
+                    }
+                }
                 if (S.kind == ST_SOS) {
                     SosGeom g = S.sg;
                     g.in_pitch = in_pitch;
@@ -1448,8 +1620,24 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                     RsGeom g = S.rg;
                     g.in_pitch = in_pitch;
                     g.out_pitch = ob.pitch;
-                    launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
-                                    (const double*)P->bufs[S.dpfb_buf].d, g, st);
+                    if (S.periodic) {
+                        RsPeriodic rp = S.rp;
+                        rp.in_pitch = in_pitch;
+                        rp.out_pitch = ob.pitch;
+                        const int64_t al = 16 / (int64_t)esz;
+                        rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
+                        const DPiece* fp = nullptr;
+                        int nfp = 0;
+                        if (S.fused_pw >= 0) {
+                            fp = P->d_pieces + P->pw[S.fused_pw].piece0;
+                            nfp = P->pw[S.fused_pw].npieces;
+                        }
+                        launch_resample_periodic(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                                 (const int*)P->bufs[S.jend_buf].d, rp, N.dtype, fp, nfp,
+                                                 P->d_ops, P->d_leaves, st);
+                    } else
+                        launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
+                                        (const double*)P->bufs[S.dpfb_buf].d, g, st);
                     s.launches = 1;
                     launches++;
                 } else {
@@ -1536,7 +1724,7 @@ void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
 void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
 void plan_destroy(Plan* P) {
     if (!P) return;
-    hipSetDevice(P->device);
+    (void)hipSetDevice(P->device);
     P->release();
     delete P;
 }

@@ -106,8 +106,29 @@ struct RsGeom {
     double delta, c0;    // arbitrary: q_m = c0 + m*delta  (two roundings)
     int64_t c0i;         // rational: q_m = c0i + m*M
     int32_t arbitrary;
+    int32_t exact;       // arbitrary kernel, integer frame rates: q_m = c0i + m*nphi*M/L exactly
     int32_t nphi, taps, nch;
     int32_t in_dtype, out_dtype;
+    int64_t in_pitch, out_pitch;
+};
+
+// Periodic variant: for a rational rate L/M the (phase, alpha) pattern repeats every
+// L outputs / M inputs.  A wave's 64 lanes are 64 independent (period, channel) rows
+// working on the SAME output phases, so the taps are wave-uniform (SGPR operands) and
+// each LDS read of an input feeds RM FMAs.
+struct RsPeriodic {
+    int64_t n_in, n_out;
+    int64_t L, M;       // outputs / inputs per (super-)period
+    int64_t nperiods;
+    int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == 64
+    int32_t ngroups;    // groups of RM consecutive outputs per period
+    int32_t kw;         // inputs in a group's window
+    int32_t tile_len;   // inputs per channel staged in LDS
+    int32_t lds_pitch;  // doubles between channels in LDS
+    int32_t jlo;        // input index (relative to the tile's first period base) of LDS slot 0
+    int32_t nch;
+    int32_t vec_ok;     // 16-byte aligned vector stores are legal
+    int32_t nwaves;     // waves per workgroup (groups are dealt to waves in contiguous blocks)
     int64_t in_pitch, out_pitch;
 };
 

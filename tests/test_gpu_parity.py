@@ -33,7 +33,7 @@ def test_case_matches_oracle(name):
         err = relerr(got, want)
         assert err <= TOL, f"{name}: rel err {err:.3e}"
         # in practice both sides are fp64 throughout: keep a much tighter watch too
-        assert err <= (1e-6 if got.dtype == np.float32 else 1e-11), f"{name}: rel err {err:.3e}"
+        assert err <= (1e-6 if got.dtype == np.float32 else 1e-9), f"{name}: rel err {err:.3e}"
 
 
 def test_sink_into_device_tensor():
