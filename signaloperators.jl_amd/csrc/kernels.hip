@@ -11,6 +11,8 @@
 //   k_sumsq_*     K4  Normpower reduction (reference src/filters.jl:296-309)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/sigops.h"
 #include "kernels.h"
 #include "sigops_internal.h"
@@ -19,77 +21,131 @@ namespace so {
 
 // ---------------------------------------------------------------------------
 // leaf evaluators
+// All leaf parameters are wave-uniform (scalar registers); only the frame index n (and,
+// in channel-vectorised evaluation, nothing else) lives per lane.  sf is -1/0/+1, so the
+// per-lane address math is one 64-bit add in the common planar case (no 64-bit multiplies,
+// which are quarter-rate on CDNA).
 __device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
-    int64_t f = (int64_t)L.sf * n + L.df;
-    if (L.mode == LM_CYCLE) {  // x[(i-1)%end+1]  reference src/padding.jl:132
-        f = f % L.modn;
-    } else if (L.mode == LM_MIRROR) {  // reference src/padding.jl:142-148
-        int64_t cnt = f / L.modn, rem = f % L.modn;
-        f = (cnt & 1) ? L.modn - rem - 1 : rem;
-    }
-    int64_t ch = (int64_t)L.sc * c + L.dc;
-    int64_t off = f * L.fstride + ch * L.cstride;
+    int64_t f = L.df;
+    if (L.sf > 0) f += n;
+    else if (L.sf < 0) f -= n;
+    // (cycle / mirror padding, reference src/padding.jl:132-148, is resolved on the host
+    //  into one piece per wrap with sf = +1 / -1: no integer division on the device)
+    const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;  // uniform
+    const int64_t off = (L.fstride == 1 ? f : f * L.fstride) + choff;
     if (L.dtype == SO_F32) return (double)((const float*)L.base)[off];
     return ((const double*)L.base)[off];
+}
+
+// Compact fp64 sin/cos kernels (Taylor on |t| <= 1/4 after exact octant reduction).  The
+// device library's sinpi/cos carry large-argument paths that cost ~40 VGPRs of pressure in
+// every kernel that inlines the interpreter; these need ~12 and are accurate to ~1 ulp.
+__device__ __forceinline__ void sincospi_quarter(double t, double& s, double& c) {
+    const double t2 = t * t;
+    double ps = 7.952054001475513e-07;
+    ps = fma(ps, t2, -2.1915353447830217e-05);
+    ps = fma(ps, t2, 0.00046630280576761255);
+    ps = fma(ps, t2, -0.0073704309457143504);
+    ps = fma(ps, t2, 0.08214588661112823);
+    ps = fma(ps, t2, -0.5992645293207921);
+    ps = fma(ps, t2, 2.5501640398773455);
+    ps = fma(ps, t2, -5.16771278004997);
+    const double t3 = t2 * t;
+    s = fma(t, 3.141592653589793, fma(t, 1.2246467991473532e-16, t3 * ps));
+    double pc = -1.3878952462213771e-07;
+    pc = fma(pc, t2, 4.303069587032947e-06);
+    pc = fma(pc, t2, -0.0001046381049248457);
+    pc = fma(pc, t2, 0.0019295743094039231);
+    pc = fma(pc, t2, -0.02580689139001406);
+    pc = fma(pc, t2, 0.2353306303588932);
+    pc = fma(pc, t2, -1.3352627688545895);
+    pc = fma(pc, t2, 4.0587121264167685);
+    pc = fma(pc, t2, -4.934802200544679);
+    c = fma(pc, t2, 1.0);
+}
+// sinpi(x) with Julia's semantics: exact at integers and half-integers (src/functions.jl:57-60)
+__device__ __forceinline__ double sinpi_c(double x) {
+    const double k = rint(2.0 * x);
+    const double t = fma(-0.5, k, x);  // exact, |t| <= 1/4
+    double s, c;
+    sincospi_quarter(t, s, c);
+    const int q = (int)((long long)k & 3);
+    const double r = (q & 1) ? c : s;
+    return (q & 2) ? -r : r;
+}
+// cos(x), x in radians, |x| < 2^20: two-term Cody-Waite reduction to x = k*pi/2 + r
+__device__ __forceinline__ double cos_c(double x) {
+    const double k = rint(x * 0.6366197723675814);
+    double r = fma(-k, 1.5707963267948966, x);
+    r = fma(-k, 6.123233995736766e-17, r);
+    double s, c;
+    sincospi_quarter(r * 0.3183098861837907, s, c);  // r/pi in [-1/4, 1/4]
+    const int q = (int)((long long)k & 3);
+    const double v = (q & 1) ? s : c;  // cos(r + k pi/2): c, -s, -c, s
+    return (q == 1 || q == 2) ? -v : v;
 }
 
 // reference src/functions.jl:53-60 — every operation separately rounded (Julia does
 // not contract), frame index is 1-based so the first sample is t = 1/fs
 __device__ __forceinline__ double func_eval(const DLeaf& L, int64_t n) {
-    double i1 = (double)((int64_t)L.sf * n + L.df + 1);
+    double i1 = (double)((L.sf ? n : 0) + L.df + 1);
     double t = __ddiv_rn(i1, L.v2);
     if (L.flag) {
         double ph = __dadd_rn(__dmul_rn(t, L.v0), L.v1);
-        if (L.mode == SO_FN_SIN) return sinpi(2.0 * ph);
-        double a = __dmul_rn(6.283185307179586, fmod(ph, 1.0));
-        return L.mode == SO_FN_COS ? cos(a) : a;
+        if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * ph);
+        double a = __dmul_rn(6.283185307179586, ph - trunc(ph));  // 2π*(ph % 1.0)
+        return L.mode == SO_FN_COS ? cos_c(a) : a;
     }
     double tt = __dadd_rn(t, L.v1);
-    if (L.mode == SO_FN_SIN) return sinpi(2.0 * tt);
-    return L.mode == SO_FN_COS ? cos(tt) : tt;
+    if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * tt);
+    return L.mode == SO_FN_COS ? cos_c(tt) : tt;
 }
 
 // reference src/ramps.jl:60-72
 __device__ __forceinline__ double ramp_eval(const DLeaf& L, int64_t n) {
-    int64_t n0 = (int64_t)L.sf * n + L.df;
+    int64_t n0 = (L.sf ? n : 0) + L.df;
     double x;
     if (L.flag == 0)
         x = __ddiv_rn((double)n0, L.v0);
     else
         x = __dsub_rn(1.0, __ddiv_rn((double)(n0 + 1 - L.modn), L.v0));
-    return L.mode == SO_RAMP_SINRAMP ? sinpi(0.5 * x) : x;
+    return L.mode == SO_RAMP_SINRAMP ? sinpi_c(0.5 * x) : x;
 }
 
 // ---------------------------------------------------------------------------
-// 4-deep register stack machine over E frames per thread.  Program words are
+// D-deep register stack machine over E elements per thread.  Program words are
 // wave-uniform (scalar loads); the stack lives in VGPRs (static indexing only).
-template <int E>
-struct Frames {
-    int64_t n[E];
-};
-
-#define SO_PUSH(expr)                 \
-    _Pragma("unroll") for (int e = 0; e < E; ++e) { \
-        s3[e] = s2[e];                \
-        s2[e] = s1[e];                \
-        s1[e] = s0[e];                \
-        s0[e] = (expr);               \
+// D is 2 for left-fold chains (almost every tree) and kStackDepth otherwise, which keeps
+// the register footprint of the common case small enough for high occupancy.
+//   CV == false: element e is frame n[e] of channel c (K1: E frames per thread).
+//   CV == true : element e is channel c+e of the single frame n[0] (stage-kernel tile
+//                staging: all channels of a frame at once -> E independent loads in flight).
+#define SO_PUSH(expr)                                   \
+    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
+        _Pragma("unroll") for (int d = D - 1; d > 0; --d) st[d][e] = st[d - 1][e]; \
+        st[0][e] = (expr);                              \
     }
-#define SO_BIN(opr)                   \
-    _Pragma("unroll") for (int e = 0; e < E; ++e) { \
-        s0[e] = s1[e] opr s0[e];      \
-        s1[e] = s2[e];                \
-        s2[e] = s3[e];                \
+#define SO_POP1()                                       \
+    _Pragma("unroll") for (int d = 1; d < D - 1; ++d) st[d][e] = st[d + 1][e];
+#define SO_BIN(opr)                                     \
+    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
+        st[0][e] = st[1][e] opr st[0][e];               \
+        SO_POP1()                                       \
     }
 
-template <int E>
+// HEAVY == false drops the generator/ramp opcodes (the planner always hoists them into the
+// per-frame program), so the per-sample interpreter carries no transcendental code.
+template <int E, bool CV, int D, bool HEAVY>
 __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc, int len,
                                             const DLeaf* __restrict__ leaves,
-                                            const int64_t (&n)[E], int c,
-                                            double (&F)[kMaxFrameSlots][E], double (&out)[E]) {
-    double s0[E], s1[E], s2[E], s3[E];
+                                            const int64_t (&n)[CV ? 1 : E], int c,
+                                            double (&F)[kMaxFrameSlots][CV ? 1 : E],
+                                            double (&out)[E]) {
+    double st[D][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) s0[e] = s1[e] = s2[e] = s3[e] = 0.0;
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[d][e] = 0.0;
     for (int i = 0; i < len; ++i) {
         const DOp op = ops[pc + i];
         switch (op.code) {
@@ -100,7 +156,7 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
         }
         case OP_LOAD: {
             const DLeaf& L = leaves[op.arg];
-            SO_PUSH(leaf_load(L, n[e], c));
+            SO_PUSH(leaf_load(L, n[CV ? 0 : e], CV ? c + e : c));
             break;
         }
         case OP_SCALAR: {
@@ -108,55 +164,56 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
             SO_PUSH(v);
             break;
         }
-        case OP_FUNC: {
-            const DLeaf& L = leaves[op.arg];
-            SO_PUSH(func_eval(L, n[e]));
+        case OP_FUNC:
+            if constexpr (HEAVY) {
+                const DLeaf& L = leaves[op.arg];
+                SO_PUSH(func_eval(L, n[CV ? 0 : e]));
+            }
             break;
-        }
-        case OP_RAMP: {
-            const DLeaf& L = leaves[op.arg];
-            SO_PUSH(ramp_eval(L, n[e]));
+        case OP_RAMP:
+            if constexpr (HEAVY) {
+                const DLeaf& L = leaves[op.arg];
+                SO_PUSH(ramp_eval(L, n[CV ? 0 : e]));
+            }
             break;
-        }
         case OP_ADD: SO_BIN(+); break;
         case OP_SUB: SO_BIN(-); break;
         case OP_MUL: SO_BIN(*); break;
         case OP_DIV: SO_BIN(/); break;
         case OP_NEG:
 #pragma unroll
-            for (int e = 0; e < E; ++e) s0[e] = -s0[e];
+            for (int e = 0; e < E; ++e) st[0][e] = -st[0][e];
             break;
         case OP_ROUND32:
 #pragma unroll
-            for (int e = 0; e < E; ++e) s0[e] = (double)(float)s0[e];
+            for (int e = 0; e < E; ++e) st[0][e] = (double)(float)st[0][e];
             break;
         case OP_STOREF:
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 switch (op.arg) {
-                case 0: F[0][e] = s0[e]; break;
-                case 1: F[1][e] = s0[e]; break;
-                case 2: F[2][e] = s0[e]; break;
-                default: F[3][e] = s0[e]; break;
+                case 0: F[0][CV ? 0 : e] = st[0][e]; break;
+                case 1: F[1][CV ? 0 : e] = st[0][e]; break;
+                case 2: F[2][CV ? 0 : e] = st[0][e]; break;
+                default: F[3][CV ? 0 : e] = st[0][e]; break;
                 }
-                s0[e] = s1[e];
-                s1[e] = s2[e];
-                s2[e] = s3[e];
+                st[0][e] = st[1][e];
+                SO_POP1()
             }
             break;
         case OP_LOADF:
             switch (op.arg) {
-            case 0: SO_PUSH(F[0][e]); break;
-            case 1: SO_PUSH(F[1][e]); break;
-            case 2: SO_PUSH(F[2][e]); break;
-            default: SO_PUSH(F[3][e]); break;
+            case 0: SO_PUSH(F[0][CV ? 0 : e]); break;
+            case 1: SO_PUSH(F[1][CV ? 0 : e]); break;
+            case 2: SO_PUSH(F[2][CV ? 0 : e]); break;
+            default: SO_PUSH(F[3][CV ? 0 : e]); break;
             }
             break;
         default: break;
         }
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = s0[e];
+    for (int e = 0; e < E; ++e) out[e] = st[0][e];
 }
 
 // K1: one workgroup = kBlock*E consecutive frames x a channel chunk of one piece.
@@ -194,9 +251,14 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
 #pragma unroll
         for (int e = 0; e < E; ++e) F[k][e] = 0.0;
     double v[E];
-    if (P.frame_len > 0) run_program<E>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+    const bool deep = P.depth > 2;  // wave-uniform
+    if (P.frame_len > 0) {
+        if (deep) run_program<E, false, kStackDepth, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+        else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+    }
     for (int c = cbeg; c < cend; ++c) {
-        run_program<E>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
+        if (deep) run_program<E, false, kStackDepth, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
+        else run_program<E, false, 2, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
         if (out.dtype == SO_F32) {
             float* o = (float*)out.base + (int64_t)c * out.cstride;
 #pragma unroll
@@ -427,151 +489,304 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
                            dpfb, g, (double*)y);
 }
 
-// K3p: periodic polyphase resampler (rational L/M).  Workgroup = 256 threads = 4 waves;
-// tile = pt periods x ct channels = 64 rows, staged once in LDS as fp64 (coalesced
-// global reads, 3 % halo).  Lane = row.  Each wave walks its share of the period's output
-// groups; per group the RM x kw tap table is wave-uniform (scalar loads -> SGPR FMA
-// operands) and every ds_read_b64 of an input sample feeds RM fp64 FMAs, so neither LDS
-// bandwidth nor tap traffic limits the kernel: HBM streaming does.
-//   tab  [ngroups][kw][RM]  combined taps h + alpha*dh, oldest input first, zero padded
-//   jend [ngroups]          newest input of the group's window, relative to the period base
-template <typename T, int RM>
-__global__ __launch_bounds__(1024) void k_resample_periodic(const T* __restrict__ x,
-                                                              const double* __restrict__ tab,
-                                                              const int* __restrict__ jend,
-                                                              RsPeriodic g, T* __restrict__ y,
-                                                              const DPiece* __restrict__ pieces,
-                                                              int npieces,
-                                                              const DOp* __restrict__ ops,
-                                                              const DLeaf* __restrict__ leaves) {
-    extern __shared__ double lds[];
-    const int64_t P0 = (int64_t)blockIdx.x * g.pt;
-    const int c0 = blockIdx.y * g.ct;
-    const int64_t xbase = P0 * g.M + g.jlo;  // global input index of LDS slot 0 (can be < 0)
-    if (npieces == 0) {
-        // plain planar source
-        for (int c = 0; c < g.ct; ++c) {
-            const T* xp = x + (int64_t)(c0 + c) * g.in_pitch;
-            double* lp = lds + c * g.lds_pitch;
-            for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
-                const int64_t gi = xbase + i;
-                lp[i] = (gi >= 0 && gi < g.n_in) ? (double)xp[gi] : 0.0;  // zero padding
-            }
-        }
-    } else {
-        // fused source: the child's pointwise program (mapsignal / ramps / cuts /
-        // generators) is evaluated straight into the LDS tile; the intermediate never
-        // touches HBM.  Pieces are walked one at a time so control flow stays wave-uniform.
+// ---------------------------------------------------------------------------
+// K3p: periodic polyphase resampler (rational L/M), persistent and software-pipelined.
+//
+// Tile = pt periods x ct channels = 64 rows, staged in LDS as fp64 (coalesced 16-byte
+// global reads, ~3 % halo).  One workgroup per CU loops over tiles with TWO LDS buffers
+// and wave specialisation: waves [0,ncompute) compute tile t from one buffer while the
+// remaining (loader) waves stage tile t+1 into the other; one __syncthreads per tile.
+// HBM streaming therefore never stops for the arithmetic.
+//
+// Source: a list of *carriers* (sorted frame ranges).  A carrier is a planar array
+// x[c*cstride + n + df] plus up to 4 steps  v = v (op) F_k[n]  /  F_k[n] (op) v  whose F_k
+// come from the piece's per-frame program (ramps, generators, constants: reference
+// src/ramps.jl:60-72, src/functions.jl:53-60, src/mapsignal.jl:249-255).  This covers
+// Amplify/Mix/Ramp chains over one array without ever materialising them; anything more
+// general is materialised by K1 first and arrives as a 0-step carrier.
+//
+// Compute: for a group of 16 consecutive outputs of the period, the 64 rows x 16 outputs
+// block is the product  Y[64 x 16] = X[64 x kw] * Tap[kw x 16]  (X = the rows' input
+// windows, Tap = the group's combined taps h + alpha*dh, zero outside each output's
+// support).  It is evaluated with v_mfma_f64_16x16x4_f64 used purely as a register-blocking
+// device: each lane supplies ONE input sample (one ds_read_b64) and ONE tap (a register,
+// loaded once per kernel) per 1024 multiply-adds, so neither LDS bandwidth nor tap
+// delivery limits the kernel (a scalar-operand VALU formulation measured ~700 clk per
+// 64-byte tap line on the scalar cache).  The kernel stays HBM-bound, which is the
+// roofline it is reported against.
+//   tab  [ngroups][KS*4][16] taps, oldest input first, zero padded to KS k-steps
+//   jend [ngroups]           newest input of the group's window, relative to the period base
+// Operand maps (cdna_hip_programming.md §3): A[l&15][k=l>>4], B[k=l>>4][l&15],
+// D: col = l&15, row = (l>>4) + 4*reg.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Stage one input tile (CT channels x tile_len frames from global frame xbase) into an LDS
+// buffer as fp64, zero-padded outside [0,n_in) (Pad(x.signal,zero), reference
+// src/filters.jl:240).  Thread = one 16-byte vector of V frames, all CT channels: CT
+// independent vector loads in flight per thread.  Vectors that straddle a carrier or signal
+// edge (or unaligned carriers) are processed one frame at a time through the same code.
+template <typename T, int CT>
+__device__ __forceinline__ void stage_tile(const RsPeriodic& g, int64_t xbase, int c0,
+                                           double* __restrict__ buf,
+                                           const DCarrier* __restrict__ car, int ncar,
+                                           const DOp* __restrict__ ops,
+                                           const DLeaf* __restrict__ leaves, int tid, int nthr) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    const int nvec = (g.tile_len + V - 1) / V;  // lds_pitch leaves room for the round-up
+    int ci = 0;
+    {  // first carrier whose end is beyond the tile start (carriers are sorted)
+        int a = 0, b = ncar - 1;
         const int64_t lo = xbase > 0 ? xbase : 0;
-        const int64_t hi = xbase + g.tile_len < g.n_in ? xbase + g.tile_len : g.n_in;
-        for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
-            const int64_t gi = xbase + i;
-            if (gi < 0 || gi >= g.n_in)
-                for (int c = 0; c < g.ct; ++c) lds[c * g.lds_pitch + i] = 0.0;
-        }
-        int a = 0, b = npieces - 1;
-        while (a < b) {  // first piece whose end is beyond lo (pieces are sorted by frame)
+        while (a < b) {
             int mid = (a + b) >> 1;
-            if (pieces[mid].b > lo) b = mid;
+            if (car[mid].b > lo) b = mid;
             else a = mid + 1;
         }
-        for (int pi = a; pi < npieces && pieces[pi].a < hi; ++pi) {
-            const DPiece P = pieces[pi];
-            const int64_t fa = P.a > lo ? P.a : lo;
-            const int64_t fb = P.b < hi ? P.b : hi;
-            for (int64_t gi = fa + threadIdx.x; gi < fb; gi += blockDim.x) {
-                int64_t n[1] = {gi};
-                double F[kMaxFrameSlots][1];
-                double v[1];
-#pragma unroll
-                for (int k = 0; k < kMaxFrameSlots; ++k) F[k][0] = 0.0;
-                if (P.frame_len > 0) run_program<1>(ops, P.frame_pc, P.frame_len, leaves, n, c0, F, v);
-                const int slot = (int)(gi - xbase);
-                for (int c = 0; c < g.ct; ++c) {
-                    run_program<1>(ops, P.samp_pc, P.samp_len, leaves, n, c0 + c, F, v);
-                    // the reference stores the child into a buffer of the child's sample
-                    // type before filtering (src/filters.jl:207,244)
-                    lds[c * g.lds_pitch + slot] = sizeof(T) == 4 ? (double)(float)v[0] : v[0];
-                }
-            }
-        }
+        ci = a;
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pl = lane % g.pt, cl = lane / g.pt;
-    const int64_t period = P0 + pl;
-    const int rowbase = cl * g.lds_pitch + pl * (int)g.M - g.jlo - (g.kw - 1);
-    T* yp = y + (int64_t)(c0 + cl) * g.out_pitch + period * g.L;
-    const int64_t mbase = period * g.L;
-    const int nwaves = blockDim.x >> 6;
-    const int gper = (g.ngroups + nwaves - 1) / nwaves;
-    const int gbeg = wave * gper;
-    const int gend = min(g.ngroups, gbeg + gper);
-    for (int gi = gbeg; gi < gend; ++gi) {
-        const double* __restrict__ tg = tab + (size_t)gi * g.kw * RM;
-        const double* __restrict__ xr = lds + (rowbase + jend[gi]);
-        double acc[RM];
+    for (int iv = tid; iv < nvec; iv += nthr) {
+        const int64_t gi = xbase + (int64_t)iv * V;
+        int cj = ci;
+        while (cj + 1 < ncar && car[cj].b <= gi) ++cj;  // mostly 0 iterations
+        // (a carrier without an array -- base == nullptr -- is a purely generated piece)
+        const bool vec = gi >= car[cj].a && gi + V <= car[cj].b && gi >= 0 && gi + V <= g.n_in &&
+                         (car[cj].base == nullptr ||
+                          (car[cj].vec_ok && (((gi + car[cj].df) % V) == 0) &&
+                           car[cj].dtype == (sizeof(T) == 4 ? SO_F32 : SO_F64)));
+        const int nsub = vec ? 1 : V;
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int64_t g0 = gi + sub;  // first (vec) or only (scalar) frame of this pass
+            int ck = cj;
+            while (ck + 1 < ncar && car[ck].b <= g0) ++ck;
+            const DCarrier& C = car[ck];
+            const bool ok = vec || (g0 >= 0 && g0 < g.n_in && g0 >= C.a && g0 < C.b);
+            // ---- per-frame values first (keeps the interpreter's registers dead while the
+            //      CT loads are in flight) ----
+            const bool steps = ok && C.nsteps > 0;
+            double F[kMaxFrameSlots][V];
 #pragma unroll
-        for (int r = 0; r < RM; ++r) acc[r] = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < g.kw; ++k) {
-            const double xv = xr[k];
+            for (int k = 0; k < kMaxFrameSlots; ++k)
 #pragma unroll
-            for (int r = 0; r < RM; ++r) acc[r] = fma(tg[k * RM + r], xv, acc[r]);
-        }
-        const int r0 = gi * RM;
-        if (period < g.nperiods) {
-            if (g.vec_ok && r0 + RM <= g.L && mbase + r0 + RM <= g.n_out) {
-                if constexpr (sizeof(T) == 8) {
+                for (int e = 0; e < V; ++e) F[k][e] = 0.0;
+            if (steps && C.frame_len > 0) {
+                int64_t nn[V];
+                double fo[V];
 #pragma unroll
-                    for (int r = 0; r < RM; r += 2) {
-                        double2 v;
-                        v.x = acc[r];
-                        v.y = acc[r + 1];
-                        *reinterpret_cast<double2*>(yp + r0 + r) = v;
-                    }
-                } else {
+                for (int e = 0; e < V; ++e) nn[e] = vec ? g0 + e : g0;
+                run_program<V, false, 2, true>(ops, C.frame_pc, C.frame_len, leaves, nn, c0, F, fo);
+            }
+            // ---- loads (CT independent loads in flight) ----
+            double val[CT][V];
+            if (C.base == nullptr) {
 #pragma unroll
-                    for (int r = 0; r < RM; r += 4) {
-                        float4 v;
-                        v.x = (float)acc[r];
-                        v.y = (float)acc[r + 1];
-                        v.z = (float)acc[r + 2];
-                        v.w = (float)acc[r + 3];
-                        *reinterpret_cast<float4*>(yp + r0 + r) = v;
-                    }
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) val[c][e] = 0.0;
+            } else if (vec) {
+                const T* xp = (const T*)C.base + (int64_t)c0 * C.cstride + g0 + C.df;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const vecT v = *reinterpret_cast<const vecT*>(xp + (int64_t)c * C.cstride);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) val[c][e] = (double)v[e];
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < RM; ++r)
-                    if (r0 + r < g.L && mbase + r0 + r < g.n_out) yp[r0 + r] = (T)acc[r];
+                for (int c = 0; c < CT; ++c) {
+                    double xv = 0.0;
+                    if (ok) {
+                        const int64_t off = (int64_t)(c0 + c) * C.cstride + g0 + C.df;
+                        xv = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
+                                               : ((const double*)C.base)[off];
+                    }
+#pragma unroll
+                    for (int e = 0; e < V; ++e) val[c][e] = xv;
+                }
+            }
+            // ---- steps ----
+            if (steps) {
+                for (int i = 0; i < C.nsteps; ++i) {  // wave-uniform
+                    const int op = C.op[i], arg = C.arg[i], slot = arg & 0xff;
+                    const bool flip = arg & 0x100, r32 = arg & 0x200;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const double m = slot == 0 ? F[0][e] : slot == 1 ? F[1][e] : slot == 2 ? F[2][e] : F[3][e];
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            double v = val[c][e];
+                            switch (op) {
+                            case OP_ADD: v = v + m; break;
+                            case OP_SUB: v = flip ? m - v : v - m; break;
+                            case OP_MUL: v = v * m; break;
+                            case OP_DIV: v = flip ? m / v : v / m; break;
+                            case OP_NEG: v = -v; break;
+                            case OP_LOADF: v = m; break;  // generated piece: the value IS the slot
+                            default: break;  // OP_ROUND32: only the rounding below
+                            }
+                            if (r32) v = (double)(float)v;  // Julia Float32 arithmetic
+                            val[c][e] = v;
+                        }
+                    }
+                }
+                if (sizeof(T) == 4) {  // the reference stores the child in the child's sample
+                                       // type before filtering (src/filters.jl:207,244)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) val[c][e] = (double)(float)val[c][e];
+                }
+            }
+            // ---- LDS stores ----
+            if (vec) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) buf[c * g.lds_pitch + iv * V + e] = val[c][e];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) buf[c * g.lds_pitch + iv * V + sub] = val[c][0];
             }
         }
     }
 }
 
-void launch_resample_periodic(const void* x, void* y, const double* tab, const int* jend,
-                              const RsPeriodic& g, int dtype, const DPiece* pieces, int npieces,
-                              const DOp* ops, const DLeaf* leaves, hipStream_t st) {
-    if (g.n_out <= 0) return;
-    constexpr int RM = 8;
-    dim3 grid((unsigned)((g.nperiods + g.pt - 1) / g.pt), (unsigned)(g.nch / g.ct));
-    size_t lds = (size_t)g.ct * g.lds_pitch * sizeof(double);
+template <typename T, int CT, int KS, int G>
+__global__ __launch_bounds__(1024) void k_resample_periodic(const double* __restrict__ tab,
+                                                              const int* __restrict__ jend,
+                                                              RsPeriodic g, T* __restrict__ y,
+                                                              const DCarrier* __restrict__ car,
+                                                              int ncar,
+                                                              const DOp* __restrict__ ops,
+                                                              const DLeaf* __restrict__ leaves) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int nc = g.ncompute;
+    const int bufsz = CT * g.lds_pitch;
+    const int64_t ntx = (g.nperiods + g.pt - 1) / g.pt;
+    const int64_t ntiles = ntx * (g.nch / CT);
+    int64_t t = blockIdx.x;
+    // The two roles run separate loops with the same number of workgroup barriers (whole
+    // waves take one branch), so their register live ranges do not overlap.
+    if (wave >= nc) {
+        // ---- loader waves: stage tile `it` while the compute waves work on tile it-1 ----
+        const int ltid = (int)threadIdx.x - nc * 64, lthr = (nwaves - nc) * 64;
+        for (int it = 0; t - gridDim.x < ntiles; t += gridDim.x, ++it) {
+            if (t < ntiles && !((g.pad & 2) && it > 0))
+                stage_tile<T, CT>(g, (t % ntx) * g.pt * g.M + g.jlo, (int)(t / ntx) * CT,
+                                  lds + (it & 1) * bufsz, car, ncar, ops, leaves, ltid, lthr);
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- compute waves ----
+    const int kq = lane >> 4, n16 = lane & 15;
+    const int ptmask = g.pt - 1, ptshift = g.ptshift;  // pt is a power of two
+    const int gbeg = wave * G;
+    double breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
+    int rowoff[4];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            breg[gg][s] = gbeg + gg < g.ngroups ? tab[((size_t)(gbeg + gg) * KS + s) * 64 + lane] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
+        rowoff[q] = (rho >> ptshift) * g.lds_pitch + (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
+    }
+    __syncthreads();  // tile 0 staged (loader iteration 0)
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+        const double* __restrict__ cur = lds + (it & 1) * bufsz;
+        const int64_t P0 = (t % ntx) * g.pt;
+        const int c0 = (int)(t / ntx) * CT;
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+            const int gi = gbeg + gg;
+            if (gi < g.ngroups && !(g.pad & 1)) {
+                const int je = jend[gi];
+                v4d acc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double a = cur[rowoff[q] + je + 4 * s];
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, breg[gg][s], acc[q], 0, 0, 0);
+                    }
+                }
+                const int r = gi * 16 + n16;  // output index inside the period
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
+                        const int64_t period = P0 + (rho & ptmask);
+                        const int64_t m = period * g.L + r;
+                        if (period < g.nperiods && r < g.L && m < g.n_out && !(g.pad & 4))
+                            y[(int64_t)(c0 + (rho >> ptshift)) * g.out_pitch + m] = (T)acc[q][i];
+                    }
+            }
+        }
+        __syncthreads();  // loaders finished tile it+1; everyone finished reading tile it
+    }
+}
+
+template <typename T, int CT, int KS, int G>
+static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
+                        const DCarrier* car, int ncar, const DOp* ops, const DLeaf* leaves,
+                        hipStream_t st) {
+    const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
+    dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
+    size_t lds = (size_t)2 * CT * g.lds_pitch * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<double, RM>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<float, RM>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (dtype == SO_F32)
-        hipLaunchKernelGGL((k_resample_periodic<float, RM>), grid, dim3(64 * g.nwaves), lds, st,
-                           (const float*)x, tab, jend, g, (float*)y, pieces, npieces, ops, leaves);
-    else
-        hipLaunchKernelGGL((k_resample_periodic<double, RM>), grid, dim3(64 * g.nwaves), lds, st,
-                           (const double*)x, tab, jend, g, (double*)y, pieces, npieces, ops, leaves);
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G>), grid, dim3(64 * g.nwaves), lds, st, tab,
+                       jend, g, (T*)y, car, ncar, ops, leaves);
+}
+
+template <typename T, int CT>
+static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPeriodic& g,
+                        const DCarrier* car, int ncar, const DOp* ops, const DLeaf* leaves,
+                        hipStream_t st) {
+    const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+#define SO_RP(KS_, G_)                                                                   \
+    if (g.kw == 4 * KS_ && gper == G_) {                                                  \
+        launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, car, ncar, ops, leaves, st);         \
+        return 0;                                                                         \
+    }
+    SO_RP(12, 1) SO_RP(14, 1) SO_RP(16, 1) SO_RP(20, 1) SO_RP(28, 1) SO_RP(14, 2)
+#undef SO_RP
+    return -1;
+}
+
+// returns 0 when launched, -1 if no instantiation fits (caller falls back to k_resample)
+int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
+                             int dtype, const DCarrier* car, int ncar, const DOp* ops,
+                             const DLeaf* leaves, hipStream_t st) {
+    if (g.n_out <= 0) return 0;
+    if (dtype == SO_F32) {
+        switch (g.ct) {
+        case 8: return launch_rp_ct<float, 8>(y, tab, jend, g, car, ncar, ops, leaves, st);
+        case 4: return launch_rp_ct<float, 4>(y, tab, jend, g, car, ncar, ops, leaves, st);
+        case 2: return launch_rp_ct<float, 2>(y, tab, jend, g, car, ncar, ops, leaves, st);
+        default: return launch_rp_ct<float, 1>(y, tab, jend, g, car, ncar, ops, leaves, st);
+        }
+    }
+    switch (g.ct) {
+    case 8: return launch_rp_ct<double, 8>(y, tab, jend, g, car, ncar, ops, leaves, st);
+    case 4: return launch_rp_ct<double, 4>(y, tab, jend, g, car, ncar, ops, leaves, st);
+    case 2: return launch_rp_ct<double, 2>(y, tab, jend, g, car, ncar, ops, leaves, st);
+    default: return launch_rp_ct<double, 1>(y, tab, jend, g, car, ncar, ops, leaves, st);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -112,7 +113,8 @@ struct Stage {
     int64_t in_offset = 0;  // elements (direct)
     int64_t in_pitch = 0, in_frames = 0;
     int pw_step = -1;  // pointwise step materialising the input
-    int fused_pw = -1; // pointwise program evaluated inside the stage kernel's staging loop
+    std::vector<DCarrier> carriers;  // periodic resampler: input expressed as carriers
+    int car_buf = -1;
     // SOS
     std::vector<SosCoefs> groups;
     SosGeom sg{};
@@ -277,6 +279,8 @@ struct Plan {
     void use_stage(Stage& S, const Rect& r, const Map& m);
     void process_stage(int sid);
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
+    bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
+    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out);
     void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
              bool allow_hoist);
     int depth(int e) const;
@@ -535,19 +539,39 @@ std::vector<Piece> Plan::pad_pieces(int child, int padkind, double padvalue, con
         if (C.nd.kind != SO_NODE_ARRAY)
             fail(SO_ERR_INVALID, "Attemped to specify an indexing pad function for a signal which is not known to support `getindex`.");
         if (C.len.n == 0) fail(SO_ERR_LENGTH, "cannot index an empty array");
-        Expr e;
-        e.op = E_LOAD;
-        e.dtype = C.dtype;
-        e.leaf = mk_leafmap(m);
-        e.leaf.mode = padkind == SO_PAD_CYCLE ? LM_CYCLE : LM_MIRROR;
-        e.leaf.modn = C.len.n;
-        e.leaf.fstride = C.nd.s0;
-        e.leaf.cstride = C.nd.s1;
-        e.leaf.dtype = C.dtype;
-        e.array_node = child;
-        e.mono = (m.sc == 0);
+        // one piece per wrap of the array: cycle -> x[f - k*N]; mirror -> odd wraps run
+        // backwards x[(k+1)*N - 1 - f]  (reference src/padding.jl:132-148)
+        const int64_t Nc = C.len.n;
+        auto wrap_load = [&](Rect rr, int sf, int64_t df) {
+            Expr e;
+            e.op = E_LOAD;
+            e.dtype = C.dtype;
+            e.leaf = mk_leafmap(Map{sf, df, m.sc, m.dc});
+            e.leaf.fstride = C.nd.s0;
+            e.leaf.cstride = C.nd.s1;
+            e.leaf.dtype = C.dtype;
+            e.array_node = child;
+            e.mono = (m.sc == 0);
+            out.push_back({rr, add_expr(e)});
+        };
         count_array(child);
-        out.push_back({r, add_expr(e)});
+        if (m.sf == 0) {
+            int64_t k = m.df / Nc, rem = m.df % Nc;
+            bool rev = padkind == SO_PAD_MIRROR && (k & 1);
+            wrap_load(r, 0, rev ? Nc - 1 - rem : rem);
+            break;
+        }
+        if ((r.b - r.a) / Nc > 65536)
+            fail(SO_ERR_UNSUPPORTED, "cycle/mirror padding over more than 65536 repetitions is not lowered");
+        for (int64_t f0 = r.a + m.df; f0 < r.b + m.df;) {
+            int64_t k = f0 / Nc;
+            int64_t f1 = std::min(r.b + m.df, (k + 1) * Nc);
+            Rect rr{f0 - m.df, f1 - m.df, r.c0, r.c1};
+            bool rev = padkind == SO_PAD_MIRROR && (k & 1);
+            if (rev) wrap_load(rr, -1, (k + 1) * Nc - 1 - m.df);
+            else wrap_load(rr, 1, m.df - k * Nc);
+            f0 = f1;
+        }
         break;
     }
     default: fail(SO_ERR_INVALID, "unknown padding kind");
@@ -915,8 +939,14 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtyp
         std::vector<DOp> code, fcode;
         std::map<int, int> hoisted;
         int nchp = p.r.c1 - p.r.c0;
-        gen(p.e, code, hoisted, fcode, nchp > 1);
+        // generators / ramps always go to the per-frame program: the per-sample interpreter
+        // has no transcendental opcodes
+        gen(p.e, code, hoisted, fcode, true);
+        for (auto& o : code)
+            if (o.code == OP_FUNC || o.code == OP_RAMP)
+                fail(SO_ERR_UNSUPPORTED, "more than 4 distinct generator/ramp sub-expressions in one fused piece");
         DPiece d{};
+        d.depth = std::max(2, depth(p.e));
         d.a = p.r.a;
         d.b = p.r.b;
         d.c0 = p.r.c0;
@@ -1075,7 +1105,7 @@ void Plan::process_stage(int sid) {
         stages[sid].rg = g;
         // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
         if ((!g.arbitrary || g.exact) && need >= 2048) {
-            constexpr int RM = 8;
+            constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
             const int64_t Lb = g.L, Mb = g.M;
             int ct = 1;
             for (int c : {8, 4, 2})
@@ -1084,7 +1114,11 @@ void Plan::process_stage(int sid) {
                     break;
                 }
             const int pt = 64 / ct;
+            // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
+            // (b) a tile (pt super-periods) covers ~1100 input frames per channel
+            int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
             int64_t t = std::max<int64_t>(1, 1100 / (pt * Mb));
+            t = std::max<int64_t>(tmin, t / tmin * tmin);
             if (Lb * t > 4096) t = std::max<int64_t>(1, 4096 / Lb);
             const int64_t Ls = Lb * t, Ms = Mb * t;
             auto pos = [&](int64_t r, int64_t& j, int& p, double& alpha) {
@@ -1112,13 +1146,32 @@ void Plan::process_stage(int sid) {
                 jend[gi] = (int)jr[r1 - 1];
                 maxspan = std::max(maxspan, jr[r1 - 1] - jr[r0]);
             }
-            const int kw = g.taps + (int)maxspan;
-            const int jlo = jend[0] - (kw - 1);
+            // k-steps: smallest instantiated KS covering taps + span (tab is zero padded);
+            // compute waves: one (or two) groups each, taps stay in registers
+            int kw = 0, ncomp = 0;
+            {
+                const int ksneed = (g.taps + (int)maxspan + 3) / 4;
+                int gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
+                if (const char* ev = std::getenv("SIGOPS_RS_GPER")) gper = std::atoi(ev);  // tuning knob
+                const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14};
+                if (gper == 1) {
+                    for (int k : ks1)
+                        if (!kw && k >= ksneed) kw = 4 * k;
+                } else if (gper == 2) {
+                    for (int k : ks2)
+                        if (!kw && k >= ksneed) kw = 4 * k;
+                }
+                if (kw) ncomp = (ngroups + gper - 1) / gper;
+            }
+            // first staged input, rounded down to a multiple of 4 frames so that tiles start
+            // on a 16-byte boundary (vector loads) whenever pt*M is a multiple of 4
+            int jlo = jend[0] - (kw - 1);
+            jlo -= ((jlo % 4) + 4) % 4;
             const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
-            int64_t pitch = (tile_len + 1) | 1;  // odd pitch: spreads channels over LDS banks
+            int64_t pitch = (tile_len + 4) | 1;  // odd pitch (LDS banks) with room for vector round-up
             size_t lds_bytes = (size_t)ct * pitch * 8;
             size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
-            if (lds_bytes <= 79 * 1024 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
+            if (kw && lds_bytes <= 80 * 1024 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
                 const double* h = (const double*)nd.p0;
                 std::vector<double> tab((size_t)ngroups * kw * RM, 0.0);
                 for (int gi = 0; gi < ngroups; ++gi) {
@@ -1148,14 +1201,15 @@ void Plan::process_stage(int sid) {
                 rp.lds_pitch = (int)pitch;
                 rp.jlo = jlo;
                 rp.nch = N.nch;
-                // waves per workgroup: a divisor of the group count keeps the waves balanced;
-                // 2 workgroups/CU x up to 16 waves hide the scalar tap-load latency
-                rp.nwaves = 8;
-                for (int w = 16; w >= 4; --w)
-                    if (ngroups % w == 0) {
-                        rp.nwaves = w;
-                        break;
-                    }
+                rp.ptshift = pt == 64 ? 6 : pt == 32 ? 5 : pt == 16 ? 4 : 3;
+                // persistent kernel: 16 waves per workgroup, one workgroup per CU; compute waves
+                // own one or two groups each, the rest are loader waves
+                rp.nwaves = 16;
+                rp.ncompute = ncomp;
+                rp.grid = 256;
+                if (const char* ev = std::getenv("SIGOPS_RS_NWAVES")) rp.nwaves = std::max(2, std::min(16, std::atoi(ev)));
+                if (const char* ev = std::getenv("SIGOPS_RS_GRID")) rp.grid = std::max(1, std::atoi(ev));
+                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rp.pad = std::atoi(ev);  // ablation knob
                 stages[sid].periodic = true;
                 stages[sid].rp = rp;
                 stages[sid].tab_host = tab;
@@ -1297,11 +1351,9 @@ void Plan::process_stage(int sid) {
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
-    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic &&
-               std::all_of(ps.begin(), ps.end(), [&](const Piece& p) { return p.r.c0 == 0 && p.r.c1 == N.nch; })) {
-        // fuse the child's program into the kernel's LDS staging (no intermediate in HBM)
-        std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
-        S.fused_pw = emit_pointwise(ps, -3, in_dtype);
+    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers)) {
+        // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
+        // staging, no intermediate in HBM
         S.in_buf = -1;
         S.in_array_node = -1;
     } else if (!direct) {
@@ -1311,6 +1363,130 @@ void Plan::process_stage(int sid) {
         S.in_offset = 0;
         S.pw_step = emit_pointwise(ps, S.in_buf, in_dtype);
     }
+    if (S.kind == ST_RESAMPLE && S.periodic && S.carriers.empty()) {
+        // plain source (direct array / stage buffer / materialised input): one 0-step carrier
+        DCarrier c{};
+        c.a = 0;
+        c.b = in_frames;
+        c.dtype = in_dtype;
+        c.array_node = S.in_array_node;
+        c.buf = S.in_array_node >= 0 ? -1 : S.in_buf;
+        c.df = S.in_offset;
+        c.cstride = S.in_array_node >= 0 ? (N.nch == 1 ? 0 : S.in_pitch) : -1;  // -1: buffer pitch
+        S.carriers.push_back(c);
+    }
+    if (!S.carriers.empty()) S.car_buf = raw_buf(S.carriers.size() * sizeof(DCarrier));
+}
+
+// e == carrier load combined with channel-independent operands by a short chain of ops?
+bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
+    const Expr e = exprs[ei];
+    auto add_step = [&](int op, int mono_expr, bool flip, bool round32) {
+        if (C.nsteps >= 4) return false;
+        int slot = 0;
+        if (mono_expr >= 0) {
+            auto it = std::find(monos.begin(), monos.end(), mono_expr);
+            if (it == monos.end()) {
+                if ((int)monos.size() >= kMaxFrameSlots) return false;
+                monos.push_back(mono_expr);
+                slot = (int)monos.size() - 1;
+            } else slot = (int)(it - monos.begin());
+        }
+        C.op[C.nsteps] = op;
+        C.arg[C.nsteps] = slot | (flip ? 0x100 : 0) | (round32 ? 0x200 : 0);
+        C.nsteps++;
+        return true;
+    };
+    if (e.mono && C.nsteps == 0 && C.base == nullptr && C.buf == -1 && C.array_node == -1) {
+        // channel-independent piece (generator, constant, padding value): no array at all,
+        // the value is a per-frame slot
+        C.dtype = e.dtype == SO_F32 ? SO_F32 : SO_F64;
+        return add_step(OP_LOADF, ei, false, false);
+    }
+    switch (e.op) {
+    case E_LOAD: {
+        const DLeaf& L = e.leaf;
+        if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1) return false;
+        if (e.array_node < 0 && L.dc != 0) return false;
+        if (L.dc < 0) return false;
+        C.dtype = L.dtype;
+        C.array_node = e.array_node;
+        C.buf = e.array_node >= 0 ? -1 : L.buf;
+        C.cstride = L.cstride;  // -1: buffer pitch (patched in finalize)
+        C.df = L.df + (e.array_node >= 0 ? L.dc * L.cstride : 0);
+        if (e.array_node >= 0) count_array(e.array_node);
+        return true;
+    }
+    case E_RETYPE: return match_carrier(e.a, C, monos);
+    case E_ROUND32: return match_carrier(e.a, C, monos) && add_step(OP_ROUND32, -1, false, true);
+    case E_NEG: return match_carrier(e.a, C, monos) && add_step(OP_NEG, -1, false, false);
+    case E_ADD:
+    case E_SUB:
+    case E_MUL:
+    case E_DIV: {
+        int oc = e.op == E_ADD ? OP_ADD : e.op == E_SUB ? OP_SUB : e.op == E_MUL ? OP_MUL : OP_DIV;
+        bool r32 = e.dtype == SO_F32;
+        if (exprs[e.b].mono) {
+            DCarrier c2 = C;
+            std::vector<int> m2 = monos;
+            if (match_carrier(e.a, c2, m2)) {
+                C = c2;
+                monos = m2;
+                return add_step(oc, e.b, false, r32);
+            }
+        }
+        if (exprs[e.a].mono) {
+            DCarrier c2 = C;
+            std::vector<int> m2 = monos;
+            if (match_carrier(e.b, c2, m2)) {
+                C = c2;
+                monos = m2;
+                return add_step(oc, e.a, true, r32);
+            }
+        }
+        return false;
+    }
+    default: return false;
+    }
+}
+
+bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out) {
+    std::vector<Piece> ps = ps_in;
+    for (auto& p : ps)
+        if (p.r.c0 != 0 || p.r.c1 != nch) return false;
+    std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
+    std::vector<DCarrier> cs;
+    std::vector<std::vector<int>> monos_all;
+    for (auto& p : ps) {
+        DCarrier c{};
+        c.buf = -1;
+        c.array_node = -1;
+        std::vector<int> monos;
+        if (!match_carrier(p.e, c, monos)) return false;
+        c.a = p.r.a;
+        c.b = p.r.b;
+        cs.push_back(c);
+        monos_all.push_back(monos);
+    }
+    // commit: compile the per-frame programs
+    for (size_t i = 0; i < cs.size(); ++i) {
+        DCarrier& c = cs[i];
+        std::vector<DOp> fcode;
+        int dmax = 2;
+        for (size_t k = 0; k < monos_all[i].size(); ++k) {
+            std::map<int, int> none;
+            gen(monos_all[i][k], fcode, none, fcode, false);
+            fcode.push_back(DOp{OP_STOREF, (int)k});
+            dmax = std::max(dmax, depth(monos_all[i][k]));
+        }
+        if (dmax > 2) return false;  // the in-kernel frame interpreter is the 2-deep one
+        c.frame_pc = (int)ops.size();
+        c.frame_len = (int)fcode.size();
+        c.depth = dmax;
+        ops.insert(ops.end(), fcode.begin(), fcode.end());
+    }
+    out = cs;
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1344,6 +1520,15 @@ void Plan::finalize() {
             host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
         }
     }
+    for (auto& S : stages)
+        for (auto& c : S.carriers)
+            if (c.array_node >= 0 && !nodes[c.array_node].nd.i0 && !array_buf.count(c.array_node)) {
+                const so_node_t& nd = nodes[c.array_node].nd;
+                size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
+                int b = raw_buf(extent * dsize(nd.dtype));
+                array_buf[c.array_node] = b;
+                host_leaves.push_back(HostLeaf{c.array_node, nd.p0, extent * dsize(nd.dtype), b});
+            }
     for (auto& S : stages)
         if (S.in_array_node >= 0 && !nodes[S.in_array_node].nd.i0 && !array_buf.count(S.in_array_node)) {
             const so_node_t& nd = nodes[S.in_array_node].nd;
@@ -1380,6 +1565,25 @@ void Plan::finalize() {
             L.base = bufs[L.buf].d;
             if (L.cstride == -1) L.cstride = bufs[L.buf].pitch;
         }
+    }
+    for (auto& S : stages) {
+        if (S.carriers.empty()) continue;
+        for (auto& c : S.carriers) {
+            if (c.array_node >= 0) {
+                const so_node_t& nd = nodes[c.array_node].nd;
+                if (!nd.i0 && !array_buf.count(c.array_node)) fail(SO_ERR_RUNTIME, "internal: carrier array without device copy");
+                c.base = nd.i0 ? array_ptr[c.array_node] : bufs[array_buf[c.array_node]].d;
+            } else if (c.buf >= 0) {
+                c.base = bufs[c.buf].d;
+                if (c.cstride == -1) c.cstride = bufs[c.buf].pitch;
+            } else {
+                c.base = nullptr;  // generated piece
+                c.cstride = 0;
+            }
+            const int64_t V = 16 / (int64_t)dsize(c.dtype);
+            c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
+        }
+        HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
     }
     // upload tables
     if (!pieces.empty()) {
@@ -1571,8 +1775,8 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                 size_t esz = dsize(N.dtype);
                 const char* inp;
                 int64_t in_pitch;
-                if (S.fused_pw >= 0) {
-                    inp = nullptr;
+                if (S.kind == ST_RESAMPLE && S.periodic) {
+                    inp = nullptr;  // the periodic kernel reads through its carriers
                     in_pitch = 0;
                 } else if (S.in_array_node >= 0) {
                     const so_node_t& nd = P->nodes[S.in_array_node].nd;
@@ -1626,15 +1830,11 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                         rp.out_pitch = ob.pitch;
                         const int64_t al = 16 / (int64_t)esz;
                         rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
-                        const DPiece* fp = nullptr;
-                        int nfp = 0;
-                        if (S.fused_pw >= 0) {
-                            fp = P->d_pieces + P->pw[S.fused_pw].piece0;
-                            nfp = P->pw[S.fused_pw].npieces;
-                        }
-                        launch_resample_periodic(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                                 (const int*)P->bufs[S.jend_buf].d, rp, N.dtype, fp, nfp,
-                                                 P->d_ops, P->d_leaves, st);
+                        if (launch_resample_periodic(ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                                     (const int*)P->bufs[S.jend_buf].d, rp, N.dtype,
+                                                     (const DCarrier*)P->bufs[S.car_buf].d, (int)S.carriers.size(),
+                                                     P->d_ops, P->d_leaves, st) != 0)
+                            fail(SO_ERR_RUNTIME, "internal: no periodic resampler instantiation for this geometry");
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);

@@ -62,7 +62,22 @@ struct DPiece {
     int64_t block0;  // first workgroup of this piece
     int64_t nblk_f;  // workgroups along frames
     int32_t chc;     // channels per workgroup
-    int32_t pad;
+    int32_t depth;   // stack depth the programs need (2 -> small-register interpreter)
+};
+
+// A carrier: one planar array read at (frame n, channel c) -> base[c*cstride + n + df],
+// followed by up to 4 steps against per-frame values (see k_resample_periodic).
+struct DCarrier {
+    int64_t a, b;  // frames [a,b) of the stage input this carrier covers
+    const void* base;
+    int64_t cstride, df;
+    int32_t dtype;
+    int32_t buf;         // >=0: base patched from plan buffer (like DLeaf)
+    int32_t array_node;  // ARRAY node the base comes from, or -1
+    int32_t vec_ok;      // base/cstride allow 16-byte vector loads
+    int32_t frame_pc, frame_len, depth, nsteps;
+    int32_t op[4];   // OpCode
+    int32_t arg[4];  // slot | flip<<8 | round32<<9
 };
 
 struct OutView {
@@ -113,22 +128,26 @@ struct RsGeom {
 };
 
 // Periodic variant: for a rational rate L/M the (phase, alpha) pattern repeats every
-// L outputs / M inputs.  A wave's 64 lanes are 64 independent (period, channel) rows
-// working on the SAME output phases, so the taps are wave-uniform (SGPR operands) and
-// each LDS read of an input feeds RM FMAs.
+// L outputs / M inputs: the tap pattern of a group of 16 consecutive outputs is the same
+// for every (period, channel) row, so a tile of 64 rows x 16 outputs is one small matrix
+// product against a per-group tap matrix (see k_resample_periodic).
 struct RsPeriodic {
     int64_t n_in, n_out;
     int64_t L, M;       // outputs / inputs per (super-)period
     int64_t nperiods;
     int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == 64
-    int32_t ngroups;    // groups of RM consecutive outputs per period
-    int32_t kw;         // inputs in a group's window
+    int32_t ngroups;    // groups of 16 consecutive outputs per period
+    int32_t kw;         // inputs in a group's window (multiple of 4)
     int32_t tile_len;   // inputs per channel staged in LDS
     int32_t lds_pitch;  // doubles between channels in LDS
     int32_t jlo;        // input index (relative to the tile's first period base) of LDS slot 0
     int32_t nch;
     int32_t vec_ok;     // 16-byte aligned vector stores are legal
     int32_t nwaves;     // waves per workgroup (groups are dealt to waves in contiguous blocks)
+    int32_t ptshift;    // log2(pt)
+    int32_t ncompute;   // waves [0,ncompute) compute, the rest stage the next tile
+    int32_t grid;       // persistent workgroups (one per CU)
+    int32_t pad;
     int64_t in_pitch, out_pitch;
 };
 
