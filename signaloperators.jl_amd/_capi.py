@@ -69,14 +69,13 @@ def lib():
     # SONAME as /opt/rocm's.  If ours were loaded first, a later `import torch` would bind
     # to it and fail ("No HIP GPUs are available"); so when torch is installed, load its
     # copy first and let libsigops resolve against it.
+    # Importing torch AFTER libsigops has initialised HIP was observed to hang inside
+    # torch._C's static initialisation on the GPU box, so torch (when installed) goes first.
     try:
         import importlib.util as _ilu
 
-        _spec = _ilu.find_spec("torch")
-        if _spec is not None and _spec.origin:
-            _hip = os.path.join(os.path.dirname(_spec.origin), "lib", "libamdhip64.so")
-            if os.path.exists(_hip):
-                C.CDLL(_hip, mode=C.RTLD_GLOBAL)
+        if _ilu.find_spec("torch") is not None:
+            import torch  # noqa: F401
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)

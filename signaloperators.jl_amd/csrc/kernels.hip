@@ -520,6 +520,50 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 // D: col = l&15, row = (l>>4) + 4*reg.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// v = v (op) F_k  chain of a carrier on a CT x V register block (wave-uniform control flow)
+template <int CT, int V>
+__device__ __forceinline__ void carrier_apply(const DCarrier& C, const double (&F)[kMaxFrameSlots][V],
+                                              double (&val)[CT][V], bool to_f32) {
+    for (int i = 0; i < C.nsteps; ++i) {
+        const int op = C.op[i], arg = C.arg[i], slot = arg & 0xff;
+        const bool flip = arg & 0x100, r32 = arg & 0x200;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const double m = slot == 0 ? F[0][e] : slot == 1 ? F[1][e] : slot == 2 ? F[2][e] : F[3][e];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                double v = val[c][e];
+                switch (op) {
+                case OP_ADD: v = v + m; break;
+                case OP_SUB: v = flip ? m - v : v - m; break;
+                case OP_MUL: v = v * m; break;
+                case OP_DIV: v = flip ? m / v : v / m; break;
+                case OP_NEG: v = -v; break;
+                case OP_LOADF: v = m; break;  // generated piece: the value IS the slot
+                default: break;               // OP_ROUND32: only the rounding below
+                }
+                if (r32) v = (double)(float)v;  // Julia Float32 arithmetic
+                val[c][e] = v;
+            }
+        }
+    }
+    if (to_f32) {  // the reference stores the child in the child's sample type before
+                   // filtering (src/filters.jl:207,244)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < V; ++e) val[c][e] = (double)(float)val[c][e];
+    }
+}
+
+// 16-byte-per-lane asynchronous global -> LDS copy (global_load_lds_dwordx4): the wave
+// writes 1 KiB contiguously at the wave-uniform LDS address `l`; no VGPR staging, so a few
+// loader waves keep the whole tile in flight.
+__device__ __forceinline__ void dma16(const void* g, double* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 // Stage one input tile (CT channels x tile_len frames from global frame xbase) into an LDS
 // buffer as fp64, zero-padded outside [0,n_in) (Pad(x.signal,zero), reference
 // src/filters.jl:240).  Thread = one 16-byte vector of V frames, all CT channels: CT
@@ -547,6 +591,56 @@ __device__ __forceinline__ void stage_tile(const RsPeriodic& g, int64_t xbase, i
     }
     for (int iv = tid; iv < nvec; iv += nthr) {
         const int64_t gi = xbase + (int64_t)iv * V;
+        if constexpr (sizeof(T) == 8) {
+            // fp64 fast path: a wave's 64 consecutive vectors (128 frames) lie inside one
+            // array carrier -> asynchronous DMA of all CT channel rows, then (if the carrier
+            // has steps) the same wave modifies what it copied in place.
+            const int ivb = __builtin_amdgcn_readfirstlane(iv - (tid & 63));
+            if (ivb + 64 <= nvec && !(g.pad & 8)) {
+                const int64_t gf = xbase + (int64_t)ivb * V, gl = gf + 64 * V;
+                int cu = ci;
+                while (cu + 1 < ncar && car[cu].b <= gf) ++cu;
+                const DCarrier& C = car[cu];
+                if (C.base != nullptr && C.vec_ok && C.dtype == SO_F64 && gf >= C.a && gl <= C.b &&
+                    gf >= 0 && gl <= g.n_in && (((gf + C.df) % V) == 0)) {
+                    const double* src = (const double*)C.base + (int64_t)c0 * C.cstride + gi + C.df;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        dma16(src + (int64_t)c * C.cstride, buf + c * g.lds_pitch + ivb * V);
+                    if (C.nsteps > 0) {
+                        double F[kMaxFrameSlots][V];
+#pragma unroll
+                        for (int k = 0; k < kMaxFrameSlots; ++k)
+#pragma unroll
+                            for (int e = 0; e < V; ++e) F[k][e] = 0.0;
+                        if (C.frame_len > 0) {
+                            int64_t nn[V];
+                            double fo[V];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) nn[e] = gi + e;
+                            run_program<V, false, 2, true>(ops, C.frame_pc, C.frame_len, leaves, nn, c0, F, fo);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed in LDS
+                        double val[CT][V];
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const double2 v = *reinterpret_cast<const double2*>(buf + c * g.lds_pitch + iv * V);
+                            val[c][0] = v.x;
+                            val[c][1] = v.y;
+                        }
+                        carrier_apply<CT, V>(C, F, val, false);
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            double2 v;
+                            v.x = val[c][0];
+                            v.y = val[c][1];
+                            *reinterpret_cast<double2*>(buf + c * g.lds_pitch + iv * V) = v;
+                        }
+                    }
+                    continue;
+                }
+            }
+        }
         int cj = ci;
         while (cj + 1 < ncar && car[cj].b <= gi) ++cj;  // mostly 0 iterations
         // (a carrier without an array -- base == nullptr -- is a purely generated piece)
@@ -606,38 +700,7 @@ __device__ __forceinline__ void stage_tile(const RsPeriodic& g, int64_t xbase, i
                 }
             }
             // ---- steps ----
-            if (steps) {
-                for (int i = 0; i < C.nsteps; ++i) {  // wave-uniform
-                    const int op = C.op[i], arg = C.arg[i], slot = arg & 0xff;
-                    const bool flip = arg & 0x100, r32 = arg & 0x200;
-#pragma unroll
-                    for (int e = 0; e < V; ++e) {
-                        const double m = slot == 0 ? F[0][e] : slot == 1 ? F[1][e] : slot == 2 ? F[2][e] : F[3][e];
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            double v = val[c][e];
-                            switch (op) {
-                            case OP_ADD: v = v + m; break;
-                            case OP_SUB: v = flip ? m - v : v - m; break;
-                            case OP_MUL: v = v * m; break;
-                            case OP_DIV: v = flip ? m / v : v / m; break;
-                            case OP_NEG: v = -v; break;
-                            case OP_LOADF: v = m; break;  // generated piece: the value IS the slot
-                            default: break;  // OP_ROUND32: only the rounding below
-                            }
-                            if (r32) v = (double)(float)v;  // Julia Float32 arithmetic
-                            val[c][e] = v;
-                        }
-                    }
-                }
-                if (sizeof(T) == 4) {  // the reference stores the child in the child's sample
-                                       // type before filtering (src/filters.jl:207,244)
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int e = 0; e < V; ++e) val[c][e] = (double)(float)val[c][e];
-                }
-            }
+            if (steps) carrier_apply<CT, V>(C, F, val, sizeof(T) == 4);
             // ---- LDS stores ----
             if (vec) {
 #pragma unroll
@@ -674,6 +737,10 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
     if (wave >= nc) {
         // ---- loader waves: stage tile `it` while the compute waves work on tile it-1 ----
         const int ltid = (int)threadIdx.x - nc * 64, lthr = (nwaves - nc) * 64;
+        // Loader waves issue a handful of instructions and then sleep on memory; without a
+        // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
+        // and the loads only go out once the arithmetic is over (measured: phases add up).
+        if (!(g.pad & 16)) __builtin_amdgcn_s_setprio(3);
         for (int it = 0; t - gridDim.x < ntiles; t += gridDim.x, ++it) {
             if (t < ntiles && !((g.pad & 2) && it > 0))
                 stage_tile<T, CT>(g, (t % ntx) * g.pt * g.M + g.jlo, (int)(t / ntx) * CT,
@@ -711,13 +778,24 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
                 v4d acc[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                // A operands are software-pipelined one k-step ahead (double-buffered
+                // registers) so the LDS latency hides under the previous step's 4 MFMAs; the
+                // per-step address is an immediate offset from 4 fixed row pointers.
+                const double* __restrict__ ap[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ap[q] = cur + (rowoff[q] + je);
+                double abuf[2][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) abuf[0][q] = ap[q][0];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
+                    if (s + 1 < KS) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double a = cur[rowoff[q] + je + 4 * s];
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, breg[gg][s], acc[q], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) abuf[(s + 1) & 1][q] = ap[q][4 * (s + 1)];
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
                 }
                 const int r = gi * 16 + n16;  // output index inside the period
 #pragma unroll

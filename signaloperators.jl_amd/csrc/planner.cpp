@@ -1168,7 +1168,7 @@ void Plan::process_stage(int sid) {
             int jlo = jend[0] - (kw - 1);
             jlo -= ((jlo % 4) + 4) % 4;
             const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
-            int64_t pitch = (tile_len + 4) | 1;  // odd pitch (LDS banks) with room for vector round-up
+            int64_t pitch = (tile_len + 5) & ~(int64_t)1;  // even: 16-byte aligned rows for LDS-DMA
             size_t lds_bytes = (size_t)ct * pitch * 8;
             size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
             if (kw && lds_bytes <= 80 * 1024 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
