@@ -142,8 +142,8 @@ def _array_fields(x):
 
 def _demand(x, n, out):
     """how many frames of every randn leaf a sink of n frames evaluates"""
-    if n is None or n <= 0:
-        return
+    if n is None or S.isknowninf(n) or n <= 0:
+        return  # (infinite demands are rejected by the planner with the reference's error)
     if isinstance(x, S.FuncSig):
         if x.fn == S.RANDN:
             out[id(x)] = max(out.get(id(x), 0), n)

@@ -956,7 +956,7 @@ _DESIGNS = {Lowpass: "lowpass", Highpass: "highpass", Bandpass: "bandpass", Band
 
 
 def Filt(*args, blocksize=default_blocksize, order=5, method=None, sos=None, gain=1.0):
-    if args and args[0] in _DESIGNS:  # curried Filt(Type,bounds...)
+    if args and isinstance(args[0], type) and args[0] in _DESIGNS:  # curried Filt(Type,bounds...)
         a = args
         return Curried(lambda x: Filt(x, *a, blocksize=blocksize, order=order, method=method))
     if not args and sos is not None:
@@ -966,7 +966,7 @@ def Filt(*args, blocksize=default_blocksize, order=5, method=None, sos=None, gai
         return FilteredSignal(x, RawFilterFn(sos, gain), blocksize, x.fs)
     if len(args) >= 2 and isinstance(args[1], (FilterFn, RawFilterFn)):
         return FilteredSignal(x, args[1], blocksize, x.fs)
-    if len(args) < 3 or args[1] not in _DESIGNS:
+    if len(args) < 3 or not (isinstance(args[1], type) and args[1] in _DESIGNS):
         error("Filt(x, Type, bounds...) expected")
     if method is None:
         method = Butterworth(order)

@@ -1,0 +1,118 @@
+"""Pins the oracle's DSP numerics (recalled DSP.jl algorithms) against
+independent implementations: scipy.signal.sosfilt for the DF2T cascade, an explicit
+zero-stuff + convolve + pick for the rational polyphase kernels, the vectorised closed form
+of SURVEY.md Appendix A for the arbitrary-rate kernel, and an analytic sine.  CPU only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy import signal
+
+import sigops_amd as so
+from sigops_amd import Signal, Filt, ToFramerate, Lowpass, Bandstop, Highpass, Chebyshev1, Hz, kHz, FilterFn
+from cases import F, rng
+from oracle_bridge import oracle_sink, relerr
+
+
+@pytest.mark.parametrize("spec", [
+    ("lowpass", (6.0,), ("butterworth", 5)), ("bandstop", (2.0, 12.0), ("chebyshev1", 5, 1.0)),
+    ("highpass", (8.0,), ("chebyshev1", 5, 1.0)), ("bandpass", (20.0, 30.0), ("butterworth", 3))])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_iir_matches_sosfilt(spec, dtype):
+    design, args, method = spec
+    x = F(rng(1).standard_normal((3000, 3)).astype(dtype))
+    tree = so.FilteredSignal(Signal(x, 100 * Hz), FilterFn(design, method, args), 4096, 100.0)
+    got = oracle_sink(tree)
+    sos, gain = so.design_iir(FilterFn(design, method, args), 100.0)
+    want = signal.sosfilt(sos, x.astype(np.float64), axis=0) * gain  # DF2T, zero state
+    assert got.dtype == dtype
+    assert relerr(got, want.astype(dtype)) < (1e-12 if dtype == np.float64 else 2e-7)
+
+
+def _polyphase_numpy(x, h, L, M, n_out):
+    """y[m] = (zero-stuffed x * h)[c0 + m*M], c0 = (hLen-1)/2  """
+    up = np.zeros(len(x) * L + len(h))
+    up[: len(x) * L: L] = x
+    full = np.convolve(up, h)
+    c0 = (len(h) - 1) // 2
+    idx = c0 + np.arange(n_out) * M
+    return full[idx]
+
+
+@pytest.mark.parametrize("ratio,fs_in,fs_out", [((2, 1), 20, 40), ((1, 2), 1000, 500), ((3, 2), 20, 30),
+                                                ((2, 3), 30, 20), ((3, 1), 10, 30), ((1, 3), 30, 10)])
+def test_rational_resampler_matches_convolution(ratio, fs_in, fs_out):
+    x = rng(2).standard_normal(400)
+    got = oracle_sink(ToFramerate(Signal(F(x[:, None]), fs_in * Hz), fs_out * Hz))[:, 0]
+    h = so.design_resample(ratio)
+    n_out = int(np.ceil(len(x) * fs_out / fs_in))
+    want = _polyphase_numpy(x, h, ratio[0], ratio[1], n_out)
+    assert got.shape[0] == n_out
+    assert relerr(got, want) < 1e-12
+
+
+def _arbitrary_closed_form(x, h, nphi, L, M, n_out):
+    """vectorised Appendix-A formula with exact rational positions (integer rates)"""
+    hlen = len(h)
+    taps = -(-hlen // nphi)
+    c0 = (hlen - 1) // 2
+    m = np.arange(n_out, dtype=np.int64)
+    N = m * (nphi * M)
+    qi = c0 + N // L
+    alpha = (N % L) / L
+    j, p = qi // nphi, qi % nphi
+    hp = np.concatenate([h, np.zeros(nphi * taps + 1)])
+    dh = np.concatenate([np.diff(h), [0.0], np.zeros(nphi * taps + 1)])
+    y = np.zeros(n_out)
+    xp = np.concatenate([np.zeros(taps), x, np.zeros(taps + 2)])
+    for k in range(taps):
+        xv = xp[j - k + taps]
+        y += (hp[p + nphi * k] + alpha * dh[p + nphi * k]) * xv
+    return y
+
+
+def test_arbitrary_resampler_matches_closed_form():
+    x = rng(3).standard_normal(20000)
+    got = oracle_sink(ToFramerate(Signal(F(x[:, None]), 44.1 * kHz), 48 * kHz))[:, 0]
+    h = so.design_resample(48000 / 44100)
+    want = _arbitrary_closed_form(x, h, 32, 160, 147, got.shape[0])
+    assert got.shape[0] == int(np.ceil(20000 * 48000 / 44100))
+    assert relerr(got, want) < 1e-12
+
+
+@pytest.mark.parametrize("fs_out", [48000.0, 16000.0])
+def test_resampled_sine_is_the_analytic_sine(fs_out):
+    """440 Hz sine in -> 440 Hz sine out, time aligned: output m=0 sits at input n=1
+    (t = 1/fs_in, reference first-frame convention); error = the 60 dB design ripple."""
+    fs_in = 44100.0
+    n = np.arange(1, 44101)
+    x = np.sin(2 * np.pi * 440.0 * n / fs_in)
+    y = oracle_sink(ToFramerate(Signal(F(x[:, None]), fs_in * Hz), fs_out * Hz))[:, 0]
+    t = 1.0 / fs_in + np.arange(y.shape[0]) / fs_out
+    want = np.sin(2 * np.pi * 440.0 * t)
+    interior = slice(200, y.shape[0] - 200)
+    assert np.max(np.abs(y[interior] - want[interior])) < 1e-3
+
+
+def test_phase_accumulator_divergence_is_documented():
+    """DSP.jl accumulates the phase in floating point; the oracle uses exact positions
+    (SURVEY.md Appendix C-1).  Measure the divergence on a tie-heavy rate."""
+    code = ("import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.');"
+            "import numpy as np, sigops_amd as so; from oracle_bridge import oracle_sink;"
+            "x=np.asfortranarray(np.random.default_rng(4).standard_normal((8000,1)));"
+            "y=oracle_sink(so.ToFramerate(so.Signal(x,44.1*so.kHz),48*so.kHz));"
+            "np.save(sys.argv[1], y)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(root, "tests", f"_acc_{flag}.npy")
+        env = dict(os.environ, SO_ORACLE_PHASE_ACCUMULATE=flag)
+        subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
+        outs.append(np.load(path))
+        os.remove(path)
+    err = relerr(outs[1], outs[0])
+    # tie cases flip between neighbouring phases: small but far above 1e-6 is possible
+    assert outs[0].shape == outs[1].shape
+    assert err < 1e-3
