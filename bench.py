@@ -34,6 +34,20 @@ def build_tree(so, noise, seconds):
             | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz))
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as
+    MI355X_MICROARCH.md §HBM prescribes: 2*FETCH_SIZE + WRITE_SIZE); null when the run is
+    not the default workload the counters were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc_hbm.json")
+    if args.seconds != 600.0 or args.channels != 8 or args.dtype != "f64" or not os.path.exists(path):
+        return None
+    if os.environ.get("SIGOPS_BENCH_PLAIN"):
+        return None
+    with open(path) as f:
+        return json.load(f).get("corrected_bytes_per_launch")
+
+
 def cpu_baseline(so, seconds, nch, dtype):
     """Oracle (port of the reference's single-threaded block-pull engine) on a bounded
     sample of the same workload.  Only this leg of bench.py touches oracle/."""
@@ -63,8 +77,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=600.0, help="signal duration (600 = full config)")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
-    ap.add_argument("--cpu-seconds", type=float, default=30.0,
-                    help="signal seconds for the bounded CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=600.0,
+                    help="signal seconds for the bounded CPU-oracle sample (0 = skip); the oracle does "
+                         "~5e6 frames/s on one core, so the full 600 s workload is ~6-10 s of CPU work")
     args = ap.parse_args()
 
     import numpy as np
@@ -174,7 +189,7 @@ def main():
             "hbm_GBps_whole_sink": algo / (ms_per_step * 1e-3) / 1e9,
             "algorithmic_bytes_per_step": algo,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": kname,
                          "kernel_ms": k_avg_ms, "kernel_algorithmic_bytes": kbytes,
                          "all_kernels_ms": sum(tot_ms) / len(tot_ms)},
         }

@@ -1,0 +1,179 @@
+# SignalOperatorsHIP.jl — reference-side glue for libsigops (include/sigops.h).
+#
+# NOTE: Julia is not installed in the build image or on the GPU box (SURVEY.md probe
+# table), so this file has never been executed.  It is the binding a maintainer of
+# haberdashPI/SignalOperators.jl would add (see INTEGRATION.md): a sink type `HIPSink`
+# whose `sink!` method lowers the lazy operator tree to the C-ABI node table instead of
+# pulling blocks (reference src/sink.jl:225-241).  Tree construction (Signal / Until /
+# Ramp / Filt / Mix / ToFramerate ...), length algebra and the ToFramerate rewrite rules
+# stay exactly as they are in the reference; only the block loop is replaced.
+#
+# The tested host-side mirror of this glue is the Python package next to this file
+# (lowering.py builds the identical node table).
+module SignalOperatorsHIP
+
+using SignalOperators
+using SignalOperators: MapSignal, FilteredSignal, CutApply, PaddedSignal, AppendSignals,
+    RampSignal, NormedSignal, SignalFunction, NumberSignal, ResamplerFn, RawFilterFn,
+    FnBr, GetChanFn, As1Channel, AsNChannels, ToEltypeFn, tuplecat, sinramp,
+    resolvelen, nframes_helper, IsSignal, SignalTrait, child
+using DSP
+
+const libsigops = get(ENV, "LIBSIGOPS", "libsigops.so")
+
+# ---- mirror of so_node_t / so_out_desc_t (include/sigops.h) -----------------------
+struct SoNode
+    kind::Int32; dtype::Int32; nch::Int32; n_children::Int32
+    children::Ptr{Int32}
+    nframes::Int64
+    fs::Float64
+    i0::Int32; i1::Int32; i2::Int32; i3::Int32
+    l0::Int64; l1::Int64
+    d0::Float64; d1::Float64; d2::Float64; d3::Float64
+    p0::Ptr{Cvoid}; p1::Ptr{Cvoid}
+    s0::Int64; s1::Int64
+end
+struct SoOutDesc
+    dtype::Int32; nch::Int32; nframes::Int64
+    frame_stride::Int64; chan_stride::Int64
+    is_device::Int32; reserved::Int32
+end
+
+const SO_F32, SO_F64, SO_I64 = Int32(0), Int32(1), Int32(2)
+const LEN_INF, LEN_MISSING = Int64(-1), Int64(-2)
+@enum Kind::Int32 ARRAY=0 CONST=1 FUNC=2 UNTIL=3 AFTER=4 PAD=5 APPEND=6 RAMP=7 MAP=8 FILT_SOS=9 RESAMPLE=10 NORMPOWER=11
+
+sodtype(::Type{Float32}) = SO_F32
+sodtype(::Type{Float64}) = SO_F64
+sodtype(::Type{<:Integer}) = SO_I64
+sodtype(T) = error("HIPSink lowers Float32/Float64 signals only; use the stock sink for $T")
+solen(n::Number) = Int64(n)
+solen(::Missing) = LEN_MISSING
+solen(n) = isinf(n) ? LEN_INF : error("unexpected length $n")
+sofs(fs) = ismissing(fs) ? NaN : Float64(fs)
+
+"""
+    HIPSink{T}
+
+Sink type: `sink(x, HIPSink)` evaluates `x` on the MI355X engine and returns a
+`(Array, framerate)` tuple like the stock `Tuple` sink.
+"""
+struct HIPSink{T} <: AbstractMatrix{T}
+    data::Matrix{T}
+end
+Base.size(x::HIPSink) = size(x.data)
+Base.getindex(x::HIPSink, i...) = getindex(x.data, i...)
+SignalOperators.initsink(x, ::Type{<:HIPSink}) =
+    HIPSink(Array{sampletype(x)}(undef, nframes(x), nchannels(x)))
+
+mutable struct Lowering
+    nodes::Vector{SoNode}
+    keep::Vector{Any}          # GC roots for every pointer handed to C
+    memo::IdDict{Any,Int32}
+end
+Lowering() = Lowering(SoNode[], Any[], IdDict{Any,Int32}())
+
+function push_node!(lw, x, kind; kids=Int32[], i0=0, i1=0, i2=0, i3=0, l0=0, l1=0,
+                    d0=0.0, d1=0.0, p0=C_NULL, p1=C_NULL, s0=0, s1=0,
+                    dtype=sodtype(sampletype(x)), nch=nchannels(x))
+    push!(lw.keep, kids)
+    node = SoNode(Int32(kind), dtype, Int32(nch), Int32(length(kids)),
+                  isempty(kids) ? C_NULL : pointer(kids), solen(nframes(x)), sofs(framerate(x)),
+                  i0, i1, i2, i3, l0, l1, d0, d1, 0.0, 0.0, p0, p1, s0, s1)
+    push!(lw.nodes, node)
+    Int32(length(lw.nodes) - 1)
+end
+
+lower!(lw, x) = get!(() -> lower_node!(lw, x), lw.memo, x)
+
+function lower_node!(lw, x::Union{AbstractArray,Tuple{<:AbstractArray,<:Number}})
+    data = x isa Tuple ? x[1] : x
+    push!(lw.keep, data)
+    push_node!(lw, x, ARRAY; p0=pointer(data), l0=size(data, 1), i0=0,
+               s0=stride(data, 1), s1=ndims(data) > 1 ? stride(data, 2) : 0)
+end
+lower_node!(lw, x::NumberSignal) =
+    push_node!(lw, x, CONST; d0=Float64(x.val), i0=sodtype(typeof(x.val)), nch=1)
+function lower_node!(lw, x::SignalFunction)
+    code = x.fn === sin ? 0 : x.fn === cos ? 1 : x.fn === identity ? 2 :
+        error("Signal($(x.fn)) is an opaque closure: materialise it with the stock sink first")
+    push_node!(lw, x, FUNC; i0=code, i1=ismissing(x.ω) ? 0 : 1,
+               d0=ismissing(x.ω) ? 0.0 : Float64(x.ω), d1=x.ϕ, nch=1, dtype=SO_F64)
+end
+function lower_node!(lw, x::CutApply{<:Any,<:Any,K}) where K
+    c = lower!(lw, child(x))
+    push_node!(lw, x, K <: Val{:Until} ? UNTIL : AFTER; kids=Int32[c], l0=resolvelen(x))
+end
+function lower_node!(lw, x::PaddedSignal{<:Any,<:Any,E}) where E
+    c = lower!(lw, child(x))
+    p = x.Pad
+    kind, val, vec = p === zero ? (2, 0.0, C_NULL) : p === one ? (3, 0.0, C_NULL) :
+        p === lastframe ? (4, 0.0, C_NULL) : p === cycle ? (5, 0.0, C_NULL) :
+        p === mirror ? (6, 0.0, C_NULL) : p isa Number ? (0, Float64(p), C_NULL) :
+        p isa Union{Tuple,AbstractVector} ? (1, 0.0, pointer(push!(lw.keep, Float64.(collect(p)))[end])) :
+        error("opaque padding closure")
+    push_node!(lw, x, PAD; kids=Int32[c], i0=kind, i1=E ? 1 : 0, d0=val, p0=vec)
+end
+lower_node!(lw, x::AppendSignals) =
+    push_node!(lw, x, APPEND; kids=Int32[lower!(lw, s) for s in x.signals])
+function lower_node!(lw, x::RampSignal{D}) where D
+    fn = x.fn === sinramp ? 0 : x.fn === identity ? 1 : error("opaque ramp closure")
+    push_node!(lw, x, RAMP; kids=Int32[lower!(lw, child(x))], i0=D === :on ? 0 : 1, i1=fn,
+               l0=resolvelen(x))
+end
+function lower_node!(lw, x::MapSignal)
+    fn = x.fn isa FnBr ? x.fn.fn : x.fn
+    code, extra = fn === (+) ? (0, 0) : fn === (*) ? (1, 0) : fn === (-) ? (2, 0) : fn === (/) ? (3, 0) :
+        fn === tuplecat ? (4, 0) : fn isa GetChanFn ? (5, fn.n) : fn isa As1Channel ? (6, 0) :
+        fn isa AsNChannels ? (7, fn.ch) : fn isa ToEltypeFn ? (8, sodtype(typeof(fn).parameters[1])) :
+        fn === reverse ? (9, 0) : error("OperateOn($fn): opaque closure, not lowerable")
+    pad = x.padding === one ? 3 : x.padding === zero ? 2 : error("opaque map padding")
+    push_node!(lw, x, MAP; kids=Int32[lower!(lw, s) for s in x.signals], i0=code,
+               i1=x.bychannel ? 1 : 0, i2=pad, i3=extra)
+end
+function lower_node!(lw, x::FilteredSignal)
+    c = lower!(lw, child(x))
+    if x.fn isa ResamplerFn                         # reference src/reformatting.jl:92-98
+        h = Float64.(DSP.resample_filter(x.fn.ratio))
+        push!(lw.keep, h)
+        if x.fn.ratio isa Rational
+            push_node!(lw, x, RESAMPLE; kids=Int32[c], i0=0, i1=numerator(x.fn.ratio),
+                       l0=numerator(x.fn.ratio), l1=denominator(x.fn.ratio), p0=pointer(h),
+                       i2=length(h), i3=x.blocksize)
+        else
+            push_node!(lw, x, RESAMPLE; kids=Int32[c], i0=1, i1=32, d0=Float64(x.fn.ratio),
+                       p0=pointer(h), i2=length(h), i3=x.blocksize)
+        end
+    else                                            # reference src/filters.jl:10-11,94
+        f = convert(SecondOrderSections, x.fn(framerate(x)))
+        sos = Float64[c for b in f.biquads for c in (b.b0, b.b1, b.b2, 1.0, b.a1, b.a2)]
+        push!(lw.keep, sos)
+        push_node!(lw, x, FILT_SOS; kids=Int32[c], i0=length(f.biquads), p0=pointer(sos),
+                   d0=Float64(f.g), i1=x.blocksize)
+    end
+end
+lower_node!(lw, x::NormedSignal) = push_node!(lw, x, NORMPOWER; kids=Int32[lower!(lw, child(x))])
+
+check(st) = st == 0 || error(unsafe_string(ccall((:so_last_error, libsigops), Cstring, ())))
+
+# The method the engine plugs into: reference src/sink.jl:225-226 dispatch point.
+function SignalOperators.sink!(result::HIPSink{T}, x, ::IsSignal) where T
+    lw = Lowering()
+    root = lower!(lw, x)
+    desc = Ref(SoOutDesc(sodtype(T), size(result, 2), size(result, 1), 1, size(result, 1), 0, 0))
+    plan = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve lw result begin
+        check(ccall((:so_plan_create, libsigops), Int32,
+                    (Ptr{SoNode}, Int32, Int32, Ref{SoOutDesc}, Int32, Ref{Ptr{Cvoid}}),
+                    lw.nodes, length(lw.nodes), root, desc, 0, plan))
+        try
+            check(ccall((:so_plan_execute, libsigops), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                        plan[], result.data, C_NULL))
+        finally
+            ccall((:so_plan_destroy, libsigops), Cvoid, (Ptr{Cvoid},), plan[])
+        end
+    end
+    nothing
+end
+
+end # module
