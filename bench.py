@@ -28,7 +28,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def build_tree(so, noise, seconds):
-    if os.environ.get("SIGOPS_BENCH_PLAIN"):  # tuning aid: resampler alone, no fused Amplify
+    v = os.environ.get("SIGOPS_BENCH_PLAIN")  # tuning aids (not the reported workload)
+    if v == "gain":  # finite fused chain: constant gain
+        return so.Signal(noise, 44.1 * so.kHz) | so.Amplify(2.0) | so.ToFramerate(48 * so.kHz)
+    if v == "finite":  # the modulator cut to the array's length: a single carrier
+        return (so.Signal(noise, 44.1 * so.kHz)
+                | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz) | so.Until(seconds * so.s)) | so.ToFramerate(48 * so.kHz))
+    if v:  # resampler alone, no fused Amplify
         return so.Signal(noise, 44.1 * so.kHz) | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz)
     return (so.Signal(noise, 44.1 * so.kHz) | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz))
             | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz))

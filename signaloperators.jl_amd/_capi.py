@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsigops.so")
+LIB_PATH = os.environ.get("SIGOPS_LIB") or os.path.join(_HERE, "csrc", "libsigops.so")  # SIGOPS_LIB: A/B tuning builds
 
 SO_F32, SO_F64, SO_I64 = 0, 1, 2
 SO_LEN_INF, SO_LEN_MISSING, SO_LEN_UNCHECKED = -1, -2, -3

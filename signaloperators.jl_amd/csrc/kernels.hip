@@ -596,8 +596,12 @@ __device__ __forceinline__ void stage_tile(const RsPeriodic& g, int64_t xbase, i
             // array carrier -> asynchronous DMA of all CT channel rows, then (if the carrier
             // has steps) the same wave modifies what it copied in place.
             const int ivb = __builtin_amdgcn_readfirstlane(iv - (tid & 63));
-            if (ivb + 64 <= nvec && !(g.pad & 8)) {
-                const int64_t gf = xbase + (int64_t)ivb * V, gl = gf + 64 * V;
+            if (!(g.pad & 8)) {
+                // (a partial last chunk is fine: inactive lanes of an exec-masked
+                //  global_load_lds write nothing -- verified on gfx950; without this the
+                //  partial chunk took the slow generic path: 1.45 -> 1.18 ms on config 3)
+                const int nact = nvec - ivb < 64 ? nvec - ivb : 64;
+                const int64_t gf = xbase + (int64_t)ivb * V, gl = gf + (int64_t)nact * V;
                 int cu = ci;
                 while (cu + 1 < ncar && car[cu].b <= gf) ++cu;
                 const DCarrier& C = car[cu];
@@ -745,7 +749,8 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
             if (t < ntiles && !((g.pad & 2) && it > 0))
                 stage_tile<T, CT>(g, (t % ntx) * g.pt * g.M + g.jlo, (int)(t / ntx) * CT,
                                   lds + (it & 1) * bufsz, car, ncar, ops, leaves, ltid, lthr);
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // copies + in-place steps done
+            __builtin_amdgcn_s_barrier();
         }
         return;
     }
@@ -765,7 +770,8 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
         const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
         rowoff[q] = (rho >> ptshift) * g.lds_pitch + (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
     }
-    __syncthreads();  // tile 0 staged (loader iteration 0)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // taps loaded
+    __builtin_amdgcn_s_barrier();  // tile 0 staged (loader iteration 0)
     for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
         const double* __restrict__ cur = lds + (it & 1) * bufsz;
         const int64_t P0 = (t % ntx) * g.pt;
@@ -810,7 +816,11 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
                     }
             }
         }
-        __syncthreads();  // loaders finished tile it+1; everyone finished reading tile it
+        // Raw barrier: __syncthreads() would also drain vmcnt(0), i.e. make the compute waves
+        // wait for their output stores every tile.  The LDS reads of this tile were consumed
+        // by the MFMAs above, so only lgkmcnt matters here; stores stay in flight.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // loaders finished tile it+1; all finished reading tile it
     }
 }
 

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1113,6 +1114,10 @@ void Plan::process_stage(int sid) {
                     ct = c;
                     break;
                 }
+            if (const char* ev = std::getenv("SIGOPS_RS_CT")) {  // tuning knob
+                int c = std::atoi(ev);
+                if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
+            }
             const int pt = 64 / ct;
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
             // (b) a tile (pt super-periods) covers ~1100 input frames per channel
@@ -1583,6 +1588,10 @@ void Plan::finalize() {
             const int64_t V = 16 / (int64_t)dsize(c.dtype);
             c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
         }
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            for (auto& c : S.carriers)
+                std::fprintf(stderr, "[sigops] carrier [%lld,%lld) base=%p cstride=%lld df=%lld dtype=%d vec_ok=%d nsteps=%d frame_len=%d depth=%d\n",
+                             (long long)c.a, (long long)c.b, c.base, (long long)c.cstride, (long long)c.df, c.dtype, c.vec_ok, c.nsteps, c.frame_len, c.depth);
         HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
     }
     // upload tables
