@@ -303,80 +303,134 @@ __device__ __forceinline__ double sos_step(double x, double (&s)[2 * NS], const 
     return y;
 }
 
-template <int NS, typename T>
-__global__ __launch_bounds__(kBlock) void k_sos_state(const T* __restrict__ x, SosGeom g,
-                                                      SosCoefs cf, double* __restrict__ v) {
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t nseq = (int64_t)(g.nchunks - 1) * g.nch;
-    if (tid >= nseq) return;
-    const int k = (int)(tid % (g.nchunks - 1));
-    const int ch = (int)(tid / (g.nchunks - 1));
-    const int64_t end = (int64_t)(k + 1) * g.chunk;
-    const int64_t beg = end - (g.warm < g.chunk ? g.warm : g.chunk);
-    const T* xp = x + (int64_t)ch * g.in_pitch;
+// Tiled streaming of 64 sequences per wave (sequence = one chunk of one channel).  A tile is
+// 64 rows x kTT frames: the wave loads it with coalesced 128-byte row segments (4 rows per
+// load instruction), parks it in LDS with an odd row pitch, then every lane walks ITS row
+// (conflict-free, stride kTT+1) through the DF2T cascade with the section states in registers
+// and, for the apply pass, writes the outputs back through LDS the same coalesced way.
+// APPLY == false: pass 1 (final state of the last min(L,W) frames from zero state)
+// APPLY == true : pass 3 (outputs from the propagated initial state)
+constexpr int kTT = 16;
+
+template <int NS, typename T, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T* __restrict__ y,
+                                                      const double* __restrict__ s0,
+                                                      double* __restrict__ v, SosGeom g,
+                                                      SosCoefs cf) {
+    __shared__ double tile[kBlock / 64][64 * (kTT + 1)];
+    __shared__ int64_t rowbase[kBlock / 64][64];  // element offset of each row's first frame
+    __shared__ int rowlen[kBlock / 64][64];       // frames this row has to process
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nck = APPLY ? g.nchunks : g.nchunks - 1;  // pass 1 skips every channel's last chunk
+    const int64_t nseq = (int64_t)nck * g.nch;
+    const int64_t seq = ((int64_t)blockIdx.x * (kBlock / 64) + w) * 64 + lane;
+    const bool live = seq < nseq;
+    const int k = live ? (int)(seq % nck) : 0;
+    const int ch = live ? (int)(seq / nck) : 0;
+    int64_t beg = (int64_t)k * g.chunk;
+    int64_t end = beg + g.chunk < g.n ? beg + g.chunk : g.n;
+    if (!APPLY) beg = end - (g.warm < g.chunk ? g.warm : g.chunk);  // full chunks only: end = beg+L
+    const int len = live ? (int)(end - beg) : 0;
+    rowbase[w][lane] = beg;  // frame offset (the row's channel is kept in rowch)
+    rowlen[w][lane] = len;
     double s[2 * NS];
 #pragma unroll
     for (int d = 0; d < 2 * NS; ++d) s[d] = 0.0;
-    for (int64_t i = beg; i < end; ++i) (void)sos_step<NS>((double)xp[i], s, cf);
-    double* vp = v + ((int64_t)ch * g.nchunks + k) * (2 * NS);
+    if (APPLY && live && k > 0 && s0 != nullptr) {
+        const double* sp = s0 + ((int64_t)ch * g.nchunks + k) * (2 * NS);
 #pragma unroll
-    for (int d = 0; d < 2 * NS; ++d) vp[d] = s[d];
+        for (int d = 0; d < 2 * NS; ++d) s[d] = sp[d];
+    }
+    // every row of this wave belongs to a (chunk, channel); rows are consecutive chunks of one
+    // channel except where the wave straddles a channel boundary, so the per-row channel is
+    // kept alongside the frame offset
+    __shared__ int rowch[kBlock / 64][64];
+    rowch[w][lane] = ch;
+    __builtin_amdgcn_wave_barrier();
+    int maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    double* tl = tile[w];
+    const int rsub = lane >> 4, col = lane & 15;  // load/store role: 4 rows x 16 columns
+    for (int t0 = 0; t0 < maxlen; t0 += kTT) {
+        // ---- coalesced load: 16 instructions x (4 rows x 128 B) ----
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int r = j * 4 + rsub;
+            const int rl = rowlen[w][r];
+            double xv = 0.0;
+            if (t0 + col < rl)
+                xv = (double)x[(int64_t)rowch[w][r] * g.in_pitch + rowbase[w][r] + t0 + col];
+            tl[r * (kTT + 1) + col] = xv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- every lane: its own row through the cascade ----
+        double* row = tl + lane * (kTT + 1);
+#pragma unroll
+        for (int t = 0; t < kTT; ++t) {
+            const double yv = sos_step<NS>(row[t], s, cf);
+            if (APPLY) row[t] = yv * cf.gain;
+            // (frames past a short row's end are zeros and never stored; their effect on
+            //  the state is irrelevant: only full chunks feed pass 1)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (APPLY) {
+            // ---- coalesced store ----
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int r = j * 4 + rsub;
+                if (t0 + col < rowlen[w][r])
+                    y[(int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col] = (T)tl[r * (kTT + 1) + col];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!APPLY && live) {
+        double* vp = v + ((int64_t)ch * g.nchunks + k) * (2 * NS);
+#pragma unroll
+        for (int d = 0; d < 2 * NS; ++d) vp[d] = s[d];
+    }
 }
 
-// mpow: [kterms][D][D] row-major, mpow[0] = I
+// mpow: [kterms][D][D] row-major, mpow[0] = I.  The matrices are workgroup-uniform: they are
+// staged through LDS one term at a time and read as LDS broadcasts (as scalar-cache operands
+// they cost ~700 clk per 64-byte line, which made this pass the slowest of the three).
 template <int NS>
 __global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ v,
                                                      const double* __restrict__ mpow, SosGeom g,
                                                      double* __restrict__ s0) {
     constexpr int D = 2 * NS;
+    __shared__ double mj[D * D];
     const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    if (tid >= nseq) return;
-    const int k = (int)(tid % g.nchunks);
-    const int ch = (int)(tid / g.nchunks);
+    const bool live = tid < nseq;
+    const int k = live ? (int)(tid % g.nchunks) : 0;
+    const int ch = live ? (int)(tid / g.nchunks) : 0;
     double acc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    const int K = k < g.kterms ? k : g.kterms;
-    for (int j = K; j >= 1; --j) {  // smallest terms first
-        const double* vp = v + ((int64_t)ch * g.nchunks + (k - j)) * D;
-        const double* m = mpow + (int64_t)(j - 1) * D * D;
-        double vv[D];
+    for (int j = g.kterms; j >= 1; --j) {  // smallest terms first
+        __syncthreads();
+        if ((int)threadIdx.x < D * D) mj[threadIdx.x] = mpow[(int64_t)(j - 1) * D * D + threadIdx.x];
+        __syncthreads();
+        if (live && j <= k) {
+            const double* vp = v + ((int64_t)ch * g.nchunks + (k - j)) * D;
+            double vv[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) vv[d] = vp[d];
+            for (int d = 0; d < D; ++d) vv[d] = vp[d];
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-            double a = acc[r];
+            for (int r = 0; r < D; ++r) {
+                double a = acc[r];
 #pragma unroll
-            for (int d = 0; d < D; ++d) a += m[r * D + d] * vv[d];
-            acc[r] = a;
+                for (int d = 0; d < D; ++d) a += mj[r * D + d] * vv[d];
+                acc[r] = a;
+            }
         }
     }
-    double* sp = s0 + ((int64_t)ch * g.nchunks + k) * D;
+    if (live) {
+        double* sp = s0 + ((int64_t)ch * g.nchunks + k) * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) sp[d] = acc[d];
-}
-
-template <int NS, typename T>
-__global__ __launch_bounds__(kBlock) void k_sos_apply(const T* __restrict__ x,
-                                                      const double* __restrict__ s0, SosGeom g,
-                                                      SosCoefs cf, T* __restrict__ y) {
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    if (tid >= nseq) return;
-    const int k = (int)(tid % g.nchunks);
-    const int ch = (int)(tid / g.nchunks);
-    const int64_t beg = (int64_t)k * g.chunk;
-    const int64_t end = beg + g.chunk < g.n ? beg + g.chunk : g.n;
-    const T* xp = x + (int64_t)ch * g.in_pitch;
-    T* yp = y + (int64_t)ch * g.out_pitch;
-    double s[2 * NS];
-    const double* sp = s0 + ((int64_t)ch * g.nchunks + k) * (2 * NS);
-#pragma unroll
-    for (int d = 0; d < 2 * NS; ++d) s[d] = (s0 != nullptr && k > 0) ? sp[d] : 0.0;
-    for (int64_t i = beg; i < end; ++i) {
-        const double yv = sos_step<NS>((double)xp[i], s, cf);
-        yp[i] = (T)(yv * cf.gain);
+        for (int d = 0; d < D; ++d) sp[d] = acc[d];
     }
 }
 
@@ -386,14 +440,14 @@ static void launch_sos_t(const void* x, void* y, double* v, double* s0, const do
     const int64_t nseq = (int64_t)g.nchunks * g.nch;
     if (g.nchunks > 1) {
         const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
-        hipLaunchKernelGGL((k_sos_state<NS, T>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, st, (const T*)x, g, cf, v);
+        hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, st, (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
         hipLaunchKernelGGL((k_sos_scan<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, st, v, mpow, g, s0);
     }
-    hipLaunchKernelGGL((k_sos_apply<NS, T>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, (const T*)x, g.nchunks > 1 ? s0 : nullptr, g, cf,
-                       (T*)y);
+    hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, (const T*)x, (T*)y, g.nchunks > 1 ? (const double*)s0 : nullptr,
+                       (double*)nullptr, g, cf);
 }
 
 template <typename T>

@@ -1248,9 +1248,15 @@ void Plan::process_stage(int sid) {
         g.n = need;
         g.nch = N.nch;
         const double tol = std::ldexp(1.0, -70);
+        // chunk length: as many sequences (chunks x channels) as the machine can hold; every
+        // pass is latency-bound per sequence, so shorter chunks win down to L = 64 (sweep on
+        // config 2: L=64 0.205 ms, 128 0.208, 256 0.293, 512 0.531)
         int64_t target = 262144 / std::max(1, N.nch);
         int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
         int64_t L = (need + nchunks - 1) / nchunks;
+        if (const char* ev = std::getenv("SIGOPS_SOS_CHUNK")) {  // tuning knob
+            L = std::max(32, std::atoi(ev));
+        }
         L = (L + 31) / 32 * 32;
         std::vector<std::vector<double>> mp;
         int K = 1;
