@@ -25,6 +25,11 @@ def build(force=False, verbose=True):
         o = os.path.join(HERE, s.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-x", "hip", "-c", os.path.join(HERE, s), "-o", o]
+        if s == "kernels.hip":
+            # MachineLICM hoists the fp64 polynomial constants of sin/cos out of the resampler's
+            # loader loop into VGPR pairs and then SPILLS them; every scratch reload waits
+            # vmcnt(0) and drains the LDS-DMA ring (measured: tile issue took a full transfer)
+            cmd[1:1] = ["-mllvm", "-disable-machine-licm"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

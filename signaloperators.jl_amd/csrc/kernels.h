@@ -14,8 +14,7 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
                      const RsGeom& g, hipStream_t st);
 // returns 0 when launched, -1 when no instantiation fits the geometry
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
-                             int dtype, const DCarrier* car, int ncar, const DOp* ops,
-                             const DLeaf* leaves, hipStream_t st);
+                             int dtype, const RsGlobalTables& gsrc, hipStream_t st);
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
                 int nparts, double* rms, hipStream_t st);
 }  // namespace so

@@ -112,6 +112,19 @@ __device__ __forceinline__ double ramp_eval(const DLeaf& L, int64_t n) {
     return L.mode == SO_RAMP_SINRAMP ? sinpi_c(0.5 * x) : x;
 }
 
+// One per-frame slot in closed form (DCarrier::slot_kind): the same arithmetic as the
+// interpreter's OP_CONST / OP_SCALAR / OP_FUNC / OP_RAMP, without the stack machine.
+__device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n) {
+    double v;
+    switch (kind & 0xff) {
+    case OP_CONST: v = L.v0; break;
+    case OP_SCALAR: v = *(const double*)L.base; break;
+    case OP_FUNC: v = func_eval(L, n); break;
+    default: v = ramp_eval(L, n); break;
+    }
+    return (kind & 0x100) ? (double)(float)v : v;
+}
+
 // ---------------------------------------------------------------------------
 // D-deep register stack machine over E elements per thread.  Program words are
 // wave-uniform (scalar loads); the stack lives in VGPRs (static indexing only).
@@ -546,11 +559,13 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 // ---------------------------------------------------------------------------
 // K3p: periodic polyphase resampler (rational L/M), persistent and software-pipelined.
 //
-// Tile = pt periods x ct channels = 64 rows, staged in LDS as fp64 (coalesced 16-byte
-// global reads, ~3 % halo).  One workgroup per CU loops over tiles with TWO LDS buffers
-// and wave specialisation: waves [0,ncompute) compute tile t from one buffer while the
-// remaining (loader) waves stage tile t+1 into the other; one __syncthreads per tile.
-// HBM streaming therefore never stops for the arithmetic.
+// Tile = pt periods x ct channels = 32 rows, staged in LDS as fp64 from a 128-byte aligned
+// global start (whole cache lines per LDS-DMA instruction, ~5 % halo).  One workgroup per CU
+// loops over tiles with a RING of nslots (3-4) LDS slots and wave specialisation: waves
+// [0,ncompute) compute tile i while the loader waves already have tiles i+1 .. i+nslots-2
+// in flight; the loaders retire a tile with a COUNTED s_waitcnt vmcnt(N) (N = the LDS-DMA
+// instructions this wave issued for younger tiles), so HBM reads never drain at a tile
+// boundary; one raw s_barrier per tile (cdna_hip_programming.md, 3-buffer glds span).
 //
 // Source: a list of *carriers* (sorted frame ranges).  A carrier is a planar array
 // x[c*cstride + n + df] plus up to 4 steps  v = v (op) F_k[n]  /  F_k[n] (op) v  whose F_k
@@ -559,8 +574,8 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 // Amplify/Mix/Ramp chains over one array without ever materialising them; anything more
 // general is materialised by K1 first and arrives as a 0-step carrier.
 //
-// Compute: for a group of 16 consecutive outputs of the period, the 64 rows x 16 outputs
-// block is the product  Y[64 x 16] = X[64 x kw] * Tap[kw x 16]  (X = the rows' input
+// Compute: for a group of 16 consecutive outputs of the period, the 32 rows x 16 outputs
+// block is the product  Y[32 x 16] = X[32 x kw] * Tap[kw x 16]  (X = the rows' input
 // windows, Tap = the group's combined taps h + alpha*dh, zero outside each output's
 // support).  It is evaluated with v_mfma_f64_16x16x4_f64 used purely as a register-blocking
 // device: each lane supplies ONE input sample (one ds_read_b64) and ONE tap (a register,
@@ -573,12 +588,22 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 // Operand maps (cdna_hip_programming.md §3): A[l&15][k=l>>4], B[k=l>>4][l&15],
 // D: col = l&15, row = (l>>4) + 4*reg.
 typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kRsRows = 32;  // rows per tile = 2 MFMA row-tiles
+constexpr int kRsQ = kRsRows / 16;
 
 // v = v (op) F_k  chain of a carrier on a CT x V register block (wave-uniform control flow)
-template <int CT, int V>
-__device__ __forceinline__ void carrier_apply(const DCarrier& C, const double (&F)[kMaxFrameSlots][V],
+// (CarT: DCarrier in memory, or StepTab in registers -- hence the fully unrolled, guarded loop:
+//  register arrays must be indexed statically)
+struct StepTab {
+    int nsteps;
+    int op[4], arg[4];
+};
+template <int CT, int V, typename CarT>
+__device__ __forceinline__ void carrier_apply(const CarT& C, const double (&F)[kMaxFrameSlots][V],
                                               double (&val)[CT][V], bool to_f32) {
-    for (int i = 0; i < C.nsteps; ++i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= C.nsteps) break;
         const int op = C.op[i], arg = C.arg[i], slot = arg & 0xff;
         const bool flip = arg & 0x100, r32 = arg & 0x200;
 #pragma unroll
@@ -610,201 +635,469 @@ __device__ __forceinline__ void carrier_apply(const DCarrier& C, const double (&
     }
 }
 
-// 16-byte-per-lane asynchronous global -> LDS copy (global_load_lds_dwordx4): the wave
-// writes 1 KiB contiguously at the wave-uniform LDS address `l`; no VGPR staging, so a few
-// loader waves keep the whole tile in flight.
-__device__ __forceinline__ void dma16(const void* g, double* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// LDS accesses the compiler must not see (it cannot tell them from the LDS-DMA destinations
+// in flight and would wait vmcnt(0)); the caller orders them with explicit waits.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const double* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)p;
+}
+__device__ __forceinline__ v2d lds_ld16(uint32_t a) {
+    v2d v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st16(uint32_t a, v2d v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(v2d (&v)[N]) {  // results of lds_ld16 are valid after this
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
 }
 
-// Stage one input tile (CT channels x tile_len frames from global frame xbase) into an LDS
-// buffer as fp64, zero-padded outside [0,n_in) (Pad(x.signal,zero), reference
-// src/filters.jl:240).  Thread = one 16-byte vector of V frames, all CT channels: CT
-// independent vector loads in flight per thread.  Vectors that straddle a carrier or signal
-// edge (or unaligned carriers) are processed one frame at a time through the same code.
+// 16-byte-per-lane asynchronous global -> LDS copy (global_load_lds_dwordx4): the wave
+// writes 1 KiB contiguously at the wave-uniform LDS address `l`; no VGPR staging, so a few
+// loader waves keep whole tiles in flight.
+// Issued from inline asm on purpose: with the builtin, hipcc knows an LDS write is pending on
+// the VM counter and puts s_waitcnt vmcnt(0) in front of later LDS reads it cannot prove
+// disjoint (even reads of an unrelated __shared__ object were hit), which drains the ring of
+// tiles in flight.  Hidden from the compiler, the only waits are the counted ones below; its
+// own vmcnt(N) for ordinary loads only get stricter (in-order return), never wrong.
+__device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "s"(lds_byte_addr), "v"(g)
+                 : "memory", "m0");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate).
+// Rounding n DOWN is always safe (a stricter wait).
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define SO_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 24 ? 24 : n)) {
+        SO_W(0) SO_W(1) SO_W(2) SO_W(3) SO_W(4) SO_W(5) SO_W(6) SO_W(7) SO_W(8) SO_W(9) SO_W(10)
+        SO_W(11) SO_W(12) SO_W(13) SO_W(14) SO_W(15) SO_W(16) SO_W(17) SO_W(18) SO_W(19) SO_W(20)
+        SO_W(21) SO_W(22) SO_W(23) SO_W(24)
+    }
+#undef SO_W
+}
+
+// cycle stamp of workgroup 0 (tuning aid, SIGOPS_RS_TRACE)
+__device__ __forceinline__ void rs_stamp(const RsPeriodic& g, int wave, int it, int k) {
+    if (g.trace != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it < kRsTraceIters)
+        g.trace[(wave * kRsTraceIters + it) * kRsTraceStamps + k] = clock64();
+}
+
+__device__ __forceinline__ int64_t rfl64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Is the wave's chunk of 64 consecutive 16-byte vectors [gf,gl) a plain copy out of one fp64
+// array carrier (so it can go by LDS-DMA)?  `cu` returns the carrier.  Pure function of the
+// chunk position: the issue pass and the modify pass must agree on it.
+__device__ __forceinline__ bool rs_dma_chunk(const RsPeriodic& g, const RsCtl& ctl, int64_t gf,
+                                             int64_t gl, int& cu) {
+    const DCarrier* car = ctl.car;
+    const int ncar = ctl.ncar;
+    cu = 0;
+    while (cu + 1 < ncar && car[cu].b <= gf) ++cu;  // carriers are sorted
+    const DCarrier& C = car[cu];
+    return !(g.pad & 8) && C.base != nullptr && C.vec_ok && C.dtype == SO_F64 && gf >= C.a &&
+           gl <= C.b && gf >= 0 && gl <= g.n_in && (((gf + C.df) & 1) == 0);
+}
+
+// In-place carrier steps on one lane's 16-byte vector of each of the CT channel rows of a
+// staged fp64 tile.  LDS access in asm: a compiler-visible ds_read of an LDS-DMA destination
+// could be ordered behind vmcnt(0); the caller's counted wait is the real ordering.
+template <int CT, typename CarT>
+__device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT& C,
+                                          const double (&F)[kMaxFrameSlots][2]) {
+    v2d raw[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * 8u);
+    lds_wait(raw);
+    double val[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        val[c][0] = raw[c][0];
+        val[c][1] = raw[c][1];
+    }
+    carrier_apply<CT, 2>(C, F, val, false);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        v2d v;
+        v[0] = val[c][0];
+        v[1] = val[c][1];
+        lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, v);
+    }
+}
+
+// Slow path of the staging (tile edges, f32 sources, generated pieces, unaligned arrays): one
+// 16-byte vector per lane, load -> carrier steps -> LDS store, synchronously.  Deliberately NOT
+// inlined: it holds the frame interpreter and a CT x V register block, and inlining it made the
+// loader's hot loop spill to scratch -- a scratch reload waits vmcnt(0), i.e. drains every
+// LDS-DMA in flight (measured: the issue pass took as long as a whole tile transfer).
 template <typename T, int CT>
-__device__ __forceinline__ void stage_tile(const RsPeriodic& g, int64_t xbase, int c0,
-                                           double* __restrict__ buf,
-                                           const DCarrier* __restrict__ car, int ncar,
-                                           const DOp* __restrict__ ops,
-                                           const DLeaf* __restrict__ leaves, int tid, int nthr) {
+__device__ __attribute__((noinline)) void stage_generic(int64_t n_in, int lds_pitch,
+                                                        const DCarrier* __restrict__ car, int ncar,
+                                                        const DOp* __restrict__ ops,
+                                                        const DLeaf* __restrict__ leaves,
+                                                        int64_t gi, int iv, int ci, int c0,
+                                                        double* __restrict__ buf) {
+    struct { int64_t n_in; int lds_pitch; } g{n_in, lds_pitch};
     constexpr int V = 16 / sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(V)));
-    const int nvec = (g.tile_len + V - 1) / V;  // lds_pitch leaves room for the round-up
-    int ci = 0;
-    {  // first carrier whose end is beyond the tile start (carriers are sorted)
-        int a = 0, b = ncar - 1;
-        const int64_t lo = xbase > 0 ? xbase : 0;
-        while (a < b) {
-            int mid = (a + b) >> 1;
-            if (car[mid].b > lo) b = mid;
-            else a = mid + 1;
+    int cj = ci;
+    while (cj + 1 < ncar && car[cj].b <= gi) ++cj;  // mostly 0 iterations
+    // (a carrier without an array -- base == nullptr -- is a purely generated piece)
+    const bool vec = gi >= car[cj].a && gi + V <= car[cj].b && gi >= 0 && gi + V <= g.n_in &&
+                     (car[cj].base == nullptr ||
+                      (car[cj].vec_ok && (((gi + car[cj].df) % V) == 0) &&
+                       car[cj].dtype == (sizeof(T) == 4 ? SO_F32 : SO_F64)));
+    const int nsub = vec ? 1 : V;
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int64_t g0 = gi + sub;  // first (vec) or only (scalar) frame of this pass
+        int ck = cj;
+        while (ck + 1 < ncar && car[ck].b <= g0) ++ck;
+        const DCarrier& C = car[ck];
+        const bool ok = vec || (g0 >= 0 && g0 < g.n_in && g0 >= C.a && g0 < C.b);
+        // ---- per-frame values first (keeps the interpreter's registers dead while
+        //      the CT loads are in flight) ----
+        const bool steps = ok && C.nsteps > 0;
+        double F[kMaxFrameSlots][V];
+#pragma unroll
+        for (int k = 0; k < kMaxFrameSlots; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) F[k][e] = 0.0;
+        if (steps && C.frame_len > 0) {
+            int64_t nn[V];
+            double fo[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) nn[e] = vec ? g0 + e : g0;
+            run_program<V, false, 2, true>(ops, C.frame_pc, C.frame_len, leaves, nn, c0, F, fo);
         }
-        ci = a;
+        // ---- loads (CT independent loads in flight) ----
+        double val[CT][V];
+        if (C.base == nullptr) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < V; ++e) val[c][e] = 0.0;
+        } else if (vec) {
+            const T* xp = (const T*)C.base + (int64_t)c0 * C.cstride + g0 + C.df;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const vecT v = *reinterpret_cast<const vecT*>(xp + (int64_t)c * C.cstride);
+#pragma unroll
+                for (int e = 0; e < V; ++e) val[c][e] = (double)v[e];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                double xv = 0.0;
+                if (ok) {
+                    const int64_t off = (int64_t)(c0 + c) * C.cstride + g0 + C.df;
+                    xv = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
+                                           : ((const double*)C.base)[off];
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) val[c][e] = xv;
+            }
+        }
+        // ---- steps ----
+        if (steps) carrier_apply<CT, V>(C, F, val, sizeof(T) == 4);
+        // ---- LDS stores ----
+        if (vec) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < V; ++e) buf[c * g.lds_pitch + iv * V + e] = val[c][e];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) buf[c * g.lds_pitch + iv * V + sub] = val[c][0];
+        }
     }
-    for (int iv = tid; iv < nvec; iv += nthr) {
+}
+
+// Stage one input tile (CT channels x nfr frames from global frame xbase) into an LDS slot
+// as fp64, zero-padded outside [0,n_in) (Pad(x.signal,zero), reference src/filters.jl:240).
+//   PASS 0 (issue):  per wave-chunk of 64 vectors either fire CT LDS-DMA instructions (fp64
+//                    array carrier; returns how many were issued) or, for anything else
+//                    (edges, f32, generated pieces), load -> steps -> LDS store right away.
+//   PASS 1 (modify): after the wave's own DMA of this tile has landed (`allowed` = DMA
+//                    instructions it issued for younger tiles), apply the carrier steps in
+//                    place to exactly the chunks it copied.
+template <typename T, int CT, int PASS>
+__device__ __forceinline__ int stage_tile(const RsPeriodic& g, int64_t xbase, int nfr, int c0,
+                                          double* __restrict__ buf, const RsCtl& ctl,
+                                          const RsGlobalTables& gsrc, int tid, int nthr, int allowed) {
+    const DCarrier* car = ctl.car;
+    const int ncar = ctl.ncar;
+    const DOp* ops = ctl.ops;
+    const DLeaf* leaves = ctl.leaves;
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    const int nvec = (nfr + V - 1) / V;  // lds_pitch leaves room for the round-up
+    int ndma = 0;
+    bool waited = false;
+    const int ci = 0;  // (<= kCtlCar carriers: the slow path scans from the first)
+    // wave-uniform loop over chunks of 64 vectors; lane l owns vector ivb + l
+    const int lane = tid & 63;
+    for (int ivb = __builtin_amdgcn_readfirstlane(tid - lane); ivb < nvec; ivb += nthr) {
+        const int iv = ivb + lane;
+        const bool act = iv < nvec;
         const int64_t gi = xbase + (int64_t)iv * V;
         if constexpr (sizeof(T) == 8) {
-            // fp64 fast path: a wave's 64 consecutive vectors (128 frames) lie inside one
-            // array carrier -> asynchronous DMA of all CT channel rows, then (if the carrier
-            // has steps) the same wave modifies what it copied in place.
-            const int ivb = __builtin_amdgcn_readfirstlane(iv - (tid & 63));
-            if (!(g.pad & 8)) {
-                // (a partial last chunk is fine: inactive lanes of an exec-masked
-                //  global_load_lds write nothing -- verified on gfx950; without this the
-                //  partial chunk took the slow generic path: 1.45 -> 1.18 ms on config 3)
-                const int nact = nvec - ivb < 64 ? nvec - ivb : 64;
-                const int64_t gf = xbase + (int64_t)ivb * V, gl = gf + (int64_t)nact * V;
-                int cu = ci;
-                while (cu + 1 < ncar && car[cu].b <= gf) ++cu;
+            // fp64 fast path: a wave's 64 consecutive vectors (128 frames; fewer in the
+            // exec-masked last chunk -- inactive lanes of a global_load_lds write nothing)
+            // lie inside one array carrier -> asynchronous DMA of all CT channel rows.
+            const int nact = nvec - ivb < 64 ? nvec - ivb : 64;
+            const int64_t gf = xbase + (int64_t)ivb * V, gl = gf + (int64_t)nact * V;
+            int cu;
+            if (rs_dma_chunk(g, ctl, gf, gl, cu)) {
                 const DCarrier& C = car[cu];
-                if (C.base != nullptr && C.vec_ok && C.dtype == SO_F64 && gf >= C.a && gl <= C.b &&
-                    gf >= 0 && gl <= g.n_in && (((gf + C.df) % V) == 0)) {
-                    const double* src = (const double*)C.base + (int64_t)c0 * C.cstride + gi + C.df;
+                if constexpr (PASS == 0) {
+                    const int64_t cs = C.cstride;
+                    const double* src = (const double*)C.base + ((int64_t)c0 * cs + C.df) + gi;
+                    if (act) {
+                        const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr(buf + ivb * V));
 #pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        dma16(src + (int64_t)c * C.cstride, buf + c * g.lds_pitch + ivb * V);
-                    if (C.nsteps > 0) {
-                        double F[kMaxFrameSlots][V];
+                        for (int c = 0; c < CT; ++c)
+                            dma16(src + (int64_t)c * cs,
+                                  __builtin_amdgcn_readfirstlane(la + (uint32_t)(c * g.lds_pitch) * 8u));
+                    }
+                    ndma += CT;
+                } else if (C.nsteps > 0 && !(g.pad & 32)) {
+                    double F[kMaxFrameSlots][V];
 #pragma unroll
-                        for (int k = 0; k < kMaxFrameSlots; ++k)
+                    for (int k = 0; k < kMaxFrameSlots; ++k)
 #pragma unroll
-                            for (int e = 0; e < V; ++e) F[k][e] = 0.0;
-                        if (C.frame_len > 0) {
-                            int64_t nn[V];
-                            double fo[V];
+                        for (int e = 0; e < V; ++e) F[k][e] = 0.0;
+                    if (!(g.pad & 64)) {
+                        for (int k = 0; k < C.nslots; ++k) {
+                            const DLeaf& L = leaves[C.slot_leaf[k]];
+                            const int kind = C.slot_kind[k];
 #pragma unroll
-                            for (int e = 0; e < V; ++e) nn[e] = gi + e;
-                            run_program<V, false, 2, true>(ops, C.frame_pc, C.frame_len, leaves, nn, c0, F, fo);
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed in LDS
-                        double val[CT][V];
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            const double2 v = *reinterpret_cast<const double2*>(buf + c * g.lds_pitch + iv * V);
-                            val[c][0] = v.x;
-                            val[c][1] = v.y;
-                        }
-                        carrier_apply<CT, V>(C, F, val, false);
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            double2 v;
-                            v.x = val[c][0];
-                            v.y = val[c][1];
-                            *reinterpret_cast<double2*>(buf + c * g.lds_pitch + iv * V) = v;
+                            for (int e = 0; e < V; ++e) {
+                                const double v = slot_eval(kind, L, gi + e);
+                                switch (k) {
+                                case 0: F[0][e] = v; break;
+                                case 1: F[1][e] = v; break;
+                                case 2: F[2][e] = v; break;
+                                default: F[3][e] = v; break;
+                                }
+                            }
                         }
                     }
-                    continue;
-                }
-            }
-        }
-        int cj = ci;
-        while (cj + 1 < ncar && car[cj].b <= gi) ++cj;  // mostly 0 iterations
-        // (a carrier without an array -- base == nullptr -- is a purely generated piece)
-        const bool vec = gi >= car[cj].a && gi + V <= car[cj].b && gi >= 0 && gi + V <= g.n_in &&
-                         (car[cj].base == nullptr ||
-                          (car[cj].vec_ok && (((gi + car[cj].df) % V) == 0) &&
-                           car[cj].dtype == (sizeof(T) == 4 ? SO_F32 : SO_F64)));
-        const int nsub = vec ? 1 : V;
-#pragma unroll 1
-        for (int sub = 0; sub < nsub; ++sub) {
-            const int64_t g0 = gi + sub;  // first (vec) or only (scalar) frame of this pass
-            int ck = cj;
-            while (ck + 1 < ncar && car[ck].b <= g0) ++ck;
-            const DCarrier& C = car[ck];
-            const bool ok = vec || (g0 >= 0 && g0 < g.n_in && g0 >= C.a && g0 < C.b);
-            // ---- per-frame values first (keeps the interpreter's registers dead while the
-            //      CT loads are in flight) ----
-            const bool steps = ok && C.nsteps > 0;
-            double F[kMaxFrameSlots][V];
-#pragma unroll
-            for (int k = 0; k < kMaxFrameSlots; ++k)
-#pragma unroll
-                for (int e = 0; e < V; ++e) F[k][e] = 0.0;
-            if (steps && C.frame_len > 0) {
-                int64_t nn[V];
-                double fo[V];
-#pragma unroll
-                for (int e = 0; e < V; ++e) nn[e] = vec ? g0 + e : g0;
-                run_program<V, false, 2, true>(ops, C.frame_pc, C.frame_len, leaves, nn, c0, F, fo);
-            }
-            // ---- loads (CT independent loads in flight) ----
-            double val[CT][V];
-            if (C.base == nullptr) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-#pragma unroll
-                    for (int e = 0; e < V; ++e) val[c][e] = 0.0;
-            } else if (vec) {
-                const T* xp = (const T*)C.base + (int64_t)c0 * C.cstride + g0 + C.df;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const vecT v = *reinterpret_cast<const vecT*>(xp + (int64_t)c * C.cstride);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) val[c][e] = (double)v[e];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    double xv = 0.0;
-                    if (ok) {
-                        const int64_t off = (int64_t)(c0 + c) * C.cstride + g0 + C.df;
-                        xv = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
-                                               : ((const double*)C.base)[off];
+                    if (!waited) {  // this tile's DMA landed in LDS
+                        wait_vmcnt_le(allowed);
+                        waited = true;
                     }
-#pragma unroll
-                    for (int e = 0; e < V; ++e) val[c][e] = xv;
+                    if (act) rmw_chunk<CT>(lds_addr(buf + iv * V), g.lds_pitch, C, F);
                 }
-            }
-            // ---- steps ----
-            if (steps) carrier_apply<CT, V>(C, F, val, sizeof(T) == 4);
-            // ---- LDS stores ----
-            if (vec) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-#pragma unroll
-                    for (int e = 0; e < V; ++e) buf[c * g.lds_pitch + iv * V + e] = val[c][e];
-            } else {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) buf[c * g.lds_pitch + iv * V + sub] = val[c][0];
+                continue;
             }
         }
+        if constexpr (PASS == 0)
+            if (act) stage_generic<T, CT>(g.n_in, g.lds_pitch, gsrc.car, ctl.ncar, gsrc.ops, gsrc.leaves, gi, iv, ci, c0, buf);
     }
+    if constexpr (PASS == 1) {
+        if (!waited) wait_vmcnt_le(allowed);
+    }
+    return ndma;
 }
 
 template <typename T, int CT, int KS, int G>
-__global__ __launch_bounds__(1024) void k_resample_periodic(const double* __restrict__ tab,
-                                                              const int* __restrict__ jend,
-                                                              RsPeriodic g, T* __restrict__ y,
-                                                              const DCarrier* __restrict__ car,
-                                                              int ncar,
-                                                              const DOp* __restrict__ ops,
-                                                              const DLeaf* __restrict__ leaves) {
+__global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
+    const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, T* __restrict__ y,
+    RsGlobalTables gsrc) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int nc = g.ncompute;
+    const int S = g.nslots;
     const int bufsz = CT * g.lds_pitch;
     const int64_t ntx = (g.nperiods + g.pt - 1) / g.pt;
-    const int64_t ntiles = ntx * (g.nch / CT);
-    int64_t t = blockIdx.x;
+    const int64_t stride = gridDim.x;
+    // Control block (carriers, slot leaves) -> LDS once per workgroup: the loader waves must not
+    // depend on global / kernarg loads inside the tile loop (they queue behind the HBM stream;
+    // measured ~1000 cycles per dependent scalar load while the chip streams).
+    // (A separate __shared__ object, not part of the dynamic ring: hipcc orders every LDS read
+    //  that may alias an LDS-DMA destination behind s_waitcnt vmcnt(0), which would drain the
+    //  ring at each control read.)
+    __shared__ RsCtl sctl;
+    {
+        const int* src = reinterpret_cast<const int*>(gsrc.ctl);
+        int* dst = reinterpret_cast<int*>(&sctl);
+        for (int i = threadIdx.x; i < (int)(sizeof(RsCtl) / 4); i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const RsCtl& ctl = sctl;
+    // Tile `it` of this workgroup is tile  t = blockIdx.x + it*gridDim.x  = (tc, tx): channel group
+    // tc = t / ntx, x-tile tx = t % ntx.  Both roles step (tc, tx) and the tile's first input
+    // frame xb incrementally -- one 64-bit division per kernel, not per tile (the loader's
+    // per-tile control code is on the critical path: a single wave retires roughly one
+    // instruction per 5 cycles).  The tile is staged from the 128-byte aligned frame below xb.
+    const int64_t ptM = (int64_t)g.pt * g.M;
+    const int64_t dq = stride / ntx, dr = stride % ntx;
+    const int64_t ngrp = g.nch / CT;
+    struct TilePos {
+        int64_t tc, tx, xb;
+    };
+    auto tile_first = [&]() {
+        TilePos p;
+        p.tc = (int64_t)blockIdx.x / ntx;
+        p.tx = (int64_t)blockIdx.x % ntx;
+        p.xb = p.tx * ptM + g.jlo;
+        return p;
+    };
+    auto tile_next = [&](TilePos& p) {
+        p.tc += dq;
+        p.tx += dr;
+        p.xb += dr * ptM;
+        if (p.tx >= ntx) {
+            p.tx -= ntx;
+            p.xb -= ntx * ptM;
+            ++p.tc;
+        }
+    };
     // The two roles run separate loops with the same number of workgroup barriers (whole
     // waves take one branch), so their register live ranges do not overlap.
     if (wave >= nc) {
-        // ---- loader waves: stage tile `it` while the compute waves work on tile it-1 ----
+        // ---- loader waves ----
         const int ltid = (int)threadIdx.x - nc * 64, lthr = (nwaves - nc) * 64;
+        const int llane = ltid & 63;
+        const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
+        // fast tiles: one fp64 array carrier covers the whole staged range -> straight-line DMA
+        // issue with the carrier's facts in scalar registers (read from the LDS control block
+        // once), no per-chunk carrier logic
+        const DCarrier& C0 = ctl.car[0];
+        const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
+        const double* base0 = (const double*)rfl64((int64_t)(uintptr_t)C0.base);
+        const int nsteps0 = __builtin_amdgcn_readfirstlane(C0.nsteps);
+        // (tiles inside carrier 0 -- normally all but the signal's edges -- see nothing of the
+        //  other carriers, e.g. the generated tail of an infinite Amplify)
+        const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) &&
+                            !(df0 & 1) && !(g.pad & 8) && sizeof(T) == 8;
+        StepTab st0;  // carrier 0's steps and slot recipes, in registers
+        int sk0[4], sl0[4];
+        st0.nsteps = nsteps0;
+        const int nslots0 = __builtin_amdgcn_readfirstlane(C0.nslots);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st0.op[k] = __builtin_amdgcn_readfirstlane(C0.op[k]);
+            st0.arg[k] = __builtin_amdgcn_readfirstlane(C0.arg[k]);
+            sk0[k] = __builtin_amdgcn_readfirstlane(C0.slot_kind[k]);
+            sl0[k] = __builtin_amdgcn_readfirstlane(C0.slot_leaf[k]);
+        }
+        const int64_t lo_ok = a0 > 0 ? a0 : 0;
+        const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
         // Loader waves issue a handful of instructions and then sleep on memory; without a
         // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
         // and the loads only go out once the arithmetic is over (measured: phases add up).
         if (!(g.pad & 16)) __builtin_amdgcn_s_setprio(3);
-        for (int it = 0; t - gridDim.x < ntiles; t += gridDim.x, ++it) {
-            if (t < ntiles && !((g.pad & 2) && it > 0))
-                stage_tile<T, CT>(g, (t % ntx) * g.pt * g.M + g.jlo, (int)(t / ntx) * CT,
-                                  lds + (it & 1) * bufsz, car, ncar, ops, leaves, ltid, lthr);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // copies + in-place steps done
-            __builtin_amdgcn_s_barrier();
+        const int A = S - 2;  // tiles in flight beyond the one being retired
+        int cnt0 = 0, cnt1 = 0;  // DMA instructions of the youngest / second youngest issued tile
+        auto is_fast = [&](const TilePos& p, int64_t& xa, int& nfr) {
+            const int sh = (int)(p.xb & 15);
+            xa = p.xb - sh;
+            nfr = g.tile_len + sh;
+            return single && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
+        };
+        auto issue = [&](const TilePos& p, int slot, int tr_it) {
+            int n = 0;
+            if (p.tc < ngrp && !((g.pad & 2) && tr_it != kRsTraceIters)) {
+                int64_t xa;
+                int nfr;
+                const int c0 = (int)p.tc * CT;
+                rs_stamp(g, wave, tr_it, 4);
+                if (is_fast(p, xa, nfr)) {
+                    const int nvec = (nfr + 1) >> 1;
+                    const double* row = base0 + ((int64_t)c0 * cs0 + df0 + xa);
+                    const uint32_t lbase = __builtin_amdgcn_readfirstlane(lds_addr(lds + slot * bufsz));
+                    rs_stamp(g, wave, tr_it, 5);
+                    for (int ivb = lw64; ivb < nvec; ivb += lthr) {
+                        if (ivb + llane < nvec) {
+                            const double* src = row + 2 * (ivb + llane);
+#pragma unroll
+                            for (int c = 0; c < CT; ++c)
+                                dma16(src + (int64_t)c * cs0,
+                                      __builtin_amdgcn_readfirstlane(lbase + (uint32_t)(c * g.lds_pitch + 2 * ivb) * 8u));
+                        }
+                        n += CT;
+                    }
+                    rs_stamp(g, wave, tr_it, 6);
+                } else {
+                    n = stage_tile<T, CT, 0>(g, xa, nfr, c0, lds + slot * bufsz, ctl, gsrc, ltid, lthr, 0);
+                }
+            }
+            cnt1 = cnt0;
+            cnt0 = n;
+        };
+        TilePos pn = tile_first();  // next tile to issue
+        int sn = 0;                 // ... and its slot
+        for (int k = 0; k <= A; ++k) {
+            issue(pn, sn, kRsTraceIters);
+            tile_next(pn);
+            sn = sn + 1 == S ? 0 : sn + 1;
+        }
+        TilePos pr = tile_first();  // tile being retired
+        int sr = 0;                 // ... and its slot
+        for (int it = 0;; ++it) {
+            const int allowed = A >= 2 ? cnt0 + cnt1 : (A == 1 ? cnt0 : 0);
+            const bool live = pr.tc < ngrp;
+            rs_stamp(g, wave, it, 0);
+            int64_t xa;
+            int nfr;
+            const bool fast = is_fast(pr, xa, nfr);
+            if (live && !((g.pad & 2) && it > 0) && !fast) {
+                stage_tile<T, CT, 1>(g, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz, ctl, gsrc, ltid,
+                                     lthr, allowed);
+            } else if (live && fast && nsteps0 > 0 && !(g.pad & 32)) {
+                // carrier 0's steps in place on the chunks this wave copied
+                const int nvec = (nfr + 1) >> 1;
+                const uint32_t lbase = lds_addr(lds + sr * bufsz);
+                bool waited = false;
+                for (int ivb = lw64; ivb < nvec; ivb += lthr) {
+                    const int iv = ivb + llane;
+                    const int64_t gi = xa + 2 * (int64_t)iv;
+                    double F[kMaxFrameSlots][2];
+#pragma unroll
+                    for (int k = 0; k < kMaxFrameSlots; ++k) {
+                        F[k][0] = 0.0;
+                        F[k][1] = 0.0;
+                        if (k < nslots0 && !(g.pad & 64)) {
+                            const DLeaf L = ctl.leaves[sl0[k]];
+                            F[k][0] = slot_eval(sk0[k], L, gi);
+                            F[k][1] = slot_eval(sk0[k], L, gi + 1);
+                        }
+                    }
+                    if (!waited) {  // this tile's DMA landed in LDS
+                        wait_vmcnt_le(allowed);
+                        waited = true;
+                    }
+                    if (iv < nvec) rmw_chunk<CT>(lbase + (uint32_t)iv * 16u, g.lds_pitch, st0, F);
+                }
+                if (!waited) wait_vmcnt_le(allowed);
+            } else {
+                wait_vmcnt_le(allowed);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS stores / in-place steps done
+            rs_stamp(g, wave, it, 1);
+            __builtin_amdgcn_s_barrier();  // publishes this tile; the slot of the previous one is free
+            rs_stamp(g, wave, it, 2);
+            if (!live) break;  // (the compute waves' last barrier)
+            issue(pn, sn, it);
+            rs_stamp(g, wave, it, 3);
+            tile_next(pn);
+            tile_next(pr);
+            sn = sn + 1 == S ? 0 : sn + 1;
+            sr = sr + 1 == S ? 0 : sr + 1;
         }
         return;
     }
@@ -813,121 +1106,147 @@ __global__ __launch_bounds__(1024) void k_resample_periodic(const double* __rest
     const int ptmask = g.pt - 1, ptshift = g.ptshift;  // pt is a power of two
     const int gbeg = wave * G;
     double breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
-    int rowoff[4];
+    int rowoff[kRsQ];
 #pragma unroll
     for (int gg = 0; gg < G; ++gg)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             breg[gg][s] = gbeg + gg < g.ngroups ? tab[((size_t)(gbeg + gg) * KS + s) * 64 + lane] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kRsQ; ++q) {
         const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
         rowoff[q] = (rho >> ptshift) * g.lds_pitch + (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
     }
+    int jeg[G];  // newest input of each group's window
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) jeg[gg] = gbeg + gg < g.ngroups ? jend[gbeg + gg] : 0;
+    // output offsets of this lane's 4 accumulator rows per row-tile, relative to the tile's
+    // (channel c0, period P0) origin
+    int64_t yoff[kRsQ][4];
+#pragma unroll
+    for (int q = 0; q < kRsQ; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
+            yoff[q][i] = (int64_t)(rho >> ptshift) * g.out_pitch + (int64_t)(rho & ptmask) * g.L + n16;
+        }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // taps loaded
-    __builtin_amdgcn_s_barrier();  // tile 0 staged (loader iteration 0)
-    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
-        const double* __restrict__ cur = lds + (it & 1) * bufsz;
-        const int64_t P0 = (t % ntx) * g.pt;
-        const int c0 = (int)(t / ntx) * CT;
+    __builtin_amdgcn_s_barrier();  // tile 0 staged
+    int slot = 0, it = 0;
+    for (TilePos p = tile_first(); p.tc < ngrp; tile_next(p), ++it) {
+        rs_stamp(g, wave, it, 0);
+        const int sh = (int)(p.xb & 15);
+        const double* __restrict__ cur = lds + slot * bufsz + sh;
+        const int64_t P0 = p.tx * g.pt;
+        const int c0 = (int)p.tc * CT;
+        T* __restrict__ ytile = y + ((int64_t)c0 * g.out_pitch + P0 * g.L);
+        // interior tile: every row's period is complete -> no per-element bounds checks
+        const bool interior = P0 + g.pt <= g.nperiods && (P0 + g.pt) * g.L <= g.n_out;
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
             const int gi = gbeg + gg;
             if (gi < g.ngroups && !(g.pad & 1)) {
-                const int je = jend[gi];
-                v4d acc[4];
+                const int je = jeg[gg];
+                v4d acc[kRsQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < kRsQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
                 // A operands are software-pipelined one k-step ahead (double-buffered
-                // registers) so the LDS latency hides under the previous step's 4 MFMAs; the
-                // per-step address is an immediate offset from 4 fixed row pointers.
-                const double* __restrict__ ap[4];
+                // registers) so the LDS latency hides under the previous step's MFMAs; the
+                // per-step address is an immediate offset from fixed row pointers.
+                const double* __restrict__ ap[kRsQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ap[q] = cur + (rowoff[q] + je);
-                double abuf[2][4];
+                for (int q = 0; q < kRsQ; ++q) ap[q] = cur + (rowoff[q] + je);
+                double abuf[2][kRsQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) abuf[0][q] = ap[q][0];
+                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = ap[q][0];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s + 1 < KS) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) abuf[(s + 1) & 1][q] = ap[q][4 * (s + 1)];
+                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = ap[q][4 * (s + 1)];
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < kRsQ; ++q)
                         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
                 }
                 const int r = gi * 16 + n16;  // output index inside the period
+                if (g.pad & 4) continue;
+                if (interior && gi * 16 + 16 <= g.L) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < kRsQ; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
-                        const int64_t period = P0 + (rho & ptmask);
-                        const int64_t m = period * g.L + r;
-                        if (period < g.nperiods && r < g.L && m < g.n_out && !(g.pad & 4))
-                            y[(int64_t)(c0 + (rho >> ptshift)) * g.out_pitch + m] = (T)acc[q][i];
-                    }
+                        for (int i = 0; i < 4; ++i) ytile[yoff[q][i] + gi * 16] = (T)acc[q][i];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kRsQ; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rho = 16 * q + kq + 4 * i;
+                            const int64_t period = P0 + (rho & ptmask);
+                            const int64_t m = period * g.L + r;
+                            if (period < g.nperiods && r < g.L && m < g.n_out)
+                                ytile[yoff[q][i] + gi * 16] = (T)acc[q][i];
+                        }
+                }
             }
         }
         // Raw barrier: __syncthreads() would also drain vmcnt(0), i.e. make the compute waves
         // wait for their output stores every tile.  The LDS reads of this tile were consumed
         // by the MFMAs above, so only lgkmcnt matters here; stores stay in flight.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // loaders finished tile it+1; all finished reading tile it
+        rs_stamp(g, wave, it, 1);
+        __builtin_amdgcn_s_barrier();  // next tile published; all finished reading this one
+        rs_stamp(g, wave, it, 2);
+        slot = slot + 1 == S ? 0 : slot + 1;
     }
 }
 
 template <typename T, int CT, int KS, int G>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
-                        const DCarrier* car, int ncar, const DOp* ops, const DLeaf* leaves,
-                        hipStream_t st) {
+                        const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = (size_t)2 * CT * g.lds_pitch * sizeof(double);
+    size_t lds = (size_t)g.nslots * CT * g.lds_pitch * sizeof(double);  // + static sizeof(RsCtl)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
         attr_done = true;
     }
     hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G>), grid, dim3(64 * g.nwaves), lds, st, tab,
-                       jend, g, (T*)y, car, ncar, ops, leaves);
+                       jend, g, (T*)y, gsrc);
 }
 
 template <typename T, int CT>
 static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPeriodic& g,
-                        const DCarrier* car, int ncar, const DOp* ops, const DLeaf* leaves,
-                        hipStream_t st) {
+                        const RsGlobalTables& gsrc, hipStream_t st) {
     const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
 #define SO_RP(KS_, G_)                                                                   \
     if (g.kw == 4 * KS_ && gper == G_) {                                                  \
-        launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, car, ncar, ops, leaves, st);         \
+        launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, gsrc, st);             \
         return 0;                                                                         \
     }
-    SO_RP(12, 1) SO_RP(14, 1) SO_RP(16, 1) SO_RP(20, 1) SO_RP(28, 1) SO_RP(14, 2)
+    SO_RP(12, 1) SO_RP(14, 1) SO_RP(16, 1) SO_RP(20, 1) SO_RP(28, 1) SO_RP(14, 2) SO_RP(14, 3)
 #undef SO_RP
     return -1;
 }
 
 // returns 0 when launched, -1 if no instantiation fits (caller falls back to k_resample)
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
-                             int dtype, const DCarrier* car, int ncar, const DOp* ops,
-                             const DLeaf* leaves, hipStream_t st) {
+                             int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
     if (dtype == SO_F32) {
         switch (g.ct) {
-        case 8: return launch_rp_ct<float, 8>(y, tab, jend, g, car, ncar, ops, leaves, st);
-        case 4: return launch_rp_ct<float, 4>(y, tab, jend, g, car, ncar, ops, leaves, st);
-        case 2: return launch_rp_ct<float, 2>(y, tab, jend, g, car, ncar, ops, leaves, st);
-        default: return launch_rp_ct<float, 1>(y, tab, jend, g, car, ncar, ops, leaves, st);
+        case 4: return launch_rp_ct<float, 4>(y, tab, jend, g, gsrc, st);
+        case 2: return launch_rp_ct<float, 2>(y, tab, jend, g, gsrc, st);
+        default: return launch_rp_ct<float, 1>(y, tab, jend, g, gsrc, st);
         }
     }
     switch (g.ct) {
-    case 8: return launch_rp_ct<double, 8>(y, tab, jend, g, car, ncar, ops, leaves, st);
-    case 4: return launch_rp_ct<double, 4>(y, tab, jend, g, car, ncar, ops, leaves, st);
-    case 2: return launch_rp_ct<double, 2>(y, tab, jend, g, car, ncar, ops, leaves, st);
-    default: return launch_rp_ct<double, 1>(y, tab, jend, g, car, ncar, ops, leaves, st);
+    case 4: return launch_rp_ct<double, 4>(y, tab, jend, g, gsrc, st);
+    case 2: return launch_rp_ct<double, 2>(y, tab, jend, g, gsrc, st);
+    default: return launch_rp_ct<double, 1>(y, tab, jend, g, gsrc, st);
     }
 }
 

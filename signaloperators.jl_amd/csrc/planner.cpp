@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -116,6 +117,7 @@ struct Stage {
     int pw_step = -1;  // pointwise step materialising the input
     std::vector<DCarrier> carriers;  // periodic resampler: input expressed as carriers
     int car_buf = -1;
+    int ctl_buf = -1;  // device copy of the RsCtl control block
     // SOS
     std::vector<SosCoefs> groups;
     SosGeom sg{};
@@ -282,6 +284,7 @@ struct Plan {
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
     bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out);
+    RsCtl make_ctl(const Stage& S) const;
     void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
              bool allow_hoist);
     int depth(int e) const;
@@ -1109,16 +1112,16 @@ void Plan::process_stage(int sid) {
             constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
             const int64_t Lb = g.L, Mb = g.M;
             int ct = 1;
-            for (int c : {8, 4, 2})
+            for (int c : {4, 2})
                 if (N.nch % c == 0) {
                     ct = c;
                     break;
                 }
             if (const char* ev = std::getenv("SIGOPS_RS_CT")) {  // tuning knob
                 int c = std::atoi(ev);
-                if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
+                if ((c == 1 || c == 2 || c == 4) && N.nch % c == 0) ct = c;
             }
-            const int pt = 64 / ct;
+            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in kernels.hip)
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
             // (b) a tile (pt super-periods) covers ~1100 input frames per channel
             int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
@@ -1153,16 +1156,16 @@ void Plan::process_stage(int sid) {
             }
             // k-steps: smallest instantiated KS covering taps + span (tab is zero padded);
             // compute waves: one (or two) groups each, taps stay in registers
-            int kw = 0, ncomp = 0;
+            int kw = 0, ncomp = 0, gper = 0;
             {
                 const int ksneed = (g.taps + (int)maxspan + 3) / 4;
-                int gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
+                gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
                 if (const char* ev = std::getenv("SIGOPS_RS_GPER")) gper = std::atoi(ev);  // tuning knob
                 const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14};
                 if (gper == 1) {
                     for (int k : ks1)
                         if (!kw && k >= ksneed) kw = 4 * k;
-                } else if (gper == 2) {
+                } else if (gper == 2 || gper == 3) {
                     for (int k : ks2)
                         if (!kw && k >= ksneed) kw = 4 * k;
                 }
@@ -1173,10 +1176,16 @@ void Plan::process_stage(int sid) {
             int jlo = jend[0] - (kw - 1);
             jlo -= ((jlo % 4) + 4) % 4;
             const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
-            int64_t pitch = (tile_len + 5) & ~(int64_t)1;  // even: 16-byte aligned rows for LDS-DMA
+            // +15: tiles are staged from the 128-byte aligned frame below their first input;
+            // even pitch: 16-byte aligned rows for LDS-DMA
+            int64_t pitch = (tile_len + 15 + 5) & ~(int64_t)1;
             size_t lds_bytes = (size_t)ct * pitch * 8;
             size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
-            if (kw && lds_bytes <= 80 * 1024 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
+            // LDS ring: as many tile slots as fit in 160 KiB, at most 4 (2 tiles in flight
+            // beyond the one being retired), at least 2 (plain double buffering)
+            int nslots = (int)std::min<size_t>(4, (160 * 1024 - sizeof(RsCtl) - 64) / std::max<size_t>(1, lds_bytes));
+            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) nslots = std::min(nslots, std::max(2, std::atoi(ev)));
+            if (kw && nslots >= 2 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
                 const double* h = (const double*)nd.p0;
                 std::vector<double> tab((size_t)ngroups * kw * RM, 0.0);
                 for (int gi = 0; gi < ngroups; ++gi) {
@@ -1206,10 +1215,11 @@ void Plan::process_stage(int sid) {
                 rp.lds_pitch = (int)pitch;
                 rp.jlo = jlo;
                 rp.nch = N.nch;
-                rp.ptshift = pt == 64 ? 6 : pt == 32 ? 5 : pt == 16 ? 4 : 3;
-                // persistent kernel: 16 waves per workgroup, one workgroup per CU; compute waves
-                // own one or two groups each, the rest are loader waves
-                rp.nwaves = 16;
+                rp.ptshift = pt == 32 ? 5 : pt == 16 ? 4 : pt == 8 ? 3 : 2;
+                rp.nslots = nslots;
+                // persistent kernel: 16 waves per workgroup (8 when a wave owns three groups and
+                // needs the registers), one workgroup per CU; the waves that do not compute load
+                rp.nwaves = gper >= 3 ? 8 : 16;
                 rp.ncompute = ncomp;
                 rp.grid = 256;
                 if (const char* ev = std::getenv("SIGOPS_RS_NWAVES")) rp.nwaves = std::max(2, std::min(16, std::atoi(ev)));
@@ -1386,7 +1396,10 @@ void Plan::process_stage(int sid) {
         c.cstride = S.in_array_node >= 0 ? (N.nch == 1 ? 0 : S.in_pitch) : -1;  // -1: buffer pitch
         S.carriers.push_back(c);
     }
-    if (!S.carriers.empty()) S.car_buf = raw_buf(S.carriers.size() * sizeof(DCarrier));
+    if (!S.carriers.empty()) {
+        S.car_buf = raw_buf(S.carriers.size() * sizeof(DCarrier));
+        S.ctl_buf = raw_buf(sizeof(RsCtl));
+    }
 }
 
 // e == carrier load combined with channel-independent operands by a short chain of ops?
@@ -1479,25 +1492,98 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         cs.push_back(c);
         monos_all.push_back(monos);
     }
-    // commit: compile the per-frame programs
+    // compile the per-frame programs; everything must fit the kernel-argument control block
+    if (cs.size() > (size_t)kCtlCar) return false;
+    std::vector<std::vector<DOp>> fcodes(cs.size());
+    size_t nops_total = 0;
+    std::set<int> leafset;
+    const size_t leaves_before = leaves.size();
     for (size_t i = 0; i < cs.size(); ++i) {
         DCarrier& c = cs[i];
-        std::vector<DOp> fcode;
+        std::vector<DOp>& fcode = fcodes[i];
         int dmax = 2;
+        c.nslots = (int)monos_all[i].size();
         for (size_t k = 0; k < monos_all[i].size(); ++k) {
+            // closed form for the kernel's hot loop: a single leaf, optionally rounded to
+            // Float32; compound per-frame expressions are not fused
+            int ei = monos_all[i][k], r32 = 0;
+            for (;;) {
+                const Expr& ex = exprs[ei];
+                if (ex.op == E_RETYPE) ei = ex.a;
+                else if (ex.op == E_ROUND32) { r32 = 0x100; ei = ex.a; }
+                else break;
+            }
+            const int eop = exprs[ei].op;
+            const int kind = eop == E_CONST ? OP_CONST : eop == E_SCALAR ? OP_SCALAR : eop == E_FUNC ? OP_FUNC : eop == E_RAMP ? OP_RAMP : -1;
+            if (kind < 0) {
+                leaves.resize(leaves_before);
+                leaf_array_node.resize(leaves_before);
+                return false;
+            }
+            c.slot_leaf[k] = add_leaf(exprs[ei]);
+            c.slot_kind[k] = kind | r32;
+            leafset.insert(c.slot_leaf[k]);
             std::map<int, int> none;
             gen(monos_all[i][k], fcode, none, fcode, false);
             fcode.push_back(DOp{OP_STOREF, (int)k});
             dmax = std::max(dmax, depth(monos_all[i][k]));
         }
-        if (dmax > 2) return false;  // the in-kernel frame interpreter is the 2-deep one
-        c.frame_pc = (int)ops.size();
-        c.frame_len = (int)fcode.size();
         c.depth = dmax;
-        ops.insert(ops.end(), fcode.begin(), fcode.end());
+        nops_total += fcode.size();
+        for (auto& o : fcode)
+            if (o.code <= OP_RAMP) leafset.insert(o.arg);
+        // the in-kernel frame interpreter is the 2-deep one
+        if (dmax > 2 || nops_total > (size_t)kCtlOps || leafset.size() > (size_t)kCtlLeaves) {
+            leaves.resize(leaves_before);  // drop what gen() appended
+            leaf_array_node.resize(leaves_before);
+            return false;
+        }
+    }
+    // commit
+    for (size_t i = 0; i < cs.size(); ++i) {
+        cs[i].frame_pc = (int)ops.size();
+        cs[i].frame_len = (int)fcodes[i].size();
+        ops.insert(ops.end(), fcodes[i].begin(), fcodes[i].end());
     }
     out = cs;
     return true;
+}
+
+// Kernel-argument control block of a periodic resampler stage: carriers with their frame
+// programs and leaves re-indexed into the block (built per execute from the patched tables).
+RsCtl Plan::make_ctl(const Stage& S) const {
+    RsCtl ctl{};
+    std::map<int, int> leafmap;
+    for (const DCarrier& c0 : S.carriers) {
+        if (ctl.ncar >= kCtlCar) throw PlanError{SO_ERR_RUNTIME, "internal: carrier control block overflow"};
+        DCarrier c = c0;
+        c.frame_pc = ctl.nops;
+        for (int k = 0; k < c0.frame_len; ++k) {
+            DOp o = ops[c0.frame_pc + k];
+            if (o.code <= OP_RAMP) {
+                auto it = leafmap.find(o.arg);
+                if (it == leafmap.end()) {
+                    if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
+                    ctl.leaves[ctl.nleaves] = leaves[o.arg];
+                    it = leafmap.emplace(o.arg, ctl.nleaves++).first;
+                }
+                o.arg = it->second;
+            }
+            if (ctl.nops >= kCtlOps) throw PlanError{SO_ERR_RUNTIME, "internal: op control block overflow"};
+            ctl.ops[ctl.nops++] = o;
+        }
+        for (int k = 0; k < c0.nslots; ++k) {
+            auto it = leafmap.find(c0.slot_leaf[k]);
+            if (it == leafmap.end()) {
+                if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
+                ctl.leaves[ctl.nleaves] = leaves[c0.slot_leaf[k]];
+                it = leafmap.emplace(c0.slot_leaf[k], ctl.nleaves++).first;
+            }
+            c.slot_leaf[k] = it->second;
+        }
+        ctl.car[ctl.ncar++] = c;
+    }
+    return ctl;
 }
 
 // ---------------------------------------------------------------------------
@@ -1599,6 +1685,10 @@ void Plan::finalize() {
                 std::fprintf(stderr, "[sigops] carrier [%lld,%lld) base=%p cstride=%lld df=%lld dtype=%d vec_ok=%d nsteps=%d frame_len=%d depth=%d\n",
                              (long long)c.a, (long long)c.b, c.base, (long long)c.cstride, (long long)c.df, c.dtype, c.vec_ok, c.nsteps, c.frame_len, c.depth);
         HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
+        {
+            const RsCtl ctl = make_ctl(S);
+            HIPCHECK(hipMemcpy(bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice));
+        }
     }
     // upload tables
     if (!pieces.empty()) {
@@ -1845,11 +1935,36 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                         rp.out_pitch = ob.pitch;
                         const int64_t al = 16 / (int64_t)esz;
                         rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
+                        static long long* d_trace = nullptr;  // SIGOPS_RS_TRACE tuning aid
+                        const bool tracing = std::getenv("SIGOPS_RS_TRACE") != nullptr;
+                        const size_t trace_n = (size_t)16 * kRsTraceIters * kRsTraceStamps;
+                        if (tracing) {
+                            if (!d_trace) HIPCHECK(hipMalloc(&d_trace, trace_n * 8));
+                            HIPCHECK(hipMemsetAsync(d_trace, 0, trace_n * 8, st));
+                            rp.trace = d_trace;
+                        }
                         if (launch_resample_periodic(ob.d, (const double*)P->bufs[S.tab_buf].d,
                                                      (const int*)P->bufs[S.jend_buf].d, rp, N.dtype,
-                                                     (const DCarrier*)P->bufs[S.car_buf].d, (int)S.carriers.size(),
-                                                     P->d_ops, P->d_leaves, st) != 0)
+                                                     RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves},
+                                                     st) != 0)
                             fail(SO_ERR_RUNTIME, "internal: no periodic resampler instantiation for this geometry");
+                        if (tracing) {
+                            std::vector<long long> tr(trace_n);
+                            HIPCHECK(hipStreamSynchronize(st));
+                            HIPCHECK(hipMemcpy(tr.data(), d_trace, trace_n * 8, hipMemcpyDeviceToHost));
+                            long long t0 = 0;
+                            for (size_t i = 0; i < trace_n; ++i)
+                                if (tr[i] && (!t0 || tr[i] < t0)) t0 = tr[i];
+                            for (int w = 0; w < rp.nwaves; ++w)
+                                for (int it = 0; it < kRsTraceIters; ++it) {
+                                    const long long* q = &tr[((size_t)w * kRsTraceIters + it) * kRsTraceStamps];
+                                    if (!q[0]) continue;
+                                    std::fprintf(stderr, "[rs-trace] %s w%02d it%02d", w < rp.ncompute ? "C" : "L", w, it);
+                                    for (int k = 0; k < kRsTraceStamps; ++k)
+                                        std::fprintf(stderr, " %lld", q[k] ? q[k] - t0 : -1);
+                                    std::fprintf(stderr, "\n");
+                                }
+                        }
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);
@@ -1927,6 +2042,25 @@ int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& e
                 err = "so_plan_set_array: leaf upload failed";
                 return SO_ERR_RUNTIME;
             }
+        // carriers of fused resampler stages (by value at launch + a device copy for the slow path)
+        for (auto& S : P->stages) {
+            bool touched = false;
+            for (auto& c : S.carriers)
+                if (c.array_node == node_index) {
+                    c.base = data;
+                    const int64_t V = 16 / (int64_t)dsize(c.dtype);
+                    c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
+                    touched = true;
+                }
+            if (touched) {
+                const RsCtl ctl = P->make_ctl(S);
+                if (hipMemcpy(P->bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(P->bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice) != hipSuccess) {
+                    err = "so_plan_set_array: carrier upload failed";
+                    return SO_ERR_RUNTIME;
+                }
+            }
+        }
     }
     return SO_OK;
 }

@@ -78,6 +78,35 @@ struct DCarrier {
     int32_t frame_pc, frame_len, depth, nsteps;
     int32_t op[4];   // OpCode
     int32_t arg[4];  // slot | flip<<8 | round32<<9
+    // closed form of the frame program (what the resampler's loader evaluates in its hot
+    // loop): slot k = leaf slot_leaf[k] evaluated as slot_kind[k] (OP_CONST / OP_SCALAR /
+    // OP_FUNC / OP_RAMP, | 0x100: rounded to Float32)
+    int32_t nslots;
+    int32_t slot_leaf[4];
+    int32_t slot_kind[4];
+    int32_t pad_;
+};
+
+// Control block of the periodic resampler's fused source.  Every workgroup copies it into LDS
+// at kernel start, so the loader waves read carriers / slot leaves with ds_reads instead of
+// dependent global or kernarg loads that queue behind the HBM stream they are trying to keep
+// busy.  Plans that do not fit are materialised by K1 and arrive as one 0-step carrier.
+constexpr int kCtlCar = 4, kCtlOps = 32, kCtlLeaves = 6;
+struct RsCtl {
+    int32_t ncar, nops, nleaves, pad;
+    DCarrier car[kCtlCar];      // frame_pc indexes `ops` below
+    DOp ops[kCtlOps];           // leaf operands index `leaves` below
+    DLeaf leaves[kCtlLeaves];
+};
+
+// The same tables in global memory (carriers index the plan-wide ops / leaves): used only by
+// the out-of-line slow path of the staging, which must not take the address of kernel
+// arguments (that would move them to scratch).
+struct RsGlobalTables {
+    const RsCtl* ctl;  // copied to LDS at kernel start
+    const DCarrier* car;
+    const DOp* ops;
+    const DLeaf* leaves;
 };
 
 struct OutView {
@@ -135,7 +164,7 @@ struct RsPeriodic {
     int64_t n_in, n_out;
     int64_t L, M;       // outputs / inputs per (super-)period
     int64_t nperiods;
-    int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == 64
+    int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == 32
     int32_t ngroups;    // groups of 16 consecutive outputs per period
     int32_t kw;         // inputs in a group's window (multiple of 4)
     int32_t tile_len;   // inputs per channel staged in LDS
@@ -147,8 +176,12 @@ struct RsPeriodic {
     int32_t ptshift;    // log2(pt)
     int32_t ncompute;   // waves [0,ncompute) compute, the rest stage the next tile
     int32_t grid;       // persistent workgroups (one per CU)
-    int32_t pad;
+    int32_t pad;        // ablation bits (SIGOPS_RS_DEBUG)
+    int32_t nslots;     // LDS ring depth (tiles resident per workgroup)
+    int32_t reserved;
     int64_t in_pitch, out_pitch;
+    long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };
+constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
 
 }  // namespace so
