@@ -78,8 +78,8 @@ def cpu_baseline(so, seconds, nch, dtype):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--seconds", type=float, default=600.0, help="signal duration (600 = full config)")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])

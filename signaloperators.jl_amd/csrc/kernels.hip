@@ -125,6 +125,29 @@ __device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n)
     return (kind & 0x100) ? (double)(float)v : v;
 }
 
+// frames n and n+1 at once
+__device__ __forceinline__ void slot_eval2(int kind, const DLeaf& L, int64_t n, double& o0, double& o1) {
+    double v0, v1;
+    switch (kind & 0xff) {
+    case OP_CONST: v0 = v1 = L.v0; break;
+    case OP_SCALAR: v0 = v1 = *(const double*)L.base; break;
+    case OP_FUNC:
+        v0 = func_eval(L, n);
+        v1 = func_eval(L, n + 1);
+        break;
+    default:
+        v0 = ramp_eval(L, n);
+        v1 = ramp_eval(L, n + 1);
+        break;
+    }
+    if (kind & 0x100) {
+        v0 = (double)(float)v0;
+        v1 = (double)(float)v1;
+    }
+    o0 = v0;
+    o1 = v1;
+}
+
 // ---------------------------------------------------------------------------
 // D-deep register stack machine over E elements per thread.  Program words are
 // wave-uniform (scalar loads); the stack lives in VGPRs (static indexing only).
@@ -598,34 +621,54 @@ struct StepTab {
     int nsteps;
     int op[4], arg[4];
 };
-template <int CT, int V, typename CarT>
+template <int CT, int V, bool DIV = true, typename CarT>
 __device__ __forceinline__ void carrier_apply(const CarT& C, const double (&F)[kMaxFrameSlots][V],
                                               double (&val)[CT][V], bool to_f32) {
+    // The opcode switch is OUTSIDE the element loops (wave-uniform branch, then CT*V straight
+    // operations); the other way round the code grows by the number of cases per element --
+    // with fp64 division among them, ~9000 instructions for CT=8 -- and the loader thrashes
+    // the instruction cache.  DIV == false drops the division cases (fast path of the loader).
+#define SO_STEP(EXPR)                                  \
+    _Pragma("unroll") for (int e = 0; e < V; ++e) {    \
+        const double m = mm[e];                        \
+        (void)m;                                       \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c) { \
+            const double v = val[c][e];                \
+            (void)v;                                   \
+            val[c][e] = (EXPR);                        \
+        }                                              \
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i >= C.nsteps) break;
         const int op = C.op[i], arg = C.arg[i], slot = arg & 0xff;
         const bool flip = arg & 0x100, r32 = arg & 0x200;
+        double mm[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const double m = slot == 0 ? F[0][e] : slot == 1 ? F[1][e] : slot == 2 ? F[2][e] : F[3][e];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                double v = val[c][e];
-                switch (op) {
-                case OP_ADD: v = v + m; break;
-                case OP_SUB: v = flip ? m - v : v - m; break;
-                case OP_MUL: v = v * m; break;
-                case OP_DIV: v = flip ? m / v : v / m; break;
-                case OP_NEG: v = -v; break;
-                case OP_LOADF: v = m; break;  // generated piece: the value IS the slot
-                default: break;               // OP_ROUND32: only the rounding below
-                }
-                if (r32) v = (double)(float)v;  // Julia Float32 arithmetic
-                val[c][e] = v;
+        for (int e = 0; e < V; ++e) mm[e] = slot == 0 ? F[0][e] : slot == 1 ? F[1][e] : slot == 2 ? F[2][e] : F[3][e];
+        switch (op) {
+        case OP_ADD: SO_STEP(v + m) break;
+        case OP_SUB:
+            if (flip) { SO_STEP(m - v) } else { SO_STEP(v - m) }
+            break;
+        case OP_MUL: SO_STEP(v * m) break;
+        case OP_DIV:
+            if constexpr (DIV) {
+                if (flip) { SO_STEP(m / v) } else { SO_STEP(v / m) }
             }
+            break;
+        case OP_NEG: SO_STEP(-v) break;
+        case OP_LOADF: SO_STEP(m) break;  // generated piece: the value IS the slot
+        default: break;                            // OP_ROUND32: only the rounding below
+        }
+        if (r32) {  // Julia Float32 arithmetic
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < V; ++e) val[c][e] = (double)(float)val[c][e];
         }
     }
+#undef SO_STEP
     if (to_f32) {  // the reference stores the child in the child's sample type before
                    // filtering (src/filters.jl:207,244)
 #pragma unroll
@@ -653,7 +696,8 @@ template <int N>
 __device__ __forceinline__ void lds_wait(v2d (&v)[N]) {  // results of lds_ld16 are valid after this
     if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
 }
 
 // 16-byte-per-lane asynchronous global -> LDS copy (global_load_lds_dwordx4): the wave
@@ -712,7 +756,7 @@ __device__ __forceinline__ bool rs_dma_chunk(const RsPeriodic& g, const RsCtl& c
 // In-place carrier steps on one lane's 16-byte vector of each of the CT channel rows of a
 // staged fp64 tile.  LDS access in asm: a compiler-visible ds_read of an LDS-DMA destination
 // could be ordered behind vmcnt(0); the caller's counted wait is the real ordering.
-template <int CT, typename CarT>
+template <int CT, bool DIV, typename CarT>
 __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT& C,
                                           const double (&F)[kMaxFrameSlots][2]) {
     v2d raw[CT];
@@ -725,7 +769,7 @@ __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT
         val[c][0] = raw[c][0];
         val[c][1] = raw[c][1];
     }
-    carrier_apply<CT, 2>(C, F, val, false);
+    carrier_apply<CT, 2, DIV>(C, F, val, false);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         v2d v;
@@ -736,12 +780,9 @@ __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT
 }
 
 // Slow path of the staging (tile edges, f32 sources, generated pieces, unaligned arrays): one
-// 16-byte vector per lane, load -> carrier steps -> LDS store, synchronously.  Deliberately NOT
-// inlined: it holds the frame interpreter and a CT x V register block, and inlining it made the
-// loader's hot loop spill to scratch -- a scratch reload waits vmcnt(0), i.e. drains every
-// LDS-DMA in flight (measured: the issue pass took as long as a whole tile transfer).
+// 16-byte vector per lane, load -> carrier steps -> LDS store, synchronously.
 template <typename T, int CT>
-__device__ __attribute__((noinline)) void stage_generic(int64_t n_in, int lds_pitch,
+__device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
                                                         const DCarrier* __restrict__ car, int ncar,
                                                         const DOp* __restrict__ ops,
                                                         const DLeaf* __restrict__ leaves,
@@ -823,6 +864,29 @@ __device__ __attribute__((noinline)) void stage_generic(int64_t n_in, int lds_pi
     }
 }
 
+// fp32 sources (V = 4 elements per vector) need more registers than the 128 the 16-wave kernel
+// has: out of line for them, so that the spills stay inside the callee -- a scratch reload in
+// the loader's loop waits vmcnt(0) and drains every LDS-DMA in flight.  The fp64 kernels inline
+// it and use no scratch at all (a kernel with a scratch frame costs ~0.1 ms per launch here).
+template <typename T, int CT>
+__device__ __attribute__((noinline)) void stage_generic_ool(int64_t n_in, int lds_pitch,
+                                                            const DCarrier* __restrict__ car, int ncar,
+                                                            const DOp* __restrict__ ops,
+                                                            const DLeaf* __restrict__ leaves,
+                                                            int64_t gi, int iv, int ci, int c0,
+                                                            double* __restrict__ buf) {
+    stage_generic_impl<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
+}
+template <typename T, int CT>
+__device__ __forceinline__ void stage_generic(int64_t n_in, int lds_pitch,
+                                              const DCarrier* __restrict__ car, int ncar,
+                                              const DOp* __restrict__ ops,
+                                              const DLeaf* __restrict__ leaves, int64_t gi, int iv,
+                                              int ci, int c0, double* __restrict__ buf) {
+    if constexpr (sizeof(T) == 8) stage_generic_impl<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
+    else stage_generic_ool<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
+}
+
 // Stage one input tile (CT channels x nfr frames from global frame xbase) into an LDS slot
 // as fp64, zero-padded outside [0,n_in) (Pad(x.signal,zero), reference src/filters.jl:240).
 //   PASS 0 (issue):  per wave-chunk of 64 vectors either fire CT LDS-DMA instructions (fp64
@@ -897,7 +961,7 @@ __device__ __forceinline__ int stage_tile(const RsPeriodic& g, int64_t xbase, in
                         wait_vmcnt_le(allowed);
                         waited = true;
                     }
-                    if (act) rmw_chunk<CT>(lds_addr(buf + iv * V), g.lds_pitch, C, F);
+                    if (act) rmw_chunk<CT, true>(lds_addr(buf + iv * V), g.lds_pitch, C, F);
                 }
                 continue;
             }
@@ -970,8 +1034,21 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     // waves take one branch), so their register live ranges do not overlap.
     if (wave >= nc) {
         // ---- loader waves ----
-        const int ltid = (int)threadIdx.x - nc * 64, lthr = (nwaves - nc) * 64;
-        const int llane = ltid & 63;
+        // Loader waves are numbered so that those on the SIMDs with the fewest compute waves come
+        // first (waves go to SIMD wave&3): the first chunks of a tile are the full ones, and a
+        // loader wave next to three MFMA-issuing waves runs ~30 % slower than one next to two.
+        int lidx = 0;
+        {
+            auto ncomp_on = [&](int w) { return (nc - (w & 3) + 3) >> 2; };  // compute waves on w's SIMD
+            const int mine = ncomp_on(wave);
+            for (int w = nc; w < nwaves; ++w) {
+                const int other = ncomp_on(w);
+                if (other < mine || (other == mine && w < wave)) ++lidx;
+            }
+        }
+        const int lthr = (nwaves - nc) * 64;
+        const int ltid = lidx * 64 + lane;
+        const int llane = lane;
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
         // fast tiles: one fp64 array carrier covers the whole staged range -> straight-line DMA
         // issue with the carrier's facts in scalar registers (read from the LDS control block
@@ -984,6 +1061,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         //  other carriers, e.g. the generated tail of an infinite Amplify)
         const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) &&
                             !(df0 & 1) && !(g.pad & 8) && sizeof(T) == 8;
+        bool nodiv0 = true;  // (division steps take the general in-place path: code size)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nsteps0 && __builtin_amdgcn_readfirstlane(C0.op[k]) == OP_DIV) nodiv0 = false;
         StepTab st0;  // carrier 0's steps and slot recipes, in registers
         int sk0[4], sl0[4];
         st0.nsteps = nsteps0;
@@ -1007,7 +1088,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             const int sh = (int)(p.xb & 15);
             xa = p.xb - sh;
             nfr = g.tile_len + sh;
-            return single && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
+            return single && nodiv0 && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
         };
         auto issue = [&](const TilePos& p, int slot, int tr_it) {
             int n = 0;
@@ -1020,7 +1101,6 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     const int nvec = (nfr + 1) >> 1;
                     const double* row = base0 + ((int64_t)c0 * cs0 + df0 + xa);
                     const uint32_t lbase = __builtin_amdgcn_readfirstlane(lds_addr(lds + slot * bufsz));
-                    rs_stamp(g, wave, tr_it, 5);
                     for (int ivb = lw64; ivb < nvec; ivb += lthr) {
                         if (ivb + llane < nvec) {
                             const double* src = row + 2 * (ivb + llane);
@@ -1031,7 +1111,6 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                         }
                         n += CT;
                     }
-                    rs_stamp(g, wave, tr_it, 6);
                 } else {
                     n = stage_tile<T, CT, 0>(g, xa, nfr, c0, lds + slot * bufsz, ctl, gsrc, ltid, lthr, 0);
                 }
@@ -1068,20 +1147,31 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     const int64_t gi = xa + 2 * (int64_t)iv;
                     double F[kMaxFrameSlots][2];
 #pragma unroll
-                    for (int k = 0; k < kMaxFrameSlots; ++k) {
-                        F[k][0] = 0.0;
-                        F[k][1] = 0.0;
-                        if (k < nslots0 && !(g.pad & 64)) {
-                            const DLeaf L = ctl.leaves[sl0[k]];
-                            F[k][0] = slot_eval(sk0[k], L, gi);
-                            F[k][1] = slot_eval(sk0[k], L, gi + 1);
+                    for (int k = 0; k < kMaxFrameSlots; ++k) F[k][0] = F[k][1] = 0.0;
+                    // one copy of the evaluator, looped over the slots (register arrays are
+                    // indexed through select chains / a switch on the wave-uniform k)
+#pragma unroll 1
+                    for (int k = 0; k < nslots0 && !(g.pad & 64); ++k) {
+                        const int kind = k == 0 ? sk0[0] : k == 1 ? sk0[1] : k == 2 ? sk0[2] : sk0[3];
+                        const int li = k == 0 ? sl0[0] : k == 1 ? sl0[1] : k == 2 ? sl0[2] : sl0[3];
+                        const DLeaf L = ctl.leaves[li];
+                        double f0, f1;
+                        slot_eval2(kind, L, gi, f0, f1);
+                        switch (k) {
+                        case 0: F[0][0] = f0; F[0][1] = f1; break;
+                        case 1: F[1][0] = f0; F[1][1] = f1; break;
+                        case 2: F[2][0] = f0; F[2][1] = f1; break;
+                        default: F[3][0] = f0; F[3][1] = f1; break;
                         }
                     }
                     if (!waited) {  // this tile's DMA landed in LDS
+                        rs_stamp(g, wave, it, 5);
                         wait_vmcnt_le(allowed);
                         waited = true;
+                        rs_stamp(g, wave, it, 6);
                     }
-                    if (iv < nvec) rmw_chunk<CT>(lbase + (uint32_t)iv * 16u, g.lds_pitch, st0, F);
+                    if (iv < nvec) rmw_chunk<CT, false>(lbase + (uint32_t)iv * 16u, g.lds_pitch, st0, F);
+                    rs_stamp(g, wave, it, 7);
                 }
                 if (!waited) wait_vmcnt_le(allowed);
             } else {
@@ -1238,12 +1328,14 @@ int launch_resample_periodic(void* y, const double* tab, const int* jend, const 
     if (g.n_out <= 0) return 0;
     if (dtype == SO_F32) {
         switch (g.ct) {
+        case 8: return launch_rp_ct<float, 8>(y, tab, jend, g, gsrc, st);
         case 4: return launch_rp_ct<float, 4>(y, tab, jend, g, gsrc, st);
         case 2: return launch_rp_ct<float, 2>(y, tab, jend, g, gsrc, st);
         default: return launch_rp_ct<float, 1>(y, tab, jend, g, gsrc, st);
         }
     }
     switch (g.ct) {
+    case 8: return launch_rp_ct<double, 8>(y, tab, jend, g, gsrc, st);
     case 4: return launch_rp_ct<double, 4>(y, tab, jend, g, gsrc, st);
     case 2: return launch_rp_ct<double, 2>(y, tab, jend, g, gsrc, st);
     default: return launch_rp_ct<double, 1>(y, tab, jend, g, gsrc, st);

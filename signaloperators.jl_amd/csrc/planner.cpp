@@ -1111,15 +1111,17 @@ void Plan::process_stage(int sid) {
         if ((!g.arbitrary || g.exact) && need >= 2048) {
             constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
             const int64_t Lb = g.L, Mb = g.M;
+            // (8 channels per tile when possible: per-frame gains of a fused source are evaluated
+            //  once per tile row-group, and 8 rows give every loader wave exactly one chunk)
             int ct = 1;
-            for (int c : {4, 2})
+            for (int c : {8, 4, 2})
                 if (N.nch % c == 0) {
                     ct = c;
                     break;
                 }
             if (const char* ev = std::getenv("SIGOPS_RS_CT")) {  // tuning knob
                 int c = std::atoi(ev);
-                if ((c == 1 || c == 2 || c == 4) && N.nch % c == 0) ct = c;
+                if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
             }
             const int pt = 32 / ct;  // tile = 32 rows (kRsRows in kernels.hip)
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
