@@ -125,6 +125,32 @@ __device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n)
     return (kind & 0x100) ? (double)(float)v : v;
 }
 
+// A leaf read from LDS sits in vector registers; its mode/flag fields then look lane-varying
+// to the compiler and every `if (L.flag)` / `L.mode == ...` becomes compute-both-and-select
+// (all three trig kernels per frame).  Passing the fields through readfirstlane makes the
+// branches scalar again.
+__device__ __forceinline__ double rfl_f64(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ DLeaf leaf_uniform(const DLeaf& L) {
+    DLeaf U = L;
+    const uint64_t b = (uint64_t)(uintptr_t)L.base;
+    U.base = (const void*)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                      __builtin_amdgcn_readfirstlane((uint32_t)b));
+    U.v0 = rfl_f64(L.v0);
+    U.v1 = rfl_f64(L.v1);
+    U.v2 = rfl_f64(L.v2);
+    U.df = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.df)));
+    U.modn = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.modn)));
+    U.sf = __builtin_amdgcn_readfirstlane(L.sf);
+    U.mode = __builtin_amdgcn_readfirstlane(L.mode);
+    U.flag = __builtin_amdgcn_readfirstlane(L.flag);
+    return U;
+}
+
 // frames n and n+1 at once
 __device__ __forceinline__ void slot_eval2(int kind, const DLeaf& L, int64_t n, double& o0, double& o1) {
     double v0, v1;
@@ -715,6 +741,42 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
                  : "memory", "m0");
 }
 
+// One chunk (up to 64 lanes x 16 bytes) of CT channel rows by LDS-DMA with NO vector-ALU
+// instruction: scalar row bases + one per-lane byte offset register (global saddr form), exec
+// mask built by scalar code.  While the compute waves of the SIMD run their MFMA burst a loader
+// wave gets a vector-ALU issue slot only every ~64+ cycles (fp64 MFMA and VALU share the ALUs),
+// so per-DMA address arithmetic on the VALU costs more than the copy itself.
+#define SO_DMA_ROW(I) "s_mov_b32 m0, %[l" #I "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[voff], %[b" #I "]\n\t"
+template <int CT>
+__device__ __forceinline__ void dma_rows(uint64_t mask, uint32_t voff, const double* base, int64_t row_stride,
+                                         uint32_t lds, uint32_t lds_stride) {
+    uint64_t sv;
+    const double* b0 = base;
+    const double* b1 = base + row_stride;
+    const double* b2 = base + 2 * row_stride;
+    const double* b3 = base + 3 * row_stride;
+    if constexpr (CT == 1) {
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv)
+                     : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds)
+                     : "memory", "m0");
+    } else if constexpr (CT == 2) {
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) SO_DMA_ROW(1) "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv)
+                     : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds), [b1] "s"(b1), [l1] "s"(lds + lds_stride)
+                     : "memory", "m0");
+    } else {
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) SO_DMA_ROW(1) SO_DMA_ROW(2) SO_DMA_ROW(3) "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv)
+                     : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds), [b1] "s"(b1), [l1] "s"(lds + lds_stride),
+                       [b2] "s"(b2), [l2] "s"(lds + 2 * lds_stride), [b3] "s"(b3), [l3] "s"(lds + 3 * lds_stride)
+                     : "memory", "m0");
+        if constexpr (CT == 8)
+            dma_rows<4>(mask, voff, base + 4 * row_stride, row_stride, lds + 4 * lds_stride, lds_stride);
+    }
+}
+#undef SO_DMA_ROW
+
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate).
 // Rounding n DOWN is always safe (a stricter wait).
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
@@ -739,10 +801,17 @@ __device__ __forceinline__ int64_t rfl64(int64_t v) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// the few geometry fields the general staging path needs (passed by value to its out-of-line
+// copy: taking the address of the kernel-argument struct would move it to scratch)
+struct RsStageGeom {
+    int64_t n_in;
+    int32_t lds_pitch, pad;
+};
+
 // Is the wave's chunk of 64 consecutive 16-byte vectors [gf,gl) a plain copy out of one fp64
 // array carrier (so it can go by LDS-DMA)?  `cu` returns the carrier.  Pure function of the
 // chunk position: the issue pass and the modify pass must agree on it.
-__device__ __forceinline__ bool rs_dma_chunk(const RsPeriodic& g, const RsCtl& ctl, int64_t gf,
+__device__ __forceinline__ bool rs_dma_chunk(const RsStageGeom& g, const RsCtl& ctl, int64_t gf,
                                              int64_t gl, int& cu) {
     const DCarrier* car = ctl.car;
     const int ncar = ctl.ncar;
@@ -759,6 +828,11 @@ __device__ __forceinline__ bool rs_dma_chunk(const RsPeriodic& g, const RsCtl& c
 template <int CT, bool DIV, typename CarT>
 __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT& C,
                                           const double (&F)[kMaxFrameSlots][2]) {
+    if constexpr (CT > 4) {  // four rows at a time: 8 x 16 bytes in flight is 32 registers twice over
+        rmw_chunk<4, DIV>(la, lds_pitch, C, F);
+        rmw_chunk<CT - 4, DIV>(la + (uint32_t)(4 * lds_pitch) * 8u, lds_pitch, C, F);
+        return;
+    }
     v2d raw[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * 8u);
@@ -896,7 +970,7 @@ __device__ __forceinline__ void stage_generic(int64_t n_in, int lds_pitch,
 //                    instructions it issued for younger tiles), apply the carrier steps in
 //                    place to exactly the chunks it copied.
 template <typename T, int CT, int PASS>
-__device__ __forceinline__ int stage_tile(const RsPeriodic& g, int64_t xbase, int nfr, int c0,
+__device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, int nfr, int c0,
                                           double* __restrict__ buf, const RsCtl& ctl,
                                           const RsGlobalTables& gsrc, int tid, int nthr, int allowed) {
     const DCarrier* car = ctl.car;
@@ -967,12 +1041,27 @@ __device__ __forceinline__ int stage_tile(const RsPeriodic& g, int64_t xbase, in
             }
         }
         if constexpr (PASS == 0)
-            if (act) stage_generic<T, CT>(g.n_in, g.lds_pitch, gsrc.car, ctl.ncar, gsrc.ops, gsrc.leaves, gi, iv, ci, c0, buf);
+            if (act) stage_generic_impl<T, CT>(g.n_in, g.lds_pitch, gsrc.car, ctl.ncar, gsrc.ops, gsrc.leaves, gi, iv, ci, c0, buf);
     }
     if constexpr (PASS == 1) {
         if (!waited) wait_vmcnt_le(allowed);
     }
     return ndma;
+}
+
+// The general staging path out of line: it carries the frame interpreter and CT x V register
+// blocks, and inlined next to the loader's fast path it pushes that past the 128-register
+// budget -- spills there are scratch reloads with s_waitcnt vmcnt(0) in the middle of the
+// LDS-DMA ring.  Only tiles at a signal/carrier edge and non-fp64 sources come here.
+template <typename T, int CT, int PASS>
+__device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pitch, int pad, int64_t xbase,
+                                                        int nfr, int c0, double* __restrict__ buf,
+                                                        const RsCtl* ctl, const DCarrier* gcar,
+                                                        const DOp* gops, const DLeaf* gleaves, int tid,
+                                                        int nthr, int allowed) {
+    const RsStageGeom g{n_in, lds_pitch, pad};
+    const RsGlobalTables gsrc{nullptr, gcar, gops, gleaves};
+    return stage_tile<T, CT, PASS>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
 }
 
 template <typename T, int CT, int KS, int G>
@@ -1030,6 +1119,116 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             ++p.tc;
         }
     };
+    // fast tiles: one fp64 array carrier covers the whole staged range -> straight-line DMA
+    // issue with the carrier's facts in scalar registers (read from the LDS control block
+    // once), no per-chunk carrier logic
+    const DCarrier& C0 = ctl.car[0];
+    const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
+    const double* base0 = (const double*)rfl64((int64_t)(uintptr_t)C0.base);
+    const int nsteps0 = __builtin_amdgcn_readfirstlane(C0.nsteps);
+    // (tiles inside carrier 0 -- normally all but the signal's edges -- see nothing of the
+    //  other carriers, e.g. the generated tail of an infinite Amplify)
+    const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) &&
+                        !(df0 & 1) && !(g.pad & 8) && sizeof(T) == 8;
+    bool nodiv0 = true;  // (division steps take the general in-place path: code size)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nsteps0 && __builtin_amdgcn_readfirstlane(C0.op[k]) == OP_DIV) nodiv0 = false;
+    StepTab st0;  // carrier 0's steps and slot recipes, in registers
+    st0.nsteps = nsteps0;
+    const int nslots0 = __builtin_amdgcn_readfirstlane(C0.nslots);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        st0.op[k] = __builtin_amdgcn_readfirstlane(C0.op[k]);
+        st0.arg[k] = __builtin_amdgcn_readfirstlane(C0.arg[k]);
+    }
+    const int64_t lo_ok = a0 > 0 ? a0 : 0;
+    const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
+    auto is_fast = [&](const TilePos& p, int64_t& xa, int& nfr) __attribute__((always_inline)) {
+        const int sh = (int)(p.xb & 15);
+        xa = p.xb - sh;
+        nfr = g.tile_len + sh;
+        return single && nodiv0 && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
+    };
+    // Gain ring (g.fslots > 0): the per-frame slot values of a fused source -- sin generators,
+    // ramps: ~150 fp64 instructions per frame -- are evaluated by ALL sixteen waves, two tiles
+    // ahead, into one of two LDS arrays F[slot][frame]; the loader's in-place step then only
+    // reads them.  Left to the six loader waves alone the evaluation sits on their critical
+    // path (issue -> wait -> modify -> barrier) and the kernel runs 25 % below its plain-copy
+    // speed.
+    const bool fused0 = nsteps0 > 0 && !(g.pad & 32);
+    const bool fring = g.fslots > 0 && fused0 && nslots0 <= g.fslots;
+    double* const fbase = lds + (size_t)S * bufsz;
+    // Who evaluates which frames.  fp64 MFMA and fp64 VALU run on the same ALUs here (matrix and
+    // vector fp64 peak are equal on MI355X): a loader wave's gain arithmetic only gets issue
+    // slots once the compute waves on its SIMD have finished their MFMA burst (measured: 4-6k
+    // cycles for 1.4k of work), so the evaluation belongs at the END of the compute waves' own
+    // iteration.  Shares of 64 frames are dealt so that MFMA + gain work per SIMD comes out even
+    // (10 compute waves on 4 SIMDs: 3+2, 3+2, 2+3, 2+3 units).
+    int share0, share1 = -1, nshares;
+    {
+        auto ncomp_on = [&](int w) { return (nc - (w & 3) + 3) >> 2; };
+        int minc = 1 << 30, maxc = 0;
+        for (int sd = 0; sd < 4 && sd < nc; ++sd) {
+            minc = min(minc, ncomp_on(sd));
+            maxc = max(maxc, ncomp_on(sd));
+        }
+        const bool uneven = minc < maxc;
+        // class A: compute waves on the least loaded SIMDs (one share each, the first wave of
+        // such a SIMD a second one); class B: the other compute waves; then the loader waves
+        int nA = 0, nA2 = 0, nB = 0, iA = 0, iA2 = 0, iB = 0;
+        for (int w = 0; w < nc; ++w) {
+            const bool a = uneven && ncomp_on(w) == minc;
+            if (a) {
+                if (w < wave) ++iA;
+                ++nA;
+                if (w < 4) {
+                    if (w < wave) ++iA2;
+                    ++nA2;
+                }
+            } else {
+                if (w < wave) ++iB;
+                ++nB;
+            }
+        }
+        nshares = nA + nA2 + nB + (nwaves - nc);
+        if (wave >= nc) share0 = nA + nA2 + nB + (wave - nc);
+        else if (uneven && ncomp_on(wave) == minc) {
+            share0 = iA;
+            if (wave < 4) share1 = nA + iA2;
+        } else share0 = nA + nA2 + iB;
+    }
+    const int kind0 = __builtin_amdgcn_readfirstlane(ctl.car[0].slot_kind[0]);
+    const DLeaf leaf0 = leaf_uniform(ctl.leaves[min(kCtlLeaves - 1, max(0, __builtin_amdgcn_readfirstlane(ctl.car[0].slot_leaf[0])))]);
+    auto f_duty = [&](const TilePos& p, int fb) __attribute__((always_inline)) {
+        int64_t xa;
+        int nfr;
+        if (!fring || share0 * 64 >= g.tile_len || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
+        double* Fb = fbase + (size_t)fb * g.fslots * g.fpitch;
+#pragma unroll 1
+        for (int k = 0; k < nslots0; ++k) {
+            // (slot 0's recipe is kept in scalar registers for the whole kernel; further slots
+            //  are re-read from the LDS control block)
+            const int kind = k == 0 ? kind0 : __builtin_amdgcn_readfirstlane(ctl.car[0].slot_kind[k]);
+            const DLeaf L = k == 0 ? leaf0 : leaf_uniform(ctl.leaves[__builtin_amdgcn_readfirstlane(ctl.car[0].slot_leaf[k])]);
+#pragma unroll 1
+            for (int sp = 0; sp < 2; ++sp) {
+                const int shr = sp ? share1 : share0;
+                if (shr < 0) break;
+                for (int f = (nfr - g.tile_len) + shr * 64 + lane; f < nfr; f += nshares * 64)
+                    Fb[k * g.fpitch + f] = slot_eval(kind, L, xa + f);
+            }
+        }
+    };
+    // prologue: gains of tiles 0 and 1, published by one extra barrier (both roles)
+    TilePos pf = tile_first();  // next tile whose gains are due
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        f_duty(pf, k);
+        tile_next(pf);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // The two roles run separate loops with the same number of workgroup barriers (whole
     // waves take one branch), so their register live ranges do not overlap.
     if (wave >= nc) {
@@ -1050,46 +1249,14 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const int ltid = lidx * 64 + lane;
         const int llane = lane;
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
-        // fast tiles: one fp64 array carrier covers the whole staged range -> straight-line DMA
-        // issue with the carrier's facts in scalar registers (read from the LDS control block
-        // once), no per-chunk carrier logic
-        const DCarrier& C0 = ctl.car[0];
-        const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
-        const double* base0 = (const double*)rfl64((int64_t)(uintptr_t)C0.base);
-        const int nsteps0 = __builtin_amdgcn_readfirstlane(C0.nsteps);
-        // (tiles inside carrier 0 -- normally all but the signal's edges -- see nothing of the
-        //  other carriers, e.g. the generated tail of an infinite Amplify)
-        const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) &&
-                            !(df0 & 1) && !(g.pad & 8) && sizeof(T) == 8;
-        bool nodiv0 = true;  // (division steps take the general in-place path: code size)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < nsteps0 && __builtin_amdgcn_readfirstlane(C0.op[k]) == OP_DIV) nodiv0 = false;
-        StepTab st0;  // carrier 0's steps and slot recipes, in registers
-        int sk0[4], sl0[4];
-        st0.nsteps = nsteps0;
-        const int nslots0 = __builtin_amdgcn_readfirstlane(C0.nslots);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st0.op[k] = __builtin_amdgcn_readfirstlane(C0.op[k]);
-            st0.arg[k] = __builtin_amdgcn_readfirstlane(C0.arg[k]);
-            sk0[k] = __builtin_amdgcn_readfirstlane(C0.slot_kind[k]);
-            sl0[k] = __builtin_amdgcn_readfirstlane(C0.slot_leaf[k]);
-        }
-        const int64_t lo_ok = a0 > 0 ? a0 : 0;
-        const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
         // Loader waves issue a handful of instructions and then sleep on memory; without a
         // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
         // and the loads only go out once the arithmetic is over (measured: phases add up).
         if (!(g.pad & 16)) __builtin_amdgcn_s_setprio(3);
+        const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));  // byte address of the ring
+        const uint32_t lane16 = (uint32_t)llane * 16u;                            // per-lane byte offset in a chunk
         const int A = S - 2;  // tiles in flight beyond the one being retired
         int cnt0 = 0, cnt1 = 0;  // DMA instructions of the youngest / second youngest issued tile
-        auto is_fast = [&](const TilePos& p, int64_t& xa, int& nfr) {
-            const int sh = (int)(p.xb & 15);
-            xa = p.xb - sh;
-            nfr = g.tile_len + sh;
-            return single && nodiv0 && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
-        };
         auto issue = [&](const TilePos& p, int slot, int tr_it) {
             int n = 0;
             if (p.tc < ngrp && !((g.pad & 2) && tr_it != kRsTraceIters)) {
@@ -1100,19 +1267,17 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 if (is_fast(p, xa, nfr)) {
                     const int nvec = (nfr + 1) >> 1;
                     const double* row = base0 + ((int64_t)c0 * cs0 + df0 + xa);
-                    const uint32_t lbase = __builtin_amdgcn_readfirstlane(lds_addr(lds + slot * bufsz));
+                    const uint32_t lbase = lds_base + (uint32_t)(slot * bufsz) * 8u;
                     for (int ivb = lw64; ivb < nvec; ivb += lthr) {
-                        if (ivb + llane < nvec) {
-                            const double* src = row + 2 * (ivb + llane);
-#pragma unroll
-                            for (int c = 0; c < CT; ++c)
-                                dma16(src + (int64_t)c * cs0,
-                                      __builtin_amdgcn_readfirstlane(lbase + (uint32_t)(c * g.lds_pitch + 2 * ivb) * 8u));
-                        }
+                        const int nact = nvec - ivb;  // lanes of this chunk (scalar)
+                        const uint64_t mask = nact >= 64 ? ~0ull : ((1ull << nact) - 1ull);
+                        dma_rows<CT>(mask, lane16, row + 2 * ivb, cs0, lbase + (uint32_t)(2 * ivb) * 8u,
+                                     (uint32_t)g.lds_pitch * 8u);
                         n += CT;
                     }
                 } else {
-                    n = stage_tile<T, CT, 0>(g, xa, nfr, c0, lds + slot * bufsz, ctl, gsrc, ltid, lthr, 0);
+                    n = stage_tile_ool<T, CT, 0>(g.n_in, g.lds_pitch, g.pad, xa, nfr, c0, lds + slot * bufsz, &sctl,
+                                                 gsrc.car, gsrc.ops, gsrc.leaves, ltid, lthr, 0);
                 }
             }
             cnt1 = cnt0;
@@ -1134,46 +1299,36 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             int64_t xa;
             int nfr;
             const bool fast = is_fast(pr, xa, nfr);
-            if (live && !((g.pad & 2) && it > 0) && !fast) {
-                stage_tile<T, CT, 1>(g, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz, ctl, gsrc, ltid,
-                                     lthr, allowed);
-            } else if (live && fast && nsteps0 > 0 && !(g.pad & 32)) {
-                // carrier 0's steps in place on the chunks this wave copied
+            // (a fused source without a gain ring -- it did not fit in LDS -- takes the general
+            //  in-place path: same chunk ownership as the fast issue)
+            if (live && !((g.pad & 2) && it > 0) && (!fast || (fused0 && !fring))) {
+                stage_tile_ool<T, CT, 1>(g.n_in, g.lds_pitch, g.pad, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz,
+                                         &sctl, gsrc.car, gsrc.ops, gsrc.leaves, ltid, lthr, allowed);
+            } else if (live && fast && fring) {
+                // carrier 0's steps in place on the chunks this wave copied, gains from the ring
                 const int nvec = (nfr + 1) >> 1;
                 const uint32_t lbase = lds_addr(lds + sr * bufsz);
-                bool waited = false;
+                const double* Fb = fbase + (size_t)(it & 1) * g.fslots * g.fpitch;
+                rs_stamp(g, wave, it, 5);
+                wait_vmcnt_le(allowed);  // this tile's DMA landed in LDS
+                rs_stamp(g, wave, it, 6);
                 for (int ivb = lw64; ivb < nvec; ivb += lthr) {
                     const int iv = ivb + llane;
-                    const int64_t gi = xa + 2 * (int64_t)iv;
-                    double F[kMaxFrameSlots][2];
+                    if (iv < nvec) {
+                        double F[kMaxFrameSlots][2];
 #pragma unroll
-                    for (int k = 0; k < kMaxFrameSlots; ++k) F[k][0] = F[k][1] = 0.0;
-                    // one copy of the evaluator, looped over the slots (register arrays are
-                    // indexed through select chains / a switch on the wave-uniform k)
-#pragma unroll 1
-                    for (int k = 0; k < nslots0 && !(g.pad & 64); ++k) {
-                        const int kind = k == 0 ? sk0[0] : k == 1 ? sk0[1] : k == 2 ? sk0[2] : sk0[3];
-                        const int li = k == 0 ? sl0[0] : k == 1 ? sl0[1] : k == 2 ? sl0[2] : sl0[3];
-                        const DLeaf L = ctl.leaves[li];
-                        double f0, f1;
-                        slot_eval2(kind, L, gi, f0, f1);
-                        switch (k) {
-                        case 0: F[0][0] = f0; F[0][1] = f1; break;
-                        case 1: F[1][0] = f0; F[1][1] = f1; break;
-                        case 2: F[2][0] = f0; F[2][1] = f1; break;
-                        default: F[3][0] = f0; F[3][1] = f1; break;
+                        for (int k = 0; k < kMaxFrameSlots; ++k) {
+                            F[k][0] = F[k][1] = 0.0;
+                            if (k < nslots0) {
+                                const double2 v = *reinterpret_cast<const double2*>(Fb + k * g.fpitch + 2 * iv);
+                                F[k][0] = v.x;
+                                F[k][1] = v.y;
+                            }
                         }
+                        rmw_chunk<CT, false>(lbase + (uint32_t)iv * 16u, g.lds_pitch, st0, F);
                     }
-                    if (!waited) {  // this tile's DMA landed in LDS
-                        rs_stamp(g, wave, it, 5);
-                        wait_vmcnt_le(allowed);
-                        waited = true;
-                        rs_stamp(g, wave, it, 6);
-                    }
-                    if (iv < nvec) rmw_chunk<CT, false>(lbase + (uint32_t)iv * 16u, g.lds_pitch, st0, F);
-                    rs_stamp(g, wave, it, 7);
                 }
-                if (!waited) wait_vmcnt_le(allowed);
+                rs_stamp(g, wave, it, 7);
             } else {
                 wait_vmcnt_le(allowed);
             }
@@ -1184,6 +1339,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             if (!live) break;  // (the compute waves' last barrier)
             issue(pn, sn, it);
             rs_stamp(g, wave, it, 3);
+            f_duty(pf, it & 1);  // gains of tile it+2
+            rs_stamp(g, wave, it, 4);
+            tile_next(pf);
             tile_next(pn);
             tile_next(pr);
             sn = sn + 1 == S ? 0 : sn + 1;
@@ -1283,6 +1441,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         // Raw barrier: __syncthreads() would also drain vmcnt(0), i.e. make the compute waves
         // wait for their output stores every tile.  The LDS reads of this tile were consumed
         // by the MFMAs above, so only lgkmcnt matters here; stores stay in flight.
+        rs_stamp(g, wave, it, 3);
+        f_duty(pf, it & 1);  // this wave's share of the gains of tile it+2
+        tile_next(pf);
+        rs_stamp(g, wave, it, 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rs_stamp(g, wave, it, 1);
         __builtin_amdgcn_s_barrier();  // next tile published; all finished reading this one
@@ -1296,7 +1458,7 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = (size_t)g.nslots * CT * g.lds_pitch * sizeof(double);  // + static sizeof(RsCtl)
+    size_t lds = ((size_t)g.nslots * CT * g.lds_pitch + (size_t)2 * g.fslots * g.fpitch) * sizeof(double);  // + static RsCtl
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,

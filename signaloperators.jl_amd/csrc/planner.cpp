@@ -1379,6 +1379,22 @@ void Plan::process_stage(int sid) {
         // staging, no intermediate in HBM
         S.in_buf = -1;
         S.in_array_node = -1;
+        // gain ring: two LDS arrays [slots][tile frames] next to the tile ring, if at least two
+        // tile slots still fit (see k_resample_periodic)
+        {
+            RsPeriodic& rp = S.rp;
+            const int ns0 = S.carriers[0].nslots;
+            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 8;
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            const int fpitch = (rp.tile_len + 16 + 1) & ~1;
+            const size_t fbytes = (size_t)2 * ns0 * fpitch * 8;
+            if (ns0 > 0 && S.carriers[0].nsteps > 0 && !std::getenv("SIGOPS_RS_NOFRING") &&
+                fbytes + 2 * tile_bytes <= avail) {
+                rp.fslots = ns0;
+                rp.fpitch = fpitch;
+                rp.nslots = (int)std::min<size_t>(rp.nslots, (avail - fbytes) / tile_bytes);
+            }
+        }
     } else if (!direct) {
         S.in_buf = new_buf(in_frames, N.nch, in_dtype);
         S.in_pitch = -1;
