@@ -707,8 +707,8 @@ __device__ __forceinline__ void carrier_apply(const CarT& C, const double (&F)[k
 // LDS accesses the compiler must not see (it cannot tell them from the LDS-DMA destinations
 // in flight and would wait vmcnt(0)); the caller orders them with explicit waits.
 typedef double v2d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lds_addr(const double* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)p;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 __device__ __forceinline__ v2d lds_ld16(uint32_t a) {
     v2d v;
@@ -748,13 +748,13 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
 // so per-DMA address arithmetic on the VALU costs more than the copy itself.
 #define SO_DMA_ROW(I) "s_mov_b32 m0, %[l" #I "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[voff], %[b" #I "]\n\t"
 template <int CT>
-__device__ __forceinline__ void dma_rows(uint64_t mask, uint32_t voff, const double* base, int64_t row_stride,
-                                         uint32_t lds, uint32_t lds_stride) {
+__device__ __forceinline__ void dma_rows(uint64_t mask, uint32_t voff, const char* base, int64_t row_stride,
+                                         uint32_t lds, uint32_t lds_stride) {  // strides in bytes
     uint64_t sv;
-    const double* b0 = base;
-    const double* b1 = base + row_stride;
-    const double* b2 = base + 2 * row_stride;
-    const double* b3 = base + 3 * row_stride;
+    const char* b0 = base;
+    const char* b1 = base + row_stride;
+    const char* b2 = base + 2 * row_stride;
+    const char* b3 = base + 3 * row_stride;
     if constexpr (CT == 1) {
         asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) "s_mov_b64 exec, %[sv]"
                      : [sv] "=&s"(sv)
@@ -861,7 +861,7 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
                                                         const DOp* __restrict__ ops,
                                                         const DLeaf* __restrict__ leaves,
                                                         int64_t gi, int iv, int ci, int c0,
-                                                        double* __restrict__ buf) {
+                                                        T* __restrict__ buf) {
     struct { int64_t n_in; int lds_pitch; } g{n_in, lds_pitch};
     constexpr int V = 16 / sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(V)));
@@ -930,10 +930,10 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int e = 0; e < V; ++e) buf[c * g.lds_pitch + iv * V + e] = val[c][e];
+                for (int e = 0; e < V; ++e) buf[c * g.lds_pitch + iv * V + e] = (T)val[c][e];
         } else {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) buf[c * g.lds_pitch + iv * V + sub] = val[c][0];
+            for (int c = 0; c < CT; ++c) buf[c * g.lds_pitch + iv * V + sub] = (T)val[c][0];
         }
     }
 }
@@ -948,7 +948,7 @@ __device__ __attribute__((noinline)) void stage_generic_ool(int64_t n_in, int ld
                                                             const DOp* __restrict__ ops,
                                                             const DLeaf* __restrict__ leaves,
                                                             int64_t gi, int iv, int ci, int c0,
-                                                            double* __restrict__ buf) {
+                                                            T* __restrict__ buf) {
     stage_generic_impl<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
 }
 template <typename T, int CT>
@@ -956,7 +956,7 @@ __device__ __forceinline__ void stage_generic(int64_t n_in, int lds_pitch,
                                               const DCarrier* __restrict__ car, int ncar,
                                               const DOp* __restrict__ ops,
                                               const DLeaf* __restrict__ leaves, int64_t gi, int iv,
-                                              int ci, int c0, double* __restrict__ buf) {
+                                              int ci, int c0, T* __restrict__ buf) {
     if constexpr (sizeof(T) == 8) stage_generic_impl<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
     else stage_generic_ool<T, CT>(n_in, lds_pitch, car, ncar, ops, leaves, gi, iv, ci, c0, buf);
 }
@@ -971,7 +971,7 @@ __device__ __forceinline__ void stage_generic(int64_t n_in, int lds_pitch,
 //                    place to exactly the chunks it copied.
 template <typename T, int CT, int PASS>
 __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, int nfr, int c0,
-                                          double* __restrict__ buf, const RsCtl& ctl,
+                                          T* __restrict__ buf, const RsCtl& ctl,
                                           const RsGlobalTables& gsrc, int tid, int nthr, int allowed) {
     const DCarrier* car = ctl.car;
     const int ncar = ctl.ncar;
@@ -1055,7 +1055,7 @@ __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, i
 // LDS-DMA ring.  Only tiles at a signal/carrier edge and non-fp64 sources come here.
 template <typename T, int CT, int PASS>
 __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pitch, int pad, int64_t xbase,
-                                                        int nfr, int c0, double* __restrict__ buf,
+                                                        int nfr, int c0, T* __restrict__ buf,
                                                         const RsCtl* ctl, const DCarrier* gcar,
                                                         const DOp* gops, const DLeaf* gleaves, int tid,
                                                         int nthr, int allowed) {
@@ -1068,7 +1068,12 @@ template <typename T, int CT, int KS, int G>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, T* __restrict__ y,
     RsGlobalTables gsrc) {
-    extern __shared__ double lds[];
+    // LDS: ring of nslots tiles in the SAMPLE type (fp32 tiles are converted at the A-operand
+    // read, so fp32 sources go by LDS-DMA too), then the fp64 gain ring
+    extern __shared__ double lds_raw[];
+    T* const lds = reinterpret_cast<T*>(lds_raw);
+    constexpr int V = 16 / (int)sizeof(T);       // frames per 16-byte vector
+    constexpr int kAlign = 128 / (int)sizeof(T);  // frames per 128-byte line
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -1128,8 +1133,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const int nsteps0 = __builtin_amdgcn_readfirstlane(C0.nsteps);
     // (tiles inside carrier 0 -- normally all but the signal's edges -- see nothing of the
     //  other carriers, e.g. the generated tail of an infinite Amplify)
-    const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) &&
-                        !(df0 & 1) && !(g.pad & 8) && sizeof(T) == 8;
+    const bool single = __builtin_amdgcn_readfirstlane((int)(C0.base != nullptr && C0.vec_ok &&
+                                                             C0.dtype == (sizeof(T) == 8 ? SO_F64 : SO_F32))) &&
+                        !(df0 & (V - 1)) && !(g.pad & 8);
     bool nodiv0 = true;  // (division steps take the general in-place path: code size)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -1145,10 +1151,12 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const int64_t lo_ok = a0 > 0 ? a0 : 0;
     const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
     auto is_fast = [&](const TilePos& p, int64_t& xa, int& nfr) __attribute__((always_inline)) {
-        const int sh = (int)(p.xb & 15);
+        const int sh = (int)(p.xb & (kAlign - 1));
         xa = p.xb - sh;
         nfr = g.tile_len + sh;
-        return single && nodiv0 && xa >= lo_ok && xa + ((nfr + 1) & ~1) <= hi_ok;
+        // (in-place steps of the fast path are fp64-only; fused fp32 sources take the general path)
+        return single && nodiv0 && (sizeof(T) == 8 || nsteps0 == 0) && xa >= lo_ok &&
+               xa + ((nfr + V - 1) & ~(V - 1)) <= hi_ok;
     };
     // Gain ring (g.fslots > 0): the per-frame slot values of a fused source -- sin generators,
     // ramps: ~150 fp64 instructions per frame -- are evaluated by ALL sixteen waves, two tiles
@@ -1157,8 +1165,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     // path (issue -> wait -> modify -> barrier) and the kernel runs 25 % below its plain-copy
     // speed.
     const bool fused0 = nsteps0 > 0 && !(g.pad & 32);
-    const bool fring = g.fslots > 0 && fused0 && nslots0 <= g.fslots;
-    double* const fbase = lds + (size_t)S * bufsz;
+    const bool fring = sizeof(T) == 8 && g.fslots > 0 && fused0 && nslots0 <= g.fslots;
+    double* const fbase = lds_raw + ((size_t)S * bufsz * sizeof(T) + 7) / 8;
     // Who evaluates which frames.  fp64 MFMA and fp64 VALU run on the same ALUs here (matrix and
     // vector fp64 peak are equal on MI355X): a loader wave's gain arithmetic only gets issue
     // slots once the compute waves on its SIMD have finished their MFMA burst (measured: 4-6k
@@ -1265,14 +1273,14 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 const int c0 = (int)p.tc * CT;
                 rs_stamp(g, wave, tr_it, 4);
                 if (is_fast(p, xa, nfr)) {
-                    const int nvec = (nfr + 1) >> 1;
-                    const double* row = base0 + ((int64_t)c0 * cs0 + df0 + xa);
-                    const uint32_t lbase = lds_base + (uint32_t)(slot * bufsz) * 8u;
+                    const int nvec = (nfr + V - 1) / V;
+                    const char* row = (const char*)base0 + ((int64_t)c0 * cs0 + df0 + xa) * (int64_t)sizeof(T);
+                    const uint32_t lbase = lds_base + (uint32_t)(slot * bufsz) * (uint32_t)sizeof(T);
                     for (int ivb = lw64; ivb < nvec; ivb += lthr) {
                         const int nact = nvec - ivb;  // lanes of this chunk (scalar)
                         const uint64_t mask = nact >= 64 ? ~0ull : ((1ull << nact) - 1ull);
-                        dma_rows<CT>(mask, lane16, row + 2 * ivb, cs0, lbase + (uint32_t)(2 * ivb) * 8u,
-                                     (uint32_t)g.lds_pitch * 8u);
+                        dma_rows<CT>(mask, lane16, row + (int64_t)ivb * 16, cs0 * (int64_t)sizeof(T),
+                                     lbase + (uint32_t)ivb * 16u, (uint32_t)g.lds_pitch * (uint32_t)sizeof(T));
                         n += CT;
                     }
                 } else {
@@ -1383,8 +1391,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     int slot = 0, it = 0;
     for (TilePos p = tile_first(); p.tc < ngrp; tile_next(p), ++it) {
         rs_stamp(g, wave, it, 0);
-        const int sh = (int)(p.xb & 15);
-        const double* __restrict__ cur = lds + slot * bufsz + sh;
+        const int sh = (int)(p.xb & (kAlign - 1));
+        const T* __restrict__ cur = lds + slot * bufsz + sh;
         const int64_t P0 = p.tx * g.pt;
         const int c0 = (int)p.tc * CT;
         T* __restrict__ ytile = y + ((int64_t)c0 * g.out_pitch + P0 * g.L);
@@ -1401,17 +1409,17 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 // A operands are software-pipelined one k-step ahead (double-buffered
                 // registers) so the LDS latency hides under the previous step's MFMAs; the
                 // per-step address is an immediate offset from fixed row pointers.
-                const double* __restrict__ ap[kRsQ];
+                const T* __restrict__ ap[kRsQ];
 #pragma unroll
                 for (int q = 0; q < kRsQ; ++q) ap[q] = cur + (rowoff[q] + je);
                 double abuf[2][kRsQ];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = ap[q][0];
+                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = (double)ap[q][0];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s + 1 < KS) {
 #pragma unroll
-                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = ap[q][4 * (s + 1)];
+                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
                     }
 #pragma unroll
                     for (int q = 0; q < kRsQ; ++q)
@@ -1458,7 +1466,7 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = ((size_t)g.nslots * CT * g.lds_pitch + (size_t)2 * g.fslots * g.fpitch) * sizeof(double);  // + static RsCtl
+    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch) * 8;  // + static RsCtl
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,

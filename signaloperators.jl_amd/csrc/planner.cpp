@@ -1178,10 +1178,11 @@ void Plan::process_stage(int sid) {
             int jlo = jend[0] - (kw - 1);
             jlo -= ((jlo % 4) + 4) % 4;
             const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
-            // +15: tiles are staged from the 128-byte aligned frame below their first input;
-            // even pitch: 16-byte aligned rows for LDS-DMA
-            int64_t pitch = (tile_len + 15 + 5) & ~(int64_t)1;
-            size_t lds_bytes = (size_t)ct * pitch * 8;
+            // tiles are kept in LDS in the sample type and staged from the 128-byte aligned frame
+            // below their first input (+15 / +31 frames); rows are 16-byte multiples for LDS-DMA
+            const int64_t esz_t = (int64_t)dsize(N.dtype), vfr = 16 / esz_t;
+            int64_t pitch = (tile_len + (128 / esz_t - 1) + 2 * vfr + vfr - 1) / vfr * vfr;
+            size_t lds_bytes = ((size_t)ct * pitch * esz_t + 7) / 8 * 8;
             size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
             // LDS ring: as many tile slots as fit in 160 KiB, at most 4 (2 tiles in flight
             // beyond the one being retired), at least 2 (plain double buffering)
@@ -1384,7 +1385,7 @@ void Plan::process_stage(int sid) {
         {
             RsPeriodic& rp = S.rp;
             const int ns0 = S.carriers[0].nslots;
-            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 8;
+            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * dsize(N.dtype);
             const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
             const int fpitch = (rp.tile_len + 16 + 1) & ~1;
             const size_t fbytes = (size_t)2 * ns0 * fpitch * 8;
@@ -1512,6 +1513,11 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
     }
     // compile the per-frame programs; everything must fit the kernel-argument control block
     if (cs.size() > (size_t)kCtlCar) return false;
+    // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
+    // staging path, ~6x slower than a K1 pass + the LDS-DMA fast path), so steps on fp32 data
+    // are materialised by K1 instead of fused
+    for (auto& c : cs)
+        if (c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) return false;
     std::vector<std::vector<DOp>> fcodes(cs.size());
     size_t nops_total = 0;
     std::set<int> leafset;
