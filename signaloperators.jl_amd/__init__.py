@@ -14,6 +14,7 @@ from .signals import (  # noqa: F401
 from numpy import sin, cos  # noqa: F401  (Signal(sin), Signal(cos))
 from .engine import sink, sink_into, Plan, Array, process_sink_params, _eager  # noqa: F401
 from .lowering import lower, design_iir, design_resample  # noqa: F401
+from .wav import save_signal, load_signal  # noqa: F401
 
 until = _eager(Until)
 after = _eager(After)
