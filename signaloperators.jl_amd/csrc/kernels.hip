@@ -40,27 +40,41 @@ __device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
 // Compact fp64 sin/cos kernels (Taylor on |t| <= 1/4 after exact octant reduction).  The
 // device library's sinpi/cos carry large-argument paths that cost ~40 VGPRs of pressure in
 // every kernel that inlines the interpreter; these need ~12 and are accurate to ~1 ulp.
+// fma with a CONSTANT operand held in a scalar register pair.  hipcc otherwise materialises
+// every fp64 polynomial coefficient with two v_mov_b32 into the accumulator of a v_fmac (35 of
+// the ~110 instructions of one sinpi evaluation, all on the vector ALU that the fp64 MFMAs of
+// the resampler also need); s_mov_b32 is free by comparison.  Same operands, same rounding.
+__device__ __forceinline__ double fma_addc(double a, double b, double c_const) {  // a*b + C
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
+    return r;
+}
+__device__ __forceinline__ double fma_mulc(double a, double b_const, double c) {  // a*C + c
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_const), "v"(c));
+    return r;
+}
 __device__ __forceinline__ void sincospi_quarter(double t, double& s, double& c) {
     const double t2 = t * t;
     double ps = 7.952054001475513e-07;
-    ps = fma(ps, t2, -2.1915353447830217e-05);
-    ps = fma(ps, t2, 0.00046630280576761255);
-    ps = fma(ps, t2, -0.0073704309457143504);
-    ps = fma(ps, t2, 0.08214588661112823);
-    ps = fma(ps, t2, -0.5992645293207921);
-    ps = fma(ps, t2, 2.5501640398773455);
-    ps = fma(ps, t2, -5.16771278004997);
+    ps = fma_addc(ps, t2, -2.1915353447830217e-05);
+    ps = fma_addc(ps, t2, 0.00046630280576761255);
+    ps = fma_addc(ps, t2, -0.0073704309457143504);
+    ps = fma_addc(ps, t2, 0.08214588661112823);
+    ps = fma_addc(ps, t2, -0.5992645293207921);
+    ps = fma_addc(ps, t2, 2.5501640398773455);
+    ps = fma_addc(ps, t2, -5.16771278004997);
     const double t3 = t2 * t;
-    s = fma(t, 3.141592653589793, fma(t, 1.2246467991473532e-16, t3 * ps));
+    s = fma_mulc(t, 3.141592653589793, fma_mulc(t, 1.2246467991473532e-16, t3 * ps));
     double pc = -1.3878952462213771e-07;
-    pc = fma(pc, t2, 4.303069587032947e-06);
-    pc = fma(pc, t2, -0.0001046381049248457);
-    pc = fma(pc, t2, 0.0019295743094039231);
-    pc = fma(pc, t2, -0.02580689139001406);
-    pc = fma(pc, t2, 0.2353306303588932);
-    pc = fma(pc, t2, -1.3352627688545895);
-    pc = fma(pc, t2, 4.0587121264167685);
-    pc = fma(pc, t2, -4.934802200544679);
+    pc = fma_addc(pc, t2, 4.303069587032947e-06);
+    pc = fma_addc(pc, t2, -0.0001046381049248457);
+    pc = fma_addc(pc, t2, 0.0019295743094039231);
+    pc = fma_addc(pc, t2, -0.02580689139001406);
+    pc = fma_addc(pc, t2, 0.2353306303588932);
+    pc = fma_addc(pc, t2, -1.3352627688545895);
+    pc = fma_addc(pc, t2, 4.0587121264167685);
+    pc = fma_addc(pc, t2, -4.934802200544679);
     c = fma(pc, t2, 1.0);
 }
 // sinpi(x) with Julia's semantics: exact at integers and half-integers (src/functions.jl:57-60)
