@@ -81,6 +81,12 @@ def main():
             scenes.append(Mix(Signal(sin, ω=(500 + 25 * k) * Hz) | Until(n4 * frames), Signal(noise, 44.1 * kHz))
                           | Filt(Bandstop, 0.5 * kHz, 2 * kHz) | Ramp(10 * ms))
         run("config4 share: Append(8 x [Mix+Filt(Bandstop)+Ramp], 60s, 2ch)", Append(*scenes), so, torch, steps=5)
+    if sel and "k1" in sel:  # K1 alone: pointwise map over a large array (not a BASELINE config)
+        nk = int(26460000 * a.scale)
+        xk = dev(nk, 8)
+        run("K1 probe: Amplify(x[%d x 8], sin 5Hz) |> Ramp(1s)" % nk,
+            Amplify(Signal(xk, 44.1 * kHz), Signal(sin, ω=5 * Hz)) | Until(nk * frames) | Ramp(1 * s), so, torch, steps=5)
+        run("K1 probe: Amplify(x[%d x 8], 0.5)" % nk, Amplify(Signal(xk, 44.1 * kHz), 0.5), so, torch, steps=5)
     if not sel or "5" in sel:  # config 5 (one GPU's slab, time scaled down): 128 ch
         n5 = int(1000000 * a.scale)
         x = dev(n5, 128, uniform=True)

@@ -185,9 +185,20 @@ struct Plan {
     DLeaf* d_leaves = nullptr;
     int out_stage_buf = -1;  // device staging for a host result
     int alias_stage = -1;    // stage whose kernel writes the final output directly
+    bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
     std::vector<char> host_tmp;
     bool profiling = false;
     std::vector<hipEvent_t> events;
+    // independent step chains (Append children, Mix operands with their own filters ...) run on
+    // separate HIP streams: the small latency-bound kernels of different chains overlap
+    std::vector<std::vector<int>> step_deps;  // per step: earlier steps it must wait for
+    std::vector<int> step_lane;               // per step: 0 = the caller's stream
+    std::vector<char> step_signals;           // per step: a later step on another lane waits for it
+    int nlanes = 1;
+    std::vector<hipStream_t> lane_streams;  // [1..nlanes)
+    std::vector<hipEvent_t> step_done;
+    hipEvent_t ev_start = nullptr;
+    void plan_lanes();
     so_stats_t stats{};
     int64_t algo_bytes = 0;
     std::map<int, bool> array_counted;
@@ -1771,7 +1782,92 @@ void Plan::finalize() {
     stats.d2h_bytes = out.is_device ? 0 : out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
 }
 
+// Dependencies between steps from the plan buffers they read and write, then a lane (stream)
+// per step: a step continues on the lane of its latest dependency, a step without
+// dependencies opens the next lane (round robin over at most 8).
+void Plan::plan_lanes() {
+    const int n = (int)steps.size();
+    step_deps.assign(n, {});
+    step_lane.assign(n, 0);
+    step_signals.assign(n, 0);
+    nlanes = 1;
+    if (n < 3 || std::getenv("SIGOPS_SINGLE_STREAM")) return;
+    const int kFinal = -2;
+    std::vector<std::set<int>> rd(n), wr(n);
+    auto piece_reads = [&](const PwStep& w, std::set<int>& out) {
+        for (int pi = w.piece0; pi < w.piece0 + w.npieces; ++pi) {
+            const DPiece& P = pieces[pi];
+            for (int k = 0; k < P.frame_len + P.samp_len; ++k) {
+                const DOp& o = k < P.frame_len ? ops[P.frame_pc + k] : ops[P.samp_pc + (k - P.frame_len)];
+                if ((o.code == OP_LOAD || o.code == OP_SCALAR) && o.arg >= 0 && o.arg < (int)leaves.size() &&
+                    leaves[o.arg].buf >= 0)
+                    out.insert(leaves[o.arg].buf);
+            }
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        const Step& st = steps[i];
+        if (st.kind == 0) {
+            const PwStep& w = pw[st.idx];
+            piece_reads(w, rd[i]);
+            wr[i].insert(w.out_buf >= 0 ? w.out_buf : kFinal);
+        } else {
+            const Stage& S = stages[st.idx];
+            if (S.in_buf >= 0) rd[i].insert(S.in_buf);
+            for (auto& c : S.carriers) {
+                if (c.buf >= 0) rd[i].insert(c.buf);
+                for (int k = 0; k < c.frame_len; ++k) {
+                    const DOp& o = ops[c.frame_pc + k];
+                    if ((o.code == OP_LOAD || o.code == OP_SCALAR) && leaves[o.arg].buf >= 0) rd[i].insert(leaves[o.arg].buf);
+                }
+                for (int k = 0; k < c.nslots; ++k)
+                    if (leaves[c.slot_leaf[k]].buf >= 0) rd[i].insert(leaves[c.slot_leaf[k]].buf);
+            }
+            wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
+            if (S.kind == ST_NORM) {  // reads its own output buffer, writes the rms scalar
+                rd[i].insert(S.out_buf);
+                if (S.rms_buf >= 0) wr[i].insert(S.rms_buf);
+            }
+        }
+    }
+    auto meets = [](const std::set<int>& a, const std::set<int>& b) {
+        for (int x : a)
+            if (b.count(x)) return true;
+        return false;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (meets(rd[i], wr[j]) || meets(wr[i], wr[j]) || meets(wr[i], rd[j])) step_deps[i].push_back(j);
+    int next = 0;
+    const int kMaxLanes = 8;
+    for (int i = 0; i < n; ++i) {
+        if (step_deps[i].empty()) {
+            step_lane[i] = next % kMaxLanes;
+            ++next;
+        } else step_lane[i] = step_lane[step_deps[i].back()];
+    }
+    step_lane[n - 1] = 0;  // the last step (it produces the result) runs on the caller's stream
+    for (int i = 0; i < n; ++i) nlanes = std::max(nlanes, step_lane[i] + 1);
+    for (int i = 0; i < n; ++i)
+        for (int j : step_deps[i])
+            if (step_lane[j] != step_lane[i]) step_signals[j] = 1;
+    if (nlanes == 1) return;
+    lane_streams.assign(nlanes, nullptr);
+    for (int l = 1; l < nlanes; ++l) HIPCHECK(hipStreamCreateWithFlags(&lane_streams[l], hipStreamNonBlocking));
+    step_done.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) HIPCHECK(hipEventCreateWithFlags(&step_done[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+}
+
 void Plan::release() {
+    for (auto st_ : lane_streams)
+        if (st_) (void)hipStreamDestroy(st_);
+    lane_streams.clear();
+    for (auto e : step_done)
+        if (e) (void)hipEventDestroy(e);
+    step_done.clear();
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    ev_start = nullptr;
     for (auto& b : bufs)
         if (b.d && !b.external) (void)hipFree(b.d);
     bufs.clear();
@@ -1819,7 +1915,10 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         }
         // If the root is nothing but a full plain read of one stage's output, let that
         // stage's kernel write the sink buffer itself (saves a read+write pass).
-        if (rootp.size() == 1 && (out->frame_stride == 1 || !out->is_device)) {
+        // (a host result in interleaved layout -- WAV frames -- is produced by the root K1 step
+        //  writing the staging buffer with the result's own strides: one D2H copy, no host loop)
+        P->interleaved_host = !out->is_device && out->nch > 1 && out->chan_stride == 1 && out->frame_stride == out->nch;
+        if (rootp.size() == 1 && (out->frame_stride == 1 || !out->is_device) && !P->interleaved_host) {
             const Expr& e = P->exprs[rootp[0].e];
             if (e.op == E_LOAD && e.leaf.buf >= 0 && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 &&
                 e.leaf.df == 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && e.leaf.dtype == out->dtype) {
@@ -1842,6 +1941,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             Step st{0, rootstep, "k_pointwise", P->pw[rootstep].bytes};
             P->steps.push_back(st);
         }
+        P->plan_lanes();
     } catch (const PlanError& e) {
         status = e.status;
         err = e.msg;
@@ -1867,8 +1967,23 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
             }
         }
         int launches = 0;
+        // (profiling times the steps one after the other on the caller's stream)
+        const bool lanes = P->nlanes > 1 && !P->profiling && !std::getenv("SIGOPS_RS_TRACE");
+        hipStream_t const main_st = st;
+        std::vector<char> lane_started(P->nlanes, 0);
+        if (lanes) HIPCHECK(hipEventRecord(P->ev_start, main_st));  // after the H2D copies / earlier work
         for (size_t si = 0; si < P->steps.size(); ++si) {
             Step& s = P->steps[si];
+            const int ln = lanes ? P->step_lane[si] : 0;
+            hipStream_t st = ln == 0 ? main_st : P->lane_streams[ln];  // shadows the caller's stream
+            if (lanes) {
+                if (ln != 0 && !lane_started[ln]) {
+                    HIPCHECK(hipStreamWaitEvent(st, P->ev_start, 0));
+                    lane_started[ln] = 1;
+                }
+                for (int d : P->step_deps[si])
+                    if (P->step_lane[d] != ln) HIPCHECK(hipStreamWaitEvent(st, P->step_done[d], 0));
+            }
             if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si], st));
             if (s.kind == 0) {
                 PwStep& w = P->pw[s.idx];
@@ -1889,8 +2004,8 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                 } else {
                     Buf& b = P->bufs[P->out_stage_buf];
                     ov.base = b.d;
-                    ov.fstride = 1;
-                    ov.cstride = b.pitch;
+                    ov.fstride = P->interleaved_host ? P->out.nch : 1;
+                    ov.cstride = P->interleaved_host ? 1 : b.pitch;
                     ov.dtype = b.dtype;
                 }
                 if (w.nblocks > 0) {
@@ -2002,6 +2117,19 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
                 }
             }
             if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si + 1], st));
+            if (lanes && (P->step_signals[si] || (ln != 0 && si + 1 == P->steps.size())))
+                HIPCHECK(hipEventRecord(P->step_done[si], st));
+        }
+        if (lanes) {
+            // join: everything the side lanes did is ordered before what follows on the caller's
+            // stream (the last step of every side lane signals; wait for the last step per lane)
+            std::vector<int> last(P->nlanes, -1);
+            for (size_t si = 0; si < P->steps.size(); ++si) last[P->step_lane[si]] = (int)si;
+            for (int l = 1; l < P->nlanes; ++l)
+                if (last[l] >= 0) {
+                    if (!P->step_signals[last[l]]) HIPCHECK(hipEventRecord(P->step_done[last[l]], P->lane_streams[l]));
+                    HIPCHECK(hipStreamWaitEvent(main_st, P->step_done[last[l]], 0));
+                }
         }
         HIPCHECK(hipGetLastError());
         P->stats.n_launches = launches;
@@ -2009,7 +2137,7 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
             Buf& b = P->bufs[P->out_stage_buf];
             size_t esz = dsize(P->out.dtype);
             bool planar = P->out.frame_stride == 1 && (P->out.nch == 1 || P->out.chan_stride == P->out.nframes);
-            if (planar) {
+            if (planar || P->interleaved_host) {
                 HIPCHECK(hipMemcpyAsync(outp, b.d, b.bytes, hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
             } else {
