@@ -199,6 +199,13 @@ struct Plan {
     std::vector<hipEvent_t> step_done;
     hipEvent_t ev_start = nullptr;
     void plan_lanes();
+    // captured launch sequence (see plan_execute)
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t capture_stream = nullptr;
+    const void* graph_out = nullptr;
+    const void* last_out = nullptr;
+    int64_t array_epoch = 0, graph_epoch = -1, last_epoch = -1;
+    bool graph_failed = false;
     so_stats_t stats{};
     int64_t algo_bytes = 0;
     std::map<int, bool> array_counted;
@@ -1868,6 +1875,10 @@ void Plan::release() {
     step_done.clear();
     if (ev_start) (void)hipEventDestroy(ev_start);
     ev_start = nullptr;
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
+    capture_stream = nullptr;
     for (auto& b : bufs)
         if (b.d && !b.external) (void)hipFree(b.d);
     bufs.clear();
@@ -1952,7 +1963,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
     return P.release();
 }
 
-int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
+static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& err) {
     try {
         HIPCHECK(hipSetDevice(P->device));
         hipStream_t st = (hipStream_t)stream;
@@ -2176,12 +2187,73 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
     return SO_OK;
 }
 
+// so_plan_execute.  Plans with many small launches (config 4: 33 launches and ~40 event
+// operations per execute) are host-bound, so from the second execute with the same result
+// pointer on, the whole multi-stream launch sequence is replayed from a captured HIP graph.
+int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
+    const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
+                          !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
+    if (!eligible) return plan_execute_direct(P, outp, stream, err);
+    hipStream_t st = (hipStream_t)stream;
+    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch) {
+        if (hipSetDevice(P->device) == hipSuccess && hipGraphLaunch(P->graph_exec, st) == hipSuccess) return SO_OK;
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(P->graph_exec);  // fall back to direct launches for good
+        P->graph_exec = nullptr;
+        P->graph_failed = true;
+    }
+    if (P->graph_failed || P->last_out != outp || P->last_epoch != P->array_epoch) {
+        // first execute for this result / these arrays: plain launches (also performs the
+        // one-time function attribute calls, which must not happen inside a capture)
+        P->last_out = outp;
+        P->last_epoch = P->array_epoch;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    if (P->graph_exec) {
+        (void)hipGraphExecDestroy(P->graph_exec);
+        P->graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    // capture on a stream of our own (the caller's may be the legacy default stream, which cannot
+    // be captured); the graph is then launched on the caller's stream
+    if (!P->capture_stream && hipStreamCreateWithFlags(&P->capture_stream, hipStreamNonBlocking) != hipSuccess)
+        P->capture_stream = nullptr;
+    if (!P->capture_stream || hipSetDevice(P->device) != hipSuccess ||
+        hipStreamBeginCapture(P->capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        P->graph_failed = true;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    const int rc = plan_execute_direct(P, outp, (void*)P->capture_stream, err);
+    const hipError_t ec = hipStreamEndCapture(P->capture_stream, &graph);
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] graph capture: rc=%d end=%d (%s) graph=%p err=%s\n", rc, (int)ec, hipGetErrorString(ec), (void*)graph, err.c_str());
+    if (rc != SO_OK || ec != hipSuccess || !graph ||
+        hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        P->graph_exec = nullptr;
+        P->graph_failed = true;
+        return rc != SO_OK ? rc : plan_execute_direct(P, outp, stream, err);
+    }
+    (void)hipGraphDestroy(graph);
+    P->graph_out = outp;
+    P->graph_epoch = P->array_epoch;
+    if (hipGraphLaunch(P->graph_exec, st) != hipSuccess) {
+        (void)hipGetLastError();
+        P->graph_failed = true;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    return SO_OK;
+}
+
 int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& err) {
     if (node_index < 0 || node_index >= (int)P->nodes.size() || P->nodes[node_index].nd.kind != SO_NODE_ARRAY) {
         err = "so_plan_set_array: not an ARRAY node";
         return SO_ERR_INVALID;
     }
     P->array_ptr[node_index] = data;
+    P->array_epoch++;  // invalidates a captured launch graph
     if (P->nodes[node_index].nd.i0) {  // device leaf: patch the leaf table
         bool changed = false;
         for (size_t i = 0; i < P->leaves.size(); ++i)
