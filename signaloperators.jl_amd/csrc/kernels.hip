@@ -295,7 +295,10 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
 // K1: one workgroup = kBlock*E consecutive frames x a channel chunk of one piece.
 // Lane l handles frames base + l + e*kBlock, so every load/store instruction is a
 // fully coalesced run of 64 consecutive elements per wave.
-template <int E>
+// DEEP == false: every piece of the launch needs a stack depth <= 2 (left-fold chains: almost
+// every tree), so the 4-deep interpreters are not even compiled in -- half the registers, twice
+// the waves per SIMD, and this kernel is bound by bytes in flight.
+template <int E, bool DEEP>
 __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__ pieces,
                                                       int npieces, const DOp* __restrict__ ops,
                                                       const DLeaf* __restrict__ leaves,
@@ -327,14 +330,18 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
 #pragma unroll
         for (int e = 0; e < E; ++e) F[k][e] = 0.0;
     double v[E];
-    const bool deep = P.depth > 2;  // wave-uniform
+    const bool deep = DEEP && P.depth > 2;  // wave-uniform
     if (P.frame_len > 0) {
-        if (deep) run_program<E, false, kStackDepth, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
-        else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+        if constexpr (DEEP) {
+            if (deep) run_program<E, false, kStackDepth, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+            else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+        } else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
     }
     for (int c = cbeg; c < cend; ++c) {
-        if (deep) run_program<E, false, kStackDepth, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
-        else run_program<E, false, 2, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
+        if constexpr (DEEP) {
+            if (deep) run_program<E, false, kStackDepth, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
+            else run_program<E, false, 2, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
+        } else run_program<E, false, 2, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
         if (out.dtype == SO_F32) {
             float* o = (float*)out.base + (int64_t)c * out.cstride;
 #pragma unroll
@@ -350,10 +357,14 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
 }
 
 void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, const DOp* d_ops,
-                      const DLeaf* d_leaves, OutView out, hipStream_t st) {
+                      const DLeaf* d_leaves, OutView out, bool deep, hipStream_t st) {
     if (nblocks <= 0) return;
-    hipLaunchKernelGGL((k_pointwise<2>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
-                       npieces, d_ops, d_leaves, out);
+    if (deep)
+        hipLaunchKernelGGL((k_pointwise<kPointwiseE, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
+                           npieces, d_ops, d_leaves, out);
+    else
+        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
+                           npieces, d_ops, d_leaves, out);
 }
 
 // ---------------------------------------------------------------------------

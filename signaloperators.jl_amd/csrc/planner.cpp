@@ -142,6 +142,7 @@ struct PwStep {
     int64_t nblocks = 0;
     int out_buf = -1;  // -1: final output
     int64_t bytes = 0;
+    bool deep = false;  // some piece needs the 4-deep interpreter
 };
 
 struct Step {
@@ -953,7 +954,7 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtyp
     st.piece0 = (int)pieces.size();
     st.out_buf = out_buf;
     int64_t blk = 0;
-    constexpr int E = 2;
+    constexpr int E = kPointwiseE;
     for (auto& p : ps) {
         if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
         if (depth(p.e) > kStackDepth)
@@ -969,6 +970,7 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtyp
                 fail(SO_ERR_UNSUPPORTED, "more than 4 distinct generator/ramp sub-expressions in one fused piece");
         DPiece d{};
         d.depth = std::max(2, depth(p.e));
+        if (d.depth > 2) st.deep = true;
         d.a = p.r.a;
         d.b = p.r.b;
         d.c0 = p.r.c0;
@@ -2020,7 +2022,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     ov.dtype = b.dtype;
                 }
                 if (w.nblocks > 0) {
-                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, st);
+                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st);
                     s.launches = 1;
                     launches++;
                 }

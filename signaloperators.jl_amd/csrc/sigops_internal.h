@@ -51,6 +51,7 @@ struct DLeaf {
 };
 
 constexpr int kBlock = 256;
+constexpr int kPointwiseE = 2;  // frames per thread of k_pointwise (independent loads in flight)
 constexpr int kMaxFrameSlots = 4;
 constexpr int kStackDepth = 4;
 
