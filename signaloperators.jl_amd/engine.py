@@ -72,6 +72,20 @@ class Plan:
         if st != 0:
             raise S.ErrorException(K.last_error())
 
+    def set_array(self, k, data):
+        """so_plan_set_array: point the k-th array leaf of the tree (depth-first order) at new data
+        of the same shape, dtype and residency without re-planning."""
+        idx, sig = self.lowered.array_nodes[k]
+        if hasattr(data, "data_ptr"):
+            ptr = data.data_ptr()
+        else:
+            ptr = data.ctypes.data
+        self._keep_arrays = getattr(self, "_keep_arrays", {})
+        self._keep_arrays[k] = data
+        st = K.lib().so_plan_set_array(self.handle, idx, C.c_void_p(ptr))
+        if st != 0:
+            raise S.ErrorException(K.last_error())
+
     def set_profiling(self, on=True):
         K.lib().so_plan_set_profiling(self.handle, 1 if on else 0)
 

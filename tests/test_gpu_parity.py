@@ -89,3 +89,97 @@ def test_tile_invariance_linearity():
     yb, _ = so.sink(pipe(b))
     yab, _ = so.sink(pipe(np.asfortranarray(a + 2.0 * b)))
     assert relerr(yab, ya + 2.0 * yb) < 1e-11
+
+
+def test_plan_reuse_graph_replay_and_set_array():
+    """One plan executed repeatedly: plain launches, HIP-graph capture, replay; then the array
+    leaves are swapped with so_plan_set_array (which must invalidate the capture).  The tree has
+    two independently filtered operands (separate streams) feeding a resampler."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(17)
+    fs = 8 * so.kHz
+
+    def host(n, nch):
+        return np.asfortranarray(rng.standard_normal((n, nch)))
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+
+    def tree(a, b):
+        return (so.Mix(so.Signal(a, fs) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz),
+                       so.Signal(b, fs) | so.Filt(so.Lowpass, 1 * so.kHz))
+                | so.Ramp(5 * so.ms) | so.ToFramerate(12 * so.kHz))
+
+    A = [host(6000, 2) for _ in range(2)]
+    B = [host(6000, 2) for _ in range(2)]
+    dA, dB = [dev(a) for a in A], [dev(b) for b in B]
+    x = tree(*dA)
+    n = so.nframes(x)
+    out_t = torch.empty((2, n), dtype=torch.float64, device="cuda")
+    out = out_t.t()
+    plan = so.Plan(so.ToChannels(x, 2), (n, 2), np.float64, (out.stride(0), out.stride(1)), True)
+    stream = torch.cuda.current_stream().cuda_stream
+    want_a, want_b = oracle_sink(tree(*A)), oracle_sink(tree(*B))
+    try:
+        assert plan.stats()["n_stages"] >= 3
+        for _ in range(4):  # direct, capture + launch, replay, replay
+            out_t.zero_()
+            plan.execute(out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert relerr(out.cpu().numpy(), want_a) < 1e-10
+        for k in range(2):
+            plan.set_array(k, dB[k])
+        for _ in range(3):
+            out_t.zero_()
+            plan.execute(out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert relerr(out.cpu().numpy(), want_b) < 1e-10
+    finally:
+        plan.close()
+
+
+def test_set_array_on_fused_resampler_carrier():
+    """so_plan_set_array must also re-point the carriers of a fused resampler source"""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(23)
+    fs = 44.1 * so.kHz
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+
+    def tree(a):
+        return so.Signal(a, fs) | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(20000 * so.frames) | so.ToFramerate(48 * so.kHz)
+
+    a, b = (np.asfortranarray(rng.standard_normal((20000, 8))) for _ in range(2))
+    da, db = dev(a), dev(b)
+    x = tree(da)
+    n = so.nframes(x)
+    out_t = torch.empty((8, n), dtype=torch.float64, device="cuda")
+    out = out_t.t()
+    plan = so.Plan(so.ToChannels(x, 8), (n, 8), np.float64, (out.stride(0), out.stride(1)), True)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        plan.execute(out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert relerr(out.cpu().numpy(), oracle_sink(tree(a))) < 1e-10
+        plan.set_array(0, db)
+        plan.execute(out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert relerr(out.cpu().numpy(), oracle_sink(tree(b))) < 1e-10
+    finally:
+        plan.close()
+
+
+def test_append_after_long_filtered_child_is_a_concatenation():
+    """Documented divergence: the reference's FilteredSignal end test compares
+    a buffer-local index with the global length (src/filters.jl:224-227), so a filtered child
+    longer than one block never reports its end and `Append` keeps pulling its zero-padded tail
+    instead of moving on (the oracle reproduces that: tests/test_oracle_dsp.py).  The engine
+    implements the documented meaning of Append: each child's own frames, one after the other."""
+    rng = np.random.default_rng(29)
+    fs = 8 * so.kHz
+    a, b = (np.asfortranarray(rng.standard_normal((6000, 2))) for _ in range(2))
+    ra, rb = (so.Signal(v, fs) | so.ToFramerate(12 * so.kHz) for v in (a, b))
+    got, _ = so.sink(so.Append(ra, rb))
+    want = np.concatenate([oracle_sink(ra), oracle_sink(rb)])
+    assert relerr(got, want) < 1e-11

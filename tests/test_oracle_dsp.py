@@ -116,3 +116,19 @@ def test_phase_accumulator_divergence_is_documented():
     # tie cases flip between neighbouring phases: small but far above 1e-6 is possible
     assert outs[0].shape == outs[1].shape
     assert err < 1e-3
+
+
+def test_reference_quirk_append_never_leaves_a_long_filtered_child():
+    """SURVEY quirk C-7 made visible: in the reference a FilteredSignal longer than its block
+    never returns `nothing` (src/filters.jl:224-227 compares a buffer-local index with the global
+    length), so `Append(filtered, y)` continues with the filter's zero-padded tail instead of y.
+    The oracle follows the reference; the engine concatenates (tests/test_gpu_parity.py)."""
+    rng = np.random.default_rng(31)
+    fs = 8 * so.kHz
+    x = np.asfortranarray(rng.standard_normal((6000, 1)))
+    y = 3.0 * np.ones((9000, 1))
+    rx = so.Signal(x, fs) | so.ToFramerate(12 * so.kHz)
+    w = oracle_sink(so.Append(rx, so.Signal(y, 12 * so.kHz)))
+    assert w.shape == (18000, 1)
+    np.testing.assert_array_equal(w[:9000], oracle_sink(rx))
+    assert np.abs(w[9100:]).max() < 1e-12  # the resampler's decayed tail, not y
