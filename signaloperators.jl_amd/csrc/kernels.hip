@@ -631,6 +631,90 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 }
 
 // ---------------------------------------------------------------------------
+// K3r: row-tiled polyphase resampler for rational rates with LONG periods / filters (e.g.
+// 44.1 kHz -> 16 kHz: 441 inputs and 160 outputs per period, 148 taps per output), where one
+// period of the MFMA kernel's tile no longer fits LDS twice and the taps no longer fit registers.
+//
+// A workgroup stages pb periods x ct channels of input (one LDS tile, coalesced loads, zero
+// padded outside the signal) and produces all L outputs of those rows.  A wave covers
+// `rows = ct*pb` rows x `64/rows` consecutive output phases: lanes of one phase read the SAME
+// combined tap (h + alpha*dh, host-built table ctab[phase][age]) -- a handful of distinct
+// addresses per load instruction instead of 64 -- and their own row's input from LDS at a row
+// stride of M elements.  (The thread-per-output fallback streams a lane-private row of taps per
+// output: 1.2 KB of L2 traffic per 8-byte result on the slab config.)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x, T* __restrict__ y,
+                                                        const double* __restrict__ ctab,
+                                                        const int* __restrict__ jr, RsRows g) {
+    extern __shared__ double lds_raw[];
+    T* const lds = reinterpret_cast<T*>(lds_raw);
+    const int rows = g.ct * g.pb, ph = 64 / rows;
+    const int64_t ntx = (g.nperiods + g.pb - 1) / g.pb;
+    const int64_t tx = (int64_t)blockIdx.x % ntx, tc = (int64_t)blockIdx.x / ntx;
+    const int c0 = (int)tc * g.ct;
+    const int64_t P0 = tx * g.pb;
+    const int64_t xbase = P0 * g.M + g.jlo;  // global input frame of LDS element 0
+    // ---- stage: ct rows of tile_len frames ----
+    for (int c = 0; c < g.ct; ++c) {
+        const T* row = x + (int64_t)(c0 + c) * g.in_pitch;
+        for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
+            const int64_t n = xbase + i;
+            lds[c * g.pitch + i] = (n >= 0 && n < g.n_in) ? row[n] : (T)0;
+        }
+    }
+    __syncthreads();
+    // ---- compute ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int row = lane % rows, pl = lane / rows;  // this lane's row and phase slot
+    const int cl = row / g.pb, p = row % g.pb;
+    const int64_t period = P0 + p;
+    const T* __restrict__ xin = lds + cl * g.pitch + p * (int)g.M - g.jlo;
+    T* __restrict__ yrow = y + (int64_t)(c0 + cl) * g.out_pitch + period * g.L;
+    for (int rb = wave * ph; rb < (int)g.L; rb += nwaves * ph) {
+        const int r = rb + pl;
+        const bool live = r < (int)g.L;
+        const int rr = live ? r : (int)g.L - 1;
+        const double* __restrict__ tp = ctab + (size_t)rr * g.taps;
+        const T* __restrict__ xp = xin + jr[rr];  // newest input of this output
+        double acc0 = 0.0, acc1 = 0.0;  // two chains: the loop is latency-bound otherwise
+        int k = 0;
+        for (; k + 1 < g.taps; k += 2) {
+            acc0 = fma(tp[k], (double)xp[-k], acc0);
+            acc1 = fma(tp[k + 1], (double)xp[-(k + 1)], acc1);
+        }
+        if (k < g.taps) acc0 = fma(tp[k], (double)xp[-k], acc0);
+        const int64_t m = period * g.L + r;
+        if (live && period < g.nperiods && m < g.n_out) yrow[r] = (T)(acc0 + acc1);
+    }
+}
+
+int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const RsRows& g, int dtype,
+                         hipStream_t st) {
+    if (g.n_out <= 0) return 0;
+    const int64_t ntiles = ((g.nperiods + g.pb - 1) / g.pb) * (g.nch / g.ct);
+    const size_t esz = dtype == SO_F32 ? 4 : 8;
+    const size_t ldsb = ((size_t)g.ct * g.pitch * esz + 7) / 8 * 8;
+    if (dtype == SO_F32) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)k_resample_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+        hipLaunchKernelGGL((k_resample_rows<float>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const float*)x, (float*)y,
+                           ctab, jr, g);
+    } else {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)k_resample_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+        hipLaunchKernelGGL((k_resample_rows<double>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const double*)x,
+                           (double*)y, ctab, jr, g);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // K3p: periodic polyphase resampler (rational L/M), persistent and software-pipelined.
 //
 // Tile = pt periods x ct channels = 32 rows, staged in LDS as fp64 from a 128-byte aligned

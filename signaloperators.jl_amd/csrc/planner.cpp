@@ -129,6 +129,8 @@ struct Stage {
     std::vector<double> pfb_host, dpfb_host;
     bool periodic = false;
     RsPeriodic rp{};
+    bool rows = false;  // row-tiled resampler (k_resample_rows)
+    RsRows rr{};
     int tab_buf = -1, jend_buf = -1;
     std::vector<double> tab_host;
     std::vector<int> jend_host;
@@ -1256,6 +1258,73 @@ void Plan::process_stage(int sid) {
                 stages[sid].jend_buf = raw_buf(jend.size() * 4);
             }
         }
+        // ---- row-tiled variant: rational rates the MFMA kernel's geometry does not cover -------
+        if (!stages[sid].periodic && (!g.arbitrary || g.exact) && need >= 2048 && g.m0 == 0 &&
+            !std::getenv("SIGOPS_RS_NOROWS")) {
+            const int64_t Lb = g.L, Mb = g.M;
+            const double* h = (const double*)nd.p0;
+            std::vector<int> jr(Lb);
+            std::vector<double> ctab((size_t)Lb * g.taps, 0.0);
+            int64_t jmin = INT64_MAX, jmax = INT64_MIN;
+            for (int64_t r = 0; r < Lb; ++r) {
+                int64_t qi;
+                double alpha = 0.0;
+                if (g.arbitrary) {
+                    const int64_t Nn = r * ((int64_t)g.nphi * Mb);
+                    qi = g.c0i + Nn / Lb;
+                    alpha = (double)(Nn % Lb) / (double)Lb;
+                } else qi = g.c0i + r * Mb;
+                const int64_t j = qi / g.nphi;
+                const int p = (int)(qi % g.nphi);
+                jr[r] = (int)j;
+                jmin = std::min(jmin, j - (g.taps - 1));
+                jmax = std::max(jmax, j);
+                for (int k = 0; k < g.taps; ++k) {
+                    const int64_t hi = p + (int64_t)g.nphi * k;
+                    const double hv = hi < hlen ? h[hi] : 0.0;
+                    const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                    ctab[(size_t)r * g.taps + k] = hv + alpha * dv;
+                }
+            }
+            const int64_t esz_t = (int64_t)dsize(N.dtype);
+            int best_ct = 0, best_pb = 0;
+            int64_t best_pitch = 0, best_len = 0;
+            for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
+                for (int ct : {8, 4, 2, 1}) {
+                    if (best_ct || N.nch % ct || rows % ct) continue;
+                    const int pb = rows / ct;
+                    const int64_t tile_len = (pb - 1) * Mb + (jmax - jmin + 1);
+                    const int64_t pitch = (tile_len + 3) | 1;  // odd: rows fall on different LDS banks
+                    if ((size_t)ct * pitch * esz_t <= 150 * 1024 && tile_len < (1 << 30)) {
+                        best_ct = ct;
+                        best_pb = pb;
+                        best_pitch = pitch;
+                        best_len = tile_len;
+                    }
+                }
+            }
+            if (best_ct && jmin > INT32_MIN && jmax < INT32_MAX && (size_t)Lb * g.taps * 8 <= (64u << 20)) {
+                RsRows rr{};
+                rr.n_in = g.n_in;
+                rr.n_out = need;
+                rr.L = Lb;
+                rr.M = Mb;
+                rr.nperiods = (need + Lb - 1) / Lb;
+                rr.taps = g.taps;
+                rr.ct = best_ct;
+                rr.pb = best_pb;
+                rr.jlo = (int)jmin;
+                rr.tile_len = (int)best_len;
+                rr.pitch = (int)best_pitch;
+                rr.nch = N.nch;
+                stages[sid].rows = true;
+                stages[sid].rr = rr;
+                stages[sid].tab_host = ctab;
+                stages[sid].jend_host = jr;
+                stages[sid].tab_buf = raw_buf(ctab.size() * 8);
+                stages[sid].jend_buf = raw_buf(jr.size() * 4);
+            }
+        }
     } else if (stages[sid].kind == ST_SOS) {
         if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
         int nsec = nd.i0;
@@ -1752,7 +1821,7 @@ void Plan::finalize() {
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
-            if (S.periodic) {
+            if (S.periodic || S.rows) {
                 HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
                 HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
             }
@@ -1775,7 +1844,7 @@ void Plan::finalize() {
             Step st{0, S.pw_step, "k_pointwise", pw[S.pw_step].bytes};
             steps.push_back(st);
         }
-        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : "k_resample") : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS) st.bytes = 2 * S.need * S.sg.nch * esz;
@@ -2117,6 +2186,12 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                     std::fprintf(stderr, "\n");
                                 }
                         }
+                    } else if (S.rows) {
+                        RsRows rr = S.rr;
+                        rr.in_pitch = in_pitch;
+                        rr.out_pitch = ob.pitch;
+                        launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                             (const int*)P->bufs[S.jend_buf].d, rr, N.dtype, st);
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);

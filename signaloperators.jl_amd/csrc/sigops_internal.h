@@ -187,4 +187,19 @@ struct RsPeriodic {
 };
 constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
 
+// Row-tiled variant for rational rates whose period does not fit the MFMA kernel's LDS ring or
+// tap registers (strong downsampling: many inputs per period, long filters), see k_resample_rows.
+struct RsRows {
+    int64_t n_in, n_out;
+    int64_t L, M;        // outputs / inputs per (super-)period
+    int64_t nperiods;
+    int32_t taps;        // taps per output (columns of ctab)
+    int32_t ct, pb;      // channels x periods per workgroup tile (rows = ct*pb, a divisor of 64)
+    int32_t jlo;         // input index (relative to the tile's first period base) of LDS element 0
+    int32_t tile_len;    // inputs per channel row staged in LDS
+    int32_t pitch;       // LDS elements between channel rows
+    int32_t nch;
+    int64_t in_pitch, out_pitch;
+};
+
 }  // namespace so
