@@ -655,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
     const int64_t P0 = tx * g.pb;
     const int64_t xbase = P0 * g.M + g.jlo;  // global input frame of LDS element 0
     // ---- stage: ct rows of tile_len frames ----
-    for (int c = 0; c < g.ct; ++c) {
+    for (int c = 0; c < g.ct && !(g.debug & 2); ++c) {
         const T* row = x + (int64_t)(c0 + c) * g.in_pitch;
         for (int i = threadIdx.x; i < g.tile_len; i += blockDim.x) {
             const int64_t n = xbase + i;
@@ -663,6 +663,7 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
         }
     }
     __syncthreads();
+    if (g.debug & 1) return;
     // ---- compute ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int row = lane % rows, pl = lane / rows;  // this lane's row and phase slot
@@ -676,15 +677,23 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
         const int rr = live ? r : (int)g.L - 1;
         const double* __restrict__ tp = ctab + (size_t)rr * g.taps;
         const T* __restrict__ xp = xin + jr[rr];  // newest input of this output
-        double acc0 = 0.0, acc1 = 0.0;  // two chains: the loop is latency-bound otherwise
+        // Taps come from global memory (L1/L2 hits, but ~500 cycles each): fetch them eight at a
+        // time so that eight loads are in flight per lane, then do the eight LDS reads + FMAs.
+        // Accumulation order is k = 0,1,2,... in ONE chain per output, as in the oracle's loop.
+        double acc = 0.0;
         int k = 0;
-        for (; k + 1 < g.taps; k += 2) {
-            acc0 = fma(tp[k], (double)xp[-k], acc0);
-            acc1 = fma(tp[k + 1], (double)xp[-(k + 1)], acc1);
+        for (; k + 8 <= g.taps; k += 8) {
+            double tk[8], xk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tk[u] = tp[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xk[u] = (double)xp[-(k + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(tk[u], xk[u], acc);
         }
-        if (k < g.taps) acc0 = fma(tp[k], (double)xp[-k], acc0);
+        for (; k < g.taps; ++k) acc = fma(tp[k], (double)xp[-k], acc);
         const int64_t m = period * g.L + r;
-        if (live && period < g.nperiods && m < g.n_out) yrow[r] = (T)(acc0 + acc1);
+        if (live && period < g.nperiods && m < g.n_out) yrow[r] = (T)acc;
     }
 }
 

@@ -1317,6 +1317,7 @@ void Plan::process_stage(int sid) {
                 rr.tile_len = (int)best_len;
                 rr.pitch = (int)best_pitch;
                 rr.nch = N.nch;
+                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rr.debug = std::atoi(ev);  // ablation knob
                 stages[sid].rows = true;
                 stages[sid].rr = rr;
                 stages[sid].tab_host = ctab;

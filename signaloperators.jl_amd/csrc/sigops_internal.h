@@ -199,6 +199,7 @@ struct RsRows {
     int32_t tile_len;    // inputs per channel row staged in LDS
     int32_t pitch;       // LDS elements between channel rows
     int32_t nch;
+    int32_t debug;       // ablation bits (SIGOPS_RS_DEBUG): 1 skip compute, 2 skip staging
     int64_t in_pitch, out_pitch;
 };
 
