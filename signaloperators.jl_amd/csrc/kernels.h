@@ -13,8 +13,8 @@ int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow
 void launch_resample(const void* x, void* y, const double* pfb, const double* dpfb,
                      const RsGeom& g, hipStream_t st);
 // returns 0 when launched, -1 when no instantiation fits the geometry
-int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const RsRows& g, int dtype,
-                         hipStream_t st);
+int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
+                         const int* jend, const RsRows& g, int dtype, hipStream_t st);
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st);
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,

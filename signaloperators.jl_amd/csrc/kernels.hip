@@ -630,6 +630,8 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
                            dpfb, g, (double*)y);
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------
 // K3r: row-tiled polyphase resampler for rational rates with LONG periods / filters (e.g.
 // 44.1 kHz -> 16 kHz: 441 inputs and 160 outputs per period, 148 taps per output), where one
@@ -645,7 +647,9 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
 template <typename T>
 __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x, T* __restrict__ y,
                                                         const double* __restrict__ ctab,
-                                                        const int* __restrict__ jr, RsRows g) {
+                                                        const int* __restrict__ jr,
+                                                        const double* __restrict__ mtab,
+                                                        const int* __restrict__ jend, RsRows g) {
     extern __shared__ double lds_raw[];
     T* const lds = reinterpret_cast<T*>(lds_raw);
     const int rows = g.ct * g.pb, ph = 64 / rows;
@@ -666,6 +670,59 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
     if (g.debug & 1) return;
     // ---- compute ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (g.kw > 0) {
+        // MFMA path: unit = (group of 16 phases, 16-row tile q).  Y[16 x 16] = X[16 x kw] * Tap[kw x 16]
+        // with v_mfma_f64_16x16x4_f64; A from LDS (one sample per lane), B from the L2-resident
+        // tap block (one tap per lane, 512 contiguous bytes per wave load), both fetched four
+        // k-steps ahead.  Operand / result maps as in k_resample_periodic.
+        const int kq = lane >> 4, n16 = lane & 15;
+        const int nq = rows >> 4, nunits = g.ngroups * nq, ksteps = g.kw >> 2;
+        const int pbmask = g.pb - 1;
+        for (int u = wave; u < nunits; u += nwaves) {
+            const int gi = u / nq, q = u % nq;
+            const int rho_a = 16 * q + n16;  // A operand row of this lane
+            const T* __restrict__ ap = lds + (rho_a >> g.pbshift) * g.pitch + (rho_a & pbmask) * (int)g.M - g.jlo +
+                                       (jend[gi] - (g.kw - 1)) + kq;
+            const double* __restrict__ bp = mtab + ((size_t)gi * g.kw + kq) * 16 + n16;
+            v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+            double a0[4], b0[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sn = j < ksteps ? j : ksteps - 1;  // (never read past the tap block)
+                a0[j] = (double)ap[4 * sn];
+                b0[j] = bp[(size_t)(4 * sn) * 16];
+            }
+            for (int s4 = 0; s4 < ksteps; s4 += 4) {
+                double a1[4], b1[4];
+                const bool more = s4 + 4 < ksteps;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // next four k-steps (clamped on the last round)
+                    int sn = more ? s4 + 4 + j : s4 + j;
+                    sn = sn < ksteps ? sn : ksteps - 1;
+                    a1[j] = (double)ap[4 * sn];
+                    b1[j] = bp[(size_t)(4 * sn) * 16];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s4 + j < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], b0[j], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] = a1[j];
+                    b0[j] = b1[j];
+                }
+            }
+            const int r = gi * 16 + n16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
+                const int64_t period = P0 + (rho & pbmask);
+                const int64_t m = period * g.L + r;
+                if (period < g.nperiods && r < (int)g.L && m < g.n_out)
+                    y[(int64_t)(c0 + (rho >> g.pbshift)) * g.out_pitch + m] = (T)acc[i];
+            }
+        }
+        return;
+    }
     const int row = lane % rows, pl = lane / rows;  // this lane's row and phase slot
     const int cl = row / g.pb, p = row % g.pb;
     const int64_t period = P0 + p;
@@ -697,8 +754,8 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
     }
 }
 
-int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const RsRows& g, int dtype,
-                         hipStream_t st) {
+int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
+                         const int* jend, const RsRows& g, int dtype, hipStream_t st) {
     if (g.n_out <= 0) return 0;
     const int64_t ntiles = ((g.nperiods + g.pb - 1) / g.pb) * (g.nch / g.ct);
     const size_t esz = dtype == SO_F32 ? 4 : 8;
@@ -710,7 +767,7 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
             done = true;
         }
         hipLaunchKernelGGL((k_resample_rows<float>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const float*)x, (float*)y,
-                           ctab, jr, g);
+                           ctab, jr, mtab, jend, g);
     } else {
         static bool done = false;
         if (!done) {
@@ -718,7 +775,7 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
             done = true;
         }
         hipLaunchKernelGGL((k_resample_rows<double>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const double*)x,
-                           (double*)y, ctab, jr, g);
+                           (double*)y, ctab, jr, mtab, jend, g);
     }
     return 0;
 }
@@ -754,7 +811,6 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
 //   jend [ngroups]           newest input of the group's window, relative to the period base
 // Operand maps (cdna_hip_programming.md §3): A[l&15][k=l>>4], B[k=l>>4][l&15],
 // D: col = l&15, row = (l>>4) + 4*reg.
-typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kRsRows = 32;  // rows per tile = 2 MFMA row-tiles
 constexpr int kRsQ = kRsRows / 16;
 

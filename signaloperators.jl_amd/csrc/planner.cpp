@@ -131,6 +131,9 @@ struct Stage {
     RsPeriodic rp{};
     bool rows = false;  // row-tiled resampler (k_resample_rows)
     RsRows rr{};
+    int mtab_buf = -1, mjend_buf = -1;
+    std::vector<double> mtab_host;
+    std::vector<int> mjend_host;
     int tab_buf = -1, jend_buf = -1;
     std::vector<double> tab_host;
     std::vector<int> jend_host;
@@ -1303,8 +1306,54 @@ void Plan::process_stage(int sid) {
                     }
                 }
             }
+            // MFMA path: groups of 16 phases against a [kw x 16] tap block (rows = 16, 32 or 64)
+            std::vector<double> mtab;
+            std::vector<int> mjend;
+            int kw_m = 0, ngroups_m = 0;
+            if (best_ct && (best_ct * best_pb) % 16 == 0 && !std::getenv("SIGOPS_RS_NOROWS_MFMA")) {
+                const int64_t jmin_scalar = jmin;
+                ngroups_m = (int)((Lb + 15) / 16);
+                mjend.resize(ngroups_m);
+                int64_t maxspan = 0;
+                for (int gi = 0; gi < ngroups_m; ++gi) {
+                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
+                    mjend[gi] = jr[r1 - 1];
+                    maxspan = std::max<int64_t>(maxspan, jr[r1 - 1] - jr[r0]);
+                }
+                kw_m = (int)((g.taps + maxspan + 3) / 4 * 4);
+                mtab.assign((size_t)ngroups_m * kw_m * 16, 0.0);
+                for (int gi = 0; gi < ngroups_m; ++gi) {
+                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
+                    jmin = std::min<int64_t>(jmin, mjend[gi] - (kw_m - 1));
+                    for (int64_t r = r0; r < r1; ++r)
+                        for (int kk = 0; kk < kw_m; ++kk) {
+                            const int64_t age = jr[r] - (mjend[gi] - (kw_m - 1) + kk);
+                            if (age >= 0 && age < g.taps)
+                                mtab[((size_t)gi * kw_m + kk) * 16 + (r - r0)] = ctab[(size_t)r * g.taps + age];
+                        }
+                }
+                // the window of a group may start a few frames before the oldest tap: re-size the tile
+                const int64_t tile_len = (best_pb - 1) * Mb + (jmax - jmin + 1);
+                const int64_t pitch = (tile_len + 3) | 1;
+                if ((size_t)best_ct * pitch * esz_t <= 152 * 1024) {
+                    best_len = tile_len;
+                    best_pitch = pitch;
+                } else {
+                    kw_m = 0;
+                    mtab.clear();
+                    jmin = jmin_scalar;
+                }
+            }
             if (best_ct && jmin > INT32_MIN && jmax < INT32_MAX && (size_t)Lb * g.taps * 8 <= (64u << 20)) {
                 RsRows rr{};
+                rr.kw = kw_m;
+                rr.ngroups = ngroups_m;
+                rr.pbshift = 0;
+                while ((1 << rr.pbshift) < best_pb) ++rr.pbshift;  // pb is a power of two
+                stages[sid].mtab_host = mtab;
+                stages[sid].mjend_host = mjend;
+                stages[sid].mtab_buf = raw_buf(std::max<size_t>(mtab.size(), 1) * 8);
+                stages[sid].mjend_buf = raw_buf(std::max<size_t>(mjend.size(), 1) * 4);
                 rr.n_in = g.n_in;
                 rr.n_out = need;
                 rr.L = Lb;
@@ -1826,6 +1875,10 @@ void Plan::finalize() {
                 HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
                 HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
             }
+            if (S.rows && !S.mtab_host.empty()) {
+                HIPCHECK(hipMemcpy(bufs[S.mtab_buf].d, S.mtab_host.data(), S.mtab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4, hipMemcpyHostToDevice));
+            }
         } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
             size_t msz = 0;
             for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
@@ -2192,7 +2245,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rr.in_pitch = in_pitch;
                         rr.out_pitch = ob.pitch;
                         launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                             (const int*)P->bufs[S.jend_buf].d, rr, N.dtype, st);
+                                             (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
+                                             (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);

@@ -200,6 +200,9 @@ struct RsRows {
     int32_t pitch;       // LDS elements between channel rows
     int32_t nch;
     int32_t debug;       // ablation bits (SIGOPS_RS_DEBUG): 1 skip compute, 2 skip staging
+    // MFMA path (rows = 16 or 32): groups of 16 phases against a [kw x 16] tap block streamed
+    // from L2; kw == 0 selects the scalar path
+    int32_t kw, ngroups, pbshift;
     int64_t in_pitch, out_pitch;
 };
 

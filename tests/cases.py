@@ -392,6 +392,24 @@ def resample_then_filter():  # BASELINE config 5 rewrite: Filt over data -> resa
 
 
 @case
+def resample_down_8ch():  # K3r MFMA path: ct=8, pb=4 (44.1 kHz -> 16 kHz, 441:160)
+    x = F(rng(41).standard_normal((12000, 8)))
+    return Signal(x, 44.1 * kHz) | ToFramerate(16 * kHz)
+
+
+@case
+def resample_down_f32():  # K3r with fp32 tiles, 2 channels (ct=2, pb=32)
+    x = F(rng(42).standard_normal((12000, 2)).astype(np.float32))
+    return Signal(x, 44.1 * kHz) | ToFramerate(16 * kHz)
+
+
+@case
+def resample_down_then_until():  # K3r, mono, output cut short of a whole period
+    x = F(rng(43).standard_normal((20000, 1)))
+    return Signal(x, 48 * kHz) | ToFramerate(11.025 * kHz) | Until(4000 * frames)
+
+
+@case
 def resample_padded_computed():  # runtests.jl:440-443
     tone = Signal(sin, 20 * Hz, ω=5 * Hz) | ToChannels(2) | Until(5 * s)
     return tone | Pad(one) | Until(7 * s) | ToFramerate(40 * Hz)
