@@ -754,6 +754,17 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
     }
 }
 
+// hipFuncSetAttribute is per device: remember it per (kernel, device) -- a process that drives
+// several GPUs must raise the dynamic-LDS limit on each of them.
+static bool first_use_on_device(bool (&seen)[64]) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : (dev > 63 ? 63 : dev);
+    const bool first = !seen[dev];
+    seen[dev] = true;
+    return first;
+}
+
 int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
                          const int* jend, const RsRows& g, int dtype, hipStream_t st) {
     if (g.n_out <= 0) return 0;
@@ -761,20 +772,16 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
     const size_t esz = dtype == SO_F32 ? 4 : 8;
     const size_t ldsb = ((size_t)g.ct * g.pitch * esz + 7) / 8 * 8;
     if (dtype == SO_F32) {
-        static bool done = false;
-        if (!done) {
+        static bool seen[64];
+        if (first_use_on_device(seen))
             (void)hipFuncSetAttribute((const void*)k_resample_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-        hipLaunchKernelGGL((k_resample_rows<float>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const float*)x, (float*)y,
+        hipLaunchKernelGGL((k_resample_rows<float>), dim3((unsigned)ntiles), dim3(g.threads), ldsb, st, (const float*)x, (float*)y,
                            ctab, jr, mtab, jend, g);
     } else {
-        static bool done = false;
-        if (!done) {
+        static bool seen[64];
+        if (first_use_on_device(seen))
             (void)hipFuncSetAttribute((const void*)k_resample_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-        hipLaunchKernelGGL((k_resample_rows<double>), dim3((unsigned)ntiles), dim3(1024), ldsb, st, (const double*)x,
+        hipLaunchKernelGGL((k_resample_rows<double>), dim3((unsigned)ntiles), dim3(g.threads), ldsb, st, (const double*)x,
                            (double*)y, ctab, jr, mtab, jend, g);
     }
     return 0;
@@ -1641,13 +1648,11 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
     size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch) * 8;  // + static RsCtl
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool seen[64];
+    if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-        attr_done = true;
-    }
     hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (T*)y, gsrc);
 }

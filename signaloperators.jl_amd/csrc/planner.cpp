@@ -1292,17 +1292,28 @@ void Plan::process_stage(int sid) {
             const int64_t esz_t = (int64_t)dsize(N.dtype);
             int best_ct = 0, best_pb = 0;
             int64_t best_pitch = 0, best_len = 0;
-            for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
-                for (int ct : {8, 4, 2, 1}) {
-                    if (best_ct || N.nch % ct || rows % ct) continue;
-                    const int pb = rows / ct;
-                    const int64_t tile_len = (pb - 1) * Mb + (jmax - jmin + 1);
-                    const int64_t pitch = (tile_len + 3) | 1;  // odd: rows fall on different LDS banks
-                    if ((size_t)ct * pitch * esz_t <= 150 * 1024 && tile_len < (1 << 30)) {
-                        best_ct = ct;
-                        best_pb = pb;
-                        best_pitch = pitch;
-                        best_len = tile_len;
+            size_t rr_max_lds = 150 * 1024;
+            if (const char* ev = std::getenv("SIGOPS_RR_MAXLDS")) rr_max_lds = (size_t)std::atoi(ev) * 1024;  // tuning knob
+            // tile choice: the largest row count whose tile fits; two workgroups per CU (tiles of at
+            // most 75 KB) overlap one's staging with the other's MFMAs (config 5: 0.77 -> 0.66 ms),
+            // so that budget is tried first as long as it still gives an MFMA-able tile (>= 16 rows)
+            const bool lds_forced = std::getenv("SIGOPS_RR_MAXLDS") != nullptr;
+            for (int pass = 0; pass < 2 && !best_ct; ++pass) {
+                const size_t budget = lds_forced ? rr_max_lds : (pass == 0 ? (size_t)75 * 1024 : rr_max_lds);
+                for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
+                    if (pass == 0 && !lds_forced && rows < 16) break;
+                    for (int ct : {8, 4, 2, 1}) {
+                        if (best_ct || N.nch % ct || rows % ct) continue;
+                        const int pb = rows / ct;
+                        const int64_t tile_len = (pb - 1) * Mb + (jmax - jmin + 1);
+                        const int64_t pitch = (tile_len + 3) | 1;  // odd: rows fall on different LDS banks
+                        if ((size_t)ct * pitch * esz_t <= budget && tile_len < (1 << 30)) {
+                            best_ct = ct;
+                            best_pb = pb;
+                            best_pitch = pitch;
+                            best_len = tile_len;
+                            rr_max_lds = budget;
+                        }
                     }
                 }
             }
@@ -1335,7 +1346,7 @@ void Plan::process_stage(int sid) {
                 // the window of a group may start a few frames before the oldest tap: re-size the tile
                 const int64_t tile_len = (best_pb - 1) * Mb + (jmax - jmin + 1);
                 const int64_t pitch = (tile_len + 3) | 1;
-                if ((size_t)best_ct * pitch * esz_t <= 152 * 1024) {
+                if ((size_t)best_ct * pitch * esz_t <= rr_max_lds + 2048) {
                     best_len = tile_len;
                     best_pitch = pitch;
                 } else {
@@ -1367,6 +1378,8 @@ void Plan::process_stage(int sid) {
                 rr.pitch = (int)best_pitch;
                 rr.nch = N.nch;
                 if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rr.debug = std::atoi(ev);  // ablation knob
+                rr.threads = 1024;
+                if (const char* ev = std::getenv("SIGOPS_RR_THREADS")) rr.threads = std::max(64, std::min(1024, std::atoi(ev) / 64 * 64));  // tuning knob
                 stages[sid].rows = true;
                 stages[sid].rr = rr;
                 stages[sid].tab_host = ctab;

@@ -203,6 +203,7 @@ struct RsRows {
     // MFMA path (rows = 16 or 32): groups of 16 phases against a [kw x 16] tap block streamed
     // from L2; kw == 0 selects the scalar path
     int32_t kw, ngroups, pbshift;
+    int32_t threads;     // workgroup size
     int64_t in_pitch, out_pitch;
 };
 
