@@ -439,18 +439,29 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
     double* tl = tile[w];
     const int rsub = lane >> 4, col = lane & 15;  // load/store role: 4 rows x 16 columns
+    // The passes are latency-bound (a few waves per CU, each a chain of tile round trips): all 16
+    // loads of a tile are issued together and the NEXT tile's loads are issued before this tile's
+    // arithmetic, so a wave always has one tile (8 KB) in flight.
+    const T* xrow[16];  // this lane's 16 load rows: element address of (row, column col)
+    int xlen[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = j * 4 + rsub;
+        xlen[j] = rowlen[w][r];
+        xrow[j] = x + ((int64_t)rowch[w][r] * g.in_pitch + rowbase[w][r] + col);
+    }
+    double xv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xv[j] = col < xlen[j] ? (double)xrow[j][0] : 0.0;
     for (int t0 = 0; t0 < maxlen; t0 += kTT) {
-        // ---- coalesced load: 16 instructions x (4 rows x 128 B) ----
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int r = j * 4 + rsub;
-            const int rl = rowlen[w][r];
-            double xv = 0.0;
-            if (t0 + col < rl)
-                xv = (double)x[(int64_t)rowch[w][r] * g.in_pitch + rowbase[w][r] + t0 + col];
-            tl[r * (kTT + 1) + col] = xv;
-        }
+        // ---- tile t0 (loaded one iteration ago: 16 instructions x (4 rows x 128 B)) -> LDS ----
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tl[(j * 4 + rsub) * (kTT + 1) + col] = xv[j];
         __builtin_amdgcn_wave_barrier();
+        if (t0 + kTT < maxlen) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xv[j] = t0 + kTT + col < xlen[j] ? (double)xrow[j][t0 + kTT] : 0.0;
+        }
         // ---- every lane: its own row through the cascade ----
         double* row = tl + lane * (kTT + 1);
 #pragma unroll
