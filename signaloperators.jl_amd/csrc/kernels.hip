@@ -490,15 +490,20 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
     }
 }
 
-// mpow: [kterms][D][D] row-major, mpow[0] = I.  The matrices are workgroup-uniform: they are
-// staged through LDS one term at a time and read as LDS broadcasts (as scalar-cache operands
-// they cost ~700 clk per 64-byte line, which made this pass the slowest of the three).
+// mpow: [kterms][D][D] row-major powers of M = A^L built on the host (mpow[0] = I, mpow[1] = M);
+// the host uses them to choose the truncation K, the kernel only needs M itself.
 template <int NS>
 __global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ v,
                                                      const double* __restrict__ mpow, SosGeom g,
                                                      double* __restrict__ s0) {
     constexpr int D = 2 * NS;
-    __shared__ double mj[D * D];
+    // Horner form of  s0_k = sum_{j=1..K} M^(j-1) v_(k-j):  s <- M s + v_(k-j), oldest term first.
+    // One matrix (M = A^L, second entry of the host's power table) in LDS, read as broadcasts; no
+    // barrier and no matrix fetch per term -- the per-term global round trips of the previous
+    // power-table form made this the longest of the three passes.
+    __shared__ double m1[D * D];
+    if ((int)threadIdx.x < D * D) m1[threadIdx.x] = g.kterms >= 2 ? mpow[(int64_t)D * D + threadIdx.x] : 0.0;
+    __syncthreads();
     const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t nseq = (int64_t)g.nchunks * g.nch;
     const bool live = tid < nseq;
@@ -507,23 +512,21 @@ __global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ 
     double acc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    for (int j = g.kterms; j >= 1; --j) {  // smallest terms first
-        __syncthreads();
-        if ((int)threadIdx.x < D * D) mj[threadIdx.x] = mpow[(int64_t)(j - 1) * D * D + threadIdx.x];
-        __syncthreads();
-        if (live && j <= k) {
-            const double* vp = v + ((int64_t)ch * g.nchunks + (k - j)) * D;
-            double vv[D];
+    const int jmax = live ? (k < g.kterms ? k : g.kterms) : 0;
+    const double* vp = v + ((int64_t)ch * g.nchunks + (k - jmax)) * D;  // oldest term, then forward
+    for (int j = jmax; j >= 1; --j, vp += D) {
+        double vv[D], t[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) vv[d] = vp[d];
+        for (int d = 0; d < D; ++d) vv[d] = vp[d];
 #pragma unroll
-            for (int r = 0; r < D; ++r) {
-                double a = acc[r];
+        for (int r = 0; r < D; ++r) {
+            double a = vv[r];
 #pragma unroll
-                for (int d = 0; d < D; ++d) a += mj[r * D + d] * vv[d];
-                acc[r] = a;
-            }
+            for (int d = 0; d < D; ++d) a = fma(m1[r * D + d], acc[d], a);
+            t[r] = a;
         }
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = t[d];
     }
     if (live) {
         double* sp = s0 + ((int64_t)ch * g.nchunks + k) * D;
