@@ -38,3 +38,39 @@ def test_random_resampler_geometries(seed):
         assert got.shape == want.shape and got.dtype == want.dtype
         tol = 1e-6 if got.dtype == np.float32 else 1e-9
         assert relerr(got, want) <= tol, (fi, fo, nch, n, dt.__name__, kind)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_iir_geometries(seed):
+    """K2 (chunked exact IIR): filter type / order / design method, channel count, lengths from one
+    block to many chunks, sample type, `After` (state carried through the cut) and a `Mix` on top"""
+    rng = np.random.default_rng(seed)
+    for _ in range(14):
+        fs = float(rng.choice([8000, 16000, 44100, 48000]))
+        nch = int(rng.choice([1, 2, 3, 5, 8, 17]))
+        n = int(rng.choice([50, 700, 5000, 70000, 300000]))
+        dt = np.float64 if rng.random() < 0.7 else np.float32
+        x = np.asfortranarray(rng.standard_normal((n, nch)).astype(dt))
+        sig = so.Signal(x, fs * so.Hz)
+        typ, order = int(rng.integers(0, 4)), int(rng.integers(1, 9))
+        lo, hi = sorted(rng.uniform(0.02, 0.45, 2) * fs)
+        if hi - lo < 0.02 * fs:
+            hi = lo + 0.03 * fs
+        meth = so.Butterworth(order) if rng.random() < 0.6 else so.Chebyshev1(order, 1.0)
+        if typ == 0:
+            tree = so.Filt(sig, so.Lowpass, lo * so.Hz, method=meth)
+        elif typ == 1:
+            tree = so.Filt(sig, so.Highpass, lo * so.Hz, method=meth)
+        elif typ == 2:
+            tree = so.Filt(sig, so.Bandpass, lo * so.Hz, hi * so.Hz, method=meth)
+        else:
+            tree = so.Filt(sig, so.Bandstop, lo * so.Hz, hi * so.Hz, method=meth)
+        if rng.random() < 0.3 and n > 100:
+            tree = tree | so.After(37 * so.frames)
+        if rng.random() < 0.3:
+            tree = so.Mix(tree, so.Signal(so.sin, ω=100 * so.Hz)) | so.Until((n // 2) * so.frames)
+        want = oracle_sink(tree)
+        got = so.sink(tree)[0]
+        assert got.shape == want.shape
+        tol = 2e-6 if got.dtype == np.float32 else 1e-8
+        assert relerr(got, want) <= tol, (fs, nch, n, dt.__name__, typ, order)
