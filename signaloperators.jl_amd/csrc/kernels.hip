@@ -933,7 +933,7 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                  :
                  : "s"(lds_byte_addr), "v"(g)
-                 : "memory", "m0");
+                 : "memory");  // (m0 is reserved: hipcc keeps nothing live in it, and warns if it is listed)
 }
 
 // One chunk (up to 64 lanes x 16 bytes) of CT channel rows by LDS-DMA with NO vector-ALU
@@ -954,18 +954,18 @@ __device__ __forceinline__ void dma_rows(uint64_t mask, uint32_t voff, const cha
         asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) "s_mov_b64 exec, %[sv]"
                      : [sv] "=&s"(sv)
                      : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds)
-                     : "memory", "m0");
+                     : "memory");  // (m0 is reserved: hipcc keeps nothing live in it, and warns if it is listed)
     } else if constexpr (CT == 2) {
         asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) SO_DMA_ROW(1) "s_mov_b64 exec, %[sv]"
                      : [sv] "=&s"(sv)
                      : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds), [b1] "s"(b1), [l1] "s"(lds + lds_stride)
-                     : "memory", "m0");
+                     : "memory");  // (m0 is reserved: hipcc keeps nothing live in it, and warns if it is listed)
     } else {
         asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mask]\n\t" SO_DMA_ROW(0) SO_DMA_ROW(1) SO_DMA_ROW(2) SO_DMA_ROW(3) "s_mov_b64 exec, %[sv]"
                      : [sv] "=&s"(sv)
                      : [mask] "s"(mask), [voff] "v"(voff), [b0] "s"(b0), [l0] "s"(lds), [b1] "s"(b1), [l1] "s"(lds + lds_stride),
                        [b2] "s"(b2), [l2] "s"(lds + 2 * lds_stride), [b3] "s"(b3), [l3] "s"(lds + 3 * lds_stride)
-                     : "memory", "m0");
+                     : "memory");  // (m0 is reserved: hipcc keeps nothing live in it, and warns if it is listed)
         if constexpr (CT == 8)
             dma_rows<4>(mask, voff, base + 4 * row_stride, row_stride, lds + 4 * lds_stride, lds_stride);
     }
@@ -1169,11 +1169,8 @@ __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, i
                                           T* __restrict__ buf, const RsCtl& ctl,
                                           const RsGlobalTables& gsrc, int tid, int nthr, int allowed) {
     const DCarrier* car = ctl.car;
-    const int ncar = ctl.ncar;
-    const DOp* ops = ctl.ops;
     const DLeaf* leaves = ctl.leaves;
     constexpr int V = 16 / sizeof(T);
-    typedef T vecT __attribute__((ext_vector_type(V)));
     const int nvec = (nfr + V - 1) / V;  // lds_pitch leaves room for the round-up
     int ndma = 0;
     bool waited = false;
