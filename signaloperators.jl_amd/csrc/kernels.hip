@@ -1445,8 +1445,11 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 if (other < mine || (other == mine && w < wave)) ++lidx;
             }
         }
-        const int lthr = (nwaves - nc) * 64;
-        const int ltid = lidx * 64 + lane;
+        // g.nload > 0: only the first nload loader waves (those on the least loaded SIMDs) copy and
+        // modify; the others just keep the barrier count
+        const int nactive = g.nload > 0 && g.nload < nwaves - nc ? g.nload : nwaves - nc;
+        const int lthr = nactive * 64;
+        const int ltid = (lidx < nactive ? lidx * 64 : (1 << 30)) + lane;
         const int llane = lane;
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
         // Loader waves issue a handful of instructions and then sleep on memory; without a

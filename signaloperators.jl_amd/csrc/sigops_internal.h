@@ -181,7 +181,7 @@ struct RsPeriodic {
     int32_t nslots;     // LDS ring depth (tiles resident per workgroup)
     int32_t fslots;     // gain ring: per-frame slots held in LDS (0: none), two arrays of fslots*fpitch
     int32_t fpitch;     // doubles per slot row of the gain ring
-    int32_t reserved;
+    int32_t nload;      // loader waves that copy / modify (0: all of them)
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };
