@@ -183,3 +183,36 @@ def test_append_after_long_filtered_child_is_a_concatenation():
     got, _ = so.sink(so.Append(ra, rb))
     want = np.concatenate([oracle_sink(ra), oracle_sink(rb)])
     assert relerr(got, want) < 1e-11
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_resampler_ring_is_deterministic(fused):
+    """The persistent resampler synchronises loader and compute waves with counted vmcnt waits,
+    raw barriers and LDS rings written across barrier intervals: repeated executes over a NaN-
+    prefilled result must be bit-identical (a race shows up as a sporadic difference or a NaN)."""
+    torch = pytest.importorskip("torch")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    n_in = 44100 * 20
+    noise = torch.randn((8, n_in), dtype=torch.float64, device="cuda", generator=g).t()
+    x = so.Signal(noise, 44.1 * so.kHz)
+    if fused:
+        x = x | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(n_in * so.frames)
+    x = x | so.ToFramerate(48 * so.kHz)
+    n = so.nframes(x)
+    out_t = torch.empty((8, n), dtype=torch.float64, device="cuda")
+    out = out_t.t()
+    plan = so.Plan(so.ToChannels(x, 8), (n, 8), np.float64, (out.stride(0), out.stride(1)), True)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        plan.execute(out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ref = out_t.clone()
+        assert not torch.isnan(ref).any()
+        for _ in range(40):
+            out_t.fill_(float("nan"))
+            plan.execute(out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert torch.equal(out_t, ref)
+    finally:
+        plan.close()
