@@ -429,11 +429,11 @@ void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, cons
 // ---------------------------------------------------------------------------
 // K2: SOS IIR.  The recurrence is linear, so a chunk's output is the zero-state
 // response to its own samples plus the zero-input response to the state at its start.
-//   pass 1  k_sos_state : v_k = state at the END of chunk k from zero state (only the
+//   pass 1  k_sos_tiled<.,.,false> : v_k = state at the END of chunk k from zero state (only the
 //           last min(L,W) frames matter: older frames have decayed below 2^-70)
 //   pass 2  k_sos_scan  : s0_k = sum_{j=1..K} M^(j-1) v_{k-j},  M = A^L (host-computed
 //           powers of the cascade's state matrix); K terms until ||M^K|| < 2^-70
-//   pass 3  k_sos_apply : run DF2T on chunk k from s0_k and write the output
+//   pass 3  k_sos_tiled<.,.,true>  : run DF2T on chunk k from s0_k and write the output
 // DF2T per section (DSP.jl filt!):
 //   y = s1 + b0 x ; s1 = s2 + b1 x - a1 y ; s2 = b2 x - a2 y ; out = y*g after the cascade
 template <int NS>

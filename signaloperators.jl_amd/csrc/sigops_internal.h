@@ -159,7 +159,7 @@ struct RsGeom {
 
 // Periodic variant: for a rational rate L/M the (phase, alpha) pattern repeats every
 // L outputs / M inputs: the tap pattern of a group of 16 consecutive outputs is the same
-// for every (period, channel) row, so a tile of 64 rows x 16 outputs is one small matrix
+// for every (period, channel) row, so a tile of 32 rows x 16 outputs is one small matrix
 // product against a per-group tap matrix (see k_resample_periodic).
 struct RsPeriodic {
     int64_t n_in, n_out;
