@@ -972,6 +972,17 @@ __device__ __forceinline__ v2d lds_ld16(uint32_t a) {
 __device__ __forceinline__ void lds_st16(uint32_t a, v2d v) {
     asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
+// All of v[] live in distinct registers here.  Put between the arithmetic and the ds_write_b128s
+// of a read-modify-write: a vector-ALU write to the data registers of a 16-byte LDS store right
+// after it is a hardware hazard the compiler only pads for instructions it can see, so the
+// products must not be computed into a register pair an earlier store just read.
+template <int N>
+__device__ __forceinline__ void lds_pin(v2d (&v)[N]) {
+    if constexpr (N == 1) asm volatile("" : "+v"(v[0])::"memory");
+    else if constexpr (N == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1])::"memory");
+    else if constexpr (N == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+    else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(v2d (&v)[N]) {  // results of lds_ld16 are valid after this
     if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory");
@@ -1100,11 +1111,32 @@ __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT
     carrier_apply<CT, 2, DIV>(C, F, val, false);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        v2d v;
-        v[0] = val[c][0];
-        v[1] = val[c][1];
-        lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, v);
+        raw[c][0] = val[c][0];
+        raw[c][1] = val[c][1];
     }
+    lds_pin(raw);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
+}
+
+// The commonest in-place step, one multiply by frame slot 0 (`Amplify` by a generator, a ramp
+// or a number), without the step interpreter: per chunk of CT rows one gain read, CT reads, 2*CT
+// multiplies, CT writes.  (The general rmw_chunk spends ~4x the vector instructions on slot
+// selection and step dispatch, and every one of them waits for a gap between the MFMAs.)
+template <int CT>
+__device__ __forceinline__ void rmw_mul_chunk(uint32_t la, int lds_pitch, uint32_t fa) {
+    v2d f[1];
+    f[0] = lds_ld16(fa);
+    v2d raw[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * 8u);
+    lds_wait(f);
+    lds_wait(raw);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) raw[c] = raw[c] * f[0];
+    lds_pin(raw);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
 }
 
 // Slow path of the staging (tile edges, f32 sources, generated pieces, unaligned arrays): one
@@ -1511,6 +1543,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const int ltid = (lidx < nactive ? lidx * 64 : (1 << 30)) + lane;
         const int llane = lane;
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
+        const bool mul0 = nsteps0 == 1 && st0.op[0] == OP_MUL && (st0.arg[0] & 0x2ff) == 0 && !(g.pad & 128);
         // Loader waves issue a handful of instructions and then sleep on memory; without a
         // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
         // and the loads only go out once the arithmetic is over (measured: phases add up).
@@ -1576,7 +1609,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 rs_stamp(g, wave, it, 6);
                 for (int ivb = lw64; ivb < nvec; ivb += lthr) {
                     const int iv = ivb + llane;
-                    if (iv < nvec) {
+                    if (mul0) {
+                        if (iv < nvec) rmw_mul_chunk<CT>(lbase + (uint32_t)iv * 16u, g.lds_pitch, lds_addr(Fb) + (uint32_t)iv * 16u);
+                    } else if (iv < nvec) {
                         double F[kMaxFrameSlots][2];
 #pragma unroll
                         for (int k = 0; k < kMaxFrameSlots; ++k) {
