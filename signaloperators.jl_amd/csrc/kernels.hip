@@ -87,6 +87,32 @@ __device__ __forceinline__ double sinpi_c(double x) {
     const double r = (q & 1) ? c : s;
     return (q & 2) ? -r : r;
 }
+// sin(pi x) and cos(pi x) together (same reduction and kernels as sinpi_c)
+__device__ __forceinline__ void sincospi_c(double x, double& so, double& co) {
+    const double k = rint(2.0 * x);
+    const double t = fma(-0.5, k, x);
+    double s, c;
+    sincospi_quarter(t, s, c);
+    const int q = (int)((long long)k & 3);
+    const double rs = (q & 1) ? c : s, rc = (q & 1) ? s : c;
+    so = (q & 2) ? -rs : rs;
+    co = (q == 1 || q == 2) ? -rc : rc;
+}
+// (sin, cos)(2 pi phase) of frames i0 + stride*lane, lane < count, of a sine generator (phase as
+// in func_eval, i0 already 1-based); out of line so that its ~40 live registers do not add to
+// the resampler's main loops
+__device__ __attribute__((noinline)) void sine_table(int64_t i0, int stride, int count, double omega, double phi,
+                                                     double fs, int has_omega, double* dst) {
+    const int lane = threadIdx.x & 63;
+    if (lane < count) {
+        const double t = __ddiv_rn((double)(i0 + (int64_t)stride * lane), fs);
+        const double ph = has_omega ? __dadd_rn(__dmul_rn(t, omega), phi) : __dadd_rn(t, phi);
+        double sb, cb;
+        sincospi_c(2.0 * ph, sb, cb);
+        dst[2 * lane] = sb;
+        dst[2 * lane + 1] = cb;
+    }
+}
 // cos(x), x in radians, |x| < 2^20: two-term Cody-Waite reduction to x = k*pi/2 + r
 __device__ __forceinline__ double cos_c(double x) {
     const double k = rint(x * 0.6366197723675814);
@@ -1347,7 +1373,7 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
     return stage_tile<T, CT, PASS>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
 }
 
-template <typename T, int CT, int KS, int G>
+template <typename T, int CT, int KS, int G, bool TWO = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, T* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -1491,26 +1517,77 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
     const int kind0 = __builtin_amdgcn_readfirstlane(ctl.car[0].slot_kind[0]);
     const DLeaf leaf0 = leaf_uniform(ctl.leaves[min(kCtlLeaves - 1, max(0, __builtin_amdgcn_readfirstlane(ctl.car[0].slot_leaf[0])))]);
+    // TWO: two-level evaluation of a sine generator in slot 0 (`Amplify(x, Signal(sin, ω=...))`; the
+    // planner picks this instantiation when slot 0 is exactly that and the only slot):
+    //   sin(θ(nb) + l·δ) = sin θ(nb) · cos(l·δ) + cos θ(nb) · sin(l·δ)
+    // with nb the first frame of a share of 64 and l the lane.  (sin, cos)(l·δ) is a per-lane
+    // constant (dtab, written once); the share bases of a whole tile are one full-precision
+    // evaluation by ONE wave, lane u -> share u (b_duty, three tiles ahead, published by the
+    // tile barriers); a share is then one multiply and one fma per frame instead of the ~100
+    // vector instructions of division + reduction + two polynomials, all of which compete with
+    // the fp64 MFMAs for the same ALUs.  The phase of frame nb + l is the reference's phase of nb
+    // (src/functions.jl:57-60, every operation rounded separately) plus fl(fl(l/fs)·ω): it differs
+    // from the reference's own rounding of the phase of nb + l by a few ulp of the phase (< 1e-12
+    // in the gain after ten minutes at 5 Hz; the parity bound is 1e-6).
+    auto dtab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch; };
+    auto btab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch + 128; };
+    const bool twolvl = TWO && fring && g.ftwo;
+    auto b_duty = [&](const TilePos& p, int bb) __attribute__((always_inline)) {
+        int64_t xa;
+        int nfr;
+        if (!twolvl || wave != nwaves - 1 || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
+        sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1, 64, (g.tile_len + 63) >> 6, leaf0.v0, leaf0.v1, leaf0.v2,
+                   leaf0.flag, btab() + bb * 128);
+    };
     auto f_duty = [&](const TilePos& p, int fb) __attribute__((always_inline)) {
         int64_t xa;
         int nfr;
         if (!fring || share0 * 64 >= g.tile_len || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
         double* Fb = fbase + (size_t)fb * g.fslots * g.fpitch;
-#pragma unroll 1
-        for (int k = 0; k < nslots0; ++k) {
-            // (slot 0's recipe is kept in scalar registers for the whole kernel; further slots
-            //  are re-read from the LDS control block)
-            const int kind = k == 0 ? kind0 : __builtin_amdgcn_readfirstlane(ctl.car[0].slot_kind[k]);
-            const DLeaf L = k == 0 ? leaf0 : leaf_uniform(ctl.leaves[__builtin_amdgcn_readfirstlane(ctl.car[0].slot_leaf[k])]);
+        if constexpr (TWO) {
+            if (!twolvl) return;  // (no LDS reserved: the loaders evaluate in place)
+            const double2 d = *reinterpret_cast<const double2*>(dtab() + 2 * lane);
 #pragma unroll 1
             for (int sp = 0; sp < 2; ++sp) {
                 const int shr = sp ? share1 : share0;
                 if (shr < 0) break;
-                for (int f = (nfr - g.tile_len) + shr * 64 + lane; f < nfr; f += nshares * 64)
-                    Fb[k * g.fpitch + f] = slot_eval(kind, L, xa + f);
+                for (int u = shr; u * 64 < g.tile_len; u += nshares) {
+                    const int f = (nfr - g.tile_len) + u * 64 + lane;
+                    const double2 b = *reinterpret_cast<const double2*>(btab() + fb * 128 + 2 * u);
+                    double v = fma(b.x, d.y, b.y * d.x);
+                    if (kind0 & 0x100) v = (double)(float)v;
+                    if (f < nfr) Fb[f] = v;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < nslots0; ++k) {
+                // (slot 0's recipe is kept in scalar registers for the whole kernel; further slots
+                //  are re-read from the LDS control block)
+                const int kind = k == 0 ? kind0 : __builtin_amdgcn_readfirstlane(ctl.car[0].slot_kind[k]);
+                const DLeaf L = k == 0 ? leaf0 : leaf_uniform(ctl.leaves[__builtin_amdgcn_readfirstlane(ctl.car[0].slot_leaf[k])]);
+#pragma unroll 1
+                for (int sp = 0; sp < 2; ++sp) {
+                    const int shr = sp ? share1 : share0;
+                    if (shr < 0) break;
+                    for (int f = (nfr - g.tile_len) + shr * 64 + lane; f < nfr; f += nshares * 64)
+                        Fb[k * g.fpitch + f] = slot_eval(kind, L, xa + f);
+                }
             }
         }
     };
+    // prologue of the two-level evaluation: lane constants, share bases of tiles 0 and 1
+    if constexpr (TWO) {
+        if (twolvl) {
+            if (wave == 0) sine_table(0, 1, 64, leaf0.v0, 0.0, leaf0.v2, leaf0.flag, dtab());
+            TilePos pb0 = tile_first();
+            b_duty(pb0, 0);
+            tile_next(pb0);
+            b_duty(pb0, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
     // prologue: gains of tiles 0 and 1, published by one extra barrier (both roles)
     TilePos pf = tile_first();  // next tile whose gains are due
 #pragma unroll 1
@@ -1520,6 +1597,13 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (TWO) {
+        if (twolvl) {  // (tile 2's bases share a buffer with tile 0's, which the gains above just read)
+            b_duty(pf, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
     // The two roles run separate loops with the same number of workgroup barriers (whole
     // waves take one branch), so their register live ranges do not overlap.
     if (wave >= nc) {
@@ -1639,6 +1723,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             f_duty(pf, it & 1);  // gains of tile it+2
             rs_stamp(g, wave, it, 4);
             tile_next(pf);
+            if constexpr (TWO) b_duty(pf, (it + 1) & 1);  // share bases of tile it+3
             tile_next(pn);
             tile_next(pr);
             sn = sn + 1 == S ? 0 : sn + 1;
@@ -1750,18 +1835,18 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G>
+template <typename T, int CT, int KS, int G, bool TWO = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch) * 8;  // + static RsCtl
+    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (T*)y, gsrc);
 }
 
@@ -1771,7 +1856,13 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
     const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
 #define SO_RP(KS_, G_)                                                                   \
     if (g.kw == 4 * KS_ && gper == G_) {                                                  \
-        launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, gsrc, st);             \
+        if constexpr (sizeof(T) == 8 && CT >= 4 && G_ == 1) {                             \
+            if (g.ftwo) {                                                                 \
+                launch_rp_k<T, CT, KS_, G_, true>(y, tab, jend, g, gsrc, st);             \
+                return 0;                                                                 \
+            }                                                                             \
+        }                                                                                 \
+        launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, gsrc, st);                           \
         return 0;                                                                         \
     }
     SO_RP(12, 1) SO_RP(14, 1) SO_RP(16, 1) SO_RP(20, 1) SO_RP(28, 1) SO_RP(14, 2) SO_RP(14, 3)

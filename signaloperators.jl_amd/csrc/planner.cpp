@@ -1541,11 +1541,19 @@ void Plan::process_stage(int sid) {
             const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * dsize(N.dtype);
             const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
             const int fpitch = (rp.tile_len + 16 + 1) & ~1;
-            const size_t fbytes = (size_t)2 * ns0 * fpitch * 8;
+            // slot 0 (the only one) a sine generator: the kernel's two-level evaluation (TWO)
+            bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 4096 && ns0 == 1 && N.dtype == SO_F64 &&
+                       rp.ct >= 4 && (rp.ngroups + rp.ncompute - 1) / rp.ncompute == 1;
+            if (two) {
+                const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
+                two = (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
+            }
+            const size_t fbytes = (size_t)2 * ns0 * fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
             if (ns0 > 0 && S.carriers[0].nsteps > 0 && !std::getenv("SIGOPS_RS_NOFRING") &&
                 fbytes + 2 * tile_bytes <= avail) {
                 rp.fslots = ns0;
                 rp.fpitch = fpitch;
+                rp.ftwo = two ? 1 : 0;
                 // the in-place multiply is vector-ALU work next to the MFMAs: keep it off the
                 // SIMDs that carry the most compute waves (10 compute waves: loaders 10,11,14,15
                 // on SIMD 2/3 copy and modify, 12,13 only keep the barrier count; measured

@@ -182,10 +182,13 @@ struct RsPeriodic {
     int32_t fslots;     // gain ring: per-frame slots held in LDS (0: none), two arrays of fslots*fpitch
     int32_t fpitch;     // doubles per slot row of the gain ring
     int32_t nload;      // loader waves that copy / modify (0: all of them)
+    int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
+    int32_t pad2;
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };
 constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
+constexpr int kRsTwoDoubles = 3 * 128;  // per-lane (sin,cos) of the lane's phase offset + two buffers of 64 share bases
 
 // Row-tiled variant for rational rates whose period does not fit the MFMA kernel's LDS ring or
 // tap registers (strong downsampling: many inputs per period, long filters), see k_resample_rows.
