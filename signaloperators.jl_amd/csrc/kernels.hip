@@ -1527,8 +1527,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     // vector instructions of division + reduction + two polynomials, all of which compete with
     // the fp64 MFMAs for the same ALUs.  The phase of frame nb + l is the reference's phase of nb
     // (src/functions.jl:57-60, every operation rounded separately) plus fl(fl(l/fs)·ω): it differs
-    // from the reference's own rounding of the phase of nb + l by a few ulp of the phase (< 1e-12
-    // in the gain after ten minutes at 5 Hz; the parity bound is 1e-6).
+    // from the reference's own rounding of the phase of nb + l by a few ulp of the phase (~1e-11
+    // in the gain at 1e4 cycles, the size of the reference's own rounding error there; the
+    // parity bound is 1e-6).
     auto dtab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch; };
     auto btab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch + 128; };
     const bool twolvl = TWO && fring && g.ftwo;

@@ -216,3 +216,32 @@ def test_resampler_ring_is_deterministic(fused):
             assert torch.equal(out_t, ref)
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("nch,gen", [(8, dict(ω=5 * so.Hz)), (4, dict(ω=440 * so.Hz, ϕ=1.25)), (8, dict())])
+def test_resampler_two_level_sine_gain(nch, gen, monkeypatch):
+    """A fused `Amplify(x, Signal(sin, ...))` in front of the periodic resampler is evaluated in
+    two levels (share bases by one wave + one fma per frame, kernel variant TWO).  Same result as
+    the general per-frame evaluation (SIGOPS_RS_NOTWO) far beyond the parity bound, deep into a
+    long signal (large phases) and with an offset source, and within the bound of the oracle."""
+    rng = np.random.default_rng(31)
+    fs = 44.1 * so.kHz
+    n_in = 1_500_000
+    a = np.asfortranarray(rng.standard_normal((n_in + 1000, nch)))
+
+    def tree(arr):
+        return (so.Signal(arr, fs) | so.After(1000 * so.frames) | so.Amplify(so.Signal(so.sin, **gen))
+                | so.Until(n_in * so.frames) | so.ToFramerate(48 * so.kHz))
+
+    got, _ = so.sink(tree(a))
+    monkeypatch.setenv("SIGOPS_RS_NOTWO", "1")
+    general, _ = so.sink(tree(a))
+    assert got.shape == general.shape
+    # the two differ by a few ulp of the PHASE (up to 1.5e4 cycles here: ulp = 1.8e-12 cycles)
+    assert relerr(got, general) < 5e-11
+    assert relerr(got[-50000:], general[-50000:]) < 5e-11  # where the phase is largest
+    m = 200_000  # the oracle on a prefix (seconds of CPU)
+    want = oracle_sink(so.Signal(a[:m + 1000], fs) | so.After(1000 * so.frames) | so.Amplify(so.Signal(so.sin, **gen))
+                       | so.Until(m * so.frames) | so.ToFramerate(48 * so.kHz))
+    k = want.shape[0] - 200  # (the prefix ends where the long signal goes on)
+    assert relerr(got[:k], want[:k]) < 1e-10
