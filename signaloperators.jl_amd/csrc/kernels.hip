@@ -1533,10 +1533,19 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     auto dtab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch; };
     auto btab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch + 128; };
     const bool twolvl = TWO && fring && g.ftwo;
+    // the wave that evaluates the share bases: the last loader in the loaders' own order (see
+    // lidx below), i.e. one that sits on a SIMD with the most compute waves and, with g.nload
+    // set, has no copy / modify work of its own
+    int bwave = nc;
+    if constexpr (TWO) {
+        auto ncomp_on = [&](int w) { return (nc - (w & 3) + 3) >> 2; };
+        for (int w = nc + 1; w < nwaves; ++w)
+            if (ncomp_on(w) >= ncomp_on(bwave)) bwave = w;
+    }
     auto b_duty = [&](const TilePos& p, int bb) __attribute__((always_inline)) {
         int64_t xa;
         int nfr;
-        if (!twolvl || wave != nwaves - 1 || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
+        if (!twolvl || wave != bwave || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
         sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1, 64, (g.tile_len + 63) >> 6, leaf0.v0, leaf0.v1, leaf0.v2,
                    leaf0.flag, btab() + bb * 128);
     };
