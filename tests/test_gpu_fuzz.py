@@ -74,3 +74,34 @@ def test_random_iir_geometries(seed):
         assert got.shape == want.shape
         tol = 2e-6 if got.dtype == np.float32 else 1e-8
         assert relerr(got, want) <= tol, (fs, nch, n, dt.__name__, typ, order)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_fused_sine_gains(seed):
+    """The resampler's fused `Amplify(x, Signal(sin, ...))` source (gain ring + two-level sine
+    evaluation in the TWO kernel variant): random rates, channel groupings (8-, 4-channel tiles),
+    frequencies, phases, source offsets and cuts — including tiles at the edges and sources too
+    short for a single fast tile, which fall back to the general staging path."""
+    rng = np.random.default_rng(seed)
+    for _ in range(14):
+        fi, fo = rng.choice(RATES, 2, replace=False)
+        nch = int(rng.choice([4, 8, 12, 16]))
+        n = int(rng.choice([300, 2500, 9000, 40000]))
+        x = np.asfortranarray(rng.standard_normal((n + 64, nch)))
+        gen = {}
+        if rng.random() < 0.8:
+            gen["omega"] = float(rng.choice([0.5, 5.0, 440.0, 3000.0])) * so.Hz
+        if rng.random() < 0.5:
+            gen["phi"] = float(rng.uniform(0, 6.0))
+        sig = so.Signal(x, float(fi) * so.Hz)
+        off = int(rng.choice([0, 1, 17, 64]))
+        if off:
+            sig = sig | so.After(off * so.frames)
+        sig = sig | so.Amplify(so.Signal(so.sin, **gen)) | so.Until(n * so.frames)
+        tree = sig | so.ToFramerate(float(fo) * so.Hz)
+        if rng.random() < 0.3:
+            tree = tree | so.After(11 * so.frames)
+        want = oracle_sink(tree)
+        got = so.sink(tree)[0]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert relerr(got, want) <= 1e-9, (fi, fo, nch, n, gen, off)
