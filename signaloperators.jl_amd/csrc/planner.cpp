@@ -148,6 +148,7 @@ struct PwStep {
     int out_buf = -1;  // -1: final output
     int64_t bytes = 0;
     bool deep = false;  // some piece needs the 4-deep interpreter
+    std::vector<int> pre;  // pointwise steps that materialise sub-expressions this one reads (run first)
 };
 
 struct Step {
@@ -312,6 +313,11 @@ struct Plan {
     void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
              bool allow_hoist);
     int depth(int e) const;
+    int frame_slots(int e) const;
+    int shift_expr(int e, int64_t a, int c0);
+    int materialise(int e, const Rect& r, std::vector<int>& pre);
+    int legalise(int e, const Rect& r, std::vector<int>& pre);
+    void push_pw_step(int idx);
     int add_leaf(const Expr& e);
     void count_array(int ni);
     void finalize();
@@ -385,8 +391,8 @@ void Plan::build_nodes(const so_node_t* in, int n) {
             N.nch = c.nch;
             N.dtype = c.dtype;
             if (nd.i0 == SO_PAD_VECTOR && !nd.p0) fail(SO_ERR_INVALID, "vector padding without values");
-            if ((nd.i0 == SO_PAD_CYCLE || nd.i0 == SO_PAD_MIRROR) && c.nd.kind != SO_NODE_ARRAY)
-                fail(SO_ERR_INVALID, "Attemped to specify an indexing pad function for a signal which is not known to support `getindex`.");
+            // (an indexing pad -- cycle, mirror -- over something that is not an array is only an
+            //  error once padding actually starts, reference src/padding.jl:163-177: see pad_pieces)
             break;
         }
         case SO_NODE_APPEND: {  // reference src/appending.jl:59-76
@@ -953,9 +959,125 @@ void Plan::gen(int ei, std::vector<DOp>& code, std::map<int, int>& hoisted,
     }
 }
 
+// Per-frame slots the expression needs: its maximal channel-independent generator / ramp
+// sub-expressions (what gen() hoists; identical sub-expressions are counted twice here).
+int Plan::frame_slots(int ei) const {
+    const Expr& e = exprs[ei];
+    if (e.mono && e.heavy) return 1;
+    switch (e.op) {
+    case E_CONST:
+    case E_LOAD:
+    case E_SCALAR:
+    case E_FUNC:
+    case E_RAMP: return 0;
+    case E_NEG:
+    case E_ROUND32:
+    case E_RETYPE: return frame_slots(e.a);
+    default: return frame_slots(e.a) + frame_slots(e.b);
+    }
+}
+
+// copy of expression `ei` that, evaluated at (n, c), gives the original at (n + a, c + c0)
+int Plan::shift_expr(int ei, int64_t a, int c0) {
+    Expr e = exprs[ei];
+    switch (e.op) {
+    case E_CONST:
+    case E_SCALAR: return ei;
+    case E_LOAD:
+        e.leaf.df += (int64_t)e.leaf.sf * a;
+        e.leaf.dc += (int64_t)e.leaf.sc * c0;
+        return add_expr(e);
+    case E_FUNC:
+    case E_RAMP:
+        if (e.leaf.sf) e.leaf.df += a;  // (func_eval / ramp_eval: (sf ? n : 0) + df)
+        return add_expr(e);
+    case E_NEG:
+    case E_ROUND32:
+    case E_RETYPE: e.a = shift_expr(e.a, a, c0); return add_expr(e);
+    default:
+        e.a = shift_expr(e.a, a, c0);
+        e.b = shift_expr(e.b, a, c0);
+        return add_expr(e);
+    }
+}
+
+// Evaluate `ei` over rectangle r into a scratch buffer with one more pointwise step (appended
+// to `pre`) and return a plain load of that buffer.  Values are stored in the expression's own
+// sample type, i.e. exactly as the interpreter would have passed them on.
+int Plan::materialise(int ei, const Rect& r, std::vector<int>& pre) {
+    const int dt = exprs[ei].dtype == SO_F32 ? SO_F32 : SO_F64;
+    const int nchp = r.c1 - r.c0;
+    const int64_t nf = r.b - r.a;
+    const int buf = new_buf(nf, nchp, dt);
+    std::vector<Piece> one{Piece{Rect{0, nf, 0, nchp}, shift_expr(ei, r.a, r.c0)}};
+    pre.push_back(emit_pointwise(one, buf, dt));
+    Expr l;
+    l.op = E_LOAD;
+    l.dtype = exprs[ei].dtype;
+    l.leaf = mk_leafmap(Map{1, -r.a, 1, -(int64_t)r.c0});
+    l.leaf.fstride = 1;
+    l.leaf.cstride = -1;  // = pitch of the buffer, patched in finalize()
+    l.leaf.dtype = dt;
+    l.leaf.buf = buf;
+    l.mono = false;
+    return add_expr(l);
+}
+
+// Rewrite an expression that exceeds the interpreter's limits (stack depth kStackDepth,
+// kMaxFrameSlots per-frame slots) into one that fits, by materialising sub-expressions: the
+// reference has no such limits (it recurses through `frame`), so neither may the lowering.
+int Plan::legalise(int ei, const Rect& r, std::vector<int>& pre) {
+    Expr e = exprs[ei];
+    switch (e.op) {
+    case E_CONST:
+    case E_LOAD:
+    case E_SCALAR:
+    case E_FUNC:
+    case E_RAMP: return ei;
+    case E_NEG:
+    case E_ROUND32:
+    case E_RETYPE: {
+        const int a = legalise(e.a, r, pre);
+        if (a == e.a) return ei;
+        e.a = a;
+        e.mono = exprs[a].mono;
+        e.heavy = exprs[a].heavy;
+        return add_expr(e);
+    }
+    default: break;
+    }
+    int a = legalise(e.a, r, pre), b = legalise(e.b, r, pre);
+    if (std::max(depth(a), depth(b) + 1) > kStackDepth) b = materialise(b, r, pre);
+    auto slots_of = [&](int x, int y) {
+        return exprs[x].mono && exprs[y].mono && (exprs[x].heavy || exprs[y].heavy) ? 1 : frame_slots(x) + frame_slots(y);
+    };
+    while (slots_of(a, b) > kMaxFrameSlots) {
+        if (frame_slots(a) >= frame_slots(b)) a = materialise(a, r, pre);
+        else b = materialise(b, r, pre);
+    }
+    if (a == e.a && b == e.b) return ei;
+    e.a = a;
+    e.b = b;
+    e.mono = exprs[a].mono && exprs[b].mono;
+    e.heavy = exprs[a].heavy || exprs[b].heavy;
+    return add_expr(e);
+}
+
+void Plan::push_pw_step(int idx) {
+    for (int q : pw[idx].pre) push_pw_step(q);
+    steps.push_back(Step{0, idx, "k_pointwise", pw[idx].bytes});
+}
+
 // compile pieces into one pointwise launch writing `out_buf` (or the final output)
-int Plan::emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype) {
+int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_dtype) {
+    std::vector<Piece> ps = ps_in;
+    std::vector<int> pre;
+    for (auto& p : ps) {
+        if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
+        if (depth(p.e) > kStackDepth || frame_slots(p.e) > kMaxFrameSlots) p.e = legalise(p.e, p.r, pre);
+    }
     PwStep st;
+    st.pre = pre;
     st.piece0 = (int)pieces.size();
     st.out_buf = out_buf;
     int64_t blk = 0;
@@ -1927,10 +2049,7 @@ void Plan::finalize() {
     std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
     for (int sid : order) {
         Stage& S = stages[sid];
-        if (S.pw_step >= 0) {
-            Step st{0, S.pw_step, "k_pointwise", pw[S.pw_step].bytes};
-            steps.push_back(st);
-        }
+        if (S.pw_step >= 0) push_pw_step(S.pw_step);
         const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
@@ -2106,10 +2225,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         int rootstep = -1;
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
         P->finalize();
-        if (rootstep >= 0) {
-            Step st{0, rootstep, "k_pointwise", P->pw[rootstep].bytes};
-            P->steps.push_back(st);
-        }
+        if (rootstep >= 0) P->push_pw_step(rootstep);
         P->plan_lanes();
     } catch (const PlanError& e) {
         status = e.status;

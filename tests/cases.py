@@ -458,5 +458,28 @@ def benchmark_overall():  # test/benchmarks.jl:88-97
 
 
 @case
+def deep_right_nested():
+    """Right-nested maps seven levels deep: the fused interpreter has a 4-deep stack, the
+    reference recurses without limit -- the planner materialises sub-expressions (planner.cpp
+    legalise)."""
+    r = rng(41)
+    xs = [Signal(F(r.standard_normal((300, 2))), 100 * Hz) for _ in range(7)]
+    e = xs[6]
+    for k in (5, 4, 3, 2, 1, 0):
+        e = Mix(xs[k], e) if k % 2 else Amplify(xs[k], e)
+    return e
+
+
+@case
+def six_generators():
+    """Six distinct generators, each scaling its own array: more per-frame slots than the fused
+    kernel has (4) -- the planner materialises the surplus."""
+    r = rng(43)
+    parts = [Amplify(Signal(F(r.standard_normal((250, 2))), 100 * Hz), Signal(sin, 100 * Hz, ω=(3 + 2 * k) * Hz))
+             | Until(250 * frames) for k in range(6)]
+    return Mix(*parts) | Ramp(20 * frames)
+
+
+@case
 def empty_signal():  # runtests.jl:481-488
     return Signal(sin, 200 * Hz, ω=10 * Hz) | ToChannels(2) | Until(10 * frames) | Until(0 * frames)

@@ -105,3 +105,87 @@ def test_random_fused_sine_gains(seed):
         got = so.sink(tree)[0]
         assert got.shape == want.shape and got.dtype == want.dtype
         assert relerr(got, want) <= 1e-9, (fi, fo, nch, n, gen, off)
+
+
+def _random_tree(rng, nch, fs, depth, info):
+    """A random finite signal over the structural / pointwise operators (the planner's piece
+    algebra + K1), with an occasional stateful stage (Filt, Normpower) underneath."""
+    def leaf():
+        k = int(rng.integers(0, 4))
+        if k <= 1:
+            n = int(rng.integers(5, 400))
+            c = nch if rng.random() < 0.7 else 1
+            dt = np.float64 if rng.random() < 0.75 else np.float32
+            info["f32"] = info.get("f32", False) or dt == np.float32
+            return so.Signal(np.asfortranarray(rng.standard_normal((n, c)).astype(dt)), fs)
+        fn = so.sin if k == 2 else so.cos
+        return so.Signal(fn, fs, ω=float(rng.uniform(0.5, 40)) * so.Hz) | so.Until(int(rng.integers(5, 400)) * so.frames)
+
+    if depth == 0:
+        return leaf()
+    x = _random_tree(rng, nch, fs, depth - 1, info)
+    n = so.nframes(x)
+    if n is None or n < 0:  # length not known before evaluation: pin it
+        x = x | so.Until(150 * so.frames)
+        n = so.nframes(x)
+    op = int(rng.integers(0, 13))
+    if op == 0:
+        return x | so.Until(int(rng.integers(0, n + 1)) * so.frames)
+    if op == 1:
+        return x | so.After(int(rng.integers(0, n + 1)) * so.frames)
+    if op == 2:
+        pad = [so.zero, so.one, so.lastframe, 2.5, so.zero, so.one, so.lastframe, -0.5, so.cycle, so.mirror][int(rng.integers(0, 10))]
+        if n == 0 and pad in (so.lastframe, so.cycle, so.mirror):
+            pad = so.zero
+        return so.Pad(x, pad) | so.Until((n + int(rng.integers(1, 3 * n + 5))) * so.frames)
+    if op == 3 and n >= 4:
+        return so.Ramp(x, int(rng.integers(1, n // 2 + 1)) * so.frames)
+    if op == 4 and n >= 2:
+        return (so.RampOn if rng.random() < 0.5 else so.RampOff)(x, int(rng.integers(1, n + 1)) * so.frames)
+    if op == 5:
+        return so.Amplify(x, float(rng.uniform(-12, 6)) * so.dB)
+    if op == 6:
+        return so.Mix(x, float(rng.uniform(-1, 1)))
+    y = _random_tree(rng, nch, fs, int(rng.integers(0, depth)), info)
+    if op == 7:
+        return so.Mix(x, y)
+    if op == 8:
+        return so.Amplify(x, y)
+    if op == 9:
+        return so.Append(x, y)
+    if op == 10 and n >= 2:
+        return so.FadeTo(x, y, int(rng.integers(1, max(1, min(n, so.nframes(y) or 1)) + 1)) * so.frames)
+    if op == 11 and n >= 30:
+        return so.Filt(x, so.Lowpass, float(rng.uniform(0.05, 0.4)) * fs)
+    if op == 12 and n >= 1:
+        return so.Normpower(x)
+    return so.Append(y, x)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_operator_trees(seed):
+    """Random trees of Until / After / Pad / Ramp / Amplify / Mix / Append / FadeTo (+ Filt,
+    Normpower) over arrays, generators and numbers against the oracle: lengths and dtypes equal,
+    values within the parity bound; a tree the oracle rejects must be rejected by the engine too."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(25):
+        nch = int(rng.choice([1, 2, 3]))
+        fs = float(rng.choice([50, 100, 8000])) * so.Hz
+        info = {}
+        tree = _random_tree(rng, nch, fs, int(rng.integers(1, 6)), info)
+        try:
+            want = oracle_sink(tree)
+        except Exception:
+            with pytest.raises(Exception):
+                so.sink(tree)
+            continue
+        got = so.sink(tree)[0]
+        assert got.shape == want.shape and got.dtype == want.dtype, repr(tree)[:300]
+        if want.size:
+            ok = np.isfinite(want).all()
+            # Float32 anywhere in the tree (even under a Float64 result): Float32 bound
+            tol = 2e-6 if info.get("f32") else 1e-9
+            if ok:
+                assert relerr(got, want) <= tol, repr(tree)[:400]
+            else:
+                assert np.array_equal(np.isfinite(got), np.isfinite(want)), repr(tree)[:400]
