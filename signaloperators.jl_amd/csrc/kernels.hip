@@ -1145,12 +1145,13 @@ __device__ __forceinline__ void rmw_chunk(uint32_t la, int lds_pitch, const CarT
     for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
 }
 
-// The commonest in-place step, one multiply by frame slot 0 (`Amplify` by a generator, a ramp
-// or a number), without the step interpreter: per chunk of CT rows one gain read, CT reads, 2*CT
-// multiplies, CT writes.  (The general rmw_chunk spends ~4x the vector instructions on slot
-// selection and step dispatch, and every one of them waits for a gap between the MFMAs.)
-template <int CT>
-__device__ __forceinline__ void rmw_mul_chunk(uint32_t la, int lds_pitch, uint32_t fa) {
+// The commonest in-place steps, ONE multiply / add / subtract with frame slot 0 (`Amplify` or `Mix`
+// with a generator, a ramp or a number), without the step interpreter: per chunk of CT rows one
+// slot read, CT reads, 2*CT arithmetic instructions, CT writes.  (The general rmw_chunk spends ~4x
+// the vector instructions on slot selection and step dispatch, and every one of them waits for
+// a gap between the MFMAs.)  OP: 0 v*m, 1 v+m, 2 v-m, 3 m-v.
+template <int CT, int OP>
+__device__ __forceinline__ void rmw_one_chunk(uint32_t la, int lds_pitch, uint32_t fa) {
     v2d f[1];
     f[0] = lds_ld16(fa);
     v2d raw[CT];
@@ -1159,7 +1160,8 @@ __device__ __forceinline__ void rmw_mul_chunk(uint32_t la, int lds_pitch, uint32
     lds_wait(f);
     lds_wait(raw);
 #pragma unroll
-    for (int c = 0; c < CT; ++c) raw[c] = raw[c] * f[0];
+    for (int c = 0; c < CT; ++c)
+        raw[c] = OP == 0 ? raw[c] * f[0] : OP == 1 ? raw[c] + f[0] : OP == 2 ? raw[c] - f[0] : f[0] - raw[c];
     lds_pin(raw);
 #pragma unroll
     for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
@@ -1637,7 +1639,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const int ltid = (lidx < nactive ? lidx * 64 : (1 << 30)) + lane;
         const int llane = lane;
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
-        const bool mul0 = nsteps0 == 1 && st0.op[0] == OP_MUL && (st0.arg[0] & 0x2ff) == 0 && !(g.pad & 128);
+        // one step `v (op) slot0`, no Float32 rounding: 0 mul, 1 add, 2 v-m, 3 m-v; -1: step interpreter
+        int one0 = -1;
+        if (nsteps0 == 1 && (st0.arg[0] & 0x2ff) == 0 && !(g.pad & 128))
+            one0 = st0.op[0] == OP_MUL ? 0 : st0.op[0] == OP_ADD ? 1 : st0.op[0] == OP_SUB ? ((st0.arg[0] & 0x100) ? 3 : 2) : -1;
         // Loader waves issue a handful of instructions and then sleep on memory; without a
         // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
         // and the loads only go out once the arithmetic is over (measured: phases add up).
@@ -1703,8 +1708,16 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 rs_stamp(g, wave, it, 6);
                 for (int ivb = lw64; ivb < nvec; ivb += lthr) {
                     const int iv = ivb + llane;
-                    if (mul0) {
-                        if (iv < nvec) rmw_mul_chunk<CT>(lbase + (uint32_t)iv * 16u, g.lds_pitch, lds_addr(Fb) + (uint32_t)iv * 16u);
+                    if (one0 >= 0) {
+                        if (iv < nvec) {
+                            const uint32_t la = lbase + (uint32_t)iv * 16u, fa = lds_addr(Fb) + (uint32_t)iv * 16u;
+                            switch (one0) {
+                            case 0: rmw_one_chunk<CT, 0>(la, g.lds_pitch, fa); break;
+                            case 1: rmw_one_chunk<CT, 1>(la, g.lds_pitch, fa); break;
+                            case 2: rmw_one_chunk<CT, 2>(la, g.lds_pitch, fa); break;
+                            default: rmw_one_chunk<CT, 3>(la, g.lds_pitch, fa); break;
+                            }
+                        }
                     } else if (iv < nvec) {
                         double F[kMaxFrameSlots][2];
 #pragma unroll

@@ -1790,7 +1790,7 @@ bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
 bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out) {
     std::vector<Piece> ps = ps_in;
     for (auto& p : ps)
-        if (p.r.c0 != 0 || p.r.c1 != nch) return false;
+        if (p.r.c0 != 0 || p.r.c1 != nch) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 1); return false; }
     std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
     std::vector<DCarrier> cs;
     std::vector<std::vector<int>> monos_all;
@@ -1799,19 +1799,19 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         c.buf = -1;
         c.array_node = -1;
         std::vector<int> monos;
-        if (!match_carrier(p.e, c, monos)) return false;
+        if (!match_carrier(p.e, c, monos)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 2); return false; }
         c.a = p.r.a;
         c.b = p.r.b;
         cs.push_back(c);
         monos_all.push_back(monos);
     }
     // compile the per-frame programs; everything must fit the kernel-argument control block
-    if (cs.size() > (size_t)kCtlCar) return false;
+    if (cs.size() > (size_t)kCtlCar) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 3); return false; }
     // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
     // staging path, ~6x slower than a K1 pass + the LDS-DMA fast path), so steps on fp32 data
     // are materialised by K1 instead of fused
     for (auto& c : cs)
-        if (c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) return false;
+        if (c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
     std::vector<std::vector<DOp>> fcodes(cs.size());
     size_t nops_total = 0;
     std::set<int> leafset;
@@ -1829,6 +1829,10 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
                 const Expr& ex = exprs[ei];
                 if (ex.op == E_RETYPE) ei = ex.a;
                 else if (ex.op == E_ROUND32) { r32 = 0x100; ei = ex.a; }
+                // `0 + g` / `g + 0`: the zero-padded tail of a `Mix` operand under a generator (the
+                // sum differs from g only in the sign of a zero)
+                else if (ex.op == E_ADD && is_const(ex.a, 0.0)) ei = ex.b;
+                else if ((ex.op == E_ADD || ex.op == E_SUB) && is_const(ex.b, 0.0)) ei = ex.a;  // (g - 0 == g exactly)
                 else break;
             }
             const int eop = exprs[ei].op;
@@ -1836,7 +1840,7 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
             if (kind < 0) {
                 leaves.resize(leaves_before);
                 leaf_array_node.resize(leaves_before);
-                return false;
+                { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 5); return false; }
             }
             c.slot_leaf[k] = add_leaf(exprs[ei]);
             c.slot_kind[k] = kind | r32;
@@ -1854,7 +1858,7 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         if (dmax > 2 || nops_total > (size_t)kCtlOps || leafset.size() > (size_t)kCtlLeaves) {
             leaves.resize(leaves_before);  // drop what gen() appended
             leaf_array_node.resize(leaves_before);
-            return false;
+            { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 6); return false; }
         }
     }
     // commit

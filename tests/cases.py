@@ -458,6 +458,24 @@ def benchmark_overall():  # test/benchmarks.jl:88-97
 
 
 @case
+def resample_mix_sine_8ch():  # BASELINE metric's "Mix ... Resample": one fused add in the resampler's staging
+    x = F(rng(47).standard_normal((6000, 8)))
+    return Mix(Signal(x, 44.1 * kHz), Signal(sin, ω=440 * Hz)) | Until(6000 * frames) | ToFramerate(48 * kHz)
+
+
+@case
+def resample_sub_sine():  # the fused one-step routine's v-m form (4-channel tiles)
+    x = F(rng(53).standard_normal((5100, 4)))  # (longer than the cut: no `0 - sin` tail, which is not fused)
+    return OperateOn("-", Signal(x, 44.1 * kHz), Signal(sin, ω=100 * Hz)) | Until(5000 * frames) | ToFramerate(48 * kHz)
+
+
+@case
+def resample_sine_sub():  # ... and m-v
+    x = F(rng(59).standard_normal((5000, 4)))
+    return OperateOn("-", Signal(sin, ω=100 * Hz), Signal(x, 44.1 * kHz)) | Until(5000 * frames) | ToFramerate(48 * kHz)
+
+
+@case
 def deep_right_nested():
     """Right-nested maps seven levels deep: the fused interpreter has a 4-deep stack, the
     reference recurses without limit -- the planner materialises sub-expressions (planner.cpp
