@@ -73,6 +73,14 @@ def main():
         noise = dev(n2, 2)
         run("config2 Mix(sin 1kHz, noise[2ch,60s]) |> Filt(Bandstop 0.5-2kHz)",
             Mix(Signal(sin, ω=1 * kHz) | Until(n2 * frames), Signal(noise, 44.1 * kHz)) | Filt(Bandstop, 0.5 * kHz, 2 * kHz), so, torch)
+    if not sel or "ns" in sel:  # north_star's pipeline at config 3's size: Mix -> Filt -> ToFramerate, 8 ch, 600 s
+        nn = int(26460000 * a.scale)
+        noise = dev(nn, 8)
+        run("north-star pipeline: Mix(sin 1kHz, noise[8ch,600s]) |> Filt(Bandstop 0.5-2kHz) |> ToFramerate(48kHz)",
+            Mix(Signal(sin, ω=1 * kHz), Signal(noise, 44.1 * kHz)) | Until(nn * frames)
+            | Filt(Bandstop, 0.5 * kHz, 2 * kHz) | ToFramerate(48 * kHz), so, torch, steps=10)
+        del noise
+        torch.cuda.empty_cache()
     if not sel or "4" in sel:  # config 4 (one GPU's share: 8 scenes of 60 s)
         n4 = int(2646000 * a.scale)
         scenes = []
