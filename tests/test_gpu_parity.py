@@ -245,3 +245,48 @@ def test_resampler_two_level_sine_gain(nch, gen, monkeypatch):
                        | so.Until(m * so.frames) | so.ToFramerate(48 * so.kHz))
     k = want.shape[0] - 200  # (the prefix ends where the long signal goes on)
     assert relerr(got[:k], want[:k]) < 1e-10
+
+
+def test_set_array_reaches_materialised_sub_expressions():
+    """A tree beyond the fused interpreter's stack depth is split by the planner into scratch
+    buffers written by extra pointwise steps (planner.cpp legalise): plan reuse, graph replay and
+    so_plan_set_array must reach the array leaves inside those sub-expressions too."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(61)
+    fs = 100 * so.Hz
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+
+    def tree(xs):
+        e = so.Signal(xs[6], fs)
+        for k in (5, 4, 3, 2, 1, 0):
+            e = so.Mix(so.Signal(xs[k], fs), e) if k % 2 else so.Amplify(so.Signal(xs[k], fs), e)
+        return e
+
+    A = [np.asfortranarray(rng.standard_normal((4000, 2))) for _ in range(7)]
+    B = [np.asfortranarray(rng.standard_normal((4000, 2))) for _ in range(7)]
+    dA, dB = [dev(a) for a in A], [dev(b) for b in B]
+    x = tree(dA)
+    n = so.nframes(x)
+    out_t = torch.empty((2, n), dtype=torch.float64, device="cuda")
+    out = out_t.t()
+    plan = so.Plan(so.ToChannels(x, 2), (n, 2), np.float64, (out.stride(0), out.stride(1)), True)
+    stream = torch.cuda.current_stream().cuda_stream
+    want_a, want_b = oracle_sink(tree(A)), oracle_sink(tree(B))
+    try:
+        for _ in range(4):
+            out_t.zero_()
+            plan.execute(out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want_a)
+        assert plan.stats()["n_launches"] >= 2  # at least one materialising step
+        for k in range(7):
+            plan.set_array(k, dB[k])
+        for _ in range(3):
+            out_t.zero_()
+            plan.execute(out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want_b)
+    finally:
+        plan.close()
