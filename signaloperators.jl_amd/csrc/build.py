@@ -2,6 +2,7 @@
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["kernels.hip", "planner.cpp", "design.cpp", "capi.cpp"]
@@ -20,8 +21,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for s in SRCS:
+    def compile_one(s):
         o = os.path.join(HERE, s.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-x", "hip", "-c", os.path.join(HERE, s), "-o", o]
@@ -33,7 +33,11 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(o)
+        return o
+
+    # the translation units are independent: compile them side by side (kernels.hip dominates)
+    with ThreadPoolExecutor(max_workers=len(SRCS)) as pool:
+        objs = list(pool.map(compile_one, SRCS))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -1375,9 +1375,9 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
     return stage_tile<T, CT, PASS>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
-    const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, T* __restrict__ y,
+    const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
     // LDS: ring of nslots tiles in the SAMPLE type (fp32 tiles are converted at the A-operand
     // read, so fp32 sources go by LDS-DMA too), then the fp64 gain ring
@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const T* __restrict__ cur = lds + slot * bufsz + sh;
         const int64_t P0 = p.tx * g.pt;
         const int c0 = (int)p.tc * CT;
-        T* __restrict__ ytile = y + ((int64_t)c0 * g.out_pitch + P0 * g.L);
+        TO* __restrict__ ytile = y + ((int64_t)c0 * g.out_pitch + P0 * g.L);
         // interior tile: every row's period is complete -> no per-element bounds checks
         const bool interior = P0 + g.pt <= g.nperiods && (P0 + g.pt) * g.L <= g.n_out;
 #pragma unroll
@@ -1828,7 +1828,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
 #pragma unroll
                     for (int q = 0; q < kRsQ; ++q)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ytile[yoff[q][i] + gi * 16] = (T)acc[q][i];
+                        for (int i = 0; i < 4; ++i) ytile[yoff[q][i] + gi * 16] = (TO)acc[q][i];
                 } else {
 #pragma unroll
                     for (int q = 0; q < kRsQ; ++q)
@@ -1838,7 +1838,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                             const int64_t period = P0 + (rho & ptmask);
                             const int64_t m = period * g.L + r;
                             if (period < g.nperiods && r < g.L && m < g.n_out)
-                                ytile[yoff[q][i] + gi * 16] = (T)acc[q][i];
+                                ytile[yoff[q][i] + gi * 16] = (TO)acc[q][i];
                         }
                 }
             }
@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
@@ -1866,11 +1866,11 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
     size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO>), grid, dim3(64 * g.nwaves), lds, st, tab,
-                       jend, g, (T*)y, gsrc);
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO>), grid, dim3(64 * g.nwaves), lds, st, tab,
+                       jend, g, (TO*)y, gsrc);
 }
 
 template <typename T, int CT>
@@ -1880,11 +1880,17 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
 #define SO_RP(KS_, G_)                                                                   \
     if (g.kw == 4 * KS_ && gper == G_) {                                                  \
         if constexpr (sizeof(T) == 8 && CT >= 4 && G_ == 1) {                             \
+            if (g.out_f32) { /* Float64 arithmetic, Float32 result */                     \
+                if (g.ftwo) launch_rp_k<T, CT, KS_, G_, true, float>(y, tab, jend, g, gsrc, st); \
+                else launch_rp_k<T, CT, KS_, G_, false, float>(y, tab, jend, g, gsrc, st);  \
+                return 0;                                                                 \
+            }                                                                             \
             if (g.ftwo) {                                                                 \
                 launch_rp_k<T, CT, KS_, G_, true>(y, tab, jend, g, gsrc, st);             \
                 return 0;                                                                 \
             }                                                                             \
         }                                                                                 \
+        if (g.out_f32) return -1;                                                         \
         launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, gsrc, st);                           \
         return 0;                                                                         \
     }

@@ -192,6 +192,7 @@ struct Plan {
     DLeaf* d_leaves = nullptr;
     int out_stage_buf = -1;  // device staging for a host result
     int alias_stage = -1;    // stage whose kernel writes the final output directly
+    bool alias_narrow = false;  // ... rounding its Float64 values to the Float32 result
     bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
     std::vector<char> host_tmp;
     bool profiling = false;
@@ -2211,13 +2212,23 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         //  writing the staging buffer with the result's own strides: one D2H copy, no host loop)
         P->interleaved_host = !out->is_device && out->nch > 1 && out->chan_stride == 1 && out->frame_stride == out->nch;
         if (rootp.size() == 1 && (out->frame_stride == 1 || !out->is_device) && !P->interleaved_host) {
-            const Expr& e = P->exprs[rootp[0].e];
+            int re = rootp[0].e;
+            // a Float64 signal stored into a Float32 result (`convert(Float32, ·)` on write, reference
+            // src/sink.jl:262-266): the periodic resampler can round in its own store
+            if (out->dtype == SO_F32)
+                while (P->exprs[re].op == E_RETYPE || P->exprs[re].op == E_ROUND32) re = P->exprs[re].a;
+            const Expr& e = P->exprs[re];
+            const bool narrowing = e.leaf.dtype == SO_F64 && out->dtype == SO_F32 && !std::getenv("SIGOPS_NO_NARROW_STORE");
             if (e.op == E_LOAD && e.leaf.buf >= 0 && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 &&
-                e.leaf.df == 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && e.leaf.dtype == out->dtype) {
+                e.leaf.df == 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && (e.leaf.dtype == out->dtype || narrowing)) {
                 for (size_t i = 0; i < P->stages.size(); ++i)
                     if (P->stages[i].out_buf == e.leaf.buf && P->stages[i].kind != ST_NORM &&
-                        P->stages[i].need == out->nframes)
+                        P->stages[i].need == out->nframes &&
+                        (e.leaf.dtype == out->dtype || (P->stages[i].kind == ST_RESAMPLE && P->stages[i].periodic &&
+                                                        P->stages[i].rp.ct >= 4 &&
+                                                        (P->stages[i].rp.ngroups + P->stages[i].rp.ncompute - 1) / P->stages[i].rp.ncompute == 1)))
                         P->alias_stage = (int)i;
+                P->alias_narrow = P->alias_stage >= 0 && e.leaf.dtype != out->dtype;
                 if (P->alias_stage >= 0)
                     for (auto& L : P->leaves)  // any other consumer of that buffer forbids aliasing
                         if (L.buf == e.leaf.buf) P->alias_stage = -1;
@@ -2361,6 +2372,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsPeriodic rp = S.rp;
                         rp.in_pitch = in_pitch;
                         rp.out_pitch = ob.pitch;
+                        rp.out_f32 = s.idx == P->alias_stage && P->alias_narrow;
                         const int64_t al = 16 / (int64_t)esz;
                         rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
                         static long long* d_trace = nullptr;  // SIGOPS_RS_TRACE tuning aid

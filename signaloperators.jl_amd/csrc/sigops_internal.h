@@ -183,7 +183,7 @@ struct RsPeriodic {
     int32_t fpitch;     // doubles per slot row of the gain ring
     int32_t nload;      // loader waves that copy / modify (0: all of them)
     int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
-    int32_t pad2;
+    int32_t out_f32;    // fp64 kernel storing into a Float32 result (`sink` of a Float64 signal into Float32)
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };

@@ -290,3 +290,29 @@ def test_set_array_reaches_materialised_sub_expressions():
             assert np.array_equal(out.cpu().numpy(), want_b)
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("nch,leaf_dtype,fused", [(8, np.float64, True), (4, np.float32, True), (8, np.float64, False)])
+def test_float64_signal_into_float32_result(nch, leaf_dtype, fused):
+    """`sink!` of a Float64 signal into a Float32 buffer converts on write (reference
+    src/sink.jl:262-266).  When the root is the periodic resampler its fp64 kernel rounds in its
+    own store (variant with a Float32 result pointer) instead of a separate conversion pass:
+    same values as the oracle's Float64 result rounded once."""
+    rng = np.random.default_rng(67)
+    n = 20000
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(leaf_dtype))
+    sig = so.Signal(x, 44.1 * so.kHz)
+    if fused:
+        sig = sig | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(n * so.frames)
+    else:
+        sig = sig | so.ToEltype(np.float64)
+    tree = sig | so.ToFramerate(48 * so.kHz)
+    want = oracle_sink(tree)
+    assert want.dtype == np.float64
+    res = np.full((so.nframes(tree), nch), np.nan, dtype=np.float32, order="F")
+    so.sink_into(res, tree)
+    w32 = want.astype(np.float32)
+    # (the engine's Float64 values differ from the oracle's by ~1e-15: a different Float32 only
+    #  where that crosses a rounding boundary)
+    assert relerr(res.astype(np.float64), w32.astype(np.float64)) < 1e-7
+    assert np.mean(res != w32) < 1e-3
