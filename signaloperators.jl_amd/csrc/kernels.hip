@@ -1548,8 +1548,12 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         int64_t xa;
         int nfr;
         if (!twolvl || wave != bwave || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
-        sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1, 64, (g.tile_len + 63) >> 6, leaf0.v0, leaf0.v1, leaf0.v2,
-                   leaf0.flag, btab() + bb * 128);
+        const int nb = (g.tile_len + 63) >> 6;  // <= kRsTwoBases (planner)
+        sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1, 64, nb, leaf0.v0, leaf0.v1, leaf0.v2, leaf0.flag,
+                   btab() + bb * 2 * kRsTwoBases);
+        if (nb > 64)
+            sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1 + 64 * 64, 64, nb - 64, leaf0.v0, leaf0.v1, leaf0.v2,
+                       leaf0.flag, btab() + bb * 2 * kRsTwoBases + 128);
     };
     auto f_duty = [&](const TilePos& p, int fb) __attribute__((always_inline)) {
         int64_t xa;
@@ -1565,7 +1569,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 if (shr < 0) break;
                 for (int u = shr; u * 64 < g.tile_len; u += nshares) {
                     const int f = (nfr - g.tile_len) + u * 64 + lane;
-                    const double2 b = *reinterpret_cast<const double2*>(btab() + fb * 128 + 2 * u);
+                    const double2 b = *reinterpret_cast<const double2*>(btab() + fb * 2 * kRsTwoBases + 2 * u);
                     double v = fma(b.x, d.y, b.y * d.x);
                     if (kind0 & 0x100) v = (double)(float)v;
                     if (f < nfr) Fb[f] = v;
@@ -1879,13 +1883,15 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
     const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
 #define SO_RP(KS_, G_)                                                                   \
     if (g.kw == 4 * KS_ && gper == G_) {                                                  \
-        if constexpr (sizeof(T) == 8 && CT >= 4 && G_ == 1) {                             \
-            if (g.out_f32) { /* Float64 arithmetic, Float32 result */                     \
-                if (g.ftwo) launch_rp_k<T, CT, KS_, G_, true, float>(y, tab, jend, g, gsrc, st); \
-                else launch_rp_k<T, CT, KS_, G_, false, float>(y, tab, jend, g, gsrc, st);  \
-                return 0;                                                                 \
+        if constexpr (sizeof(T) == 8 && G_ == 1) {                                        \
+            if constexpr (CT >= 4) {                                                      \
+                if (g.out_f32) { /* Float64 arithmetic, Float32 result */                 \
+                    if (g.ftwo) launch_rp_k<T, CT, KS_, G_, true, float>(y, tab, jend, g, gsrc, st); \
+                    else launch_rp_k<T, CT, KS_, G_, false, float>(y, tab, jend, g, gsrc, st); \
+                    return 0;                                                             \
+                }                                                                         \
             }                                                                             \
-            if (g.ftwo) {                                                                 \
+            if (g.ftwo && !g.out_f32) {                                                   \
                 launch_rp_k<T, CT, KS_, G_, true>(y, tab, jend, g, gsrc, st);             \
                 return 0;                                                                 \
             }                                                                             \

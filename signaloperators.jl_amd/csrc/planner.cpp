@@ -1665,8 +1665,8 @@ void Plan::process_stage(int sid) {
             const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
             const int fpitch = (rp.tile_len + 16 + 1) & ~1;
             // slot 0 (the only one) a sine generator: the kernel's two-level evaluation (TWO)
-            bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 4096 && ns0 == 1 && N.dtype == SO_F64 &&
-                       rp.ct >= 4 && (rp.ngroups + rp.ncompute - 1) / rp.ncompute == 1;
+            bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases && ns0 == 1 && N.dtype == SO_F64 &&
+                       (rp.ngroups + rp.ncompute - 1) / rp.ncompute == 1;
             if (two) {
                 const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
                 two = (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;

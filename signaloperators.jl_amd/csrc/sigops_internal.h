@@ -188,7 +188,8 @@ struct RsPeriodic {
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };
 constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
-constexpr int kRsTwoDoubles = 3 * 128;  // per-lane (sin,cos) of the lane's phase offset + two buffers of 64 share bases
+constexpr int kRsTwoBases = 128;                          // share bases per tile (tiles of up to 8192 frames)
+constexpr int kRsTwoDoubles = 128 + 2 * 2 * kRsTwoBases;  // per-lane (sin,cos) of the lane's phase offset + two buffers of share bases
 
 // Row-tiled variant for rational rates whose period does not fit the MFMA kernel's LDS ring or
 // tap registers (strong downsampling: many inputs per period, long filters), see k_resample_rows.

@@ -85,7 +85,7 @@ def test_random_fused_sine_gains(seed):
     rng = np.random.default_rng(seed)
     for _ in range(14):
         fi, fo = rng.choice(RATES, 2, replace=False)
-        nch = int(rng.choice([4, 8, 12, 16]))
+        nch = int(rng.choice([1, 2, 4, 8, 12, 16]))
         n = int(rng.choice([300, 2500, 9000, 40000]))
         x = np.asfortranarray(rng.standard_normal((n + 64, nch)))
         gen = {}

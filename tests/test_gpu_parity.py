@@ -218,7 +218,8 @@ def test_resampler_ring_is_deterministic(fused):
         plan.close()
 
 
-@pytest.mark.parametrize("nch,gen", [(8, dict(ω=5 * so.Hz)), (4, dict(ω=440 * so.Hz, ϕ=1.25)), (8, dict())])
+@pytest.mark.parametrize("nch,gen", [(8, dict(ω=5 * so.Hz)), (4, dict(ω=440 * so.Hz, ϕ=1.25)), (8, dict()),
+                                     (2, dict(ω=50 * so.Hz, ϕ=0.5)), (1, dict(ω=5 * so.Hz))])
 def test_resampler_two_level_sine_gain(nch, gen, monkeypatch):
     """A fused `Amplify(x, Signal(sin, ...))` in front of the periodic resampler is evaluated in
     two levels (share bases by one wave + one fma per frame, kernel variant TWO).  Same result as
