@@ -274,6 +274,19 @@ int32_t so_design_resample_rational(int64_t num, int64_t den, double* h, int32_t
 int32_t so_design_resample_arbitrary(double rate, int32_t nphi, double* h, int32_t capacity,
                                      int32_t* hlen);
 
+/* Diagnostics, host only (no device needed): the position (newest input j, 0-based; phase p,
+ * 0-based; alpha) the arbitrary-rate resampler uses for each of the outputs 0..n_out-1.
+ * Replaces nothing in the reference: it makes visible how the engine follows DSP.jl's
+ * FIRArbitrary phase accumulator (`update`: ϕAccumulator += Δ per output; reference call site
+ * src/reformatting.jl:92-98, src/filters.jl:252-255) -- the closed form of the kernels, the
+ * period positions whose tap tables are built from the accumulator's wrap-around ties
+ * (*nbaked of them) and the sparse fix-up list (*nfix entries) combined.  h = resample_filter
+ * taps (so_design_resample_arbitrary).  SIGOPS_RS_EXACT=1 in the environment disables the
+ * accumulator emulation (closed-form positions only, a measurement aid). */
+int32_t so_resample_positions(double fs_in, double fs_out, double rate, int32_t nphi, const double* h,
+                              int32_t hlen, int64_t n_out, int64_t* j, int32_t* p, double* alpha,
+                              int64_t* nfix, int64_t* nbaked);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,21 +23,23 @@
  * vectors ("parity unpinned" for those values): they are pinned instead against
  * SciPy (sosfilt, upfirdn/firwin) and analytic sines in tests/test_oracle_dsp.py.
  *
+ * Resampler positions: the arbitrary-rate kernel (every ratio with max(num,den) > 3,
+ * src/reformatting.jl:103-111) follows DSP.jl's FIRArbitrary: the phase is ACCUMULATED in
+ * Float64, one addition of Delta per output (fir_block below).  That is the default.
+ *
  * Documented divergences from the reference:
- *   C-1  the arbitrary-rate resampler positions every output with the closed form
- *        q_m = c0 + m*Delta (two roundings, no contraction) instead of DSP.jl's
- *        sample-by-sample phase accumulator, and a block emits exactly the outputs
- *        whose newest input lies in it (DSP.outputlength can over-count by 1-2).
- *        SO_ORACLE_PHASE_ACCUMULATE=1 in the environment switches to the
- *        accumulator for divergence measurements.
- *        When both frame rates are integers (e.g. 44100 -> 48000) the rate is the exact
- *        rational L/M = fs_out/fs_in (reduced) and the positions are evaluated in exact
- *        integer arithmetic, q_m = c0 + m*Nphi*M/L, which is what DSP.jl's accumulator
- *        approximates; this fixes the tie cases (alpha == 0) that floating-point
- *        accumulation resolves by accumulated rounding error.
+ *   C-1  a block emits exactly the outputs whose newest input lies in it, i.e. what DSP.jl's
+ *        filt! writes (DSP.outputlength, which the reference uses for the block's length, can
+ *        over-count by 1-2 and would expose stale rows of the output buffer).
+ *        Measurement aid, NOT the default: SO_ORACLE_EXACT_POSITIONS=1 (or
+ *        so_oracle_set_positions(1)) positions every output with the closed form
+ *        q_m = c0 + m*Delta -- exact integer arithmetic q_m = c0 + m*Nphi*M/L when both frame
+ *        rates are integers (e.g. 44100 -> 48000).  The two differ at the wrap-around ties
+ *        (alpha == 0 at phase 0), which accumulated rounding error resolves to
+ *        (previous input, last phase, alpha ~ 1): DSP.jl then drops the tap h[0].
  *   C-2  NormedSignal honours its block offset (intended semantics).
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
+ * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off; `make native` = -march=native for timing).
  */
 #include <math.h>
 #include <setjmp.h>
@@ -127,7 +129,14 @@ struct OSig {
 };
 
 static int g_blocksize_override; /* 0 = use the node's */
-static int g_phase_accumulate;
+static int g_phase_accumulate = 1;
+static int g_position_mode = -1; /* -1: environment decides; 0: accumulator; 1: closed form */
+
+/* Resampler positions of the arbitrary-rate kernel.  0 (default) = DSP.jl's floating-point
+   phase accumulator, the reference's algorithm; 1 = closed form (exact rational positions for
+   integer frame rates), kept for divergence measurements; -1 = SO_ORACLE_EXACT_POSITIONS=1 in
+   the environment selects the closed form. */
+void so_oracle_set_positions(int mode) { g_position_mode = mode; }
 
 static double sinpi_(double x) {
     /* Julia sinpi: exact argument reduction, src/functions.jl:57-60 use it */
@@ -1128,8 +1137,11 @@ int32_t so_oracle_sink(const so_node_t* nodes, int32_t n_nodes, int32_t root,
         arena_free();
         return g_status;
     }
-    const char* pa = getenv("SO_ORACLE_PHASE_ACCUMULATE");
-    g_phase_accumulate = pa && pa[0] == '1';
+    if (g_position_mode >= 0) g_phase_accumulate = g_position_mode == 0;
+    else {
+        const char* pe = getenv("SO_ORACLE_EXACT_POSITIONS");
+        g_phase_accumulate = !(pe && pe[0] == '1');
+    }
     g_blocksize_override = blocksize_override;
     OSig* s = build(nodes, n_nodes, root);
     /* process_sink_params src/sink.jl:94-99 is the caller's check for sink();

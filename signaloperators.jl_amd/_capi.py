@@ -48,7 +48,8 @@ class so_stats_t(C.Structure):
 EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create",
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
-           "so_design_resample_rational", "so_design_resample_arbitrary"]
+           "so_design_resample_rational", "so_design_resample_arbitrary",
+           "so_resample_positions"]
 
 _lib = None
 
@@ -107,6 +108,10 @@ def lib():
     L.so_design_resample_arbitrary.restype = C.c_int32
     L.so_design_resample_arbitrary.argtypes = [C.c_double, C.c_int32, C.POINTER(C.c_double),
                                                C.c_int32, C.POINTER(C.c_int32)]
+    L.so_resample_positions.restype = C.c_int32
+    L.so_resample_positions.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double),
+                                        C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     if L.so_abi_version() != 1:
         raise EngineMissing("libsigops ABI version mismatch")
     _lib = L

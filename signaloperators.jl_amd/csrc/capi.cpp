@@ -125,4 +125,12 @@ int32_t so_design_resample_arbitrary(double rate, int32_t nphi, double* h, int32
     return copy_taps(t, h, capacity, hlen);
 }
 
+int32_t so_resample_positions(double fs_in, double fs_out, double rate, int32_t nphi, const double* h,
+                              int32_t hlen, int64_t n_out, int64_t* j, int32_t* p, double* alpha,
+                              int64_t* nfix, int64_t* nbaked) {
+    if (!h || hlen < 1 || nphi < 1 || !(rate > 0) || n_out < 0 || !j || !p || !alpha)
+        return set_err(SO_ERR_INVALID, "so_resample_positions: bad arguments");
+    return so::resample_positions(fs_in, fs_out, rate, nphi, h, hlen, n_out, j, p, alpha, nfix, nbaked);
+}
+
 }  // extern "C"

@@ -17,6 +17,7 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
                          const int* jend, const RsRows& g, int dtype, hipStream_t st);
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st);
+void launch_resample_fix(const RsFixArgs& a, hipStream_t st);
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
                 int nparts, double* rms, hipStream_t st);
 }  // namespace so

@@ -1926,6 +1926,78 @@ int launch_resample_periodic(void* y, const double* tab, const int* jend, const 
 }
 
 // ---------------------------------------------------------------------------
+// K3f: sparse fix-up of the outputs DSP.jl's floating-point phase accumulator positions
+// differently from the closed form (RsFix list built by the planner, see sigops_internal.h).
+// One wave per listed output: lane k owns tap ages k, k+64, ...; the per-frame values of a
+// fused source are evaluated once per tap and shared by all channels; the two inner products
+// (pfb and dpfb rows, DSP.jl FIRArbitrary: yLower + alpha*yUpper) are reduced across the wave.
+// Runs after the main resampler kernel on the same stream and overwrites y[m].
+__global__ __launch_bounds__(kBlock) void k_resample_fix(RsFixArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (e >= a.nfix) return;
+    const RsFix fx = a.fix[e];
+    const double* pf = a.pfb + (int64_t)fx.p * a.taps;
+    const double* df = a.dpfb + (int64_t)fx.p * a.taps;
+    const bool st32 = a.stage_dtype == SO_F32;
+    for (int c = 0; c < a.nch; ++c) {
+        double lo = 0.0, hi = 0.0;
+        for (int k = lane; k < a.taps; k += 64) {
+            const int64_t n = fx.j - k;
+            double xv = 0.0;
+            if (n >= 0 && n < a.n_in) {
+                if (a.ncar > 0) {
+                    int ck = 0;
+                    while (ck + 1 < a.ncar && a.car[ck].b <= n) ++ck;
+                    const DCarrier& C = a.car[ck];
+                    if (n >= C.a && n < C.b) {
+                        double F[kMaxFrameSlots][1];
+#pragma unroll
+                        for (int s = 0; s < kMaxFrameSlots; ++s) F[s][0] = 0.0;
+                        if (C.nsteps > 0 && C.frame_len > 0) {
+                            const int64_t nn[1] = {n};
+                            double fo[1];
+                            run_program<1, false, 2, true>(a.ops, C.frame_pc, C.frame_len, a.leaves, nn, c, F, fo);
+                        }
+                        double val[1][1] = {{0.0}};
+                        if (C.base != nullptr) {
+                            const int64_t off = (int64_t)c * C.cstride + n + C.df;
+                            val[0][0] = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
+                                                          : ((const double*)C.base)[off];
+                        }
+                        if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
+                        xv = st32 ? (double)(float)val[0][0] : val[0][0];
+                    }
+                } else {
+                    const int64_t off = (int64_t)c * a.in_pitch + n;
+                    xv = a.in_dtype == SO_F32 ? (double)((const float*)a.x)[off] : ((const double*)a.x)[off];
+                }
+            }
+            lo = fma(pf[k], xv, lo);
+            hi = fma(df[k], xv, hi);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo += __shfl_xor(lo, off, 64);
+            hi += __shfl_xor(hi, off, 64);
+        }
+        if (lane == 0) {
+            double r = lo + hi * fx.alpha;
+            if (st32) r = (double)(float)r;
+            const int64_t o = (int64_t)c * a.out_pitch + fx.m;
+            if (a.out_dtype == SO_F32) ((float*)a.y)[o] = (float)r;
+            else ((double*)a.y)[o] = r;
+        }
+    }
+}
+
+void launch_resample_fix(const RsFixArgs& a, hipStream_t st) {
+    if (a.nfix <= 0) return;
+    const int per = kBlock / 64;
+    hipLaunchKernelGGL(k_resample_fix, dim3((unsigned)((a.nfix + per - 1) / per)), dim3(kBlock), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------
 // K4: sum of squares over a planar [nch][pitch] buffer with n valid frames per
 // channel; deterministic two-stage tree (no atomics), fp64 accumulation.
 template <typename T>

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,9 @@ struct Stage {
     int tab_buf = -1, jend_buf = -1;
     std::vector<double> tab_host;
     std::vector<int> jend_host;
+    // outputs DSP.jl's phase accumulator positions differently (recomputed by k_resample_fix)
+    std::vector<RsFix> fix_host;
+    int fix_buf = -1;
     // norm
     int partial_buf = -1, rms_buf = -1;
     int nparts = 0;
@@ -1181,6 +1185,227 @@ static Mat matpow(Mat A, int64_t e, int D) {
     return R;
 }
 
+// ---------------------------------------------------------------------------
+// DSP.jl FIRArbitrary positions (reference call sites
+// src/reformatting.jl:92-98 `setphase!(self, timedelay(self))`, src/filters.jl:252-255 `filt!`):
+//     ϕAcc += Δ;  if ϕAcc > Nϕ:  xIdx += div(ϕAcc-1, Nϕ);  ϕAcc = mod(ϕAcc-1, Nϕ) + 1
+//     ϕIdx = floor(ϕAcc);  α = ϕAcc - ϕIdx
+// once per output, in Float64.  The sequence is data independent and does not depend on the
+// block size (xIdx is carried as inputDeficit), so it is replayed here once per plan and compared
+// with the kernels' closed-form rule.  At a tie (closed-form α == 0) accumulated rounding error
+// leaves the accumulator a hair below the integer: (previous phase, α ≈ 1).  The interpolated
+// taps h + α·dh are continuous there EXCEPT (a) across the wrap (ϕIdx = Nϕ, α ≈ 1, xIdx not
+// advanced: the tap h[0] of the next input is dropped) and (b) at the filter's last tap
+// (dh = [diff(h); 0] ends in 0, not -h[end]) -- differences of ~1e-3 of a sample.  For a rational
+// pattern (integer frame rates) both happen at the same place of (nearly) every period:
+// `prev[r]` marks those period positions so that the kernels' tap tables are built with the
+// accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
+// goes to the fix-up list (k_resample_fix).
+static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need,
+                                     std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
+    prev.clear();
+    fix.clear();
+    if (!g.arbitrary || need <= 0) return;
+    const int nphi = g.nphi, taps = g.taps;
+    const double dnphi = (double)nphi;
+    const bool pow2 = (nphi & (nphi - 1)) == 0;
+    const double inv = 1.0 / dnphi;
+    double hmax = 0.0;
+    for (int i = 0; i < hlen; ++i) hmax = std::max(hmax, std::fabs(h[i]));
+    auto tap = [&](int64_t q, double alpha, int64_t k) -> double {  // tap applied to input (q/nphi - k)
+        if (k < 0 || k >= taps) return 0.0;
+        const int64_t hi = q % nphi + (int64_t)nphi * k;
+        const double hv = hi < hlen ? h[hi] : 0.0;
+        const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+        return hv + alpha * dv;
+    };
+    // do the two positions give different taps (beyond the interpolation's own continuity)?
+    auto taps_differ = [&](int64_t qa, double aa, int64_t qe, double ae) {
+        const int64_t ja = qa / nphi, je = qe / nphi, dj = je - ja;
+        if (std::llabs(dj) > 1) return true;
+        double d = 0.0;
+        for (int64_t k = -1; k <= taps; ++k) d = std::max(d, std::fabs(tap(qa, aa, k) - tap(qe, ae, k + dj)));
+        return d > 4e-6 * hmax;  // (positions within 1e-6 of each other move a tap by < 1e-6*|dh|)
+    };
+    // setphase!(kernel, τ), τ = (hLen-1)/(2Nϕ)
+    const double tau = (double)(hlen - 1) / 2.0 / dnphi;
+    const double w = std::floor(tau), fr = tau - w;
+    int64_t xb = (int64_t)std::llround(w) * nphi;  // (xIdx-1)*Nϕ, xIdx = inputDeficit = 1 + w
+    double acc = fr * dnphi + 1.0;
+    const double delta = g.delta;
+    // closed-form rule of the kernels
+    const bool exact = g.exact != 0;
+    const int64_t L = g.L, dq = exact ? ((int64_t)nphi * g.M) / L : 0, dfr = exact ? ((int64_t)nphi * g.M) % L : 0;
+    int64_t qe = g.c0i, fe = 0;
+    struct Rec { int64_t m, qa; double alpha; };
+    std::vector<Rec> rec;
+    std::vector<int8_t> memo((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
+    for (int64_t m = 0; m < need; ++m) {
+        const int pi = (int)acc;  // floor: acc >= 1
+        const int64_t qa = xb + pi - 1;
+        double qe_frac = 0.0;
+        if (!exact) {
+            const double t = (double)m * delta;  // two separately rounded operations, like rs_pos
+            const double q = g.c0 + t;
+            const double fl = std::floor(q);
+            qe = (int64_t)fl;
+            qe_frac = q - fl;
+        }
+        if (qa != qe) {
+            const double alpha = acc - (double)pi;
+            const double ae = exact ? (double)fe / (double)L : qe_frac;
+            bool differ;
+            const bool tie = exact && fe == 0 && std::llabs(qa - qe) == 1 && (alpha < 1e-6 || alpha > 1.0 - 1e-6);
+            if (tie) {
+                int8_t& mm = memo[(size_t)(qe % nphi) * 4 + (qa > qe ? 2 : 0) + (alpha > 0.5 ? 1 : 0)];
+                if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
+                differ = mm != 0;
+            } else differ = taps_differ(qa, alpha, qe, ae);
+            if (differ) rec.push_back(Rec{m, qa, alpha});
+        }
+        if (exact) {
+            qe += dq;
+            fe += dfr;
+            if (fe >= L) {
+                fe -= L;
+                ++qe;
+            }
+        }
+        acc += delta;
+        if (acc > dnphi) {
+            // xIdx += div(ϕAcc-1, Nϕ); ϕAcc = mod(ϕAcc-1, Nϕ) + 1.  (ϕAcc-1 and the remainder are
+            // exact, the final +1 rounds: the same real number as ϕAcc - k·Nϕ rounded once)
+            const double a1 = acc - 1.0;
+            if (a1 < dnphi) {
+                // k == 0: unchanged
+            } else if (a1 < 2.0 * dnphi) {
+                xb += nphi;
+                acc -= dnphi;
+            } else if (pow2) {
+                const double k = std::floor(a1 * inv);
+                xb += (int64_t)k * nphi;
+                acc -= k * dnphi;
+            } else {
+                const double k = std::floor(a1 / dnphi);
+                xb += (int64_t)k * nphi;
+                acc = std::fmod(a1, dnphi) + 1.0;
+            }
+        }
+    }
+    auto exact_q = [&](int64_t m) {
+        const int64_t Nn = m * ((int64_t)nphi * g.M);
+        return g.c0i + Nn / L;
+    };
+    auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
+    if (exact && L <= 65536) {
+        // majority per period position among the deviations of the form (fine position - 1, α ≈ 1)
+        std::vector<int64_t> cnt(L, 0);
+        for (const Rec& r : rec)
+            if (baked(r)) cnt[r.m % L]++;
+        prev.assign(L, 0);
+        bool any = false;
+        for (int64_t r = 0; r < L; ++r) {
+            const int64_t occ = need > r ? (need - 1 - r) / L + 1 : 0;
+            if (occ > 0 && 2 * cnt[r] > occ) prev[r] = 1, any = true;
+        }
+        if (!any) prev.clear();
+    }
+    // fix-up list: deviations the tables do not already contain + outputs at baked positions
+    // where the accumulator agreed with the closed form after all
+    if (!prev.empty()) {
+        for (int64_t r = 0; r < L; ++r) {
+            if (!prev[r]) continue;
+            size_t k = 0;
+            for (int64_t m = r; m < need; m += L) {  // outputs at a baked position
+                while (k < rec.size() && rec[k].m < m) ++k;
+                if (k < rec.size() && rec[k].m == m) continue;  // deviates: baked, or listed below
+                const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
+                fix.push_back(RsFix{m, q / nphi, (int32_t)(q % nphi), 0, (double)(Nn % L) / (double)L});
+            }
+        }
+        for (const Rec& r : rec) {
+            if (prev[r.m % L] && baked(r)) continue;  // what the tables contain
+            fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
+        }
+    } else {
+        for (const Rec& r : rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
+    }
+    std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
+}
+
+// integer frame rates: the arbitrary-rate kernel's rate is the exact rational fs_out/fs_in
+static void rs_detect_exact(RsGeom& g, double fo, double fi, double rate) {
+    if (fo == std::floor(fo) && fi == std::floor(fi) && fo >= 1 && fi >= 1 && fo < 2147483648.0 &&
+        fi < 2147483648.0 && fo / fi == rate) {
+        int64_t a = (int64_t)fo, b = (int64_t)fi;
+        while (b) {
+            int64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        int64_t Lx = (int64_t)fo / a, Mx = (int64_t)fi / a;
+        if (Lx <= 8192 && Mx <= 1048576) {
+            g.exact = 1;
+            g.L = Lx;
+            g.M = Mx;
+        }
+    }
+}
+
+// Diagnostics (host only): the (newest input, phase, alpha) the arbitrary-rate resampler kernels
+// use for outputs [0,n_out) -- closed form, baked period positions and fix-up list combined.
+int resample_positions(double fs_in, double fs_out, double rate, int nphi, const double* h, int hlen,
+                       int64_t n_out, int64_t* jo, int32_t* po, double* ao, int64_t* nfix, int64_t* nbaked) {
+    RsGeom g{};
+    g.arbitrary = 1;
+    g.nphi = nphi;
+    g.delta = (double)nphi / rate;
+    g.c0 = (double)(hlen - 1) / 2.0;
+    g.c0i = (hlen - 1) / 2;
+    g.taps = (hlen + nphi - 1) / nphi;
+    rs_detect_exact(g, fs_out, fs_in, rate);
+    std::vector<uint8_t> prev;
+    std::vector<RsFix> fix;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!std::getenv("SIGOPS_RS_EXACT")) replay_phase_accumulator(g, h, hlen, n_out, prev, fix);
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] phase accumulator replay: %lld outputs, %.1f ms\n", (long long)n_out,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    for (int64_t m = 0; m < n_out; ++m) {
+        int64_t qi;
+        double alpha;
+        if (g.exact) {
+            const int64_t Nn = m * ((int64_t)nphi * g.M);
+            qi = g.c0i + Nn / g.L;
+            alpha = (double)(Nn % g.L) / (double)g.L;
+            if (!prev.empty() && prev[m % g.L]) {
+                qi -= 1;
+                alpha = 1.0;
+            }
+        } else {
+            const double t = (double)m * g.delta;
+            const double q = g.c0 + t;
+            const double fl = std::floor(q);
+            qi = (int64_t)fl;
+            alpha = q - fl;
+        }
+        jo[m] = qi / nphi;
+        po[m] = (int32_t)(qi % nphi);
+        ao[m] = alpha;
+    }
+    for (const RsFix& f : fix) {
+        jo[f.m] = f.j;
+        po[f.m] = f.p;
+        ao[f.m] = f.alpha;
+    }
+    if (nfix) *nfix = (int64_t)fix.size();
+    if (nbaked) {
+        *nbaked = 0;
+        for (uint8_t b : prev) *nbaked += b;
+    }
+    return SO_OK;
+}
+
 void Plan::process_stage(int sid) {
     // NOTE: `stages` may grow while lowering the child; re-take references after.
     int ni = stages[sid].node;
@@ -1209,25 +1434,7 @@ void Plan::process_stage(int sid) {
         g.nch = N.nch;
         g.m0 = 0;
         g.n_out = need;
-        if (g.arbitrary) {
-            // integer frame rates: the rate is the exact rational fs_out/fs_in
-            double fo = nd.fs, fi = C.fs;
-            if (fo == std::floor(fo) && fi == std::floor(fi) && fo >= 1 && fi >= 1 &&
-                fo < 2147483648.0 && fi < 2147483648.0 && fo / fi == nd.d0) {
-                int64_t a = (int64_t)fo, b = (int64_t)fi;
-                while (b) {
-                    int64_t t = a % b;
-                    a = b;
-                    b = t;
-                }
-                int64_t Lx = (int64_t)fo / a, Mx = (int64_t)fi / a;
-                if (Lx <= 8192 && Mx <= 1048576) {
-                    g.exact = 1;
-                    g.L = Lx;
-                    g.M = Mx;
-                }
-            }
-        }
+        if (g.arbitrary) rs_detect_exact(g, nd.fs, C.fs, nd.d0);
         // newest input of the last needed output
         int64_t jl;
         if (g.arbitrary && g.exact) {
@@ -1255,6 +1462,15 @@ void Plan::process_stage(int sid) {
         stages[sid].dpfb_buf = raw_buf(stages[sid].dpfb_host.size() * 8);
         g.in_dtype = g.out_dtype = N.dtype;
         stages[sid].rg = g;
+        // reference positions: DSP.jl's phase accumulator (SIGOPS_RS_EXACT=1 keeps the closed form)
+        std::vector<uint8_t> wrap;
+        if (g.arbitrary && !std::getenv("SIGOPS_RS_EXACT")) {
+            replay_phase_accumulator(g, (const double*)nd.p0, hlen, need, wrap, stages[sid].fix_host);
+            if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
+        }
+        // position of period output r as the tap tables see it: the closed form, or the
+        // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
+        auto wrap_at = [&](int64_t r) { return !wrap.empty() && wrap[r % g.L]; };
         // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
         if ((!g.arbitrary || g.exact) && need >= 2048) {
             constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
@@ -1288,6 +1504,10 @@ void Plan::process_stage(int sid) {
                 } else {
                     qi = g.c0i + r * Mb;
                     alpha = 0.0;
+                }
+                if (wrap_at(r)) {
+                    qi -= 1;
+                    alpha = 1.0;
                 }
                 j = qi / g.nphi;
                 p = (int)(qi % g.nphi);
@@ -1401,6 +1621,10 @@ void Plan::process_stage(int sid) {
                     qi = g.c0i + Nn / Lb;
                     alpha = (double)(Nn % Lb) / (double)Lb;
                 } else qi = g.c0i + r * Mb;
+                if (wrap_at(r)) {
+                    qi -= 1;
+                    alpha = 1.0;
+                }
                 const int64_t j = qi / g.nphi;
                 const int p = (int)(qi % g.nphi);
                 jr[r] = (int)j;
@@ -2031,6 +2255,8 @@ void Plan::finalize() {
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.fix_buf >= 0)
+                HIPCHECK(hipMemcpy(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix), hipMemcpyHostToDevice));
             if (S.periodic || S.rows) {
                 HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
                 HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
@@ -2417,6 +2643,33 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);
                     s.launches = 1;
                     launches++;
+                    if (S.fix_buf >= 0) {  // the outputs DSP.jl's phase accumulator places differently
+                        RsFixArgs fa{};
+                        fa.fix = (const RsFix*)P->bufs[S.fix_buf].d;
+                        fa.nfix = (int64_t)S.fix_host.size();
+                        fa.pfb = (const double*)P->bufs[S.pfb_buf].d;
+                        fa.dpfb = (const double*)P->bufs[S.dpfb_buf].d;
+                        fa.n_in = g.n_in;
+                        fa.taps = g.taps;
+                        fa.nch = N.nch;
+                        fa.stage_dtype = N.dtype;
+                        fa.out_dtype = (s.idx == P->alias_stage && P->alias_narrow) ? SO_F32 : N.dtype;
+                        if (S.periodic) {
+                            fa.car = (const DCarrier*)P->bufs[S.car_buf].d;
+                            fa.ncar = (int)S.carriers.size();
+                            fa.ops = P->d_ops;
+                            fa.leaves = P->d_leaves;
+                        } else {
+                            fa.x = inp;
+                            fa.in_pitch = in_pitch;
+                            fa.in_dtype = N.dtype;
+                        }
+                        fa.y = ob.d;
+                        fa.out_pitch = ob.pitch;
+                        launch_resample_fix(fa, st);
+                        s.launches++;
+                        launches++;
+                    }
                 } else {
                     launch_rms(ob.d, N.dtype, S.need, N.nch, ob.pitch, (double*)P->bufs[S.partial_buf].d,
                                S.nparts, (double*)P->bufs[S.rms_buf].d, st);

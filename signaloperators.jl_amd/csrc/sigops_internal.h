@@ -157,6 +157,41 @@ struct RsGeom {
     int64_t in_pitch, out_pitch;
 };
 
+// DSP.jl's FIRArbitrary positions its outputs with a floating-point phase accumulator
+// (ϕAccumulator += Δ once per output; reference call site
+// src/reformatting.jl:92-98 + src/filters.jl:248-255).  The kernels position outputs in closed
+// form; the planner replays the accumulator on the host (it is data independent) and lists the
+// outputs whose (newest input, phase) it resolves differently in a way that matters -- the
+// wrap-around ties, where the accumulator sits a rounding error below Nϕ+1 and the first tap
+// h[0] is dropped.  k_resample_fix recomputes exactly those outputs with the accumulator's
+// (j, p, alpha) after the main kernel.
+struct RsFix {
+    int64_t m;      // output frame
+    int64_t j;      // newest input (0-based)
+    int32_t p;      // phase (0-based)
+    int32_t pad;
+    double alpha;
+};
+struct RsFixArgs {
+    const RsFix* fix;
+    int64_t nfix;
+    const double* pfb;   // [nphi][taps]
+    const double* dpfb;
+    int64_t n_in;
+    int32_t taps, nch;
+    int32_t stage_dtype;  // sample type of the resampler stage (inputs are rounded to it)
+    int32_t out_dtype;    // element type of y (Float32 result of a Float64 stage: rounded on store)
+    // source: carriers (ncar > 0) or a plain planar array
+    const DCarrier* car;
+    const DOp* ops;
+    const DLeaf* leaves;
+    int32_t ncar, in_dtype;
+    const void* x;
+    int64_t in_pitch;
+    void* y;
+    int64_t out_pitch;
+};
+
 // Periodic variant: for a rational rate L/M the (phase, alpha) pattern repeats every
 // L outputs / M inputs: the tap pattern of a group of 16 consecutive outputs is the same
 // for every (period, channel) row, so a tile of 32 rows x 16 outputs is one small matrix

@@ -25,8 +25,25 @@ def oracle_lib():
         L.so_oracle_nframes.restype = C.c_int64
         L.so_oracle_nframes.argtypes = [C.POINTER(K.so_node_t), C.c_int32, C.c_int32]
         L.so_oracle_last_error.restype = C.c_char_p
+        L.so_oracle_set_positions.restype = None
+        L.so_oracle_set_positions.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+class oracle_positions:
+    """with oracle_positions("exact"): ... -- resampler positions of the oracle's arbitrary-rate
+    kernel: "accumulate" (default, DSP.jl's Float64 phase accumulator = the reference's algorithm)
+    or "exact" (closed form; measurement aid, see oracle/sigops_oracle.c header)."""
+
+    def __init__(self, mode):
+        self.mode = {"accumulate": 0, "exact": 1}[mode]
+
+    def __enter__(self):
+        oracle_lib().so_oracle_set_positions(self.mode)
+
+    def __exit__(self, *exc):
+        oracle_lib().so_oracle_set_positions(-1)
 
 
 def oracle_sink_lowered(lw, nframes, nch, dtype, blocksize=0):

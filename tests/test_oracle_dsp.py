@@ -13,7 +13,7 @@ from scipy import signal
 import sigops_amd as so
 from sigops_amd import Signal, Filt, ToFramerate, Lowpass, Bandstop, Highpass, Chebyshev1, Hz, kHz, FilterFn
 from cases import F, rng
-from oracle_bridge import oracle_sink, relerr
+from oracle_bridge import oracle_sink, oracle_positions, relerr
 
 
 @pytest.mark.parametrize("spec", [
@@ -73,13 +73,53 @@ def _arbitrary_closed_form(x, h, nphi, L, M, n_out):
     return y
 
 
-def test_arbitrary_resampler_matches_closed_form():
+def test_arbitrary_resampler_exact_mode_matches_closed_form():
+    """the oracle's opt-in closed-form mode against the vectorised Appendix-A formula"""
     x = rng(3).standard_normal(20000)
-    got = oracle_sink(ToFramerate(Signal(F(x[:, None]), 44.1 * kHz), 48 * kHz))[:, 0]
+    with oracle_positions("exact"):
+        got = oracle_sink(ToFramerate(Signal(F(x[:, None]), 44.1 * kHz), 48 * kHz))[:, 0]
     h = so.design_resample(48000 / 44100)
     want = _arbitrary_closed_form(x, h, 32, 160, 147, got.shape[0])
     assert got.shape[0] == int(np.ceil(20000 * 48000 / 44100))
     assert relerr(got, want) < 1e-12
+
+
+def _fir_arbitrary_reference(x, h, nphi, rate, n_out):
+    """DSP.jl 0.6 FIRArbitrary restated independently of the oracle's C:
+    setphase!(timedelay), then per output  y = dot(pfb[:,ϕIdx], window) + α·dot(dpfb[:,ϕIdx], window)
+    and update(): ϕAcc += Δ; wrap with div/mod; ϕIdx = floor(ϕAcc); α = ϕAcc - ϕIdx."""
+    hlen = len(h)
+    taps = -(-hlen // nphi)
+    hp = np.concatenate([h, np.zeros(nphi * taps + 1 - hlen)])
+    dh = np.concatenate([np.diff(h), [0.0], np.zeros(nphi * taps + 1 - hlen)])
+    xp = np.concatenate([np.zeros(taps), x, np.zeros(taps + 2)])
+    delta = nphi / rate
+    tau = (hlen - 1) / 2 / nphi
+    frac, whole = np.modf(tau)
+    x_idx = 1 + int(round(whole))  # inputDeficit = 1 + throwaway
+    acc = frac * nphi + 1.0
+    y = np.empty(n_out)
+    k = np.arange(taps)
+    for m in range(n_out):
+        phi = int(np.floor(acc))
+        alpha = acc - phi
+        win = xp[x_idx - 1 - k + taps]
+        y[m] = np.dot(hp[phi - 1 + nphi * k], win) + alpha * np.dot(dh[phi - 1 + nphi * k], win)
+        acc += delta
+        if acc > nphi:
+            x_idx += int(np.floor(acc - 1)) // nphi
+            acc = np.mod(acc - 1, nphi) + 1
+    return y
+
+
+def test_arbitrary_resampler_default_is_the_phase_accumulator():
+    """The oracle's DEFAULT is the reference's algorithm (DSP.jl FIRArbitrary: Float64 phase
+    accumulator), checked against an independent restatement."""
+    x = rng(3).standard_normal(6000)
+    got = oracle_sink(ToFramerate(Signal(F(x[:, None]), 44.1 * kHz), 48 * kHz))[:, 0]
+    h = so.design_resample(48000 / 44100)
+    want = _fir_arbitrary_reference(x, h, 32, 48000 / 44100, got.shape[0])
+    assert relerr(got, want) < 1e-13
 
 
 @pytest.mark.parametrize("fs_out", [48000.0, 16000.0])
@@ -96,26 +136,29 @@ def test_resampled_sine_is_the_analytic_sine(fs_out):
     assert np.max(np.abs(y[interior] - want[interior])) < 1e-3
 
 
-def test_phase_accumulator_divergence_is_documented():
-    """DSP.jl accumulates the phase in floating point; the oracle uses exact positions
-    (SURVEY.md Appendix C-1).  Measure the divergence on a tie-heavy rate."""
-    code = ("import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.');"
-            "import numpy as np, sigops_amd as so; from oracle_bridge import oracle_sink;"
-            "x=np.asfortranarray(np.random.default_rng(4).standard_normal((8000,1)));"
-            "y=oracle_sink(so.ToFramerate(so.Signal(x,44.1*so.kHz),48*so.kHz));"
-            "np.save(sys.argv[1], y)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("0", "1"):
-        path = os.path.join(root, "tests", f"_acc_{flag}.npy")
-        env = dict(os.environ, SO_ORACLE_PHASE_ACCUMULATE=flag)
-        subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
-        outs.append(np.load(path))
-        os.remove(path)
-    err = relerr(outs[1], outs[0])
-    # tie cases flip between neighbouring phases: small but far above 1e-6 is possible
-    assert outs[0].shape == outs[1].shape
-    assert err < 1e-3
+def test_phase_accumulator_divergence_is_one_edge_tap():
+    """Closed-form positions vs DSP.jl's accumulator on 44.1 -> 48 kHz.
+    At a tie (closed-form alpha == 0) the accumulator sits a rounding error below: (previous
+    phase, alpha ~ 1).  The interpolated taps h + alpha*dh agree there except at the two ends of
+    the filter: output 80 of every 160-output period is the wrap-around tie (phase 32, xIdx not
+    advanced: the tap h[0] of the next input is dropped), output 55 the last-tap tie
+    (dh = [diff(h); 0] ends in 0, so h[end] survives where the closed form has moved past it).
+    Everywhere else the two modes agree to rounding."""
+    x = rng(4).standard_normal(8000)
+    tree = ToFramerate(Signal(F(x[:, None]), 44.1 * kHz), 48 * kHz)
+    acc = oracle_sink(tree)[:, 0]
+    with oracle_positions("exact"):
+        exact = oracle_sink(tree)[:, 0]
+    assert 1e-5 < relerr(acc, exact) < 1e-4
+    m = np.arange(acc.shape[0])
+    wrap, last = m % 160 == 80, m % 160 == 55
+    assert np.abs(acc - exact)[~(wrap | last)].max() < 1e-11
+    h = so.design_resample(48000 / 44100)
+    xp = np.concatenate([x, np.zeros(64)])
+    # closed-form newest input j = (592 + 29.4 m) div 32 (0-based)
+    j = (592 + (m * 32 * 147) // 160) // 32
+    np.testing.assert_allclose((exact - acc)[wrap], h[0] * xp[j[wrap]], atol=1e-11)
+    np.testing.assert_allclose((acc - exact)[last], h[-1] * xp[j[last] - 37], atol=1e-11)
 
 
 def test_reference_quirk_append_never_leaves_a_long_filtered_child():
