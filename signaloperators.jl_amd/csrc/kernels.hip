@@ -660,6 +660,220 @@ int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow
 }
 
 // ---------------------------------------------------------------------------
+// K2 single pass: one read and one write of the signal (the three-pass form above reads it twice).
+//
+// A workgroup takes the next tile in TIME ORDER (atomic ticket), stages ncht channels x tf frames
+// in LDS and gives lane (c,k) the sub-chunk k (kSosLc frames) of channel c:
+//   1. zero-state DF2T over the lane's sub-chunk                    -> v_k  (state at its end)
+//   2. inclusive scan over k with powers of M = A^lc (Kogge-Stone, lane shuffles)
+//                                                    P_k = sum_{i<=k} M^(k-i) v_i ; V = P_last
+//   3. V (the tile's zero-state end state, a function of the tile's own samples only) is
+//      published with a flag; the state entering the tile is
+//          sigma = sum_{j>=0} (A^tf)^j V_(t-1-j),  truncated after kt terms (||(A^tf)^kt|| < 2^-70)
+//      -- a look-back over kt earlier tiles that are all in flight or done (lower tickets), and
+//      whose V never waits for anything: no serial chain through the tiles.
+//   4. s0_k = P_(k-1) + M^k sigma (M^k by binary expansion of k), DF2T from s0_k in place, and
+//      the tile is stored.
+// State matrices are lower block-triangular (cascade), so only those entries are multiplied.
+// The arithmetic that produces the outputs is the same DF2T recurrence as DSP.jl's filt! from a
+// start state that differs from the sequential one by rounding (~1e-16 relative).
+template <int D>
+__device__ __forceinline__ void matvec_tri(const double* __restrict__ m, const double (&v)[D], double (&out)[D]) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c <= (r | 1); ++c) a = fma(m[r * D + c], v[c], a);
+        out[r] = a;
+    }
+}
+
+template <int NS, typename T>
+__global__ __launch_bounds__(kBlock) void k_sos_onepass(const T* __restrict__ x, T* __restrict__ y, SosOne g,
+                                                        SosCoefs cf, const double* __restrict__ tabs,
+                                                        int* __restrict__ sync, double* __restrict__ vpub) {
+    constexpr int D = 2 * NS;
+    constexpr int LC = kSosLc, LP = kSosLc + 1;  // odd pitch: the lanes' rows fall on different banks
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    extern __shared__ double lds_raw[];
+    double* const tile = lds_raw;                              // [ncht][nsub][LP]
+    double* const ksm = lds_raw + (size_t)g.ncht * g.nsub * LP;  // [nlev][D*D]
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) s_ticket = atomicAdd(&sync[0], 1);
+    for (int i = tid; i < g.nlev * D * D; i += nthr) ksm[i] = tabs[i];
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int tt = ticket / g.ncg, cg = ticket - tt * g.ncg;  // time-major: (t-1, cg) has a lower ticket
+    const int64_t f0 = (int64_t)tt * g.tf;
+    const int c0 = cg * g.ncht;
+    // ---- stage the tile (16-byte loads, eight in flight per lane) ----
+    const int vrow = g.tf / V;  // vectors per channel row
+    const int nvec = g.ncht * vrow;
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < nvec; i0 += U * nthr) {
+        vecT v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr;
+            const int c = i / vrow, f = (i - c * vrow) * V;
+            const int64_t gf = f0 + f;
+            const int cc = c0 + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[u][e] = (T)0;
+            if (i < nvec && cc < g.nch && gf < g.n) {
+                const T* src = x + (int64_t)cc * g.in_pitch + gf;
+                if (g.vec_in && gf + V <= g.n) v[u] = *reinterpret_cast<const vecT*>(src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (gf + e < g.n) v[u][e] = src[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr;
+            if (i < nvec) {
+                const int c = i / vrow, f = (i - c * vrow) * V;
+                double* dst = tile + ((size_t)c * g.nsub + f / LC) * LP + (f % LC);
+#pragma unroll
+                for (int e = 0; e < V; ++e) dst[e] = (double)v[u][e];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 1: zero-state pass over the lane's sub-chunk ----
+    const int c = tid / g.nsub, k = tid - c * g.nsub;
+    double* const row = tile + (size_t)tid * LP;  // (c*nsub + k)
+    double s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = 0.0;
+#pragma unroll 8
+    for (int n = 0; n < LC; ++n) (void)sos_step<NS>(row[n], s, cf);
+    // ---- 2: inclusive scan over k ----
+    for (int lev = 0; lev < g.nlev; ++lev) {
+        const int d = 1 << lev;
+        double p[D], q[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) p[i] = __shfl_up(s[i], d, g.nsub);
+        matvec_tri<D>(ksm + lev * D * D, p, q);
+        if (k >= d) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) s[i] += q[i];
+        }
+    }
+    // ---- 3: publish V, look back ----
+    const int64_t vt = ((int64_t)cg * g.ntiles + tt) * g.ncht;
+    if (k == g.nsub - 1) {
+        double* vp = vpub + (vt + c) * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) __hip_atomic_store(vp + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&sync[1 + cg * g.ntiles + tt], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    double e0[D];  // P_(k-1)
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double up = __shfl_up(s[i], 1, g.nsub);
+        e0[i] = k > 0 ? up : 0.0;
+    }
+    const int nb = tt < g.kt ? tt : g.kt;  // earlier tiles that still matter
+    if (nb > 0) {  // (wave-uniform)
+        double w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = 0.0;
+        if (k < nb) {
+            const int tp = tt - 1 - k;
+            const int* fp = sync + 1 + cg * g.ntiles + tp;
+            while (__hip_atomic_load(fp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+            const double* vp = vpub + (((int64_t)cg * g.ntiles + tp) * g.ncht + c) * D;
+            double vv[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) vv[i] = __hip_atomic_load(vp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            matvec_tri<D>(tabs + (size_t)(g.nlev + k) * D * D, vv, w);  // (A^tf)^k V_(t-1-k)
+        }
+        for (int off = g.nsub >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) w[i] += __shfl_xor(w[i], off, g.nsub);
+        }
+        // M^k sigma by the binary expansion of k
+        for (int lev = 0; lev < g.nlev; ++lev) {
+            double q[D];
+            matvec_tri<D>(ksm + lev * D * D, w, q);
+            if ((k >> lev) & 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) w[i] = q[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) e0[i] += w[i];
+    }
+    // ---- 4: the outputs, in place ----
+#pragma unroll 8
+    for (int n = 0; n < LC; ++n) row[n] = sos_step<NS>(row[n], e0, cf) * cf.gain;
+    __syncthreads();
+    for (int i0 = tid; i0 < nvec; i0 += U * nthr) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr;
+            if (i >= nvec) break;
+            const int cr = i / vrow, f = (i - cr * vrow) * V;
+            const int64_t gf = f0 + f;
+            const int cc = c0 + cr;
+            if (cc >= g.nch || gf >= g.n) continue;
+            const double* src = tile + ((size_t)cr * g.nsub + f / LC) * LP + (f % LC);
+            T* dst = y + (int64_t)cc * g.out_pitch + gf;
+            if (g.vec_out && gf + V <= g.n) {
+                vecT o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = (T)src[e];
+                *reinterpret_cast<vecT*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (gf + e < g.n) dst[e] = (T)src[e];
+            }
+        }
+    }
+}
+
+template <int NS, typename T>
+static void launch_sos_one_t(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
+                             int* sync, double* vpub, hipStream_t st) {
+    const size_t ldsb = ((size_t)g.ncht * g.nsub * (kSosLc + 1) + (size_t)g.nlev * 4 * NS * NS) * 8;
+    static bool seen[64];
+    if (first_use_on_device(seen))
+        (void)hipFuncSetAttribute((const void*)k_sos_onepass<NS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipLaunchKernelGGL((k_sos_onepass<NS, T>), dim3((unsigned)(g.ntiles * g.ncg)), dim3((unsigned)(g.ncht * g.nsub)), ldsb, st,
+                       (const T*)x, (T*)y, g, cf, tabs, sync, vpub);
+}
+
+template <typename T>
+static void launch_sos_one_ns(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
+                              int* sync, double* vpub, hipStream_t st) {
+    switch (cf.nsec) {
+    case 1: launch_sos_one_t<1, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 2: launch_sos_one_t<2, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 3: launch_sos_one_t<3, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 4: launch_sos_one_t<4, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 5: launch_sos_one_t<5, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 6: launch_sos_one_t<6, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    case 7: launch_sos_one_t<7, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    default: launch_sos_one_t<8, T>(x, y, g, cf, tabs, sync, vpub, st); break;
+    }
+}
+
+void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
+                        int* sync, double* vpub, int dtype, hipStream_t st) {
+    if (g.n <= 0) return;
+    if (dtype == SO_F32) launch_sos_one_ns<float>(x, y, g, cf, tabs, sync, vpub, st);
+    else launch_sos_one_ns<double>(x, y, g, cf, tabs, sync, vpub, st);
+}
+
+// ---------------------------------------------------------------------------
 // K3: polyphase resampler.  Output m sits at fine-grid position q_m (SURVEY.md
 // Appendix A): j = newest input, p = phase, alpha = fractional phase;
 //   y[m] = sum_k pfb[p][k] x[j-k]  +  alpha * sum_k dpfb[p][k] x[j-k]

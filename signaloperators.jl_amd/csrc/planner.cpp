@@ -1201,7 +1201,7 @@ static Mat matpow(Mat A, int64_t e, int D) {
 // `prev[r]` marks those period positions so that the kernels' tap tables are built with the
 // accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
 // goes to the fix-up list (k_resample_fix).
-static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need,
+static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
                                      std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
     prev.clear();
     fix.clear();
@@ -1297,7 +1297,7 @@ static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen,
         return g.c0i + Nn / L;
     };
     auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
-    if (exact && L <= 65536) {
+    if (bake && exact && L <= 65536) {
         // majority per period position among the deviations of the form (fine position - 1, α ≈ 1)
         std::vector<int64_t> cnt(L, 0);
         for (const Rec& r : rec)
@@ -1367,7 +1367,7 @@ int resample_positions(double fs_in, double fs_out, double rate, int nphi, const
     std::vector<uint8_t> prev;
     std::vector<RsFix> fix;
     const auto t0 = std::chrono::steady_clock::now();
-    if (!std::getenv("SIGOPS_RS_EXACT")) replay_phase_accumulator(g, h, hlen, n_out, prev, fix);
+    if (!std::getenv("SIGOPS_RS_EXACT")) replay_phase_accumulator(g, h, hlen, n_out, g.exact && n_out >= 2048, prev, fix);
     if (std::getenv("SIGOPS_DEBUG_PLAN"))
         std::fprintf(stderr, "[sigops] phase accumulator replay: %lld outputs, %.1f ms\n", (long long)n_out,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -1465,8 +1465,9 @@ void Plan::process_stage(int sid) {
         // reference positions: DSP.jl's phase accumulator (SIGOPS_RS_EXACT=1 keeps the closed form)
         std::vector<uint8_t> wrap;
         if (g.arbitrary && !std::getenv("SIGOPS_RS_EXACT")) {
-            replay_phase_accumulator(g, (const double*)nd.p0, hlen, need, wrap, stages[sid].fix_host);
-            if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
+            // (period positions can only be baked into the tap tables of the periodic / row-tiled
+            //  kernels: short outputs go to the thread-per-output kernel and list every deviation)
+            replay_phase_accumulator(g, (const double*)nd.p0, hlen, need, g.exact && need >= 2048, wrap, stages[sid].fix_host);
         }
         // position of period output r as the tap tables see it: the closed form, or the
         // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
@@ -1736,6 +1737,9 @@ void Plan::process_stage(int sid) {
                 stages[sid].jend_buf = raw_buf(jr.size() * 4);
             }
         }
+        if (!wrap.empty() && !stages[sid].periodic && !stages[sid].rows)  // no tap table took the baked positions
+            replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, need, false, wrap, stages[sid].fix_host);
+        if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
     } else if (stages[sid].kind == ST_SOS) {
         if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
         int nsec = nd.i0;

@@ -140,6 +140,27 @@ struct SosGeom {
     int64_t in_pitch, out_pitch;  // elements between channels
 };
 
+// Single-pass variant (k_sos_onepass): one read and one write of the signal.  A workgroup owns a
+// tile of ncht channels x tf frames in LDS; lane (c,k) owns sub-chunk k (lc frames) of channel c.
+//   tabs = [nlev][D*D] powers M^(2^s) of M = A^lc (intra-tile scan) followed by
+//          [kt][D*D]   powers (A^tf)^j, j = 0..kt-1 (look-back over the kt previous tiles)
+//   sync = [0] ticket counter, [1 + cg*ntiles + t] "V published" flag of tile t of channel group cg
+//   vpub = [ncg][ntiles][ncht][D] zero-state end states of the tiles
+constexpr int kSosLc = 32;  // frames per lane
+struct SosOne {
+    int64_t n;       // frames to produce
+    int64_t in_pitch, out_pitch;
+    int32_t nch;
+    int32_t ncht;    // channels per tile (1, 2, 4 or 8)
+    int32_t nsub;    // sub-chunks per channel and tile (32 or 64) = lanes per channel
+    int32_t tf;      // frames per tile = nsub * kSosLc
+    int32_t ntiles;  // tiles along time
+    int32_t ncg;     // channel groups = ceil(nch / ncht)
+    int32_t nlev;    // log2(nsub)
+    int32_t kt;      // look-back terms (<= nsub)
+    int32_t vec_in, vec_out;  // 16-byte vector loads / stores are legal
+};
+
 // ---------------------------------------------------------------------------
 // Polyphase FIR resampler (DSP.jl FIRRational/FIRInterpolator/FIRDecimator/
 // FIRArbitrary kernels; call site reference
