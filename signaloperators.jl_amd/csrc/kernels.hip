@@ -11,6 +11,8 @@
 //   k_sumsq_*     K4  Normpower reduction (reference src/filters.jl:296-309)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 
 #include "../../include/sigops.h"
@@ -662,21 +664,28 @@ int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow
 // ---------------------------------------------------------------------------
 // K2 single pass: one read and one write of the signal (the three-pass form above reads it twice).
 //
-// A workgroup takes the next tile in TIME ORDER (atomic ticket), stages ncht channels x tf frames
-// in LDS and gives lane (c,k) the sub-chunk k (kSosLc frames) of channel c:
+// Every WAVE works on its own: it takes the next tile in TIME ORDER (atomic ticket; a tile is
+// 2048 frames of one channel), loads it with coalesced 16-byte accesses and transposes it
+// through a small LDS buffer so that lane k holds sub-chunk k (kSosLc consecutive frames) in
+// REGISTERS:
 //   1. zero-state DF2T over the lane's sub-chunk                    -> v_k  (state at its end)
-//   2. inclusive scan over k with powers of M = A^lc (Kogge-Stone, lane shuffles)
-//                                                    P_k = sum_{i<=k} M^(k-i) v_i ; V = P_last
+//   2. inclusive scan over the 64 lanes with powers of M = A^lc (Kogge-Stone, ds_bpermute):
+//                                                    P_k = sum_{i<=k} M^(k-i) v_i ; V = P_63
 //   3. V (the tile's zero-state end state, a function of the tile's own samples only) is
-//      published with a flag; the state entering the tile is
+//      published; the state entering the tile is
 //          sigma = sum_{j>=0} (A^tf)^j V_(t-1-j),  truncated after kt terms (||(A^tf)^kt|| < 2^-70)
-//      -- a look-back over kt earlier tiles that are all in flight or done (lower tickets), and
-//      whose V never waits for anything: no serial chain through the tiles.
-//   4. s0_k = P_(k-1) + M^k sigma (M^k by binary expansion of k), DF2T from s0_k in place, and
-//      the tile is stored.
-// State matrices are lower block-triangular (cascade), so only those entries are multiplied.
-// The arithmetic that produces the outputs is the same DF2T recurrence as DSP.jl's filt! from a
-// start state that differs from the sequential one by rounding (~1e-16 relative).
+//      -- a look-back over kt earlier tiles of the same channel that are all in flight or done
+//      (lower tickets) and whose V never waits for anything: no serial chain through the tiles.
+//      V slots are pre-set to an all-ones bit pattern (a NaN no arithmetic produces) and written
+//      with agent-scope atomic stores, so "is it there yet" and the value are ONE memory round
+//      trip, with no flag, no fence and no cache-wide writeback/invalidate.
+//   4. s0_k = P_(k-1) + M^k sigma (M^k by the binary expansion of k), DF2T from s0_k on the
+//      registers, transpose back, coalesced store.
+// No workgroup barrier after the matrices are staged: loads, arithmetic, look-back latency and
+// stores of the ~12 waves of a CU overlap on their own.  State matrices are lower
+// block-triangular (cascade), so only those entries are multiplied.  The arithmetic that
+// produces the outputs is the same DF2T recurrence as DSP.jl's filt! from a start state that
+// differs from the sequential one by rounding (~1e-16 relative).
 template <int D>
 __device__ __forceinline__ void matvec_tri(const double* __restrict__ m, const double (&v)[D], double (&out)[D]) {
 #pragma unroll
@@ -687,167 +696,238 @@ __device__ __forceinline__ void matvec_tri(const double* __restrict__ m, const d
         out[r] = a;
     }
 }
+__device__ __forceinline__ double bperm_f64(int byte_addr, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(byte_addr, lo);
+    hi = __builtin_amdgcn_ds_bpermute(byte_addr, hi);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kSosTf = 64 * kSosLc;            // frames per wave tile
+constexpr unsigned long long kSosEmpty = ~0ull;  // "not published yet"
 
 template <int NS, typename T>
-__global__ __launch_bounds__(kBlock) void k_sos_onepass(const T* __restrict__ x, T* __restrict__ y, SosOne g,
+__global__ __launch_bounds__(kBlock, 2) void k_sos_onepass(const T* __restrict__ x, T* __restrict__ y, SosOne g,
                                                         SosCoefs cf, const double* __restrict__ tabs,
                                                         int* __restrict__ sync, double* __restrict__ vpub) {
     constexpr int D = 2 * NS;
-    constexpr int LC = kSosLc, LP = kSosLc + 1;  // odd pitch: the lanes' rows fall on different banks
-    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int LC = kSosLc, LP = kSosLc + 1;  // odd pitch: the 16 rows of a round fall on different banks
+    constexpr int V = 16 / (int)sizeof(T);       // elements per 16-byte vector
+    constexpr int RV = 512 / V / 64;             // vectors per lane and round (a round = 512 frames = 16 rows)
     typedef T vecT __attribute__((ext_vector_type(V)));
     extern __shared__ double lds_raw[];
-    double* const tile = lds_raw;                              // [ncht][nsub][LP]
-    double* const ksm = lds_raw + (size_t)g.ncht * g.nsub * LP;  // [nlev][D*D]
+    double* const ksm = lds_raw;  // [nlev][D*D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T* const buf = reinterpret_cast<T*>(lds_raw + g.nlev * D * D) + wave * (16 * LP);  // this wave's transposer
+    for (int i = tid; i < g.nlev * D * D; i += blockDim.x) ksm[i] = tabs[i];
+    __syncthreads();  // (the only workgroup barrier)
+    // One ticket per workgroup and up to kSosBatch tiles per wave: same-address atomics run at
+    // ~10-30 ns each on this chip, so a ticket per tile would by itself cost more than the whole
+    // kernel (measured: 112 500 tickets = 1.36 ms with all arithmetic removed).  A wave's tiles are
+    // the SAME time tile of g.bt different channels: tile (t, c_i) waits for (t-1, c_i), which is
+    // iteration i of a wave with a lower slot number -- the chain of "publish after the previous
+    // iteration's wait" steps down one iteration per link, so it is at most g.bt long.  (Time-
+    // consecutive tiles in one wave would chain through ALL running workgroups: measured 267 ms.)
     __shared__ int s_ticket;
-    const int tid = threadIdx.x, nthr = blockDim.x;
     if (tid == 0) s_ticket = atomicAdd(&sync[0], 1);
-    for (int i = tid; i < g.nlev * D * D; i += nthr) ksm[i] = tabs[i];
     __syncthreads();
-    const int ticket = s_ticket;
-    const int tt = ticket / g.ncg, cg = ticket - tt * g.ncg;  // time-major: (t-1, cg) has a lower ticket
-    const int64_t f0 = (int64_t)tt * g.tf;
-    const int c0 = cg * g.ncht;
-    // ---- stage the tile (16-byte loads, eight in flight per lane) ----
-    const int vrow = g.tf / V;  // vectors per channel row
-    const int nvec = g.ncht * vrow;
-    constexpr int U = 8;
-    for (int i0 = tid; i0 < nvec; i0 += U * nthr) {
-        vecT v[U];
+    const int ncs = (g.nch + g.bt - 1) / g.bt;             // channel slots per time tile
+    const int64_t slot = (int64_t)s_ticket * (kBlock / 64) + wave;  // time-major: (t-1, cs) is a lower slot
+    if (slot >= (int64_t)g.ntiles * ncs) return;
+    const int tt = (int)(slot / ncs), cs = (int)(slot - (int64_t)tt * ncs);
+    const int64_t f0 = (int64_t)tt * kSosTf;
+    const int64_t left = g.n - f0;  // frames of this time tile inside the signal (>= 1)
+    const int ch0 = cs * g.bt;
+    const int nit = g.nch - ch0 < g.bt ? g.nch - ch0 : g.bt;
+    const int grp = lane >> 4, rrow = (lane & 15) * LP;
+    const int k = lane;
+    auto issue_loads = [&](int ch, vecT (&ld)[4][RV]) {
+        const T* __restrict__ xin = x + (int64_t)ch * g.in_pitch + f0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * nthr;
-            const int c = i / vrow, f = (i - c * vrow) * V;
-            const int64_t gf = f0 + f;
-            const int cc = c0 + c;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int e = 0; e < V; ++e) v[u][e] = (T)0;
-            if (i < nvec && cc < g.nch && gf < g.n) {
-                const T* src = x + (int64_t)cc * g.in_pitch + gf;
-                if (g.vec_in && gf + V <= g.n) v[u] = *reinterpret_cast<const vecT*>(src);
+            for (int j = 0; j < RV; ++j) {
+                const int f = (r * (512 / V) + j * 64 + lane) * V;
+#pragma unroll
+                for (int e = 0; e < V; ++e) ld[r][j][e] = (T)0;
+                if (g.vec_in && f + V <= left) ld[r][j] = *reinterpret_cast<const vecT*>(xin + f);
                 else {
 #pragma unroll
                     for (int e = 0; e < V; ++e)
-                        if (gf + e < g.n) v[u][e] = src[e];
+                        if (f + e < left) ld[r][j][e] = xin[f + e];
                 }
             }
+    };
+    vecT ld[4][RV];
+    issue_loads(ch0, ld);
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+        const int ch = ch0 + it;
+        T* __restrict__ yout = y + (int64_t)ch * g.out_pitch + f0;
+        // ---- four transposition rounds: lane k gets sub-chunk k in registers ----
+        T xr[LC];
+#pragma unroll
+        for (int n = 0; n < LC; ++n) xr[n] = (T)0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                const int fl = (j * 64 + lane) * V;  // frame inside the round
+                T* dst = buf + (fl / LC) * LP + (fl % LC);
+#pragma unroll
+                for (int e = 0; e < V; ++e) dst[e] = ld[r][j][e];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (grp == r) {
+#pragma unroll
+                for (int n = 0; n < LC; ++n) xr[n] = buf[rrow + n];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        // the next tile's loads fly during this tile's arithmetic
+        if (it + 1 < nit) issue_loads(ch + 1, ld);
+        // ---- 1: zero-state pass over the lane's sub-chunk ----
+        double s[D];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * nthr;
-            if (i < nvec) {
-                const int c = i / vrow, f = (i - c * vrow) * V;
-                double* dst = tile + ((size_t)c * g.nsub + f / LC) * LP + (f % LC);
+        for (int d = 0; d < D; ++d) s[d] = 0.0;
+        if (!(g.debug & 1)) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) dst[e] = (double)v[u][e];
+            for (int n = 0; n < LC; ++n) (void)sos_step<NS>((double)xr[n], s, cf);
+        }
+        // ---- 2: inclusive scan over the lanes ----
+#pragma unroll 1
+        for (int lev = 0; lev < 6 && !(g.debug & 2); ++lev) {
+            const int d = 1 << lev;
+            const int addr = (lane - d) << 2;
+            double p[D], q[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) p[i] = bperm_f64(addr, s[i]);
+            matvec_tri<D>(ksm + lev * D * D, p, q);
+            if (k >= d) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) s[i] += q[i];
             }
         }
-    }
-    __syncthreads();
-    // ---- 1: zero-state pass over the lane's sub-chunk ----
-    const int c = tid / g.nsub, k = tid - c * g.nsub;
-    double* const row = tile + (size_t)tid * LP;  // (c*nsub + k)
-    double s[D];
+        // ---- 3: publish V, look back ----
+        if (k == 63) {
+            double* vp = vpub + ((int64_t)tt * g.nch + ch) * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) s[d] = 0.0;
-#pragma unroll 8
-    for (int n = 0; n < LC; ++n) (void)sos_step<NS>(row[n], s, cf);
-    // ---- 2: inclusive scan over k ----
-    for (int lev = 0; lev < g.nlev; ++lev) {
-        const int d = 1 << lev;
-        double p[D], q[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) p[i] = __shfl_up(s[i], d, g.nsub);
-        matvec_tri<D>(ksm + lev * D * D, p, q);
-        if (k >= d) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) s[i] += q[i];
+            for (int i = 0; i < D; ++i) {
+                double pv = s[i];
+                if ((unsigned long long)__double_as_longlong(pv) == kSosEmpty) pv = __longlong_as_double(0x7ff8000000000000ll);
+                __hip_atomic_store(vp + i, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-    }
-    // ---- 3: publish V, look back ----
-    const int64_t vt = ((int64_t)cg * g.ntiles + tt) * g.ncht;
-    if (k == g.nsub - 1) {
-        double* vp = vpub + (vt + c) * D;
+        double e0[D];  // P_(k-1)
+        {
+            const int addr = (lane - 1) << 2;
 #pragma unroll
-        for (int i = 0; i < D; ++i) __hip_atomic_store(vp + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&sync[1 + cg * g.ntiles + tt], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    double e0[D];  // P_(k-1)
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const double up = __shfl_up(s[i], 1, g.nsub);
-        e0[i] = k > 0 ? up : 0.0;
-    }
-    const int nb = tt < g.kt ? tt : g.kt;  // earlier tiles that still matter
-    if (nb > 0) {  // (wave-uniform)
-        double w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) w[i] = 0.0;
-        if (k < nb) {
-            const int tp = tt - 1 - k;
-            const int* fp = sync + 1 + cg * g.ntiles + tp;
-            while (__hip_atomic_load(fp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
-            const double* vp = vpub + (((int64_t)cg * g.ntiles + tp) * g.ncht + c) * D;
-            double vv[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) vv[i] = __hip_atomic_load(vp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            matvec_tri<D>(tabs + (size_t)(g.nlev + k) * D * D, vv, w);  // (A^tf)^k V_(t-1-k)
+            for (int i = 0; i < D; ++i) {
+                const double up = bperm_f64(addr, s[i]);
+                e0[i] = k > 0 ? up : 0.0;
+            }
         }
-        for (int off = g.nsub >> 1; off > 0; off >>= 1) {
+        // ---- 4a: the outputs from P_(k-1) alone, on the registers.  The part that needs sigma is
+        //      added afterwards (superposition): the look-back's memory round trip -- the earlier
+        //      tile publishes its V at about the time this one asks for it -- hides behind this pass
+        //      instead of stalling every wave of the CU at the same point (measured: 0.5 ms).
+        // (Float64: the outputs replace the samples in their registers; Float32 samples keep the
+        //  sum in Float64 until the final rounding)
+        typedef typename std::conditional<sizeof(T) == 8, T, double>::type YT;
+        YT yloc[sizeof(T) == 8 ? 1 : LC];
+        YT* const yv = sizeof(T) == 8 ? reinterpret_cast<YT*>(xr) : yloc;
+        if (!(g.debug & 16)) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) w[i] += __shfl_xor(w[i], off, g.nsub);
+            for (int n = 0; n < LC; ++n) yv[n] = sos_step<NS>((double)xr[n], e0, cf);
         }
-        // M^k sigma by the binary expansion of k
-        for (int lev = 0; lev < g.nlev; ++lev) {
-            double q[D];
-            matvec_tri<D>(ksm + lev * D * D, w, q);
-            if ((k >> lev) & 1) {
+        const int nb = tt < g.kt ? tt : g.kt;  // earlier tiles that still matter
+        if (nb > 0 && !(g.debug & 4)) {        // (wave-uniform)
+            double w[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) w[i] = q[i];
+            for (int i = 0; i < D; ++i) w[i] = 0.0;
+            if (k < nb) {
+                const double* vp = vpub + ((int64_t)(tt - 1 - k) * g.nch + ch) * D;
+                double vv[D];
+                for (;;) {
+                    if (g.debug & 64) {
+#pragma unroll
+                        for (int i = 0; i < D; ++i) vv[i] = 0.0;
+                        break;
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        vv[i] = __hip_atomic_load(vp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned long long)__double_as_longlong(vv[i]) != kSosEmpty;
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                matvec_tri<D>(tabs + (size_t)(g.nlev + k) * D * D, vv, w);  // (A^tf)^k V_(t-1-k)
+            }
+            // sum of the first nb lanes into lane 0 (the others hold zeros), then to every lane
+            for (int off = 1; off < nb; off <<= 1) {
+                const int addr = (lane ^ off) << 2;
+#pragma unroll
+                for (int i = 0; i < D; ++i) w[i] += bperm_f64(addr, w[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) w[i] = rfl_f64(w[i]);
+            // M^k sigma by the binary expansion of k
+#pragma unroll 1
+            for (int lev = 0; lev < 6 && !(g.debug & 8); ++lev) {
+                double q[D];
+                matvec_tri<D>(ksm + lev * D * D, w, q);
+                if ((k >> lev) & 1) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) w[i] = q[i];
+                }
+            }
+            // ---- 4b: zero-input response of the sub-chunk to M^k sigma ----
+            if (!(g.debug & (16 | 32))) {
+#pragma unroll
+                for (int n = 0; n < LC; ++n) yv[n] += sos_step<NS>(0.0, w, cf);
             }
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) e0[i] += w[i];
-    }
-    // ---- 4: the outputs, in place ----
-#pragma unroll 8
-    for (int n = 0; n < LC; ++n) row[n] = sos_step<NS>(row[n], e0, cf) * cf.gain;
-    __syncthreads();
-    for (int i0 = tid; i0 < nvec; i0 += U * nthr) {
+        for (int n = 0; n < LC; ++n) xr[n] = (T)(yv[n] * cf.gain);
+        // ---- transpose back and store ----
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * nthr;
-            if (i >= nvec) break;
-            const int cr = i / vrow, f = (i - cr * vrow) * V;
-            const int64_t gf = f0 + f;
-            const int cc = c0 + cr;
-            if (cc >= g.nch || gf >= g.n) continue;
-            const double* src = tile + ((size_t)cr * g.nsub + f / LC) * LP + (f % LC);
-            T* dst = y + (int64_t)cc * g.out_pitch + gf;
-            if (g.vec_out && gf + V <= g.n) {
-                vecT o;
+        for (int r = 0; r < 4; ++r) {
+            if (grp == r) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) o[e] = (T)src[e];
-                *reinterpret_cast<vecT*>(dst) = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < V; ++e)
-                    if (gf + e < g.n) dst[e] = (T)src[e];
+                for (int n = 0; n < LC; ++n) buf[rrow + n] = xr[n];
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                const int fl = (j * 64 + lane) * V;
+                const T* src = buf + (fl / LC) * LP + (fl % LC);
+                const int f = r * 512 + fl;
+                if (g.vec_out && f + V <= left) {
+                    vecT o;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = src[e];
+                    *reinterpret_cast<vecT*>(yout + f) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (f + e < left) yout[f + e] = src[e];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
+static bool first_use_on_device(bool (&seen)[64]);
+
 template <int NS, typename T>
 static void launch_sos_one_t(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
                              int* sync, double* vpub, hipStream_t st) {
-    const size_t ldsb = ((size_t)g.ncht * g.nsub * (kSosLc + 1) + (size_t)g.nlev * 4 * NS * NS) * 8;
-    static bool seen[64];
-    if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_sos_onepass<NS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipLaunchKernelGGL((k_sos_onepass<NS, T>), dim3((unsigned)(g.ntiles * g.ncg)), dim3((unsigned)(g.ncht * g.nsub)), ldsb, st,
+    const size_t ldsb = (size_t)g.nlev * 4 * NS * NS * 8 + (size_t)(kBlock / 64) * 16 * (kSosLc + 1) * sizeof(T);
+    const int64_t nslots = (int64_t)g.ntiles * ((g.nch + g.bt - 1) / g.bt);  // one per wave
+    const int64_t per = kBlock / 64;
+    hipLaunchKernelGGL((k_sos_onepass<NS, T>), dim3((unsigned)((nslots + per - 1) / per)), dim3(kBlock), ldsb, st,
                        (const T*)x, (T*)y, g, cf, tabs, sync, vpub);
 }
 

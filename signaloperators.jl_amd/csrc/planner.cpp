@@ -124,6 +124,12 @@ struct Stage {
     SosGeom sg{};
     int mpow_buf = -1, v_buf = -1, s0_buf = -1;
     std::vector<std::vector<double>> mpow_host;  // per group
+    // single-pass kernel (k_sos_onepass)
+    bool onepass = false;
+    SosOne so1{};
+    int one_tabs_buf = -1, one_sync_buf = -1, one_vpub_buf = -1;
+    std::vector<double> one_tabs_host;    // per group: [nlev + kt][D*D]
+    std::vector<size_t> one_tabs_off;     // doubles
     // resample
     RsGeom rg{};
     int pfb_buf = -1, dpfb_buf = -1;
@@ -1760,6 +1766,67 @@ void Plan::process_stage(int sid) {
             cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
             groups.push_back(cf);
         }
+        // ---- single pass (one read, one write): wave tiles in time order with a look-back over the
+        //      zero-state end states of the kt previous tiles (see k_sos_onepass) ----
+        // Opt-in (SIGOPS_SOS_ONEPASS=1): its HBM traffic is the algorithmic minimum, but on MI355X it
+        // is bound by fp64 vector work and dependent chains at two waves per SIMD (28.8 M x 8, order
+        // 10: 1.7 ms against 1.13 ms for the three-pass form, which streams at ~5 TB/s) -- DESIGN.md.
+        if (need >= 4096 && std::getenv("SIGOPS_SOS_ONEPASS") && !std::getenv("SIGOPS_SOS_3PASS")) {
+            SosOne o{};
+            const int tf = 64 * kSosLc;
+            o.n = need;
+            o.nch = N.nch;
+            o.ntiles = (int)((need + tf - 1) / tf);
+            o.nlev = 6;
+            o.bt = std::min(4, N.nch);
+            if (const char* ev = std::getenv("SIGOPS_SOS_BT")) o.bt = std::max(1, std::min(4, std::atoi(ev)));  // tuning knob
+            if (const char* ev = std::getenv("SIGOPS_SOS_DEBUG")) o.debug = std::atoi(ev);  // ablation knob
+            const double tol1 = std::ldexp(1.0, -70);
+            bool ok = (int64_t)o.ntiles * o.nch < (1 << 30);
+            // look-back depth: first kt with ||(A^tf)^kt|| < 2^-70, the same for every group
+            int kt = 1;
+            std::vector<Mat> As, Ts;
+            for (auto& cf : groups) {
+                const int D = 2 * cf.nsec;
+                Mat A = sos_state_matrix(cf);
+                Mat T = matpow(A, tf, D);
+                As.push_back(A);
+                Ts.push_back(T);
+                Mat cur = T;
+                int k = 1;
+                while (ok && !(maxabs(cur) < tol1)) {
+                    cur = matmul(cur, T, D);
+                    if (++k > 64) ok = false;  // a pole this close to the unit circle: three-pass form
+                }
+                kt = std::max(kt, k);
+            }
+            if (ok) {
+                o.kt = kt;
+                std::vector<double> tabs;
+                std::vector<size_t> offs;
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    const int D = 2 * groups[gi].nsec;
+                    offs.push_back(tabs.size());
+                    Mat P = matpow(As[gi], kSosLc, D);  // M = A^lc, then M^2, M^4, ...
+                    for (int lev = 0; lev < o.nlev; ++lev) {
+                        tabs.insert(tabs.end(), P.begin(), P.end());
+                        P = matmul(P, P, D);
+                    }
+                    Mat cur = ident(D);
+                    for (int j = 0; j < kt; ++j) {  // (A^tf)^j
+                        tabs.insert(tabs.end(), cur.begin(), cur.end());
+                        cur = matmul(cur, Ts[gi], D);
+                    }
+                }
+                stages[sid].onepass = true;
+                stages[sid].so1 = o;
+                stages[sid].one_tabs_host = tabs;
+                stages[sid].one_tabs_off = offs;
+                stages[sid].one_tabs_buf = raw_buf(tabs.size() * 8);
+                stages[sid].one_sync_buf = raw_buf(64);
+                stages[sid].one_vpub_buf = raw_buf((size_t)o.ntiles * o.nch * 2 * kMaxSec * 8);
+            }
+        }
         // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
         SosGeom g{};
         g.n = need;
@@ -1830,7 +1897,7 @@ void Plan::process_stage(int sid) {
         g.in_dtype = g.out_dtype = N.dtype;
         stages[sid].groups = groups;
         stages[sid].mpow_host = mp;
-        if (nchunks > 1) {
+        if (nchunks > 1 && !stages[sid].onepass) {
             size_t msz = 0;
             for (auto& v : mp) msz = std::max(msz, v.size());
             stages[sid].mpow_buf = raw_buf(msz * 8 * groups.size());
@@ -2256,6 +2323,8 @@ void Plan::finalize() {
     }
     for (auto& S : stages) {
         if (S.need <= 0) continue;
+        if (S.kind == ST_SOS && S.onepass)
+            HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
@@ -2580,7 +2649,23 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;
-                    for (size_t gi = 0; gi < S.groups.size(); ++gi) {
+                    for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {
+                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
+                        SosOne o = S.so1;
+                        o.in_pitch = gi == 0 ? in_pitch : ob.pitch;
+                        o.out_pitch = ob.pitch;
+                        const int64_t al = 16 / (int64_t)esz;
+                        o.vec_in = ((uintptr_t)x % 16 == 0) && (o.in_pitch % al == 0);
+                        o.vec_out = ((uintptr_t)ob.d % 16 == 0) && (o.out_pitch % al == 0);
+                        Buf& sb = P->bufs[S.one_sync_buf];
+                        Buf& vb = P->bufs[S.one_vpub_buf];
+                        HIPCHECK(hipMemsetAsync(sb.d, 0, sb.bytes, st));     // ticket counter
+                        HIPCHECK(hipMemsetAsync(vb.d, 0xff, vb.bytes, st));  // "not published yet"
+                        launch_sos_onepass(x, ob.d, o, S.groups[gi], (const double*)P->bufs[S.one_tabs_buf].d + S.one_tabs_off[gi],
+                                           (int*)sb.d, (double*)P->bufs[S.one_vpub_buf].d, N.dtype, st);
+                        nl += 1;
+                    }
+                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosGeom gg = g;
                         if (gi > 0) gg.in_pitch = ob.pitch;

@@ -140,25 +140,24 @@ struct SosGeom {
     int64_t in_pitch, out_pitch;  // elements between channels
 };
 
-// Single-pass variant (k_sos_onepass): one read and one write of the signal.  A workgroup owns a
-// tile of ncht channels x tf frames in LDS; lane (c,k) owns sub-chunk k (lc frames) of channel c.
-//   tabs = [nlev][D*D] powers M^(2^s) of M = A^lc (intra-tile scan) followed by
+// Single-pass variant (k_sos_onepass): one read and one write of the signal.  A WAVE owns a tile of
+// 64 * kSosLc frames of one channel; lane k owns sub-chunk k (kSosLc frames) in registers.
+//   tabs = [nlev][D*D] powers M^(2^s) of M = A^lc (scan over the lanes) followed by
 //          [kt][D*D]   powers (A^tf)^j, j = 0..kt-1 (look-back over the kt previous tiles)
-//   sync = [0] ticket counter, [1 + cg*ntiles + t] "V published" flag of tile t of channel group cg
-//   vpub = [ncg][ntiles][ncht][D] zero-state end states of the tiles
+//   sync = [0] ticket counter (zeroed before every launch)
+//   vpub = [ntiles][nch][D] zero-state end states of the tiles (set to all-ones bytes = "not
+//          published yet" before every launch)
 constexpr int kSosLc = 32;  // frames per lane
 struct SosOne {
     int64_t n;       // frames to produce
     int64_t in_pitch, out_pitch;
     int32_t nch;
-    int32_t ncht;    // channels per tile (1, 2, 4 or 8)
-    int32_t nsub;    // sub-chunks per channel and tile (32 or 64) = lanes per channel
-    int32_t tf;      // frames per tile = nsub * kSosLc
-    int32_t ntiles;  // tiles along time
-    int32_t ncg;     // channel groups = ceil(nch / ncht)
-    int32_t nlev;    // log2(nsub)
-    int32_t kt;      // look-back terms (<= nsub)
+    int32_t ntiles;  // tiles along time = ceil(n / (64*kSosLc))
+    int32_t nlev;    // 6 = log2(64 lanes)
+    int32_t kt;      // look-back terms (<= 64)
     int32_t vec_in, vec_out;  // 16-byte vector loads / stores are legal
+    int32_t bt;               // tiles (channels of one time tile) per wave, 1..4
+    int32_t debug;            // ablation bits (SIGOPS_SOS_DEBUG): 1 skip pass 1, 2 skip scan, 4 skip look-back, 8 skip M^k sigma, 16 skip pass 3
 };
 
 // ---------------------------------------------------------------------------
