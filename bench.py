@@ -1,91 +1,222 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the sink hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ns|config3|config4|config5]
 
-Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on):
-    Signal(noise[26 460 000 x 8], 44.1 kHz) |> Amplify(Signal(sin, ω=5Hz)) |> Until(600s)
-        |> ToFramerate(48 kHz) |> sink          
-A step is one `so_plan_execute` of that tree with the noise leaf and the result both
-resident in HBM.  N>1: one process per GPU, each rank sinks its own independent signal
-(batched independent signals shard with no data-path collective => weak scaling).
+Default workload (the pipeline the metric and north_star name, at config 3's size):
+    Mix(Signal(sin, ω=1kHz), Signal(noise[26 460 000 x 8], 44.1 kHz)) |> Until(600 s)
+        |> Filt(Bandstop, 0.5 kHz, 2 kHz) |> ToFramerate(48 kHz) |> sink
+The reference's rewrite rules (src/filters.jl:143-148) move the resampler under the filter, so
+the engine runs K3 (polyphase resampler with the Mix fused into its staging) and then K2 (order-10
+SOS IIR at 48 kHz).  A step is one `so_plan_execute` of that tree with the noise leaf and the
+result both resident in HBM.  BASELINE config 3 (the Filt-less resampler run)
+is timed in the same process and reported as the "config3" object of the same JSON line.
 
-One JSON line is printed by rank 0 (see the driver contract in the task statement), with
-two extra objects: "roofline" (dominant kernel vs the HBM roofline, hipEvent-timed inside
-the library on the stream the kernels run on) and "cpu_baseline" (the CPU oracle — a port of
-the reference's block-pull engine — timed on this host on a bounded sample).
+N>1: one process per GPU (torch.distributed / RCCL).  `ns` / `config3`: every rank sinks its own
+independent signal (weak scaling, no collective).  `config4`: the 64 scenes of an Append are
+sharded over the ranks and the result slabs are all-gathered device to device.  `config5`: each
+rank owns a 128-channel slab of the 1024-channel signal; no exchange step.
+
+One JSON line is printed by rank 0 (driver contract) with these extra objects:
+  roofline        the dominant stage of the headline workload against the HBM roofline: its
+                  algorithmic bytes / its hipEvent time inside the library, on the stream it runs on
+  roofline_sink   the whole sink from the TIMED LOOP: algorithmic bytes of the sink / ms_per_step
+  stages          every stage of the plan (hipEvent ms, launches, algorithmic bytes)
+  parity_gate     engine vs CPU oracle on a prefix of the same input, checked BEFORE timing
+  cpu_baseline    the CPU oracle (a port of the reference's block-pull engine) rebuilt here with
+                  -O3 -march=native, timed on this host: 1 thread, and all channels in parallel
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0   # measured copy ceiling quoted by the same guide
+METRIC = "frames/sec sink() 44.1kHz 8ch Mix+Filt+Resample; achieved HBM GB/s"
 
 
-def build_tree(so, noise, seconds):
-    v = os.environ.get("SIGOPS_BENCH_PLAIN")  # tuning aids (not the reported workload)
-    if v == "gain":  # finite fused chain: constant gain
-        return so.Signal(noise, 44.1 * so.kHz) | so.Amplify(2.0) | so.ToFramerate(48 * so.kHz)
-    if v == "finite":  # the modulator cut to the array's length: a single carrier
-        return (so.Signal(noise, 44.1 * so.kHz)
-                | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz) | so.Until(seconds * so.s)) | so.ToFramerate(48 * so.kHz))
-    if v:  # resampler alone, no fused Amplify
-        return so.Signal(noise, 44.1 * so.kHz) | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz)
+# ----------------------------------------------------------------------------- trees
+def tree_ns(so, noise, n_in):
+    return (so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(noise, 44.1 * so.kHz)) | so.Until(n_in * so.frames)
+            | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz))
+
+
+def tree_config3(so, noise, n_in):
+    v = os.environ.get("SIGOPS_BENCH_PLAIN")  # tuning aid (not a reported workload): resampler alone
+    if v:
+        return so.Signal(noise, 44.1 * so.kHz) | so.Until(n_in * so.frames) | so.ToFramerate(48 * so.kHz)
     return (so.Signal(noise, 44.1 * so.kHz) | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz))
-            | so.Until(seconds * so.s) | so.ToFramerate(48 * so.kHz))
+            | so.Until(n_in * so.frames) | so.ToFramerate(48 * so.kHz))
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as
-    MI355X_MICROARCH.md §HBM prescribes: 2*FETCH_SIZE + WRITE_SIZE); null when the run is
-    not the default workload the counters were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc_hbm.json")
-    if args.seconds != 600.0 or args.channels != 8 or args.dtype != "f64" or not os.path.exists(path):
-        return None
-    if os.environ.get("SIGOPS_BENCH_PLAIN"):
-        return None
+def scene(so, noise, k, n):
+    """config 4, scene k"""
+    return (so.Mix(so.Signal(so.sin, ω=(500 + 25 * k) * so.Hz) | so.Until(n * so.frames), so.Signal(noise, 44.1 * so.kHz))
+            | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.Ramp(10 * so.ms))
+
+
+def tree_config5(so, x):
+    return so.Signal(x, 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz) | so.ToFramerate(16 * so.kHz)
+
+
+# ----------------------------------------------------------------------------- helpers
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pmc_traffic(stage_name):
+    """HBM bytes per execute of a stage from the committed rocprofv3 PMC passes of this command
+    (profiles/r02/bench_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
+    MI355X_MICROARCH.md prescribes).  A file read, NOT a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", "r02", "bench_pmc_hbm.json")
+    if not os.path.exists(path):
+        return None, None
     with open(path) as f:
-        return json.load(f).get("corrected_bytes_per_launch")
+        d = json.load(f)
+    for key, val in d.get("stages", {}).items():
+        if stage_name.startswith(key):
+            return val.get("corrected_bytes_per_execute"), "profiles/r02/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command; not this run)"
+    return None, None
 
 
-def cpu_baseline(so, seconds, nch, dtype):
-    """Oracle (port of the reference's single-threaded block-pull engine) on a bounded
-    sample of the same workload.  Only this leg of bench.py touches oracle/."""
+def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev):
+    for _ in range(warmup):
+        plan.execute(optr, stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.execute(optr, stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def stage_times(plan, optr, stream, reps=5):
+    """hipEvent time of every step (library-internal events on the launch stream), averaged"""
+    plan.set_profiling(True)
+    acc = None
+    for _ in range(reps):
+        plan.execute(optr, stream)
+        st = plan.steps()
+        if acc is None:
+            acc = [dict(s, ms=0.0) for s in st]
+        for a, s in zip(acc, st):
+            a["ms"] += s["ms"] / reps
+    plan.set_profiling(False)
+    for a in acc:
+        a["GBps"] = a["algorithmic_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
+    return acc
+
+
+def roofline_of(stage, traffic=None, source=None):
+    return {"bound": "hbm", "achieved": stage["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": stage["GBps"] / HBM_PEAK_GBS, "frac_of_copy_ceiling": stage["GBps"] / HBM_COPY_GBS,
+            "traffic": traffic, "traffic_source": source, "kernel": stage["name"], "kernel_ms": stage["ms"],
+            "launches": stage["launches"], "kernel_algorithmic_bytes": stage["algorithmic_bytes"]}
+
+
+def parity_gate(so, tree_fn, noise_host, tol=1e-6):
+    """engine vs oracle on a prefix of the same input (correctness gate before timing)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bridge import oracle_sink, relerr
+
+    n = noise_host.shape[0]
+    x = tree_fn(so, noise_host, n)
+    got = so.sink(x)[0]
+    want = oracle_sink(x)
+    err = float(relerr(got, want))
+    res = {"relerr": err, "tolerance": tol, "input_frames": int(n), "output_frames": int(got.shape[0]),
+           "oracle": "CPU restatement of the reference (DSP.jl phase-accumulator positions), tests/oracle_bridge.py"}
+    if not (got.shape == want.shape and err <= tol):
+        raise SystemExit(f"bench.py: parity gate failed before timing: {res}")
+    return res
+
+
+def cpu_baseline(so, tree_fn, seconds, nch, ndt):
+    """The oracle (kind "port": the Julia reference itself cannot run here) on the same workload,
+    rebuilt -O3 -march=native on THIS host.  Only this leg of bench.py (and the gate) touches oracle/."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    native = os.path.join(ROOT, "oracle", "_native", "libsigops_oracle.so")
+    flags = "-O3 -march=native"
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        native = None
+    import ctypes
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_bridge import oracle_sink
+    import oracle_bridge as ob
 
+    if native and os.path.exists(native):
+        ob.ORACLE_SO = native
+        ob._lib = None
+    else:
+        flags = "-O3 -march=x86-64-v3 (native rebuild failed)"
     n_in = int(round(seconds * 44100))
     rng = np.random.default_rng(1983)
-    noise = np.asfortranarray(rng.standard_normal((n_in, nch)).astype(dtype))
-    x = build_tree(so, noise, seconds)
+    noise = np.asfortranarray(rng.standard_normal((n_in, nch)).astype(ndt))
+    x = tree_fn(so, noise, n_in)
     t0 = time.perf_counter()
-    y = oracle_sink(x)
-    dt = time.perf_counter() - t0
-    return {"value": y.shape[0] / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{seconds:g} s of the same 8-ch 44.1->48 kHz pipeline "
-                      f"({y.shape[0]} output frames) on 1 thread; blocksize 4096",
-            "seconds": dt, "host_cpus": os.cpu_count()}
+    y = ob.oracle_sink(x)
+    dt1 = time.perf_counter() - t0
+    # all cores: the channels are independent for this pipeline -> one single-channel sink per thread
+    ncpu = os.cpu_count() or 1
+    nthr = min(nch, ncpu)
+    cols = [np.asfortranarray(noise[:, c:c + 1]) for c in range(nch)]
+    trees = [tree_fn(so, c, n_in) for c in cols]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nthr) as pool:
+        ys = list(pool.map(ob.oracle_sink, trees))
+    dtn = time.perf_counter() - t0
+    same = all(np.array_equal(ys[c][:, 0], y[:, c]) for c in range(nch))
+    return {"value": y.shape[0] / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"the whole workload: {seconds:g} s x {nch} ch ({y.shape[0]} output frames), blocksize 4096, 1 thread",
+            "seconds": dt1, "flags": flags + " -ffp-contract=off", "cpu_model": cpu_model(), "host_cpus": ncpu,
+            "all_cores": {"value": y.shape[0] / dtn, "unit": "frames/s", "cores": nthr, "seconds": dtn,
+                          "how": "one single-channel sink per thread (channels are independent)",
+                          "identical_to_1_thread": bool(same)}}
 
 
+# ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="ns", choices=["ns", "config3", "config4", "config5"])
     ap.add_argument("--seconds", type=float, default=600.0, help="signal duration (600 = full config)")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=600.0,
-                    help="signal seconds for the bounded CPU-oracle sample (0 = skip); the oracle does "
-                         "~5e6 frames/s on one core, so the full 600 s workload is ~6-10 s of CPU work")
+                    help="signal seconds for the CPU-oracle sample (0 = skip); the full 600 s x 8 ch pipeline "
+                         "is ~10-20 s of CPU work on one core")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 object")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,72 +242,84 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the sink engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if args.workload in ("config4", "config5"):
+        import bench_multi
+
+        return bench_multi.run(args, so, torch, dist, rank, local_rank, world, dev)
+
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     ndt = np.float64 if args.dtype == "f64" else np.float32
-    esz = 8 if args.dtype == "f64" else 4
     nch = args.channels
     n_in = int(round(args.seconds * 44100))
+    stream = torch.cuda.current_stream().cuda_stream
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1983 + rank)
     noise_t = torch.randn((nch, n_in), dtype=tdt, device=dev, generator=gen)
     noise = noise_t.t()  # [n_in x nch], column-major like Julia's Array (time fastest)
-    x = build_tree(so, noise, args.seconds)
-    n_out = so.nframes(x)
-    out_t = torch.empty((nch, n_out), dtype=tdt, device=dev)
-    out = out_t.t()
-    xs = so.ToChannels(x, nch)
 
-    t0 = time.perf_counter()
-    plan = so.Plan(xs, (n_out, nch), ndt, (out.stride(0), out.stride(1)), True, device=local_rank)
-    torch.cuda.synchronize()
-    plan_ms = (time.perf_counter() - t0) * 1e3
-    stream = torch.cuda.current_stream().cuda_stream
+    def prepare(tree_fn):
+        x = tree_fn(so, noise, n_in)
+        n_out = so.nframes(x)
+        out_t = torch.empty((nch, n_out), dtype=tdt, device=dev)
+        out = out_t.t()
+        t0 = time.perf_counter()
+        plan = so.Plan(so.ToChannels(x, nch), (n_out, nch), ndt, (out.stride(0), out.stride(1)), True, device=local_rank)
+        torch.cuda.synchronize()
+        return plan, out_t, out, n_out, (time.perf_counter() - t0) * 1e3
+
+    headline_fn = tree_ns if args.workload == "ns" else tree_config3
+    headline_name = ("north-star pipeline: Mix(sin 1kHz, noise[%d x %d] @44.1kHz) |> Until(%gs) |> Filt(Bandstop 0.5-2kHz) "
+                     "|> ToFramerate(48kHz) |> sink" if args.workload == "ns" else
+                     "config3: Signal(noise[%d x %d],44.1kHz) |> Amplify(sin 5Hz) |> Until(%gs) |> ToFramerate(48kHz) |> sink") \
+        % (n_in, nch, args.seconds) + " (device-resident leaf and result)"
+
+    # ---- correctness gate before timing (rank 0, same device noise, a prefix) ----
+    gate = None
+    if rank == 0:
+        m = min(n_in, 150_000)
+        pre = np.asfortranarray(noise_t[:, :m].t().cpu().numpy())
+        gate = parity_gate(so, headline_fn, pre, 1e-6 if args.dtype == "f64" else 2e-6)
+
+    plan, out_t, out, n_out, plan_ms = prepare(headline_fn)
     optr = out.data_ptr()
-
-    # The first ~15 launches after an idle gap run up to 20 % slower (clock / TLB ramp, measured
-    # per launch with hipEvents); a fixed pre-warm keeps short --warmup runs comparable.  It is
-    # reported as config.prewarm_steps and is never part of the timed region.
-    prewarm = max(0, 30 - args.warmup)
-    for _ in range(prewarm + args.warmup):
-        plan.execute(optr, stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.execute(optr, stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # kernel-level timing (hipEvents inside the library, same stream), averaged over K steps
-    plan.set_profiling(True)
-    kms, kbytes, kname, tot_ms = [], 0, "", []
-    for _ in range(max(3, min(args.steps, 10))):
-        plan.execute(optr, stream)
-        st = plan.stats()
-        kms.append(st["dominant_kernel_ms"])
-        tot_ms.append(st["last_exec_ms"])
-        kbytes, kname = st["dominant_kernel_bytes"], st["dominant_kernel"]
-    plan.set_profiling(False)
+    elapsed = timed_loop(plan, optr, stream, args.steps, args.warmup, torch, dist, dev)
+    stages = stage_times(plan, optr, stream)
     st = plan.stats()
     checksum = float(out_t[:, :: max(1, n_out // 4096)].double().abs().sum().item())
+    plan.close()
+    del out_t, out
+
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "ns" and not args.no_secondary:
+        p3, o3_t, o3, n3, plan3_ms = prepare(tree_config3)
+        steps3 = max(20, args.steps // 2)
+        e3 = timed_loop(p3, o3.data_ptr(), stream, steps3, args.warmup, torch, None, dev)
+        st3 = stage_times(p3, o3.data_ptr(), stream)
+        s3 = p3.stats()
+        ms3 = e3 / steps3 * 1e3
+        dom3 = max(st3, key=lambda s: s["ms"])
+        tr3, src3 = pmc_traffic("config3:" + dom3["name"])
+        secondary = {"workload": "config3: Signal(noise[%d x %d],44.1kHz) |> Amplify(sin 5Hz) |> Until(%gs) |> ToFramerate(48kHz) |> sink"
+                                 % (n_in, nch, args.seconds),
+                     "value": n3 / (ms3 * 1e-3), "unit": "frames/s", "steps": steps3, "ms_per_step": ms3,
+                     "algorithmic_bytes_per_step": s3["algorithmic_bytes"],
+                     "roofline_sink": {"achieved": s3["algorithmic_bytes"] / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": s3["algorithmic_bytes"] / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "frac_of_copy_ceiling": s3["algorithmic_bytes"] / (ms3 * 1e-3) / 1e9 / HBM_COPY_GBS,
+                                       "from": "timed loop"},
+                     "roofline": roofline_of(dom3, tr3, src3), "stages": st3, "plan_create_ms": plan3_ms}
+        p3.close()
+        del o3_t, o3
 
     if rank == 0:
-        k_avg_ms = sum(kms) / len(kms)
-        achieved = kbytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
         algo = st["algorithmic_bytes"]
         ms_per_step = elapsed / args.steps * 1e3
+        dom = max(stages, key=lambda s: s["ms"])
+        traffic, tsrc = pmc_traffic(args.workload + ":" + dom["name"])
+        sink_gbps = algo / (ms_per_step * 1e-3) / 1e9
         res = {
-            "metric": "frames/sec sink() 44.1kHz 8ch Mix+Filt+Resample; achieved HBM GB/s",
+            "metric": METRIC,
             "value": world * n_out * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -188,27 +331,25 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "config3: Signal(noise[%d x %d],44.1kHz) |> Amplify(sin 5Hz) |> Until(%gs) "
-                                   "|> ToFramerate(48kHz) |> sink (device-resident leaf and result)"
-                                   % (n_in, nch, args.seconds),
-                       "in_frames": n_in, "out_frames": n_out, "channels": nch,
+            "config": {"workload": headline_name, "in_frames": n_in, "out_frames": n_out, "channels": nch,
                        "parallelism": f"{world} independent signals, one per GPU, no collective",
-                       "plan_create_ms": plan_ms, "prewarm_steps": prewarm, "launches_per_step": st["n_launches"],
-                       "stages": st["n_stages"], "scratch_bytes": st["scratch_bytes"],
-                       "checksum": checksum},
-            "hbm_GBps_whole_sink": algo / (ms_per_step * 1e-3) / 1e9,
+                       "plan_create_ms": plan_ms, "launches_per_step": st["n_launches"], "stages": st["n_stages"],
+                       "scratch_bytes": st["scratch_bytes"], "checksum": checksum,
+                       "note": "warm-up is exactly --warmup steps; the first ~15 launches after an idle gap run up to 20% slower"},
             "algorithmic_bytes_per_step": algo,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": kname,
-                         "kernel_ms": k_avg_ms, "kernel_algorithmic_bytes": kbytes,
-                         "all_kernels_ms": sum(tot_ms) / len(tot_ms)},
+            "roofline": roofline_of(dom, traffic, tsrc),
+            "roofline_sink": {"bound": "hbm", "achieved": sink_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
+                              "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},
+            "stages": stages,
+            "parity_gate": gate,
+            "config3": secondary,
         }
         if args.cpu_seconds > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(so, args.cpu_seconds, nch, ndt)
+            res["cpu_baseline"] = cpu_baseline(so, headline_fn, args.cpu_seconds, nch, ndt)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    plan.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,159 @@
+"""Multi-GPU workloads of bench.py (`--workload config4|config5`), BASELINE.json configs[3] and [4].
+
+config4  Append of 64 independent 60 s scenes (Mix(sin, noise[2 646 000 x 2]) |> Filt(Bandstop) |> Ramp),
+         44.1 kHz, sharded in contiguous blocks of scenes over the ranks (reference: Append children
+         are independent sub-trees, src/appending.jl:59-76).  Every rank's engine writes its time
+         range straight into its slot of the exchange buffer; the slabs are all-gathered device to
+         device over RCCL/xGMI.  Total work is fixed (strong scaling).  Reported: whole-job frames/s
+         WITH the gather (`value`) and compute-only.
+config5  x[10 000 000 x 128 per GPU] |> Filt(Lowpass 4 kHz) |> ToFramerate(16 kHz): each rank owns a
+         128-channel slab of the 1024-channel signal (channels are independent, planar layout keeps a
+         slab contiguous); no exchange step (weak scaling: N x 128 channels).
+"""
+import json
+import time
+
+import numpy as np
+
+
+def _sync_time(fn, steps, warmup, torch, dist, dev):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def run(args, so, torch, dist, rank, local_rank, world, dev):
+    from bench import HBM_PEAK_GBS, METRIC, scene, tree_config5
+    from sigops_amd import sharding
+
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    ndt = np.float64 if args.dtype == "f64" else np.float32
+    esz = 8 if args.dtype == "f64" else 4
+    stream = torch.cuda.current_stream().cuda_stream
+    steps, warmup = args.steps, args.warmup
+    if args.workload == "config4":
+        nscenes, nch = 64, 2
+        n = int(round(args.seconds / 10.0 * 44100)) if args.seconds != 600.0 else 2_646_000  # 60 s scenes
+        lo, hi = sharding.block_range(nscenes, rank, world)
+        trees = []
+        keep = []
+        for k in range(lo, hi):
+            g = torch.Generator(device=dev)
+            g.manual_seed(1983 + k)
+            nz = torch.randn((nch, n), dtype=tdt, device=dev, generator=g)
+            keep.append(nz)
+            trees.append(scene(so, nz.t(), k, n))
+        counts = [(sharding.block_range(nscenes, r, world)[1] - sharding.block_range(nscenes, r, world)[0]) * n
+                  for r in range(world)]
+        width, count, total = max(counts), counts[rank], nscenes * n
+        slab = torch.zeros((nch, width), dtype=tdt, device=dev)
+        plan = None
+        if trees:
+            sub = trees[0] if len(trees) == 1 else so.Append(*trees)
+            res = slab.t()[:count]
+            t0 = time.perf_counter()
+            plan = so.Plan(so.ToChannels(sub, nch), (count, nch), ndt, (res.stride(0), res.stride(1)), True, device=local_rank)
+            torch.cuda.synchronize()
+            plan_ms = (time.perf_counter() - t0) * 1e3
+        outs = torch.empty((world, nch, width), dtype=tdt, device=dev) if world > 1 else None
+        full = torch.empty((nch, total), dtype=tdt, device=dev) if world > 1 else None
+        optr = slab.data_ptr()
+
+        def compute():
+            if plan is not None:
+                plan.execute(optr, stream)
+
+        def with_gather():
+            compute()
+            if world > 1:
+                dist.all_gather_into_tensor(outs, slab)
+                pos = 0
+                for r in range(world):  # planar [nch x total] result on every rank
+                    full[:, pos:pos + counts[r]] = outs[r, :, :counts[r]]
+                    pos += counts[r]
+
+        el_c = _sync_time(compute, steps, warmup, torch, dist, dev)
+        el_g = _sync_time(with_gather, steps, warmup, torch, dist, dev)
+        st = plan.stats() if plan is not None else {}
+        if rank == 0:
+            ms_g, ms_c = el_g / steps * 1e3, el_c / steps * 1e3
+            algo = 2 * esz * total * nch
+            print(json.dumps({
+                "metric": METRIC, "value": total / (ms_g * 1e-3), "unit": "frames/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": ms_g, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "config4: Append of 64 scenes (Mix(sin,noise[%d x 2]) |> Filt(Bandstop 0.5-2kHz) |> Ramp(10ms)) "
+                                       "@44.1kHz |> sink, scenes sharded over ranks, RCCL all-gather of the device slabs" % n,
+                           "out_frames": total, "channels": nch, "scenes_per_rank": hi - lo,
+                           "parallelism": f"append-shard x{world}, all_gather_into_tensor (device to device)",
+                           "compute_only_ms": ms_c, "compute_only_frames_per_s": total / (ms_c * 1e-3),
+                           "gather_ms": ms_g - ms_c, "launches_per_step": st.get("n_launches"),
+                           "plan_create_ms": plan_ms if plan is not None else None},
+                "algorithmic_bytes_per_step": algo,
+                "roofline": {"bound": "hbm", "achieved": algo / (ms_c * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": algo / (ms_c * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "whole sink per GPU, compute only (timed loop)"},
+                "cpu_baseline": None}), flush=True)
+    else:  # config5
+        cpg = 128
+        n = int(round(args.seconds / 600.0 * 10_000_000))
+        g = torch.Generator(device=dev)
+        g.manual_seed(1983 + rank)
+        x = torch.rand((cpg, n), dtype=tdt, device=dev, generator=g)
+        tree = tree_config5(so, x.t())
+        n_out = so.nframes(tree)
+        out_t = torch.empty((cpg, n_out), dtype=tdt, device=dev)
+        out = out_t.t()
+        t0 = time.perf_counter()
+        plan = so.Plan(so.ToChannels(tree, cpg), (n_out, cpg), ndt, (out.stride(0), out.stride(1)), True, device=local_rank)
+        torch.cuda.synchronize()
+        plan_ms = (time.perf_counter() - t0) * 1e3
+        optr = out.data_ptr()
+        el = _sync_time(lambda: plan.execute(optr, stream), steps, warmup, torch, dist, dev)
+        # size-independent checks at full size: finite, and the low-pass keeps the DC level of uniform(0,1)
+        mean = float(out_t[:, 2000:-2000].mean().item())
+        finite = bool(torch.isfinite(out_t).all().item())
+        plan.set_profiling(True)
+        plan.execute(optr, stream)
+        stages = plan.steps()
+        st = plan.stats()
+        if rank == 0:
+            ms = el / steps * 1e3
+            algo = st["algorithmic_bytes"]
+            dom = max(stages, key=lambda s: s["ms"])
+            print(json.dumps({
+                "metric": METRIC, "value": world * n_out / (ms * 1e-3), "unit": "frames/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "config5 slab: x[%d x %d per GPU] uniform(0,1) @44.1kHz |> Filt(Lowpass 4kHz) |> ToFramerate(16kHz) |> sink"
+                                       % (n, cpg),
+                           "in_frames": n, "out_frames": n_out, "channels": world * cpg,
+                           "parallelism": f"channel slabs x{world}, no collective", "plan_create_ms": plan_ms,
+                           "launches_per_step": st["n_launches"], "mean_of_result": mean, "finite": finite},
+                "algorithmic_bytes_per_step": algo, "stages": stages,
+                "roofline": {"bound": "hbm", "achieved": dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "kernel": dom["name"], "kernel_ms": dom["ms"]},
+                "roofline_sink": {"achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "from": "timed loop, per GPU"},
+                "cpu_baseline": None}), flush=True)
+        plan.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -240,6 +240,19 @@ int32_t so_plan_set_array(so_plan_t* plan, int32_t node_index, const void* data)
 
 int32_t so_plan_stats(const so_plan_t* plan, so_stats_t* stats);
 
+/* Per-step view of the same statistics: step `index` of the plan's launch sequence (a fused
+ * pointwise launch, or one stage = the launches of one IIR / resampler / Normpower node).
+ * Returns the number of steps; fills *info when 0 <= index < that number.  ms is valid after an
+ * execute with profiling enabled. */
+typedef struct so_step_info {
+    char name[64];
+    int64_t algorithmic_bytes;  /* bytes the step must read + write (its own inputs and outputs) */
+    double ms;                  /* hipEvent time of the step in the last profiled execute         */
+    int32_t launches;
+    int32_t pad;
+} so_step_info_t;
+int32_t so_plan_step_info(const so_plan_t* plan, int32_t index, so_step_info_t* info);
+
 /* When enabled, so_plan_execute brackets every kernel with hipEvents (on the stream
  * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default. */
 int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable);

@@ -45,11 +45,16 @@ class so_stats_t(C.Structure):
                 ("dominant_kernel_bytes", C.c_int64), ("dominant_kernel", C.c_char * 64)]
 
 
+class so_step_info_t(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("algorithmic_bytes", C.c_int64), ("ms", C.c_double),
+                ("launches", C.c_int32), ("pad", C.c_int32)]
+
+
 EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create",
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
-           "so_resample_positions"]
+           "so_resample_positions", "so_plan_step_info"]
 
 _lib = None
 
@@ -108,6 +113,8 @@ def lib():
     L.so_design_resample_arbitrary.restype = C.c_int32
     L.so_design_resample_arbitrary.argtypes = [C.c_double, C.c_int32, C.POINTER(C.c_double),
                                                C.c_int32, C.POINTER(C.c_int32)]
+    L.so_plan_step_info.restype = C.c_int32
+    L.so_plan_step_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(so_step_info_t)]
     L.so_resample_positions.restype = C.c_int32
     L.so_resample_positions.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double),
                                         C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),

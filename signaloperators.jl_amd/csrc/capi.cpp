@@ -76,6 +76,11 @@ int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable) {
     return SO_OK;
 }
 
+int32_t so_plan_step_info(const so_plan_t* plan, int32_t index, so_step_info_t* info) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_step_info: null plan");
+    return so::plan_step_info(plan->p, index, info);
+}
+
 void so_plan_destroy(so_plan_t* plan) {
     if (!plan) return;
     so::plan_destroy(plan->p);

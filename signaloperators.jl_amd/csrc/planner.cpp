@@ -2934,6 +2934,17 @@ int64_t plan_nframes(const Plan* P) {
 }
 void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
 void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
+int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
+    if (info && index >= 0 && index < (int)P->steps.size()) {
+        const Step& s = P->steps[index];
+        std::memset(info, 0, sizeof *info);
+        std::snprintf(info->name, sizeof info->name, "%s", s.name.c_str());
+        info->algorithmic_bytes = s.bytes;
+        info->ms = s.ms;
+        info->launches = s.launches;
+    }
+    return (int)P->steps.size();
+}
 void plan_destroy(Plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->device);

@@ -95,6 +95,17 @@ class Plan:
         return {f[0]: (getattr(s, f[0]).decode() if f[0] == "dominant_kernel" else getattr(s, f[0]))
                 for f in K.so_stats_t._fields_}
 
+    def steps(self):
+        """per-step statistics of the last (profiled) execute: so_plan_step_info"""
+        out = []
+        info = K.so_step_info_t()
+        n = K.lib().so_plan_step_info(self.handle, 0, C.byref(info))
+        for i in range(n):
+            K.lib().so_plan_step_info(self.handle, i, C.byref(info))
+            out.append({"name": info.name.decode(), "algorithmic_bytes": info.algorithmic_bytes,
+                        "ms": info.ms, "launches": info.launches})
+        return out
+
     def close(self):
         if self.handle:
             K.lib().so_plan_destroy(self.handle)

@@ -59,6 +59,15 @@ def design_resample(ratio):
     return np.array(h[:], dtype=np.float64)
 
 
+_HLEN = {}
+
+
+def _resample_hlen(ratio):
+    if ratio not in _HLEN:
+        _HLEN[ratio] = len(design_resample(ratio))
+    return _HLEN[ratio]
+
+
 def _pad_fields(pad, nch):
     """usepad resolution, reference src/padding.jl:150-192"""
     if pad is S.zero:
@@ -140,13 +149,18 @@ def _array_fields(x):
     return ptr, fstride, cstride, is_dev
 
 
-def _demand(x, n, out):
-    """how many frames of every randn leaf a sink of n frames evaluates"""
+def _demand(x, n, out, skip=0):
+    """how many frames of every randn leaf a sink of n frames reaches, and how many of the leading
+    ones are SKIPPED rather than evaluated: `After` pulls the frames it drops with skip=true
+    (reference src/cutting.jl:160-181) and a generator leaf draws nothing for them
+    (src/functions.jl:113-114 is only reached through `frame`), while stateful nodes ignore the
+    flag and evaluate their child (`Filt`, src/filters.jl:241-244)."""
     if n is None or S.isknowninf(n) or n <= 0:
         return  # (infinite demands are rejected by the planner with the reference's error)
     if isinstance(x, S.FuncSig):
         if x.fn == S.RANDN:
-            out[id(x)] = max(out.get(id(x), 0), n)
+            n0, s0 = out.get(id(x), (0, skip))
+            out[id(x)] = (max(n0, n), min(s0, skip))
         return
     if isinstance(x, (S.ArraySig, S.NumberSig, S.RampSignal)):
         return
@@ -159,31 +173,42 @@ def _demand(x, n, out):
 
     if isinstance(x, S.CutApply):
         L = x.resolvelen() or 0
-        _demand(x.signal, capped(x.signal, min(n, max(0, L)) if x.kind == "until" else n + max(0, L)), out)
+        if x.kind == "until":
+            _demand(x.signal, capped(x.signal, min(n, max(0, L))), out, skip)
+        else:
+            _demand(x.signal, capped(x.signal, n + max(0, L)), out, skip + max(0, L))
     elif isinstance(x, S.PaddedSignal):
-        _demand(x.signal, capped(x.signal, n), out)
+        _demand(x.signal, capped(x.signal, n), out, skip)
     elif isinstance(x, S.AppendSignals):
-        rem = n
+        rem, sk = n, skip
         for c in x.signals:
             cl = S.nframes(c)
             m = rem if (cl is None or S.isknowninf(cl)) else min(rem, cl)
-            _demand(c, m, out)
+            _demand(c, m, out, min(sk, m))
             rem -= m
+            sk = max(0, sk - m)
             if rem <= 0:
                 break
     elif isinstance(x, S.MapSignal):
         for c in x.signals:
-            _demand(c, capped(c, n), out)
+            _demand(c, capped(c, n), out, skip)
     elif isinstance(x, S.FilteredSignal):
         if isinstance(x.fn, S.ResamplerFn):
+            # newest input of the last output: position (hlen-1)/2 + (n-1)*Nphi/ratio on the fine
+            # grid, i.e. (n-1)/ratio inputs plus the filter's group delay (hlen-1)/(2 Nphi)
+            # (reference src/reformatting.jl:92-96 setphase!(timedelay))
             r = x.fn.ratio
+            nphi = r[0] if isinstance(r, tuple) else 32
+            hlen = _resample_hlen(r)
             r = r[0] / r[1] if isinstance(r, tuple) else r
-            m = int(math.ceil(n / r)) + 8
+            m = int(math.ceil(max(n - 1, 0) / r)) + int(math.ceil((hlen - 1) / (2 * nphi))) + 2
         else:
             m = n
-        _demand(x.signal, capped(x.signal, m), out)
+        _demand(x.signal, capped(x.signal, m), out, 0)
     elif isinstance(x, S.NormedSignal):
-        _demand(x.signal, S.nframes(x.signal), out)
+        _demand(x.signal, S.nframes(x.signal), out, 0)
+    elif isinstance(x, S.RampSignal):
+        return
 
 
 def lower(x, nframes_out=None, rng=None):
@@ -223,9 +248,10 @@ def lower(x, nframes_out=None, rng=None):
             if s.fn == S.RANDN:
                 # randn leaves are host-materialised (SURVEY.md §7 hard part 7): one
                 # N(0,1) draw per evaluated frame, in increasing frame order
-                n = need.get(id(s), 0)
+                n, skipped = need.get(id(s), (0, 0))
                 g = s.rng if s.rng is not None else (rng if rng is not None else np.random.default_rng())
-                data = np.asfortranarray(g.standard_normal((max(n, 0), 1)))
+                data = np.zeros((max(n, 0), 1), order="F")
+                data[skipped:, 0] = g.standard_normal(max(n - skipped, 0))  # skipped frames draw nothing
                 a = S.ArraySig(data, s.fs)
                 lw.keep.append(a)
                 r = common(a, K.NODE_ARRAY)

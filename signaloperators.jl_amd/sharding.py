@@ -14,7 +14,6 @@ all_gather of padded slabs).
 import numpy as np
 
 from . import signals as S
-from .engine import sink as _engine_sink
 
 
 def block_range(n, rank, world):
@@ -53,17 +52,126 @@ def shard_channels(x, rank, world):
     return (parts[0] if len(parts) == 1 else S.AddChannel(*parts)), c0, c1
 
 
-def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0):
-    """Evaluate Append(children...) with children sharded over ranks.  Returns the full
-    [nframes x nch] array on every rank when gather=True, else (local_slab, start)."""
+def _dist_info(rank, world):
     import torch.distributed as dist
 
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    compute = compute or (lambda sig: _engine_sink(sig, np.ndarray, device=device))
+    return rank, world
+
+
+def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0):
+    """Evaluate Append(children...) with children sharded over ranks.
+
+    Default compute = the HIP engine with a DEVICE-RESIDENT result: the rank's slab is written by
+    the engine straight into its slot of the exchange buffer, the slabs are all-gathered device to
+    device (RCCL over xGMI; uneven shares -> slabs padded to the widest) and the planar
+    [nframes x nch] result is assembled on the device -- no host hop anywhere.  Returns a
+    column-major torch tensor on every rank when gather=True, else (local_slab, start).
+    `compute` (tests: the CPU oracle under gloo) switches to the NumPy path."""
+    rank, world = _dist_info(rank, world)
     sub, start, count = shard_append(x, rank, world)
+    nch = x.nch
+    dt = S.float_type(x.dtype)
+    if compute is not None:
+        return _sink_append_sharded_host(x, sub, start, count, rank, world, gather, compute, device)
+    import torch
+    import torch.distributed as dist
+
+    from .engine import sink_into
+
+    tdt = torch.float32 if dt == S.F32 else torch.float64
+    counts = [shard_append(x, r, world)[2] for r in range(world)]
+    width = max(counts) if gather and world > 1 else count
+    slab = torch.zeros((nch, max(width, 1)), dtype=tdt, device=f"cuda:{device}")
+    if sub is not None and count > 0:
+        sink_into(slab.t()[:count], sub, device=device)  # result strides (1, width): written in place
+    if not gather:
+        return slab.t()[:count], start
+    if world == 1:
+        return slab.t()[:count]
+    outs = torch.empty((world, nch, width), dtype=tdt, device=slab.device)
+    dist.all_gather_into_tensor(outs, slab)
+    total = int(S.nframes(x))
+    full = torch.empty((nch, total), dtype=tdt, device=slab.device)
+    pos = 0
+    for r in range(world):
+        full[:, pos:pos + counts[r]] = outs[r, :, :counts[r]]
+        pos += counts[r]
+    return full.t()
+
+
+def sink_channels_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0):
+    """Channel-striped sink of a signal whose channels are independent: each rank evaluates its
+    contiguous slab of channels with a device-resident result.  Planar layout makes a slab one
+    contiguous block of the full result, so with equal slabs the optional all-gather writes the
+    final [nframes x nch] buffer directly (uneven: padded slabs, then assembled on the device).
+    Returns the full column-major tensor when gather=True, else (local_slab, c0, c1)."""
+    rank, world = _dist_info(rank, world)
+    x = S._assignal(x)
+    sub, c0, c1 = shard_channels(x, rank, world)
+    n = int(S.nframes(x))
+    dt = S.float_type(x.dtype)
+    if compute is not None:
+        local = np.empty((n, 0), dtype=dt) if sub is None else np.asarray(compute(sub))
+        if not gather or world == 1:
+            return (local, c0, c1) if not gather else local
+        return _gather_channels_host(local, x.nch, n, dt, world, device)
+    import torch
+    import torch.distributed as dist
+
+    from .engine import sink_into
+
+    tdt = torch.float32 if dt == S.F32 else torch.float64
+    bounds = [block_range(x.nch, r, world) for r in range(world)]
+    wmax = max(hi - lo for lo, hi in bounds)
+    even = all(hi - lo == wmax for lo, hi in bounds)
+    if gather and world > 1 and even:
+        full = torch.empty((x.nch, n), dtype=tdt, device=f"cuda:{device}")
+        mine = full[c0:c1]  # this rank's slab of the final buffer
+        sink_into(mine.t(), sub, device=device)
+        dist.all_gather_into_tensor(full.view(world, wmax, n), mine.contiguous())
+        return full.t()
+    slab = torch.zeros((max(wmax if gather else c1 - c0, 1), n), dtype=tdt, device=f"cuda:{device}")
+    if sub is not None:
+        sink_into(slab[:c1 - c0].t(), sub, device=device)
+    if not gather:
+        return slab[:c1 - c0].t(), c0, c1
+    if world == 1:
+        return slab[:c1 - c0].t()
+    outs = torch.empty((world, wmax, n), dtype=tdt, device=slab.device)
+    dist.all_gather_into_tensor(outs, slab)
+    full = torch.empty((x.nch, n), dtype=tdt, device=slab.device)
+    for r, (lo, hi) in enumerate(bounds):
+        full[lo:hi] = outs[r, :hi - lo]
+    return full.t()
+
+
+def _gather_channels_host(local, nch, n, dt, world, device):
+    import torch
+    import torch.distributed as dist
+
+    bounds = [block_range(nch, r, world) for r in range(world)]
+    wmax = max(hi - lo for lo, hi in bounds)
+    pad = np.zeros((wmax, n), dtype=dt)
+    pad[:local.shape[1]] = local.T
+    t = torch.from_numpy(pad)
+    if dist.get_backend() == "nccl":
+        t = t.cuda(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    full = np.empty((n, nch), dtype=dt, order="F")
+    for r, (lo, hi) in enumerate(bounds):
+        full[:, lo:hi] = outs[r][:hi - lo].cpu().numpy().T
+    return full
+
+
+def _sink_append_sharded_host(x, sub, start, count, rank, world, gather, compute, device):
+    """NumPy path (a caller-supplied `compute`, e.g. the CPU oracle in the gloo tests)"""
+    import torch.distributed as dist
+
     nch = x.nch
     dt = S.float_type(x.dtype)
     local = np.empty((0, nch), dtype=dt) if sub is None else np.asarray(compute(sub))

@@ -76,6 +76,35 @@ sys.exit(0 if ok else 3)
 '''
 
 
+WORKER_CH = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+import sigops_amd as so
+from sigops_amd import sharding
+from oracle_bridge import oracle_sink
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+x0 = np.asfortranarray(np.random.default_rng(3).random((6000, 5)))
+x = so.Signal(x0, 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz) | so.ToFramerate(16 * so.kHz)
+full = sharding.sink_channels_sharded(x, compute=oracle_sink)   # uneven slabs: 3 + 2 channels
+want = oracle_sink(x)
+ok = np.array_equal(full, want)
+local, c0, c1 = sharding.sink_channels_sharded(x, compute=oracle_sink, gather=False)
+ok = ok and np.array_equal(local, want[:, c0:c1])
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_channel_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker_ch.py"
+    script.write_text(WORKER_CH)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0]
+
+
 def test_append_sharding_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
