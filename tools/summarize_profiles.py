@@ -14,29 +14,46 @@ if stats:
     with open(stats) as f, open(os.path.join(dst, "bench_kernel_stats.csv"), "w", newline="") as g:
         w = csv.writer(g)
         for row in csv.reader(f):
-            row[0] = row[0][:160]  # torch's RNG kernel has a 4 KB mangled name
+            row[0] = row[0][:200]  # torch's RNG kernel has a 4 KB mangled name
             w.writerow(row)
 
-res = {}
-for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-    p = find(f"{sub}/**/*counter_collection.csv")
-    if not p:
-        continue
-    vals = []
-    with open(p) as f:
-        for row in csv.DictReader(f):
-            if "k_resample_periodic" in row.get("Kernel_Name", "") and row.get("Counter_Name") == name:
-                vals.append(float(row["Counter_Value"]))
-    if vals:
-        res[name] = {"dispatches": len(vals), "mean_KB_per_dispatch": sum(vals) / len(vals),
-                     "min": min(vals), "max": max(vals)}
-if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
-    res["note"] = ("separate --pmc passes of `python3 bench.py --steps 200 --warmup 30 --cpu-seconds 0` "
-                   "(kernel k_resample_periodic). Per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE "
-                   "under-reports wide coalesced reads by exactly 2x on gfx950, WRITE_SIZE is exact; corrected "
-                   "HBM traffic per launch = 2*FETCH + WRITE.")
-    res["corrected_bytes_per_launch"] = (2 * res["FETCH_SIZE"]["mean_KB_per_dispatch"]
-                                         + res["WRITE_SIZE"]["mean_KB_per_dispatch"]) * 1024
+STAGES = {"k_resample_periodic": ["k_resample_periodic"], "k_sos": ["k_sos_tiled", "k_sos_scan", "k_sos_onepass"],
+          "k_pointwise": ["k_pointwise"]}
+res = {"note": ("separate --pmc passes of `python3 bench.py --workload W --no-secondary --steps 100 --warmup 10 "
+                "--cpu-seconds 0`.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and "
+                "WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950, WRITE_SIZE is "
+                "exact; corrected HBM traffic = 2*FETCH + WRITE.  Per execute = summed over the stage's kernels / number of "
+                "executes."), "stages": {}}
+for wl in ("ns", "config3"):
+    per = {}
+    for name, sub in (("FETCH_SIZE", f"fetch_{wl}"), ("WRITE_SIZE", f"write_{wl}")):
+        p = find(f"{sub}/**/*counter_collection.csv")
+        if not p:
+            continue
+        with open(p) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != name:
+                    continue
+                kn = row.get("Kernel_Name", "")
+                for stage, keys in STAGES.items():
+                    if any(k in kn for k in keys):
+                        d = per.setdefault(stage, {}).setdefault(name, {})
+                        short = kn.split("(")[0][-90:]
+                        e = d.setdefault(short, [0, 0.0])
+                        e[0] += 1
+                        e[1] += float(row["Counter_Value"])
+    for stage, d in per.items():
+        if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
+        nexec = min(v[0] for v in d["FETCH_SIZE"].values())  # the kernel launched once per execute
+        fetch_kb = sum(v[1] for v in d["FETCH_SIZE"].values()) / nexec
+        write_kb = sum(v[1] for v in d["WRITE_SIZE"].values()) / nexec
+        res["stages"][f"{wl}:{stage}"] = {
+            "executes": nexec, "FETCH_SIZE_KB_per_execute": fetch_kb, "WRITE_SIZE_KB_per_execute": write_kb,
+            "corrected_bytes_per_execute": (2 * fetch_kb + write_kb) * 1024,
+            "kernels": {k: {"dispatches": v[0], "FETCH_KB_mean": v[1] / v[0],
+                            "WRITE_KB_mean": d["WRITE_SIZE"].get(k, [1, 0.0])[1] / max(1, d["WRITE_SIZE"].get(k, [1, 0.0])[0])}
+                        for k, v in d["FETCH_SIZE"].items()}}
 with open(os.path.join(dst, "bench_pmc_hbm.json"), "w") as f:
     json.dump(res, f, indent=1)
-print(json.dumps(res)[:600])
+print(json.dumps(res)[:1500])
