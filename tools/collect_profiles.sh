@@ -16,5 +16,5 @@ for W in ns config3; do
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$W -o bench --output-format csv -- python3 bench.py $ARGS > $OUT/write_$W.log 2>&1
 done
 python3 tools/summarize_profiles.py $OUT $SUM
-tail -1 $OUT/trace.log > $SUM/bench_default.json
+grep "^{" $OUT/trace.log > $SUM/bench_default.json
 ls -la $SUM
