@@ -131,12 +131,21 @@ struct OSig {
 static int g_blocksize_override; /* 0 = use the node's */
 static int g_phase_accumulate = 1;
 static int g_position_mode = -1; /* -1: environment decides; 0: accumulator; 1: closed form */
+static int g_intended; /* 0: the reference's behaviour, quirks included; 1: intended semantics */
 
 /* Resampler positions of the arbitrary-rate kernel.  0 (default) = DSP.jl's floating-point
    phase accumulator, the reference's algorithm; 1 = closed form (exact rational positions for
    integer frame rates), kept for divergence measurements; -1 = SO_ORACLE_EXACT_POSITIONS=1 in
    the environment selects the closed form. */
 void so_oracle_set_positions(int mode) { g_position_mode = mode; }
+
+/* 0 (default) = the reference as it behaves, including quirk C-7: a FilteredSignal's end test
+   compares a buffer-local index with the global length (src/filters.jl:224-227), so a filtered or
+   resampled child longer than one block never reports its end and a parent Append / Pad / Mix /
+   After keeps pulling the filter's zero-input tail.  1 = intended semantics: the child ends after
+   nframes(x) frames (what the documented meaning of those operators implies, and what the
+   engine implements).  Used by the multi-rate fuzz tests. */
+void so_oracle_set_semantics(int mode) { g_intended = mode; }
 
 static double sinpi_(double x) {
     /* Julia sinpi: exact argument reduction, src/functions.jl:57-60 use it */
@@ -477,6 +486,7 @@ struct OState {
     int64_t len;    /* nframes(block) */
     int64_t offset; /* meaning per kind */
     OState** kids;
+    int64_t gout; /* FILT/RESAMPLE: global index of the current block's first frame */
     /* UNTIL */
     int64_t cut_n;
     /* PAD */
@@ -815,6 +825,11 @@ static int nextblock(OState* st, int64_t maxlen, int skip) {
         }
         int64_t last_output_index = st->last_output_index + st->len;
         if (total == last_output_index) return 0; /* :225-227 (quirk C-7 kept) */
+        st->gout += st->len; /* frames handed out so far */
+        if (g_intended) {
+            if (st->gout >= total) return 0;
+            maxlen = imin(maxlen, total - st->gout);
+        }
         if (last_output_index < st->available_output) { /* leftover :230-235 */
             st->len = imin(maxlen, st->available_output - last_output_index);
             st->last_output_index = last_output_index;

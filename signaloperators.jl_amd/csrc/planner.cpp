@@ -1140,6 +1140,20 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
     return (int)pw.size() - 1;
 }
 
+// The C-ABI entry points run on the plan's device and leave the caller's current device as they
+// found it (a single process may drive several GPUs).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // small dense matrices for the SOS state propagation
 using Mat = std::vector<double>;
@@ -2221,37 +2235,23 @@ void Plan::finalize() {
             b.bytes = (size_t)b.pitch * (size_t)std::max(b.nch, 1) * dsize(b.dtype);
         }
     }
-    // host array leaves get a device copy
-    for (size_t i = 0; i < leaves.size(); ++i) {
-        int an = leaf_array_node[i];
-        if (an < 0) continue;
+    // host array leaves get a device copy (the leaves of pointwise programs, the carriers of fused
+    // resampler sources and the direct sources of stages go through the same validation)
+    auto stage_host_array = [&](int an) {
+        if (an < 0) return;
         const so_node_t& nd = nodes[an].nd;
-        if (nd.i0) continue;  // device-resident
-        if (!array_buf.count(an)) {
-            if (nd.s0 < 0 || nd.s1 < 0) fail(SO_ERR_UNSUPPORTED, "negative strides on host arrays are not supported");
-            size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
-            int b = raw_buf(extent * dsize(nd.dtype));
-            array_buf[an] = b;
-            host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
-        }
+        if (nd.i0 || array_buf.count(an)) return;  // device-resident, or already staged
+        if (nd.s0 < 0 || nd.s1 < 0) fail(SO_ERR_UNSUPPORTED, "negative strides on host arrays are not supported");
+        const size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
+        const int b = raw_buf(extent * dsize(nd.dtype));
+        array_buf[an] = b;
+        host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
+    };
+    for (size_t i = 0; i < leaves.size(); ++i) stage_host_array(leaf_array_node[i]);
+    for (auto& S : stages) {
+        for (auto& c : S.carriers) stage_host_array(c.array_node);
+        stage_host_array(S.in_array_node);
     }
-    for (auto& S : stages)
-        for (auto& c : S.carriers)
-            if (c.array_node >= 0 && !nodes[c.array_node].nd.i0 && !array_buf.count(c.array_node)) {
-                const so_node_t& nd = nodes[c.array_node].nd;
-                size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
-                int b = raw_buf(extent * dsize(nd.dtype));
-                array_buf[c.array_node] = b;
-                host_leaves.push_back(HostLeaf{c.array_node, nd.p0, extent * dsize(nd.dtype), b});
-            }
-    for (auto& S : stages)
-        if (S.in_array_node >= 0 && !nodes[S.in_array_node].nd.i0 && !array_buf.count(S.in_array_node)) {
-            const so_node_t& nd = nodes[S.in_array_node].nd;
-            size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
-            int b = raw_buf(extent * dsize(nd.dtype));
-            array_buf[S.in_array_node] = b;
-            host_leaves.push_back(HostLeaf{S.in_array_node, nd.p0, extent * dsize(nd.dtype), b});
-        }
     if (!out.is_device && out.nframes > 0) {
         Buf b;
         b.frames = out.nframes;
@@ -2474,6 +2474,14 @@ void Plan::release() {
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
                   int32_t device, int& status, std::string& err) {
     std::unique_ptr<Plan> P(new Plan());
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    struct Restore {
+        int d;
+        ~Restore() {
+            if (d >= 0) (void)hipSetDevice(d);
+        }
+    } restore{prev_device};
     try {
         if (!nodes || n_nodes < 1 || root < 0 || root >= n_nodes || !out)
             fail(SO_ERR_INVALID, "so_plan_create: bad arguments");
@@ -2830,6 +2838,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
 // operations per execute) are host-bound, so from the second execute with the same result
 // pointer on, the whole multi-stream launch sequence is replayed from a captured HIP graph.
 int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
+    DeviceGuard guard(P->device);
     const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
                           !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
     if (!eligible) return plan_execute_direct(P, outp, stream, err);
@@ -2891,6 +2900,7 @@ int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& e
         err = "so_plan_set_array: not an ARRAY node";
         return SO_ERR_INVALID;
     }
+    DeviceGuard guard(P->device);
     P->array_ptr[node_index] = data;
     P->array_epoch++;  // invalidates a captured launch graph
     if (P->nodes[node_index].nd.i0) {  // device leaf: patch the leaf table
@@ -2947,8 +2957,10 @@ int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
 }
 void plan_destroy(Plan* P) {
     if (!P) return;
-    (void)hipSetDevice(P->device);
-    P->release();
+    {
+        DeviceGuard guard(P->device);
+        P->release();
+    }
     delete P;
 }
 

@@ -25,6 +25,8 @@ def oracle_lib():
         L.so_oracle_nframes.restype = C.c_int64
         L.so_oracle_nframes.argtypes = [C.POINTER(K.so_node_t), C.c_int32, C.c_int32]
         L.so_oracle_last_error.restype = C.c_char_p
+        L.so_oracle_set_semantics.restype = None
+        L.so_oracle_set_semantics.argtypes = [C.c_int]
         L.so_oracle_set_positions.restype = None
         L.so_oracle_set_positions.argtypes = [C.c_int]
         _lib = L
@@ -44,6 +46,20 @@ class oracle_positions:
 
     def __exit__(self, *exc):
         oracle_lib().so_oracle_set_positions(-1)
+
+
+class oracle_semantics:
+    """with oracle_semantics("intended"): ... -- a filtered / resampled child ends after nframes(x)
+    frames instead of never (reference quirk C-7, see oracle/sigops_oracle.c so_oracle_set_semantics)"""
+
+    def __init__(self, mode):
+        self.mode = {"reference": 0, "intended": 1}[mode]
+
+    def __enter__(self):
+        oracle_lib().so_oracle_set_semantics(self.mode)
+
+    def __exit__(self, *exc):
+        oracle_lib().so_oracle_set_semantics(0)
 
 
 def oracle_sink_lowered(lw, nframes, nch, dtype, blocksize=0):

@@ -189,3 +189,67 @@ def test_random_operator_trees(seed):
                 assert relerr(got, want) <= tol, repr(tree)[:400]
             else:
                 assert np.array_equal(np.isfinite(got), np.isfinite(want)), repr(tree)[:400]
+
+
+def _multirate_tree(rng, nch, info):
+    """Multi-block (> 4096 frames) filtered / resampled children directly under Append / Pad / Mix /
+    After / Ramp -- the shapes where the reference never leaves a filtered child (quirk C-7) and the
+    engine implements the documented meaning instead."""
+    rates = [4000.0, 6000.0, 8000.0, 12000.0]
+
+    def leaf(fs, lo=3000, hi=12000):
+        n = int(rng.integers(lo, hi))
+        dt = np.float64 if rng.random() < 0.8 else np.float32
+        info["f32"] = info.get("f32", False) or dt == np.float32
+        return so.Signal(np.asfortranarray(rng.standard_normal((n, nch)).astype(dt)), fs * so.Hz)
+
+    def stateful(fs):
+        """a child that ends in a stateful stage, at rate fs"""
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            fi = float(rng.choice([r for r in rates if r != fs]))
+            return leaf(fi) | so.ToFramerate(fs * so.Hz)
+        if k == 1:
+            return leaf(fs) | so.Filt(so.Lowpass, float(rng.uniform(0.05, 0.4)) * fs * so.Hz)
+        fi = float(rng.choice([r for r in rates if r != fs]))
+        return leaf(fi) | so.Filt(so.Highpass, 0.1 * fi * so.Hz) | so.ToFramerate(fs * so.Hz)
+
+    fs = float(rng.choice(rates))
+    x = stateful(fs)
+    n = so.nframes(x)
+    op = int(rng.integers(0, 7))
+    if op == 0:
+        return so.Append(x, stateful(fs))
+    if op == 1:
+        return so.Append(x, leaf(fs, 500, 6000), stateful(fs))
+    if op == 2:
+        pad = [so.zero, so.one, so.lastframe, 2.5][int(rng.integers(0, 4))]
+        return so.Pad(x, pad) | so.Until((n + int(rng.integers(100, 6000))) * so.frames)
+    if op == 3:
+        return so.Mix(x, stateful(fs))  # different lengths: the shorter one is padded
+    if op == 4:
+        return x | so.After(int(rng.integers(1, n // 2)) * so.frames) | so.Ramp(50 * so.frames)
+    if op == 5:
+        app = so.Append(x, stateful(fs))
+        return (so.Amplify(app, so.Signal(so.sin, ω=3 * so.Hz)) | so.Until(so.nframes(app) * so.frames)
+                | so.ToFramerate(float(rng.choice(rates)) * so.Hz))
+    return so.Append(stateful(fs) | so.Normpower, x)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_multirate_multiblock_trees(seed):
+    """automated parity for the multi-rate, multi-block shapes of divergence C-7, against
+    the oracle's intended-semantics mode (a filtered child ends after nframes(x) frames)."""
+    from oracle_bridge import oracle_semantics
+
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(10):
+        nch = int(rng.choice([1, 2, 3]))
+        info = {}
+        tree = _multirate_tree(rng, nch, info)
+        with oracle_semantics("intended"):
+            want = oracle_sink(tree)
+        got = so.sink(tree)[0]
+        assert got.shape == want.shape and got.dtype == want.dtype, repr(tree)[:300]
+        tol = 2e-6 if (info.get("f32") or got.dtype == np.float32) else 1e-8
+        assert relerr(got, want) <= tol, repr(tree)[:400]
