@@ -11,7 +11,7 @@ from sigops_amd import signals as S
 from sigops_amd.lowering import lower, _DT
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libsigops_oracle.so")
+ORACLE_SO = os.environ.get("SIGOPS_ORACLE_SO") or os.path.join(ROOT, "oracle", "libsigops_oracle.so")
 _lib = None
 
 
