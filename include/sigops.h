@@ -121,7 +121,10 @@ typedef enum so_padkind {
 typedef enum so_rskind {
     SO_RS_RATIONAL = 0, /* ratio l0//l1 exact (FIRInterpolator/FIRDecimator/FIRRational);
                            Nphi = l0                                                   */
-    SO_RS_ARBITRARY = 1 /* ratio d0::Float64 (FIRArbitrary), Nphi = i1 (32)            */
+    SO_RS_ARBITRARY = 1, /* ratio d0::Float64 (FIRArbitrary), Nphi = i1 (32)           */
+    SO_RS_FIR = 2       /* Filt(x,h) with FIR coefficients h (reference src/filters.jl:96-97
+                           RawFilterFn -> DF2TFilter(PolynomialRatio(h,[1]))): ratio 1, no
+                           delay compensation, y[n] = sum_k h[k] x[n-k]; p0 = h, i2 = len  */
 } so_rskind_t;
 
 /*
@@ -279,6 +282,17 @@ typedef enum so_filt_method {
 int32_t so_design_iir(int32_t type, double f1, double f2, double fs, int32_t method,
                       int32_t order, double ripple_db, double* sos, int32_t sos_capacity,
                       int32_t* nsections, double* gain);
+
+/* digitalfilter(Type(f1[,f2];fs=fs), method) as the ZeroPoleGain object itself: zeros / poles as
+ * interleaved (re,im) pairs, `capacity` complex numbers each.  With so_zpk_to_sos this is the raw
+ * filter object path `Filt(x, digitalfilter(...))` of the reference (src/filters.jl:89-97;
+ * test/runtests.jl:365-368 expects it bit-equal to the named form). */
+int32_t so_design_iir_zpk(int32_t type, double f1, double f2, double fs, int32_t method, int32_t order,
+                          double ripple_db, double* z, int32_t* nz, double* p, int32_t* np, int32_t capacity,
+                          double* k);
+/* DF2TFilter(::ZeroPoleGain) -> SecondOrderSections + gain (resolve_filter, src/filters.jl:94). */
+int32_t so_zpk_to_sos(const double* z, int32_t nz, const double* p, int32_t np, double k, double* sos,
+                      int32_t sos_capacity, int32_t* nsections, double* gain);
 
 /* resample_filter(ratio): rational (num/den, Nphi=num) or arbitrary (rate, nphi).
  * Call with h==NULL to get the length in *hlen. */

@@ -337,6 +337,7 @@ static void fir_init(Fir* f, const so_node_t* nd, double fs_in) {
     } else {
         f->L = nd->l0;
         f->M = nd->l1;
+        if (nd->i0 == SO_RS_FIR) f->L = f->M = 1; /* Filt(x,h): DF2TFilter(PolynomialRatio(h,[1])) */
         f->nphi = (int)f->L;
     }
     f->taps = (f->hlen + f->nphi - 1) / f->nphi; /* taps2pfb: ceil(hLen/Nϕ) */
@@ -353,7 +354,7 @@ static void fir_init(Fir* f, const so_node_t* nd, double fs_in) {
             f->dpfb[(size_t)p * f->taps + k] = dv;
         }
     /* timedelay + setphase!: output 0 sits at fine position c0=(hLen-1)/2 */
-    f->c0 = (double)(f->hlen - 1) / 2.0;
+    f->c0 = nd->i0 == SO_RS_FIR ? 0.0 : (double)(f->hlen - 1) / 2.0; /* a plain FIR is causal */
     f->hist = (double*)xalloc(sizeof(double) * (size_t)(f->taps + 1));
     if (f->arbitrary) {
         double tau = (double)(f->hlen - 1) / 2.0 / (double)f->nphi;

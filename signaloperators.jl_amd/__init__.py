@@ -9,7 +9,8 @@ from .signals import (  # noqa: F401
     Filt, Normpower, Lowpass, Highpass, Bandpass, Bandstop, Butterworth, Chebyshev1,
     ToFramerate, ToChannels, ToEltype, Format, Uniform,
     ArraySig, NumberSig, FuncSig, CutApply, PaddedSignal, AppendSignals, RampSignal,
-    MapSignal, FilteredSignal, NormedSignal, FilterFn, RawFilterFn, ResamplerFn,
+    MapSignal, FilteredSignal, NormedSignal, FilterFn, RawFilterFn, RawFirFn, ResamplerFn, digitalfilter, ZeroPoleGain, SecondOrderSections, Biquad,
+    PolynomialRatio,
 )
 from numpy import sin, cos  # noqa: F401  (Signal(sin), Signal(cos))
 from .engine import sink, sink_into, Plan, Array, process_sink_params, _eager  # noqa: F401

@@ -16,7 +16,7 @@ RAMPFN = {"sinramp": 0, "identity": 1}
 MAPFN = {"add": 0, "mul": 1, "sub": 2, "div": 3, "tuplecat": 4, "getchan": 5, "as1channel": 6,
          "asnchannels": 7, "toeltype": 8, "reversech": 9}
 PAD = {"value": 0, "vector": 1, "zero": 2, "one": 3, "lastframe": 4, "cycle": 5, "mirror": 6}
-RS_RATIONAL, RS_ARBITRARY = 0, 1
+RS_RATIONAL, RS_ARBITRARY, RS_FIR = 0, 1, 2
 FILT = {"lowpass": 0, "highpass": 1, "bandpass": 2, "bandstop": 3}
 METHOD = {"butterworth": 0, "chebyshev1": 1}
 
@@ -54,7 +54,7 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
-           "so_resample_positions", "so_plan_step_info"]
+           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos"]
 
 _lib = None
 
@@ -113,6 +113,13 @@ def lib():
     L.so_design_resample_arbitrary.restype = C.c_int32
     L.so_design_resample_arbitrary.argtypes = [C.c_double, C.c_int32, C.POINTER(C.c_double),
                                                C.c_int32, C.POINTER(C.c_int32)]
+    L.so_design_iir_zpk.restype = C.c_int32
+    L.so_design_iir_zpk.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_double)]
+    L.so_zpk_to_sos.restype = C.c_int32
+    L.so_zpk_to_sos.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_double,
+                                C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.so_plan_step_info.restype = C.c_int32
     L.so_plan_step_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(so_step_info_t)]
     L.so_resample_positions.restype = C.c_int32

@@ -103,6 +103,40 @@ int32_t so_design_iir(int32_t type, double f1, double f2, double fs, int32_t met
     return SO_OK;
 }
 
+int32_t so_design_iir_zpk(int32_t type, double f1, double f2, double fs, int32_t method, int32_t order,
+                          double ripple_db, double* z, int32_t* nz, double* p, int32_t* np, int32_t capacity,
+                          double* k) {
+    std::vector<double> zz, pp;
+    double kk = 1.0;
+    std::string err;
+    int st = so::design_iir_zpk(type, f1, f2, fs, method, order, ripple_db, zz, pp, kk, err);
+    if (st != SO_OK) return set_err(st, err);
+    if (!z || !p || !nz || !np || !k || (int)zz.size() > 2 * capacity || (int)pp.size() > 2 * capacity)
+        return set_err(SO_ERR_INVALID, "so_design_iir_zpk: output buffer too small");
+    std::memcpy(z, zz.data(), zz.size() * sizeof(double));
+    std::memcpy(p, pp.data(), pp.size() * sizeof(double));
+    *nz = (int32_t)(zz.size() / 2);
+    *np = (int32_t)(pp.size() / 2);
+    *k = kk;
+    return SO_OK;
+}
+
+int32_t so_zpk_to_sos(const double* z, int32_t nz, const double* p, int32_t np, double k, double* sos,
+                      int32_t sos_capacity, int32_t* nsections, double* gain) {
+    std::vector<double> s;
+    double g = 1.0;
+    std::string err;
+    if ((nz > 0 && !z) || (np > 0 && !p)) return set_err(SO_ERR_INVALID, "so_zpk_to_sos: null roots");
+    int st = so::zpk_to_sos(z, nz, p, np, k, s, g, err);
+    if (st != SO_OK) return set_err(st, err);
+    if (!sos || !nsections || !gain || (int)s.size() > sos_capacity)
+        return set_err(SO_ERR_INVALID, "so_zpk_to_sos: output buffer too small");
+    std::memcpy(sos, s.data(), s.size() * sizeof(double));
+    *nsections = (int32_t)(s.size() / 6);
+    *gain = g;
+    return SO_OK;
+}
+
 static int32_t copy_taps(const std::vector<double>& h, double* out, int32_t capacity, int32_t* hlen) {
     if (!hlen) return set_err(SO_ERR_INVALID, "null hlen");
     *hlen = (int32_t)h.size();

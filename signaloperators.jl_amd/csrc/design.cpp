@@ -251,8 +251,8 @@ static void zpk2sos(const ZPK& f, std::vector<double>& sos, double& gain) {
     gain = f.k;
 }
 
-int design_iir(int type, double f1, double f2, double fs, int method, int order, double ripple,
-               std::vector<double>& sos, double& gain, std::string& err) {
+static int design_zpk(int type, double f1, double f2, double fs, int method, int order, double ripple, ZPK& d,
+                      std::string& err) {
     if (order < 1 || order > 32) {
         err = "filter order must be in 1..32";
         return SO_ERR_INVALID;
@@ -284,7 +284,44 @@ int design_iir(int type, double f1, double f2, double fs, int method, int order,
         break;
     default: err = "unknown filter type"; return SO_ERR_INVALID;
     }
-    ZPK d = bilinear(a);
+    d = bilinear(a);
+    return SO_OK;
+}
+
+int design_iir(int type, double f1, double f2, double fs, int method, int order, double ripple,
+               std::vector<double>& sos, double& gain, std::string& err) {
+    ZPK d;
+    int st = design_zpk(type, f1, f2, fs, method, order, ripple, d, err);
+    if (st != SO_OK) return st;
+    zpk2sos(d, sos, gain);
+    return SO_OK;
+}
+
+// digitalfilter(...) as the ZeroPoleGain object itself (interleaved re,im pairs)
+int design_iir_zpk(int type, double f1, double f2, double fs, int method, int order, double ripple,
+                   std::vector<double>& z, std::vector<double>& p, double& k, std::string& err) {
+    ZPK d;
+    int st = design_zpk(type, f1, f2, fs, method, order, ripple, d, err);
+    if (st != SO_OK) return st;
+    z.clear();
+    p.clear();
+    for (auto& c : d.z) z.insert(z.end(), {c.real(), c.imag()});
+    for (auto& c : d.p) p.insert(p.end(), {c.real(), c.imag()});
+    k = d.k;
+    return SO_OK;
+}
+
+// DF2TFilter(::ZeroPoleGain) -> SecondOrderSections (reference src/filters.jl:94 resolve_filter)
+int zpk_to_sos(const double* z, int nz, const double* p, int np, double k, std::vector<double>& sos, double& gain,
+               std::string& err) {
+    if (nz < 0 || np < 0 || nz > np || np > 64) {
+        err = "ZeroPoleGain: need 0 <= zeros <= poles <= 64";
+        return SO_ERR_INVALID;
+    }
+    ZPK d;
+    for (int i = 0; i < nz; ++i) d.z.push_back(cd(z[2 * i], z[2 * i + 1]));
+    for (int i = 0; i < np; ++i) d.p.push_back(cd(p[2 * i], p[2 * i + 1]));
+    d.k = k;
     zpk2sos(d, sos, gain);
     return SO_OK;
 }

@@ -10,6 +10,10 @@ namespace so {
 
 int design_iir(int type, double f1, double f2, double fs, int method, int order, double ripple,
                std::vector<double>& sos, double& gain, std::string& err);
+int design_iir_zpk(int type, double f1, double f2, double fs, int method, int order, double ripple,
+                   std::vector<double>& z, std::vector<double>& p, double& k, std::string& err);
+int zpk_to_sos(const double* z, int nz, const double* p, int np, double k, std::vector<double>& sos, double& gain,
+               std::string& err);
 int design_resample_rational(int64_t num, int64_t den, std::vector<double>& h, std::string& err);
 int design_resample_arbitrary(double rate, int nphi, std::vector<double>& h, std::string& err);
 

@@ -485,7 +485,7 @@ void Plan::build_nodes(const so_node_t* in, int n) {
             N.nch = c.nch;
             N.dtype = float_of(c.dtype);
             if (!nd.p0 || nd.i2 < 1) fail(SO_ERR_INVALID, "resampler without taps");
-            if ((nd.i2 & 1) == 0) fail(SO_ERR_UNSUPPORTED, "resample_filter taps must have odd length");
+            if (nd.i0 != SO_RS_FIR && (nd.i2 & 1) == 0) fail(SO_ERR_UNSUPPORTED, "resample_filter taps must have odd length");
             break;
         }
         case SO_NODE_NORMPOWER: {
@@ -1446,10 +1446,15 @@ void Plan::process_stage(int sid) {
         if (g.nphi < 1) fail(SO_ERR_INVALID, "resampler: bad phase count");
         g.L = nd.l0;
         g.M = nd.l1;
+        const bool plain_fir = nd.i0 == SO_RS_FIR;  // Filt(x,h): ratio 1, causal, no delay compensation
+        if (plain_fir) {
+            g.nphi = 1;
+            g.L = g.M = 1;
+        }
         if (!g.arbitrary && (g.L < 1 || g.M < 1)) fail(SO_ERR_INVALID, "resampler: bad ratio");
         g.delta = g.arbitrary ? (double)g.nphi / nd.d0 : 0.0;
-        g.c0 = (double)(hlen - 1) / 2.0;
-        g.c0i = (hlen - 1) / 2;
+        g.c0 = plain_fir ? 0.0 : (double)(hlen - 1) / 2.0;
+        g.c0i = plain_fir ? 0 : (hlen - 1) / 2;
         g.taps = (hlen + g.nphi - 1) / g.nphi;
         g.nch = N.nch;
         g.m0 = 0;

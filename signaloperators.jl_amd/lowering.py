@@ -323,6 +323,11 @@ def lower(x, nframes_out=None, rng=None):
                     r.update(i0=K.RS_RATIONAL, i1=int(ratio[0]), l0=int(ratio[0]), l1=int(ratio[1]))
                 else:
                     r.update(i0=K.RS_ARBITRARY, i1=32, d0=float(ratio))
+            elif isinstance(s.fn, S.RawFirFn):
+                h = s.fn.h
+                lw.keep.append(h)
+                r = common(s, K.NODE_RESAMPLE)
+                r.update(p0=h.ctypes.data, i0=K.RS_FIR, i1=1, i2=int(h.size), i3=s.blocksize, l0=1, l1=1, children=(c,))
             else:
                 if s.fs is None:
                     S.error("Unknown frame rate: Filt needs a frame rate before `sink`")

@@ -403,6 +403,13 @@ class RawFilterFn:  # src/filters.jl:89-92
         self.gain = float(gain)
 
 
+class RawFirFn:
+    """Filt(x, h) with FIR coefficients h: DF2TFilter(PolynomialRatio(h, [1])), y[n] = sum_k h[k] x[n-k]"""
+
+    def __init__(self, h):
+        self.h = np.ascontiguousarray(np.asarray(h, dtype=np.float64).ravel())
+
+
 class ResamplerFn:  # src/util.jl:12-15
     def __init__(self, ratio, fs):
         self.ratio = ratio  # (num, den) tuple or float
@@ -932,10 +939,114 @@ def FadeTo(*args):
 
 # --------------------------------------------------------------------------
 # filters: src/filters.jl:14-20,54-66,96-97,323-326
-class Lowpass: pass  # noqa: E701
-class Highpass: pass  # noqa: E701
-class Bandpass: pass  # noqa: E701
-class Bandstop: pass  # noqa: E701
+class _Response:
+    """DSP.jl response types.  The CLASS is the tag of `Filt(Lowpass, 4kHz)`; an INSTANCE,
+    `Highpass(8, fs=100)`, is DSP.jl's response object for `digitalfilter` (test/runtests.jl:365-367)."""
+
+    def __init__(self, *bounds, fs=None):
+        self.bounds = tuple(U.inHz(b) for b in bounds)
+        self.fs = None if fs is None else float(U.inHz(fs))
+
+
+class Lowpass(_Response): pass  # noqa: E701
+class Highpass(_Response): pass  # noqa: E701
+class Bandpass(_Response): pass  # noqa: E701
+class Bandstop(_Response): pass  # noqa: E701
+
+
+class ZeroPoleGain:
+    """DSP.jl ZeroPoleGain (what `digitalfilter` returns)"""
+
+    def __init__(self, z, p, k):
+        self.z = np.asarray(z, dtype=np.complex128).ravel()
+        self.p = np.asarray(p, dtype=np.complex128).ravel()
+        self.k = float(k)
+
+
+class SecondOrderSections:
+    """DSP.jl SecondOrderSections: rows [b0 b1 b2 1 a1 a2] + gain"""
+
+    def __init__(self, sos, gain=1.0):
+        self.sos = np.asarray(sos, dtype=np.float64).reshape(-1, 6)
+        self.gain = float(gain)
+
+
+class Biquad:
+    def __init__(self, b0, b1, b2, a1, a2):
+        self.row = [float(b0), float(b1), float(b2), 1.0, float(a1), float(a2)]
+
+
+class PolynomialRatio:
+    """DSP.jl PolynomialRatio(b, a); lowered for FIR (a == [1]) and for orders <= 2 (one section)"""
+
+    def __init__(self, b, a):
+        self.b = np.asarray(b, dtype=np.float64).ravel()
+        self.a = np.asarray(a, dtype=np.float64).ravel()
+
+
+def digitalfilter(response, method):
+    """digitalfilter(Highpass(8, fs=fs), Chebyshev1(5, 1)) -> ZeroPoleGain, through the library's
+    design entry point (the same code the named form `Filt(Highpass, 8Hz, ...)` uses)"""
+    from . import _capi as K
+    import ctypes as C
+
+    if not isinstance(response, _Response) or response.fs is None:
+        error("digitalfilter needs a response object with a frame rate, e.g. Highpass(8, fs=100)")
+    order = method[1]
+    ripple = method[2] if len(method) > 2 else 0.0
+    cap = 2 * order + 2
+    z = (C.c_double * (2 * cap))()
+    p = (C.c_double * (2 * cap))()
+    nz, npl, k = C.c_int32(0), C.c_int32(0), C.c_double(0)
+    b = response.bounds
+    st = K.lib().so_design_iir_zpk(K.FILT[_DESIGNS[type(response)]], b[0], b[1] if len(b) > 1 else 0.0, response.fs,
+                                   K.METHOD[method[0]], order, ripple, z, C.byref(nz), p, C.byref(npl), cap, C.byref(k))
+    if st != 0:
+        error(K.last_error())
+    zz = np.array(z[: 2 * nz.value]).view(np.complex128)
+    pp = np.array(p[: 2 * npl.value]).view(np.complex128)
+    return ZeroPoleGain(zz, pp, k.value)
+
+
+def _raw_filter(h):
+    """RawFilterFn(h) (reference src/filters.jl:89-97): a DSP.jl filter object -> what the engine
+    lowers: SOS rows + gain (IIR; resolve_filter = DF2TFilter(h)) or FIR coefficients"""
+    from . import _capi as K
+    import ctypes as C
+
+    if isinstance(h, (RawFilterFn, RawFirFn)):
+        return h
+    if isinstance(h, SecondOrderSections):
+        return RawFilterFn(h.sos, h.gain)
+    if isinstance(h, Biquad):
+        return RawFilterFn([h.row], 1.0)
+    if isinstance(h, ZeroPoleGain):
+        z = np.ascontiguousarray(h.z).view(np.float64)
+        p = np.ascontiguousarray(h.p).view(np.float64)
+        cap = 6 * (len(h.p) + 2)
+        sos = (C.c_double * cap)()
+        nsec, gain = C.c_int32(0), C.c_double(0)
+        st = K.lib().so_zpk_to_sos(z.ctypes.data_as(C.POINTER(C.c_double)), len(h.z),
+                                   p.ctypes.data_as(C.POINTER(C.c_double)), len(h.p), h.k, sos, cap,
+                                   C.byref(nsec), C.byref(gain))
+        if st != 0:
+            error(K.last_error())
+        return RawFilterFn(np.array(sos[: 6 * nsec.value]).reshape(-1, 6), gain.value)
+    if isinstance(h, PolynomialRatio):
+        a0 = h.a[0]
+        b, a = h.b / a0, h.a / a0
+        if len(a) == 1:
+            return RawFirFn(b)
+        if len(a) <= 3 and len(b) <= 3:
+            b = np.concatenate([b, np.zeros(3 - len(b))])
+            a = np.concatenate([a, np.zeros(3 - len(a))])
+            return RawFilterFn([[b[0], b[1], b[2], 1.0, a[1], a[2]]], 1.0)
+        error("PolynomialRatio filters of order > 2 are not lowered by the HIP engine: pass SecondOrderSections "
+              "or ZeroPoleGain")
+    arr = np.asarray(h, dtype=np.float64)
+    if arr.ndim == 1 and arr.size >= 1:  # FIR coefficient vector
+        return RawFirFn(arr)
+    error(f"Filt: unsupported filter object {h!r}")
 
 
 def Butterworth(order):
@@ -955,17 +1066,34 @@ def _nyquist_check(x, hz):
 _DESIGNS = {Lowpass: "lowpass", Highpass: "highpass", Bandpass: "bandpass", Bandstop: "bandstop"}
 
 
+def _is_signal_like(v):
+    if isinstance(v, (ZeroPoleGain, SecondOrderSections, Biquad, PolynomialRatio, RawFilterFn, RawFirFn, FilterFn)):
+        return False
+    if isinstance(v, AbstractSignal) or _is_torch(v):
+        return True
+    if isinstance(v, tuple):
+        return True
+    if isinstance(v, np.ndarray):
+        return v.ndim == 2  # a 1-D vector on its own is a coefficient vector: Filt(h)
+    return False
+
+
 def Filt(*args, blocksize=default_blocksize, order=5, method=None, sos=None, gain=1.0):
     if args and isinstance(args[0], type) and args[0] in _DESIGNS:  # curried Filt(Type,bounds...)
         a = args
         return Curried(lambda x: Filt(x, *a, blocksize=blocksize, order=order, method=method))
     if not args and sos is not None:
         return Curried(lambda x: Filt(x, blocksize=blocksize, sos=sos, gain=gain))
+    if len(args) == 1 and not _is_signal_like(args[0]):  # curried Filt(h)
+        h = args[0]
+        return Curried(lambda x: Filt(x, h, blocksize=blocksize))
     x = _assignal(args[0])
     if sos is not None:  # Filt(x,h): raw DSP.jl filter object -> SOS rows
         return FilteredSignal(x, RawFilterFn(sos, gain), blocksize, x.fs)
-    if len(args) >= 2 and isinstance(args[1], (FilterFn, RawFilterFn)):
+    if len(args) == 2 and isinstance(args[1], FilterFn):
         return FilteredSignal(x, args[1], blocksize, x.fs)
+    if len(args) == 2:  # Filt(x,h): RawFilterFn(h), reference src/filters.jl:96-97
+        return FilteredSignal(x, _raw_filter(args[1]), blocksize, x.fs)
     if len(args) < 3 or not (isinstance(args[1], type) and args[1] in _DESIGNS):
         error("Filt(x, Type, bounds...) expected")
     if method is None:
