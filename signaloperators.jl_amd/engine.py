@@ -43,13 +43,33 @@ def _is_datacut(x):
     return isinstance(x, S.CutApply) and x.evaltrait == "data" and _is_datacut(x.signal)
 
 
-def _root_is_plain_array(x):
+def _root(x):
+    """root(x) with mergeroot's priorities (reference src/sink.jl:33-50, src/mapsignal.jl:60,
+    src/appending.jl:17, src/wrapping.jl:19): -> (priority, leaf) where a signal-typed container
+    (SampleBuf, AxisArray, ...) has priority 2, a plain array 1, anything else 0; the first of
+    equal priorities wins."""
     if isinstance(x, S.ArraySig):
-        return x.fs is None
-    kids = getattr(x, "children", ())
-    arrs = [c for c in kids]
-    return bool(arrs) and all(_root_is_plain_array(c) for c in arrs if not isinstance(c, (S.NumberSig, S.FuncSig))) \
-        and any(not isinstance(c, (S.NumberSig, S.FuncSig)) for c in arrs)
+        if x.container is not None:
+            return 2, x
+        if S._is_torch(x.data):
+            return 0, x
+        return (1 if x.fs is None else 0), x  # an (array, fs) tuple is not an AbstractArray
+    best = None
+    for c in getattr(x, "children", ()):  # mergeroot: the first of equal priorities wins
+        r = _root(c)
+        if best is None or r[0] > best[0]:
+            best = r
+    return best or (0, None)
+
+
+def _refineroot(x):
+    """the result type `sink(x)` picks when none is given (src/sink.jl:30-37)"""
+    pr, leaf = _root(x)
+    if pr == 2:
+        return leaf.container
+    if pr == 1:
+        return Array
+    return tuple
 
 
 class Plan:
@@ -154,9 +174,12 @@ def sink(x, to=None, *, device=0, rng=None):
     """sink(x[,to]) (reference src/sink.jl:28-37,64-92).  `to` may be None (type from
     the tree's root data), `Array`/np.ndarray, `tuple`, or "torch" (device-resident
     torch tensor, column-major)."""
+    if to is None and (isinstance(x, type) or x is tuple or (isinstance(x, str) and x == "torch")):
+        to_ = x  # sink(to::Type) = x -> sink(x,to), reference src/sink.jl:29
+        return S.Curried(lambda y: sink(y, to_, device=device, rng=rng))
     x = process_sink_params(x)
     if to is None:
-        to = Array if _root_is_plain_array(x) else tuple
+        to = _refineroot(x)
     if _is_datacut(x) and to is Array:
         # aliasing view, reference src/sink.jl:65-69: only when the sink type equals the
         # type of the underlying data (a Tuple sink of a view is copied through sink!)
@@ -175,7 +198,52 @@ def sink(x, to=None, *, device=0, rng=None):
         return res, x.fs
     res = np.empty((n, x.nch), dtype=dt, order="F")  # initsink src/sink.jl:115-119
     sink_into(res, x, device=device, rng=rng)
+    if isinstance(to, type) and hasattr(to, "initsink"):  # initsink(x, ::Type{<:SampleBuf}) etc.
+        if x.fs is None:
+            S.error("Unknown frame rate: array-type sinks carry a frame rate")
+        return to.initsink(res, x.fs)
     return res if to is Array else (res, x.fs)
+
+
+def filt(b, a, x, si=None, *, device=0):
+    """DSP.filt(b, a, x::AbstractSignal[, si]) (reference src/filters.jl:68-79): the signal is sunk
+    (HIP engine) and filtered with direct-form coefficients.  FIR (a scalar / [a0]) and orders <= 2
+    from zero state run as a `Filt` node on the device; anything else -- higher orders, a given
+    initial state `si` -- follows the reference literally: `sink(x, Array)` on the engine, then the
+    array method of `filt!`."""
+    x = S._assignal(x)
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    if si is None and (len(a) == 1 or (len(a) <= 3 and len(b) <= 3)):
+        y = sink(S.Filt(x, S.PolynomialRatio(b, a)), Array, device=device)
+        return _like_root(y, x)
+    from scipy import signal as sps
+
+    data = np.asarray(sink(x, Array, device=device), dtype=np.result_type(b.dtype, a.dtype, S.float_type(x.dtype)))
+    if si is None:
+        y = sps.lfilter(b, a, data, axis=0)
+    else:
+        zi = np.asarray(si, dtype=np.float64)
+        if zi.ndim == 1:
+            zi = np.repeat(zi[:, None], data.shape[1], axis=1)
+        y, _ = sps.lfilter(b, a, data, axis=0, zi=zi)
+    return _like_root(np.asfortranarray(y), x)
+
+
+def filt_into(data, b, a, x, si=None, *, device=0):
+    """DSP.filt!(data, b, a, x::AbstractSignal[, si]) (reference src/filters.jl:81-87)"""
+    y = filt(b, a, x, si, device=device)
+    y = np.asarray(y[0] if isinstance(y, tuple) else y)
+    np.copyto(np.asarray(data), y.reshape(np.asarray(data).shape))
+    return data
+
+
+def _like_root(y, x):
+    """initsink(ToEltype(x,R), refineroot(root(x))): the container type of the signal's root data"""
+    to = _refineroot(x)
+    if isinstance(to, type) and hasattr(to, "initsink") and x.fs is not None:
+        return to.initsink(y, x.fs)
+    return y if to is Array or x.fs is None else (y, x.fs)
 
 
 # eager lower-case forms (reference: mix(xs...) = sink(Mix(xs...)) etc.)

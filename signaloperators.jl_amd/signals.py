@@ -181,6 +181,7 @@ class ArraySig(AbstractSignal):
         self.nch = 1 if len(shape) == 1 else int(shape[1])
         self.n = int(shape[0])
         self.dtype = np.dtype(dt)
+        self.container = None  # SampleBuf / AxisArray / DimensionalArray class the data came in (root type)
 
     def nframes_helper(self):
         return self.n
@@ -596,6 +597,14 @@ def Signal(x=None, fs=None, *, ω=None, frequency=None, ϕ=0, phase=None, omega=
         if not _isconsistent(fs, x.fs):
             error(f"Signal expected to have frame rate of {fs} Hz.")
         return x
+    from .arraytypes import _Container
+
+    if isinstance(x, _Container):  # src/SampledSignals.jl:3-9, src/AxisArrays.jl:30-36, src/DimensionalData.jl:6-14
+        if not _isconsistent(fs, x.framerate):
+            error(f"Signal expected to have frame rate of {fs} Hz.")
+        a = ArraySig(x.signal_view(), x.framerate)
+        a.container = type(x)
+        return a
     if isinstance(x, tuple) and len(x) == 2 and not callable(x[0]):
         if not _isconsistent(fs, x[1]):
             error(f"Signal expected to have frame rate of {fs} Hz.")
