@@ -15,6 +15,9 @@ void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs&
                         int* sync, double* vpub, int dtype, hipStream_t st);
 void launch_resample(const void* x, void* y, const double* pfb, const double* dpfb,
                      const RsGeom& g, hipStream_t st);
+// pfbt / dpfbt: polyphase tables transposed to [taps][nphi]
+void launch_resample_tiled(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
+                           hipStream_t st);
 // returns 0 when launched, -1 when no instantiation fits the geometry
 int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
                          const int* jend, const RsRows& g, int dtype, hipStream_t st);

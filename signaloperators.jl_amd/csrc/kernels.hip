@@ -1023,6 +1023,124 @@ void launch_resample(const void* x, void* y, const double* pfb, const double* dp
                            dpfb, g, (double*)y);
 }
 
+// ---------------------------------------------------------------------------
+// K3t: tiled polyphase resampler for rates WITHOUT a usable period (irrational ratios such as the
+// reference benchmark's "resampling-irrational" x pi, non-integer frame rates, very long periods).
+// The thread-per-output kernel above streams a lane-private row of taps and inputs from L2 per
+// output (2 % of the roofline on a config-3-sized signal); here a workgroup stages ct channels x
+// ~1000 input frames once (coalesced, zero padded outside the signal) together with BOTH polyphase
+// tables, transposed to [tap][phase] so that the lanes' different phases fall on different LDS
+// banks.  A lane owns an output for all ct channels: per tap two table reads serve ct inputs, and
+// the two inner products stay separate and oldest-first (DSP.jl FIRArbitrary: yLower + alpha*yUpper).
+template <typename T, int CT>
+__global__ __launch_bounds__(kBlock) void k_resample_tiled(const T* __restrict__ x, T* __restrict__ y,
+                                                           const double* __restrict__ pfbt,
+                                                           const double* __restrict__ dpfbt, RsTiled g) {
+    extern __shared__ double lds_raw[];
+    const int taps = g.g.taps, nphi = g.g.nphi;
+    double* const tp = lds_raw;
+    double* const td = tp + (size_t)taps * nphi;
+    T* const xs = reinterpret_cast<T*>(td + (size_t)taps * nphi);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < taps * nphi; i += kBlock) {
+        tp[i] = pfbt[i];
+        td[i] = dpfbt[i];
+    }
+    const int64_t tx = (int64_t)blockIdx.x % g.ntiles, tc = (int64_t)blockIdx.x / g.ntiles;
+    const int c0 = (int)tc * CT;
+    const int64_t m0 = tx * g.tile_out;
+    const int64_t m1 = m0 + g.tile_out < g.g.n_out ? m0 + g.tile_out : g.g.n_out;
+    int64_t j0, j1;
+    int p;
+    double alpha;
+    rs_pos(g.g, g.g.m0 + m0, j0, p, alpha);
+    rs_pos(g.g, g.g.m0 + m1 - 1, j1, p, alpha);
+    const int64_t xlo = j0 - (taps - 1);  // global input frame of LDS element 0
+    const int nfr = (int)(j1 - xlo + 1);  // <= tile_in by the planner's choice of tile_out
+    for (int c = 0; c < CT; ++c) {
+        const T* row = x + (int64_t)(c0 + c) * g.g.in_pitch;
+        for (int i = tid; i < nfr; i += kBlock) {
+            const int64_t n = xlo + i;
+            xs[c * g.pitch + i] = (n >= 0 && n < g.g.n_in) ? row[n] : (T)0;  // Pad(x.signal, zero), src/filters.jl:240
+        }
+    }
+    __syncthreads();
+    for (int64_t mi = m0 + tid; mi < m1; mi += kBlock) {
+        int64_t j;
+        rs_pos(g.g, g.g.m0 + mi, j, p, alpha);
+        const T* __restrict__ xb = xs + (int)(j - xlo);
+        double lo[CT], hi[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) lo[c] = hi[c] = 0.0;
+        // oldest input first, like DSP.jl's dot; four taps per round so that the LDS reads of a
+        // round are in flight together (one wave per SIMD is latency-bound on a read-use-read chain)
+        int k = taps - 1;
+        for (; k >= 3; k -= 4) {
+            double pf[4], df[4], xv[4][CT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pf[u] = tp[(k - u) * nphi + p];
+                df[u] = td[(k - u) * nphi + p];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) xv[u][c] = (double)xb[c * g.pitch - (k - u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    lo[c] += pf[u] * xv[u][c];
+                    hi[c] += df[u] * xv[u][c];
+                }
+        }
+        for (; k >= 0; --k) {
+            const double pf = tp[k * nphi + p];
+            const double df = td[k * nphi + p];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const double xv = (double)xb[c * g.pitch - k];
+                lo[c] += pf * xv;
+                hi[c] += df * xv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const double r = g.g.arbitrary ? lo[c] + hi[c] * alpha : lo[c];
+            y[(int64_t)(c0 + c) * g.g.out_pitch + mi] = (T)r;
+        }
+    }
+}
+
+static bool first_use_on_device(bool (&seen)[64]);
+
+template <typename T>
+static void launch_resample_tiled_t(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
+                                    hipStream_t st) {
+    const size_t ldsb = ((size_t)2 * g.g.taps * g.g.nphi * 8 + (size_t)g.ct * g.pitch * sizeof(T) + 15) / 16 * 16;
+    const unsigned grid = (unsigned)(g.ntiles * (g.g.nch / g.ct));
+#define SO_RT(CTV)                                                                                                         \
+    {                                                                                                                      \
+        static bool seen[64];                                                                                              \
+        if (first_use_on_device(seen))                                                                                     \
+            (void)hipFuncSetAttribute((const void*)k_resample_tiled<T, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      160 * 1024);                                                                         \
+        hipLaunchKernelGGL((k_resample_tiled<T, CTV>), dim3(grid), dim3(kBlock), ldsb, st, (const T*)x, (T*)y, pfbt, dpfbt, g); \
+    }
+    switch (g.ct) {
+    case 8: SO_RT(8) break;
+    case 4: SO_RT(4) break;
+    case 2: SO_RT(2) break;
+    default: SO_RT(1) break;
+    }
+#undef SO_RT
+}
+
+void launch_resample_tiled(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
+                           hipStream_t st) {
+    if (g.g.n_out <= 0) return;
+    if (g.g.in_dtype == SO_F32) launch_resample_tiled_t<float>(x, y, pfbt, dpfbt, g, st);
+    else launch_resample_tiled_t<double>(x, y, pfbt, dpfbt, g, st);
+}
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------

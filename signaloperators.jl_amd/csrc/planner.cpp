@@ -136,6 +136,10 @@ struct Stage {
     std::vector<double> pfb_host, dpfb_host;
     bool periodic = false;
     RsPeriodic rp{};
+    bool tiled = false;  // tiled resampler without a period (k_resample_tiled)
+    RsTiled rt{};
+    int pfbt_buf = -1, dpfbt_buf = -1;
+    std::vector<double> pfbt_host, dpfbt_host;
     bool rows = false;  // row-tiled resampler (k_resample_rows)
     RsRows rr{};
     int mtab_buf = -1, mjend_buf = -1;
@@ -1762,6 +1766,48 @@ void Plan::process_stage(int sid) {
                 stages[sid].jend_buf = raw_buf(jr.size() * 4);
             }
         }
+        // ---- tiled variant for everything else that is long enough (no period to exploit) ----
+        if (!stages[sid].periodic && !stages[sid].rows && need >= 2048 && !std::getenv("SIGOPS_RS_NOTILED")) {
+            const int64_t esz_t = (int64_t)dsize(N.dtype);
+            const size_t tabs = (size_t)2 * g.taps * g.nphi * 8;
+            int ct = 1;
+            for (int c : {8, 4, 2})
+                if (N.nch % c == 0) {
+                    ct = c;
+                    break;
+                }
+            // inputs per output (fine-grid step / Nphi), for sizing the tile
+            const double step = g.arbitrary ? g.delta / g.nphi : (double)g.M / (double)g.L;
+            for (; ct >= 1; ct >>= 1) {
+                if (N.nch % ct) continue;
+                // two workgroups per CU when the tables allow it (their staging and arithmetic overlap)
+                size_t budget = tabs <= (size_t)24 * 1024 ? (size_t)78 * 1024 - tabs : (size_t)150 * 1024 - std::min<size_t>(tabs, 150 * 1024);
+                int64_t tile_in = (int64_t)(budget / ((size_t)ct * esz_t));
+                int64_t tile_out = (int64_t)std::floor((double)(tile_in - g.taps - 4) / step);
+                tile_out = std::min<int64_t>(tile_out, 4096);
+                if (tabs <= (size_t)100 * 1024 && tile_out >= 128) {
+                    RsTiled rt{};
+                    rt.g = g;
+                    rt.ct = ct;
+                    rt.tile_out = (int32_t)tile_out;
+                    rt.tile_in = (int32_t)tile_in;
+                    rt.pitch = (int32_t)(tile_in | 1);
+                    rt.ntiles = (need + tile_out - 1) / tile_out;
+                    stages[sid].tiled = true;
+                    stages[sid].rt = rt;
+                    stages[sid].pfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
+                    stages[sid].dpfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
+                    for (int p = 0; p < g.nphi; ++p)
+                        for (int k = 0; k < g.taps; ++k) {
+                            stages[sid].pfbt_host[(size_t)k * g.nphi + p] = stages[sid].pfb_host[(size_t)p * g.taps + k];
+                            stages[sid].dpfbt_host[(size_t)k * g.nphi + p] = stages[sid].dpfb_host[(size_t)p * g.taps + k];
+                        }
+                    stages[sid].pfbt_buf = raw_buf(stages[sid].pfbt_host.size() * 8);
+                    stages[sid].dpfbt_buf = raw_buf(stages[sid].dpfbt_host.size() * 8);
+                    break;
+                }
+            }
+        }
         if (!wrap.empty() && !stages[sid].periodic && !stages[sid].rows)  // no tap table took the baked positions
             replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, need, false, wrap, stages[sid].fix_host);
         if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
@@ -2333,6 +2379,10 @@ void Plan::finalize() {
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.tiled) {
+                HIPCHECK(hipMemcpy(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8, hipMemcpyHostToDevice));
+            }
             if (S.fix_buf >= 0)
                 HIPCHECK(hipMemcpy(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix), hipMemcpyHostToDevice));
             if (S.periodic || S.rows) {
@@ -2359,7 +2409,7 @@ void Plan::finalize() {
     for (int sid : order) {
         Stage& S = stages[sid];
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
-        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : "k_resample") : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS) st.bytes = 2 * S.need * S.sg.nch * esz;
@@ -2740,6 +2790,12 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
                                              (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
                                              (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
+                    } else if (S.tiled) {
+                        RsTiled rt = S.rt;
+                        rt.g.in_pitch = in_pitch;
+                        rt.g.out_pitch = ob.pitch;
+                        launch_resample_tiled(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
+                                              (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);

@@ -177,6 +177,18 @@ struct RsGeom {
     int64_t in_pitch, out_pitch;
 };
 
+// Tiled variant for rates without a usable period (irrational / non-integer frame rates, huge L):
+// a workgroup stages ct channels x tile_in input frames and both polyphase tables in LDS and
+// evaluates tile_out consecutive outputs with per-output closed-form positions (k_resample_tiled).
+struct RsTiled {
+    RsGeom g;
+    int32_t ct;        // channels per workgroup tile
+    int32_t tile_out;  // outputs per tile
+    int32_t tile_in;   // input frames per channel the LDS tile can hold
+    int32_t pitch;     // LDS elements between channel rows
+    int64_t ntiles;    // tiles along time
+};
+
 // DSP.jl's FIRArbitrary positions its outputs with a floating-point phase accumulator
 // (ϕAccumulator += Δ once per output; reference call site
 // src/reformatting.jl:92-98 + src/filters.jl:248-255).  The kernels position outputs in closed

@@ -89,3 +89,31 @@ def test_closed_form_positions_are_the_opt_in(monkeypatch):
     with oracle_positions("exact"):
         want = oracle_sink(tree)
     assert relerr(got, want) < 1e-11
+
+
+@pytest.mark.parametrize("fs_in,fs_out,nch,n,dt", [
+    (1000.0, 1000.0 * np.pi, 2, 40000, np.float64),      # test/benchmarks.jl "resampling-irrational"
+    (44100.5, 48000.0, 8, 60000, np.float64), (48000.0, 44100.5, 3, 50000, np.float64),
+    (1000.0, 1000.0 / np.e, 4, 80000, np.float32), (999.0, 16000.0, 1, 9000, np.float64),
+    (22050.0, 22050.0 * np.sqrt(2), 16, 30000, np.float64)])
+def test_tiled_resampler_for_rates_without_a_period(fs_in, fs_out, nch, n, dt):
+    """k_resample_tiled (irrational ratios, non-integer frame rates, very long periods) against
+    the oracle; SIGOPS_RS_NOTILED falls back to the thread-per-output kernel: same values"""
+    rng = np.random.default_rng(106)
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(dt))
+    tree = so.Signal(x, fs_in * so.Hz) | so.ToFramerate(fs_out * so.Hz)
+    got = so.sink(tree)[0]
+    want = oracle_sink(tree)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
+    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 2e-6) * np.abs(want).max()
+
+
+def test_tiled_resampler_equals_the_thread_per_output_kernel(monkeypatch):
+    rng = np.random.default_rng(107)
+    x = np.asfortranarray(rng.standard_normal((70000, 4)))
+    tree = so.Signal(x, 1000 * so.Hz) | so.ToFramerate(1000 * np.pi * so.Hz) | so.After(123 * so.frames)
+    a = so.sink(tree)[0]
+    monkeypatch.setenv("SIGOPS_RS_NOTILED", "1")
+    b = so.sink(tree)[0]
+    assert relerr(a, b) < 1e-13
