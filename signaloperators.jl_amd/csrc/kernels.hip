@@ -1624,10 +1624,11 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
         // ---- loads (CT independent loads in flight) ----
         double val[CT][V];
         if (C.base == nullptr) {
+            const double fill = C.pad_ == 2 ? 1.0 : 0.0;  // GA: a generated piece that is the gain itself
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int e = 0; e < V; ++e) val[c][e] = 0.0;
+                for (int e = 0; e < V; ++e) val[c][e] = ok ? fill : 0.0;
         } else if (vec) {
             const T* xp = (const T*)C.base + (int64_t)c0 * C.cstride + g0 + C.df;
 #pragma unroll
@@ -1787,7 +1788,11 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
     return stage_tile<T, CT, PASS>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T>
+// GA (gain at the A operand): a Float32 array times ONE Float64 per-frame gain (`Amplify(x32,
+// Signal(sin))`: the product is a Float64 signal, so it cannot be formed in the Float32 tile).  The
+// tile ring holds the raw Float32 samples (LDS-DMA, like a plain Float32 source), the gain ring is
+// three deep and the compute waves multiply while they fetch the A operand: (double)x * F[frame].
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -1887,8 +1892,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     // reads them.  Left to the six loader waves alone the evaluation sits on their critical
     // path (issue -> wait -> modify -> barrier) and the kernel runs 25 % below its plain-copy
     // speed.
-    const bool fused0 = nsteps0 > 0 && !(g.pad & 32);
-    const bool fring = sizeof(T) == 8 && g.fslots > 0 && fused0 && nslots0 <= g.fslots;
+    const bool fused0 = (nsteps0 > 0 || GA) && !(g.pad & 32);
+    const bool fring = (sizeof(T) == 8 || GA) && g.fslots > 0 && fused0 && nslots0 <= g.fslots;
+    constexpr int kFDepth = GA ? 3 : 2;  // gain arrays (GA: the compute waves still read tile it's while it+2's are written)
     double* const fbase = lds_raw + ((size_t)S * bufsz * sizeof(T) + 7) / 8;
     // Who evaluates which frames.  fp64 MFMA and fp64 VALU run on the same ALUs here (matrix and
     // vector fp64 peak are equal on MI355X): a loader wave's gain arithmetic only gets issue
@@ -1944,8 +1950,11 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     // from the reference's own rounding of the phase of nb + l by a few ulp of the phase (~1e-11
     // in the gain at 1e4 cycles, the size of the reference's own rounding error there; the
     // parity bound is 1e-6).
-    auto dtab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch; };
-    auto btab = [&]() __attribute__((always_inline)) { return fbase + (size_t)2 * g.fslots * g.fpitch + 128; };
+    auto dtab = [&]() __attribute__((always_inline)) { return fbase + (size_t)kFDepth * g.fslots * g.fpitch; };
+    auto btab = [&]() __attribute__((always_inline)) { return fbase + (size_t)kFDepth * g.fslots * g.fpitch + 128; };
+    // gain array written during iteration `it` (tile it+2) / read for tile `it`
+    auto fbw = [&](int it) __attribute__((always_inline)) { return GA ? (it + 2) % 3 : (it & 1); };
+    auto fbr = [&](int it) __attribute__((always_inline)) { return GA ? it % 3 : (it & 1); };
     const bool twolvl = TWO && fring && g.ftwo;
     // the wave that evaluates the share bases: the last loader in the loaders' own order (see
     // lidx below), i.e. one that sits on a SIMD with the most compute waves and, with g.nload
@@ -1959,7 +1968,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     auto b_duty = [&](const TilePos& p, int bb) __attribute__((always_inline)) {
         int64_t xa;
         int nfr;
-        if (!twolvl || wave != bwave || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
+        if (!twolvl || wave != bwave || !(p.tc < ngrp) || (!is_fast(p, xa, nfr) && !GA) || (g.pad & 64)) return;
         const int nb = (g.tile_len + 63) >> 6;  // <= kRsTwoBases (planner)
         sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1, 64, nb, leaf0.v0, leaf0.v1, leaf0.v2, leaf0.flag,
                    btab() + bb * 2 * kRsTwoBases);
@@ -1967,10 +1976,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             sine_table(xa + (nfr - g.tile_len) + leaf0.df + 1 + 64 * 64, 64, nb - 64, leaf0.v0, leaf0.v1, leaf0.v2,
                        leaf0.flag, btab() + bb * 2 * kRsTwoBases + 128);
     };
-    auto f_duty = [&](const TilePos& p, int fb) __attribute__((always_inline)) {
+    auto f_duty = [&](const TilePos& p, int fb, int bb) __attribute__((always_inline)) {
         int64_t xa;
         int nfr;
-        if (!fring || share0 * 64 >= g.tile_len || !(p.tc < ngrp) || !is_fast(p, xa, nfr) || (g.pad & 64)) return;
+        if (!fring || share0 * 64 >= g.tile_len || !(p.tc < ngrp) || (!is_fast(p, xa, nfr) && !GA) || (g.pad & 64)) return;
         double* Fb = fbase + (size_t)fb * g.fslots * g.fpitch;
         if constexpr (TWO) {
             if (!twolvl) return;  // (no LDS reserved: the loaders evaluate in place)
@@ -1981,7 +1990,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 if (shr < 0) break;
                 for (int u = shr; u * 64 < g.tile_len; u += nshares) {
                     const int f = (nfr - g.tile_len) + u * 64 + lane;
-                    const double2 b = *reinterpret_cast<const double2*>(btab() + fb * 2 * kRsTwoBases + 2 * u);
+                    const double2 b = *reinterpret_cast<const double2*>(btab() + bb * 2 * kRsTwoBases + 2 * u);
                     double v = fma(b.x, d.y, b.y * d.x);
                     if (kind0 & 0x100) v = (double)(float)v;
                     if (f < nfr) Fb[f] = v;
@@ -2020,7 +2029,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     TilePos pf = tile_first();  // next tile whose gains are due
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
-        f_duty(pf, k);
+        f_duty(pf, k, k);
         tile_next(pf);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2114,7 +2123,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             if (live && !((g.pad & 2) && it > 0) && (!fast || (fused0 && !fring))) {
                 stage_tile_ool<T, CT, 1>(g.n_in, g.lds_pitch, g.pad, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz,
                                          &sctl, gsrc.car, gsrc.ops, gsrc.leaves, ltid, lthr, allowed);
-            } else if (live && fast && fring) {
+            } else if (live && fast && fring && !GA) {
                 // carrier 0's steps in place on the chunks this wave copied, gains from the ring
                 const int nvec = (nfr + 1) >> 1;
                 const uint32_t lbase = lds_addr(lds + sr * bufsz);
@@ -2159,7 +2168,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             if (!live) break;  // (the compute waves' last barrier)
             issue(pn, sn, it);
             rs_stamp(g, wave, it, 3);
-            f_duty(pf, it & 1);  // gains of tile it+2
+            f_duty(pf, fbw(it), it & 1);  // gains of tile it+2
             rs_stamp(g, wave, it, 4);
             tile_next(pf);
             if constexpr (TWO) b_duty(pf, (it + 1) & 1);  // share bases of tile it+3
@@ -2176,6 +2185,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const int gbeg = wave * G;
     double breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
     int rowoff[kRsQ];
+    int goff[kRsQ];  // GA: the same offset without the channel row (gains depend on the frame only)
 #pragma unroll
     for (int gg = 0; gg < G; ++gg)
 #pragma unroll
@@ -2185,6 +2195,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     for (int q = 0; q < kRsQ; ++q) {
         const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
         rowoff[q] = (rho >> ptshift) * g.lds_pitch + (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
+        goff[q] = (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
     }
     int jeg[G];  // newest input of each group's window
 #pragma unroll
@@ -2223,16 +2234,26 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 // registers) so the LDS latency hides under the previous step's MFMAs; the
                 // per-step address is an immediate offset from fixed row pointers.
                 const T* __restrict__ ap[kRsQ];
+                const double* __restrict__ gp[kRsQ];  // GA: this tile's gains at the A operand's frames
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) ap[q] = cur + (rowoff[q] + je);
+                for (int q = 0; q < kRsQ; ++q) {
+                    ap[q] = cur + (rowoff[q] + je);
+                    gp[q] = fbase + (size_t)fbr(it) * g.fslots * g.fpitch + (sh + goff[q] + je);
+                }
                 double abuf[2][kRsQ];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = (double)ap[q][0];
+                for (int q = 0; q < kRsQ; ++q) {
+                    abuf[0][q] = (double)ap[q][0];
+                    if constexpr (GA) abuf[0][q] *= gp[q][0];
+                }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s + 1 < KS) {
 #pragma unroll
-                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
+                        for (int q = 0; q < kRsQ; ++q) {
+                            abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
+                            if constexpr (GA) abuf[(s + 1) & 1][q] *= gp[q][4 * (s + 1)];
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < kRsQ; ++q)
@@ -2263,7 +2284,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         // wait for their output stores every tile.  The LDS reads of this tile were consumed
         // by the MFMAs above, so only lgkmcnt matters here; stores stay in flight.
         rs_stamp(g, wave, it, 3);
-        f_duty(pf, it & 1);  // this wave's share of the gains of tile it+2
+        f_duty(pf, fbw(it), it & 1);  // this wave's share of the gains of tile it+2
         tile_next(pf);
         rs_stamp(g, wave, it, 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2274,19 +2295,35 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)2 * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0)) * 8;  // + static RsCtl
+    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)(GA ? 3 : 2) * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
+}
+
+// GA instantiations: Float32 tiles, Float64 arithmetic and (unless the sink buffer is Float32) result
+template <int CT>
+static int launch_rp_ga(void* y, const double* tab, const int* jend, const RsPeriodic& g,
+                        const RsGlobalTables& gsrc, hipStream_t st) {
+    const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+    if (g.kw != 4 * 14 || gper != 1) return -1;
+    if (g.out_f32) {
+        if (g.ftwo) launch_rp_k<float, CT, 14, 1, true, float, true>(y, tab, jend, g, gsrc, st);
+        else launch_rp_k<float, CT, 14, 1, false, float, true>(y, tab, jend, g, gsrc, st);
+    } else {
+        if (g.ftwo) launch_rp_k<float, CT, 14, 1, true, double, true>(y, tab, jend, g, gsrc, st);
+        else launch_rp_k<float, CT, 14, 1, false, double, true>(y, tab, jend, g, gsrc, st);
+    }
+    return 0;
 }
 
 template <typename T, int CT>
@@ -2321,6 +2358,13 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
+    if (g.ga) {
+        switch (g.ct) {
+        case 8: return launch_rp_ga<8>(y, tab, jend, g, gsrc, st);
+        case 4: return launch_rp_ga<4>(y, tab, jend, g, gsrc, st);
+        default: return -1;
+        }
+    }
     if (dtype == SO_F32) {
         switch (g.ct) {
         case 8: return launch_rp_ct<float, 8>(y, tab, jend, g, gsrc, st);
@@ -2366,18 +2410,19 @@ __global__ __launch_bounds__(kBlock) void k_resample_fix(RsFixArgs a) {
                         double F[kMaxFrameSlots][1];
 #pragma unroll
                         for (int s = 0; s < kMaxFrameSlots; ++s) F[s][0] = 0.0;
-                        if (C.nsteps > 0 && C.frame_len > 0) {
+                        if ((C.nsteps > 0 || C.pad_) && C.frame_len > 0) {
                             const int64_t nn[1] = {n};
                             double fo[1];
                             run_program<1, false, 2, true>(a.ops, C.frame_pc, C.frame_len, a.leaves, nn, c, F, fo);
                         }
-                        double val[1][1] = {{0.0}};
+                        double val[1][1] = {{C.pad_ == 2 ? 1.0 : 0.0}};
                         if (C.base != nullptr) {
                             const int64_t off = (int64_t)c * C.cstride + n + C.df;
                             val[0][0] = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
                                                           : ((const double*)C.base)[off];
                         }
                         if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
+                        if (C.pad_) val[0][0] *= F[0][0];  // GA carrier: Float32 sample times its Float64 gain
                         xv = st32 ? (double)(float)val[0][0] : val[0][0];
                     }
                 } else {

@@ -323,7 +323,7 @@ struct Plan {
     void process_stage(int sid);
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
-    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out);
+    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false);
     RsCtl make_ctl(const Stage& S) const;
     void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
              bool allow_hoist);
@@ -1430,6 +1430,23 @@ int resample_positions(double fs_in, double fs_out, double rate, int nphi, const
     return SO_OK;
 }
 
+// Can this periodic resampler stage run the GA instantiation (Float32 tiles, Float64 gain at the A
+// operand)?  Geometry the instantiations cover, and the LDS budget with three gain arrays.
+static bool ga_fits(const Stage& S, int stage_dtype) {
+    if (!S.periodic || stage_dtype != SO_F64 || std::getenv("SIGOPS_RS_NOGA")) return false;
+    const RsPeriodic& rp = S.rp;
+    const int gper = (rp.ngroups + rp.ncompute - 1) / std::max(1, rp.ncompute);
+    if (rp.kw != 56 || gper != 1 || !(rp.ct == 8 || rp.ct == 4)) return false;
+    const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+    const size_t pitch4 = (size_t)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
+    const size_t tile_bytes = (size_t)rp.ct * pitch4 * 4;
+    const size_t fpitch = (size_t)((rp.tile_len + 16 + 1) & ~1);
+    const bool ok = 3 * fpitch * 8 + kRsTwoDoubles * 8 + 2 * tile_bytes <= avail;
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] GA geometry: kw=%d gper=%d ct=%d tile_len=%d -> %s\n", rp.kw, gper, rp.ct, rp.tile_len, ok ? "fits" : "no");
+    return ok;
+}
+
 void Plan::process_stage(int sid) {
     // NOTE: `stages` may grow while lowering the child; re-take references after.
     int ni = stages[sid].node;
@@ -2011,14 +2028,32 @@ void Plan::process_stage(int sid) {
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
-    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers)) {
+    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype))) {
         // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
         // staging, no intermediate in HBM
         S.in_buf = -1;
         S.in_array_node = -1;
+        if (S.carriers[0].pad_) {
+            // GA instantiation: Float32 tiles (pitch in floats, 16-byte rows, 128-byte aligned start),
+            // three gain arrays, no in-place work for the loaders
+            RsPeriodic& rp = S.rp;
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            rp.ga = 1;
+            rp.lds_pitch = (int)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
+            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 4;
+            rp.fslots = 1;
+            rp.fpitch = (rp.tile_len + 16 + 1) & ~1;
+            const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
+            const bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases &&
+                             (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
+            rp.ftwo = two ? 1 : 0;
+            const size_t fbytes = (size_t)3 * rp.fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
+            rp.nslots = (int)std::min<size_t>(4, (avail - fbytes) / tile_bytes);
+            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) rp.nslots = std::min(rp.nslots, std::max(2, std::atoi(ev)));
+            rp.nload = 0;
+        } else {
         // gain ring: two LDS arrays [slots][tile frames] next to the tile ring, if at least two
         // tile slots still fit (see k_resample_periodic)
-        {
             RsPeriodic& rp = S.rp;
             const int ns0 = S.carriers[0].nslots;
             const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * dsize(N.dtype);
@@ -2148,7 +2183,7 @@ bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
     }
 }
 
-bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out) {
+bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out, bool allow_ga) {
     std::vector<Piece> ps = ps_in;
     for (auto& p : ps)
         if (p.r.c0 != 0 || p.r.c1 != nch) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 1); return false; }
@@ -2171,8 +2206,25 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
     // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
     // staging path, ~6x slower than a K1 pass + the LDS-DMA fast path), so steps on fp32 data
     // are materialised by K1 instead of fused
+    // ... except the commonest case, ONE Float32 array times ONE Float64 per-frame gain (`Amplify(x32,
+    // Signal(sin))`, a Float64 product): the kernel's GA instantiation keeps the raw Float32 tile
+    // and multiplies at the A operand (allow_ga: the caller has checked geometry and LDS budget)
+    // Further carriers may only be generated pieces whose value is that same gain (the tail of an
+    // infinite `Amplify`: the array's padding `one` times the gain): staged as 1.0f.
+    bool ga = false;
+    if (allow_ga && !cs.empty() && cs[0].dtype == SO_F32 && cs[0].nsteps == 1 && cs[0].op[0] == OP_MUL &&
+        !(cs[0].arg[0] & 0x200) && (cs[0].array_node >= 0 || cs[0].buf >= 0) && monos_all[0].size() == 1) {
+        ga = true;
+        for (size_t i = 1; i < cs.size(); ++i)
+            if (cs[i].base != nullptr || cs[i].array_node >= 0 || cs[i].buf >= 0 || cs[i].nsteps != 1 ||
+                cs[i].op[0] != OP_LOADF || (cs[i].arg[0] & 0x300) || monos_all[i].size() != 1 || cs[i].dtype != SO_F64)
+                ga = false;
+    }
+    if (std::getenv("SIGOPS_DEBUG_PLAN") && !cs.empty())
+        std::fprintf(stderr, "[sigops] carriers=%zu allow_ga=%d dtype=%d nsteps=%d op=%d arg=%#x monos=%zu -> ga=%d\n", cs.size(), (int)allow_ga,
+                     cs[0].dtype, cs[0].nsteps, cs[0].op[0], cs[0].arg[0], monos_all[0].size(), (int)ga);
     for (auto& c : cs)
-        if (c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
+        if (!ga && c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
     std::vector<std::vector<DOp>> fcodes(cs.size());
     size_t nops_total = 0;
     std::set<int> leafset;
@@ -2227,6 +2279,31 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         cs[i].frame_pc = (int)ops.size();
         cs[i].frame_len = (int)fcodes[i].size();
         ops.insert(ops.end(), fcodes[i].begin(), fcodes[i].end());
+    }
+    if (ga) {
+        // the generated pieces must be exactly carrier 0's gain
+        auto same_leaf = [&](int a, int b) {
+            const DLeaf &x = leaves[a], &y = leaves[b];
+            return x.base == y.base && x.fstride == y.fstride && x.cstride == y.cstride && x.df == y.df && x.dc == y.dc &&
+                   x.modn == y.modn && x.v0 == y.v0 && x.v1 == y.v1 && x.v2 == y.v2 && x.sf == y.sf && x.sc == y.sc &&
+                   x.dtype == y.dtype && x.mode == y.mode && x.flag == y.flag && x.buf == y.buf;
+        };
+        for (size_t i = 1; i < cs.size(); ++i)
+            if (cs[i].slot_kind[0] != cs[0].slot_kind[0] || !same_leaf(cs[i].slot_leaf[0], cs[0].slot_leaf[0])) ga = false;
+        if (!ga) {
+            leaves.resize(leaves_before);
+            leaf_array_node.resize(leaves_before);
+            ops.resize(ops.size() - nops_total);
+            if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 7);
+            return false;
+        }
+        // the staging code copies the raw samples (1.0f for the generated pieces); the multiply
+        // happens at the A operand
+        for (size_t i = 0; i < cs.size(); ++i) {
+            cs[i].pad_ = i == 0 ? 1 : 2;
+            cs[i].nsteps = 0;
+            cs[i].dtype = SO_F32;
+        }
     }
     out = cs;
     return true;

@@ -85,7 +85,8 @@ struct DCarrier {
     int32_t nslots;
     int32_t slot_leaf[4];
     int32_t slot_kind[4];
-    int32_t pad_;
+    int32_t pad_;  // 1: GA carrier (k_resample_periodic GA): Float32 array, its single multiply by slot 0
+                   //    is applied by the compute waves (nsteps is 0 for the staging code)
 };
 
 // Control block of the periodic resampler's fused source.  Every workgroup copies it into LDS
@@ -251,6 +252,8 @@ struct RsPeriodic {
     int32_t nload;      // loader waves that copy / modify (0: all of them)
     int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
     int32_t out_f32;    // fp64 kernel storing into a Float32 result (`sink` of a Float64 signal into Float32)
+    int32_t ga;         // GA instantiation: Float32 tiles, the gain multiplied at the A operand; lds_pitch in floats
+    int32_t pad2;
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };

@@ -317,3 +317,29 @@ def test_float64_signal_into_float32_result(nch, leaf_dtype, fused):
     #  where that crosses a rounding boundary)
     assert relerr(res.astype(np.float64), w32.astype(np.float64)) < 1e-7
     assert np.mean(res != w32) < 1e-3
+
+
+@pytest.mark.parametrize("nch,n,res_dt,gen", [(8, 300_000, np.float64, dict(ω=5 * so.Hz)), (4, 120_000, np.float64, dict(ω=440 * so.Hz, ϕ=0.3)),
+                                             (8, 50_000, np.float32, dict(ω=5 * so.Hz)), (8, 9_000, np.float64, dict()),
+                                             (4, 200_000, np.float32, dict(ω=50 * so.Hz))])
+def test_float32_array_times_float64_gain_is_fused(nch, n, res_dt, gen, monkeypatch):
+    """`Amplify(x::Float32 array, Signal(sin))` is a Float64 signal (Julia promotion).  The periodic
+    resampler's GA instantiation keeps the raw Float32 tile in LDS and multiplies at the MFMA's A
+    operand, so the product never touches HBM (it used to be materialised by a K1 pass: 1.53 ms on
+    config 3 with a Float32 leaf).  Same values as the materialising path and as the oracle."""
+    rng = np.random.default_rng(71)
+    x = np.asfortranarray(rng.standard_normal((n + 50, nch)).astype(np.float32))
+    tree = (so.Signal(x, 44.1 * so.kHz) | so.After(50 * so.frames) | so.Amplify(so.Signal(so.sin, **gen)) | so.Until(n * so.frames)
+            | so.ToFramerate(48 * so.kHz))
+    want = oracle_sink(tree)
+    assert want.dtype == np.float64
+    res = np.full((so.nframes(tree), nch), np.nan, dtype=res_dt, order="F")
+    so.sink_into(res, tree)
+    if res_dt == np.float64:
+        assert relerr(res, want) < 1e-9
+    else:
+        assert relerr(res.astype(np.float64), want.astype(np.float32).astype(np.float64)) < 1e-7
+    monkeypatch.setenv("SIGOPS_RS_NOGA", "1")
+    ref = np.full_like(res, np.nan)
+    so.sink_into(ref, tree)
+    assert relerr(res.astype(np.float64), ref.astype(np.float64)) < (1e-10 if res_dt == np.float64 else 1e-7)
