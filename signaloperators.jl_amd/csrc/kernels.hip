@@ -171,6 +171,11 @@ __device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n)
 // to the compiler and every `if (L.flag)` / `L.mode == ...` becomes compute-both-and-select
 // (all three trig kernels per frame).  Passing the fields through readfirstlane makes the
 // branches scalar again.
+__device__ __forceinline__ int64_t rfl64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ double rfl_f64(double v) {
     const uint64_t u = __builtin_bit_cast(uint64_t, v);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
@@ -361,7 +366,18 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
 // DEEP == false: every piece of the launch needs a stack depth <= 2 (left-fold chains: almost
 // every tree), so the 4-deep interpreters are not even compiled in -- half the registers, twice
 // the waves per SIMD, and this kernel is bound by bytes in flight.
-template <int E, bool DEEP>
+// CHAIN: pieces whose per-sample program is `array (op) F_s (op) F_t ...` (Amplify / Mix / Ramp chains
+// over one array: the commonest maps) skip the interpreter in the channel loop: the program is
+// decoded once into scalar registers and eight channels' 16-byte loads are issued back to back,
+// so a lane has 128 bytes in flight instead of 16 (the interpreter issues one load per channel
+// pass and then waits for it: K1 was bound by bytes in flight).
+// IL (with CHAIN): interleaved frames -- a result or a leaf with frame_stride = nch, chan_stride = 1
+// (WAV buffers, `PermutedDimsArray` inputs; reference src/WAV.jl:3-6, src/AxisArrays.jl:38-39) -- go
+// through an LDS tile of 512 frames x 8 channels: global accesses are runs of consecutive
+// elements across the workgroup (whole frames when the piece has <= 8 channels), the lanes pick
+// their (frame pair, channel) values out of LDS.  Without it a lane's accesses are nch elements
+// apart and every 16-byte access moves a 64-byte sector.
+template <int E, bool DEEP, bool CHAIN = false, bool IL = false>
 __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__ pieces,
                                                       int npieces, const DOp* __restrict__ ops,
                                                       const DLeaf* __restrict__ leaves,
@@ -379,11 +395,16 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
     const int bc = (int)(rel / P.nblk_f);
     const int cbeg = P.c0 + bc * P.chc;
     const int cend = min(P.c1, cbeg + P.chc);
+    // A workgroup walks P.sub consecutive blocks of kBlock*E frames: the piece lookup above and the
+    // program fetches are chains of dependent scalar loads (~a microsecond while the chip streams),
+    // paid once per workgroup instead of once per 64 KB.
+    for (int sb = 0; sb < P.sub; ++sb) {
     int64_t n[E], ns[E];
     bool valid[E];
     // light variant, block entirely inside the piece: lane l owns the PAIR of frames
     // (base + 2l, base + 2l + 1) and reads / writes it as one 16-byte access where alignment allows
-    const int64_t blk0 = P.a + bf * (int64_t)(kBlock * E);
+    const int64_t blk0 = P.a + (bf * P.sub + sb) * (int64_t)(kBlock * E);
+    if (blk0 >= P.b) break;
     const bool pair = !DEEP && E == 2 && blk0 + kBlock * E <= P.b;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -403,6 +424,182 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
             if (deep) run_program<E, false, kStackDepth, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
             else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
         } else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
+    }
+    if constexpr (CHAIN && !DEEP && E == 2) {
+        constexpr int kIlPitch = 9;  // doubles per frame row of the LDS tile (8 channels + 1: bank spread)
+        __shared__ double il_tile[IL ? kBlock * E * kIlPitch : 1];
+        const bool out_il = IL && out.fstride > 1 && out.cstride == 1;
+        if (P.chain && pair && (out.fstride == 1 || out_il)) {  // (wave-uniform)
+            const DLeaf& L = leaves[ops[P.samp_pc].arg];
+            const bool in_il = IL && L.fstride > 1 && L.cstride == 1;
+            const int nst = (P.samp_len - 1) >> 1;
+            int sop[4], sslot[4];  // operand: frame slot 0..3, or 4 = the constant cval[i]
+            double cval[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const DOp o = ops[P.samp_pc + 1 + 2 * (i < nst ? i : 0)];
+                sslot[i] = i < nst ? (o.code == OP_LOADF ? o.arg : 4) : 0;
+                cval[i] = i < nst && o.code == OP_CONST ? leaves[o.arg].v0 : 0.0;
+                sop[i] = i < nst ? ops[P.samp_pc + 2 + 2 * i].code : -1;
+            }
+            const bool in64 = L.dtype == SO_F64, out64 = out.dtype == SO_F64;
+            const int isz = in64 ? 8 : 4, osz = out64 ? 8 : 4;
+            constexpr int CB = 8;
+            for (int cb = cbeg; cb < cend; cb += CB) {
+                double val[CB][2];
+                // ---- loads of up to eight channels, all in flight together ----
+                const int nb = cend - cb < CB ? cend - cb : CB;  // channels of this batch
+                if (in_il) {
+                    // the batch's 512 x nb block of the interleaved leaf, element runs of nb per frame
+                    // (every wave moves and reads only ITS 128 frames of the tile: wave barriers suffice,
+                    //  the four waves of the workgroup stay independent)
+                    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, f0w = wv * 64 * E;
+                    const int64_t off0 = (blk0 + f0w + L.df) * L.fstride + ((int64_t)L.sc * cb + L.dc);
+                    if (in64 && nb == L.fstride && !(nb & 1) && ((((uintptr_t)L.base) + off0 * 8) & 15) == 0) {
+                        // whole frames: the block is one contiguous run -> 16-byte loads, all in flight
+                        const double2* src = reinterpret_cast<const double2*>((const double*)L.base + off0);
+                        const int nv = 64 * E * nb / 2;
+                        for (int v0 = ln; v0 < nv; v0 += 8 * 64) {
+                            double2 w[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (v0 + j * 64 < nv) w[j] = src[v0 + j * 64];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (v0 + j * 64 < nv) {
+                                    const int e0 = 2 * (v0 + j * 64), f = f0w + e0 / nb, cc = e0 % nb;
+                                    il_tile[f * kIlPitch + cc] = w[j].x;
+                                    il_tile[f * kIlPitch + cc + 1] = w[j].y;
+                                }
+                        }
+                    } else {
+                        for (int idx = ln; idx < 64 * E * nb; idx += 64) {
+                            const int f = idx / nb, cc = idx - f * nb;
+                            const int64_t off = off0 + (int64_t)f * L.fstride + (int64_t)L.sc * cc;
+                            il_tile[(f0w + f) * kIlPitch + cc] = in64 ? ((const double*)L.base)[off] : (double)((const float*)L.base)[off];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) {
+                        val[u][0] = u < nb ? il_tile[(2 * threadIdx.x) * kIlPitch + u] : 0.0;
+                        val[u][1] = u < nb ? il_tile[(2 * threadIdx.x + 1) * kIlPitch + u] : 0.0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                    if (in_il) break;
+                    val[u][0] = val[u][1] = 0.0;
+                    if (cb + u < cend) {
+                        const int64_t off = ((int64_t)L.sc * (cb + u) + L.dc) * L.cstride + ns[0] + L.df;
+                        const char* pa = (const char*)L.base + off * isz;
+                        const uintptr_t a0 = (uintptr_t)rfl64((int64_t)(uintptr_t)pa);  // lane 0's address
+                        if (in64) {
+                            if ((a0 & 15) == 0) {
+                                const double2 w = *reinterpret_cast<const double2*>(pa);
+                                val[u][0] = w.x;
+                                val[u][1] = w.y;
+                            } else {
+                                val[u][0] = ((const double*)pa)[0];
+                                val[u][1] = ((const double*)pa)[1];
+                            }
+                        } else if ((a0 & 7) == 0) {
+                            const float2 w = *reinterpret_cast<const float2*>(pa);
+                            val[u][0] = (double)w.x;
+                            val[u][1] = (double)w.y;
+                        } else {
+                            val[u][0] = (double)((const float*)pa)[0];
+                            val[u][1] = (double)((const float*)pa)[1];
+                        }
+                    }
+                }
+                // ---- the chain: the opcode switch outside the element loops ----
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= nst) break;
+                    double m[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        m[e] = sslot[i] == 0 ? F[0][e] : sslot[i] == 1 ? F[1][e] : sslot[i] == 2 ? F[2][e] : sslot[i] == 3 ? F[3][e] : cval[i];
+#define SO_CH(EXPR)                                          \
+    _Pragma("unroll") for (int u = 0; u < CB; ++u) _Pragma("unroll") for (int e = 0; e < 2; ++e) { \
+        const double x = val[u][e];                          \
+        val[u][e] = (EXPR);                                  \
+    }
+                    switch (sop[i]) {
+                    case OP_ADD: SO_CH(x + m[e]) break;
+                    case OP_SUB: SO_CH(x - m[e]) break;
+                    case OP_MUL: SO_CH(x * m[e]) break;
+                    default: SO_CH(x / m[e]) break;
+                    }
+#undef SO_CH
+                }
+                // ---- stores ----
+                if (out_il) {
+#pragma unroll
+                    for (int u = 0; u < CB; ++u)
+                        if (u < nb) {
+                            il_tile[(2 * threadIdx.x) * kIlPitch + u] = val[u][0];
+                            il_tile[(2 * threadIdx.x + 1) * kIlPitch + u] = val[u][1];
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, f0w = wv * 64 * E;
+                    const int64_t ooff0 = (blk0 + f0w) * out.fstride + cb;
+                    if (!(out.pad & 1) && out64 && nb == out.fstride && !(nb & 1) && ((((uintptr_t)out.base) + ooff0 * 8) & 15) == 0) {
+                        double2* dst = reinterpret_cast<double2*>((double*)out.base + ooff0);
+                        const int nv = 64 * E * nb / 2;
+                        for (int v0 = ln; v0 < nv; v0 += 64) {
+                            const int e0 = 2 * v0, f = f0w + e0 / nb, cc = e0 % nb;
+                            double2 w;
+                            w.x = il_tile[f * kIlPitch + cc];
+                            w.y = il_tile[f * kIlPitch + cc + 1];
+                            dst[v0] = w;
+                        }
+                    } else {
+                        for (int idx = ln; idx < 64 * E * nb; idx += 64) {
+                            const int f = idx / nb, cc = idx - f * nb;
+                            const int64_t off = ooff0 + (int64_t)f * out.fstride + cc;
+                            const double w = il_tile[(f0w + f) * kIlPitch + cc];
+                            if (out64) ((double*)out.base)[off] = w;
+                            else ((float*)out.base)[off] = (float)w;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                    if (cb + u < cend) {
+                        const int64_t off = (int64_t)(cb + u) * out.cstride + ns[0];
+                        char* pa = (char*)out.base + off * osz;
+                        const uintptr_t a0 = (uintptr_t)rfl64((int64_t)(uintptr_t)pa);
+                        if (out64) {
+                            if ((a0 & 15) == 0) {
+                                double2 w;
+                                w.x = val[u][0];
+                                w.y = val[u][1];
+                                *reinterpret_cast<double2*>(pa) = w;
+                            } else {
+                                ((double*)pa)[0] = val[u][0];
+                                ((double*)pa)[1] = val[u][1];
+                            }
+                        } else if ((a0 & 7) == 0) {
+                            float2 w;
+                            w.x = (float)val[u][0];
+                            w.y = (float)val[u][1];
+                            *reinterpret_cast<float2*>(pa) = w;
+                        } else {
+                            ((float*)pa)[0] = (float)val[u][0];
+                            ((float*)pa)[1] = (float)val[u][1];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
     }
     for (int c = cbeg; c < cend; ++c) {
         if constexpr (DEEP) {
@@ -441,12 +638,19 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
                 if (valid[e]) o[ns[e] * out.fstride] = v[e];
         }
     }
+    }  // sub-blocks
 }
 
 void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, const DOp* d_ops,
-                      const DLeaf* d_leaves, OutView out, bool deep, hipStream_t st) {
+                      const DLeaf* d_leaves, OutView out, bool deep, hipStream_t st, bool chain, bool il) {
     if (nblocks <= 0) return;
-    if (deep)
+    if (chain && !deep && il)
+        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false, true, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
+                           npieces, d_ops, d_leaves, out);
+    else if (chain && !deep)
+        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
+                           npieces, d_ops, d_leaves, out);
+    else if (deep)
         hipLaunchKernelGGL((k_pointwise<kPointwiseE, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
                            npieces, d_ops, d_leaves, out);
     else
@@ -1498,11 +1702,6 @@ __device__ __forceinline__ void rs_stamp(const RsPeriodic& g, int wave, int it, 
         g.trace[(wave * kRsTraceIters + it) * kRsTraceStamps + k] = clock64();
 }
 
-__device__ __forceinline__ int64_t rfl64(int64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
 
 // the few geometry fields the general staging path needs (passed by value to its out-of-line
 // copy: taking the address of the kernel-argument struct would move it to scratch)

@@ -162,6 +162,8 @@ struct PwStep {
     int out_buf = -1;  // -1: final output
     int64_t bytes = 0;
     bool deep = false;  // some piece needs the 4-deep interpreter
+    bool chain = false;  // some piece takes k_pointwise's chain path
+    bool il = false;     // ... with an interleaved leaf (the LDS-transposing instantiation)
     std::vector<int> pre;  // pointwise steps that materialise sub-expressions this one reads (run first)
 };
 
@@ -1113,6 +1115,21 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
         DPiece d{};
         d.depth = std::max(2, depth(p.e));
         if (d.depth > 2) st.deep = true;
+        // `array (op) F_s (op) F_t ...` over a planar unit-stride leaf: the kernel's chain path
+        if (d.depth <= 2 && !code.empty() && code[0].code == OP_LOAD && (code.size() & 1) && code.size() <= 9 &&
+            !std::getenv("SIGOPS_K1_NOCHAIN")) {
+            const DLeaf& L = leaves[code[0].arg];
+            // (a unit frame stride, or an interleaved leaf: channels adjacent, frames nch apart)
+            const bool leaf_il = L.cstride == 1 && L.fstride > 1 && L.sc == 1;
+            bool ok = L.mode == LM_PLAIN && L.sf == 1 && (L.fstride == 1 || leaf_il);
+            for (size_t i = 1; ok && i + 1 < code.size(); i += 2)
+                ok = (code[i].code == OP_LOADF || code[i].code == OP_CONST) && code[i + 1].code >= OP_ADD && code[i + 1].code <= OP_DIV;
+            if (ok) {
+                d.chain = 1;
+                st.chain = true;
+                if (leaf_il) st.il = true;
+            }
+        }
         d.a = p.r.a;
         d.b = p.r.b;
         d.c0 = p.r.c0;
@@ -1124,6 +1141,11 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
         d.samp_len = (int)code.size();
         ops.insert(ops.end(), code.begin(), code.end());
         d.nblk_f = (d.b - d.a + kBlock * E - 1) / (kBlock * E);
+        // long pieces: several blocks per workgroup (amortises the per-workgroup lookup latency),
+        // keeping at least ~16 workgroups per CU
+        d.sub = (int)std::max<int64_t>(1, std::min<int64_t>(2, d.nblk_f / 16384));  // (sweep on 26 M x 8: 1-2 best, 8 -10 %)
+        if (const char* ev = std::getenv("SIGOPS_K1_SUB")) d.sub = std::max(1, std::min(64, std::atoi(ev)));  // tuning knob
+        d.nblk_f = (d.nblk_f + d.sub - 1) / d.sub;
         // channel chunking: keep all channels in one workgroup unless the piece is
         // too short to fill the machine along frames
         int chc = nchp;
@@ -2748,7 +2770,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     ov.dtype = b.dtype;
                 }
                 if (w.nblocks > 0) {
-                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st);
+                    static const int il_scalar = std::getenv("SIGOPS_K1_ILSCALAR") ? 1 : 0;  // ablation knob
+                    ov.pad = il_scalar;
+                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st, w.chain,
+                                     w.il || (ov.fstride > 1 && ov.cstride == 1));
                     s.launches = 1;
                     launches++;
                 }

@@ -64,6 +64,9 @@ struct DPiece {
     int64_t nblk_f;  // workgroups along frames
     int32_t chc;     // channels per workgroup
     int32_t depth;   // stack depth the programs need (2 -> small-register interpreter)
+    int32_t chain;   // the per-sample program is `LOAD (LOADF s, binop)*` over a planar unit-stride leaf:
+                     // k_pointwise's chain path (eight channel loads in flight per lane, no interpreter)
+    int32_t sub;     // consecutive blocks of kBlock*E frames per workgroup (>= 1)
 };
 
 // A carrier: one planar array read at (frame n, channel c) -> base[c*cstride + n + df],

@@ -343,3 +343,39 @@ def test_float32_array_times_float64_gain_is_fused(nch, n, res_dt, gen, monkeypa
     ref = np.full_like(res, np.nan)
     so.sink_into(ref, tree)
     assert relerr(res.astype(np.float64), ref.astype(np.float64)) < (1e-10 if res_dt == np.float64 else 1e-7)
+
+
+@pytest.mark.parametrize("nch,n,dt", [(8, 70_000, np.float64), (2, 33_333, np.float64), (5, 20_000, np.float32), (12, 9_000, np.float64),
+                                     (1, 5_000, np.float64), (8, 600, np.float64)])
+def test_interleaved_leaves_and_results(nch, n, dt):
+    """frame-interleaved buffers (frame_stride = nch, chan_stride = 1: WAV data, row-major arrays,
+    `PermutedDimsArray` views) through k_pointwise's LDS-transposing chain path: bit-exact
+    against the planar evaluation"""
+    rng = np.random.default_rng(73)
+    x = rng.standard_normal((n, nch)).astype(dt)  # C order: interleaved frames
+    xp = np.asfortranarray(x)                      # planar copy
+    assert x.strides[1] == x.itemsize and (nch == 1 or x.strides[0] == nch * x.itemsize)
+
+    def tree(a):
+        return so.Signal(a, 8 * so.kHz) | so.Amplify(so.Signal(so.sin, ω=3 * so.Hz)) | so.Until(n * so.frames) | so.Ramp(20 * so.ms)
+
+    want = oracle_sink(tree(xp))
+    got_planar = so.sink(tree(xp))[0]
+    got_il_leaf = so.sink(tree(x))[0]
+    assert np.array_equal(got_il_leaf, got_planar)
+    res = np.full((n, nch), np.nan, dtype=want.dtype, order="C")  # interleaved result
+    so.sink_into(res, tree(x))
+    assert np.array_equal(res, got_planar)
+    assert relerr(res, want) < (1e-12 if dt == np.float64 else 2e-7)
+
+
+def test_interleaved_device_result():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(74)
+    n, nch = 100_000, 8
+    x = rng.standard_normal((n, nch))
+    xd = torch.from_numpy(x).cuda()  # row-major on the device: interleaved leaf
+    tree = so.Signal(xd, 44.1 * so.kHz) | so.Amplify(0.5)
+    out = torch.full((n, nch), float("nan"), dtype=torch.float64, device="cuda")  # interleaved result
+    so.sink_into(out, tree)
+    assert np.array_equal(out.cpu().numpy(), x * 0.5)
