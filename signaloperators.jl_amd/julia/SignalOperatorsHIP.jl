@@ -70,8 +70,46 @@ mutable struct Lowering
     nodes::Vector{SoNode}
     keep::Vector{Any}          # GC roots for every pointer handed to C
     memo::IdDict{Any,Int32}
+    need::IdDict{Any,Tuple{Int,Int}}   # randn leaves: (frames reached, leading frames skipped)
 end
-Lowering() = Lowering(SoNode[], Any[], IdDict{Any,Int32}())
+Lowering() = Lowering(SoNode[], Any[], IdDict{Any,Int32}(), IdDict{Any,Tuple{Int,Int}}())
+
+# How many frames of every `randn` leaf a sink of n frames reaches, and how many of the leading
+# ones an `After` SKIPS rather than evaluates (src/cutting.jl:160-181: skipped blocks never reach
+# `frame`, so they draw nothing; `Filt` ignores the flag, src/filters.jl:241-244).  Mirrors
+# lowering.py `_demand` of the tested Python host.
+finite_min(x, m) = (n = nframes(x); (ismissing(n) || isinf(n)) ? m : min(m, Int(n)))
+demand!(need, x, n, skip=0) = nothing
+function demand!(need, x::SignalFunction{<:SignalOperators.RandFn}, n, skip=0)
+    n0, s0 = get(need, x, (0, skip))
+    need[x] = (max(n0, n), min(s0, skip))
+end
+function demand!(need, x::CutApply{<:Any,<:Any,K}, n, skip=0) where K
+    L = max(0, resolvelen(x))
+    K <: Val{:Until} ? demand!(need, child(x), finite_min(child(x), min(n, L)), skip) :
+                       demand!(need, child(x), finite_min(child(x), n + L), skip + L)
+end
+demand!(need, x::Union{PaddedSignal,RampSignal}, n, skip=0) = demand!(need, child(x), finite_min(child(x), n), skip)
+demand!(need, x::MapSignal, n, skip=0) = foreach(s -> demand!(need, s, finite_min(s, n), skip), x.signals)
+function demand!(need, x::AppendSignals, n, skip=0)
+    rem, sk = n, skip
+    for s in x.signals
+        m = finite_min(s, rem)
+        demand!(need, s, m, min(sk, m))
+        rem -= m; sk = max(0, sk - m)
+        rem <= 0 && break
+    end
+end
+function demand!(need, x::FilteredSignal, n, skip=0)
+    m = n
+    if x.fn isa ResamplerFn   # newest input of the last output + the filter's group delay
+        h = DSP.resample_filter(x.fn.ratio)
+        nphi = x.fn.ratio isa Rational ? numerator(x.fn.ratio) : 32
+        m = ceil(Int, max(n - 1, 0) / x.fn.ratio) + ceil(Int, (length(h) - 1) / (2nphi)) + 2
+    end
+    demand!(need, child(x), finite_min(child(x), m), 0)
+end
+demand!(need, x::NormedSignal, n, skip=0) = demand!(need, child(x), Int(nframes(child(x))), 0)
 
 function push_node!(lw, x, kind; kids=Int32[], i0=0, i1=0, i2=0, i3=0, l0=0, l1=0,
                     d0=0.0, d1=0.0, p0=C_NULL, p1=C_NULL, s0=0, s1=0,
@@ -94,6 +132,26 @@ function lower_node!(lw, x::Union{AbstractArray,Tuple{<:AbstractArray,<:Number}}
 end
 lower_node!(lw, x::NumberSignal) =
     push_node!(lw, x, CONST; d0=Float64(x.val), i0=sodtype(typeof(x.val)), nch=1)
+# `Signal(randn)` (src/functions.jl:98-114): host-materialised -- one draw per EVALUATED frame in
+# increasing frame order from the leaf's own generator, zeros for the frames an `After` skips --
+# then an ARRAY node under an (unreachable) zero Pad, so that the leaf stays infinite for the planner.
+function lower_node!(lw, x::SignalFunction{<:SignalOperators.RandFn})
+    n, skipped = get(lw.need, x, (0, 0))
+    data = zeros(Float64, max(n, 0), 1)
+    for i in skipped+1:n
+        data[i, 1] = randn(x.fn.rng)
+    end
+    push!(lw.keep, data)
+    push!(lw.nodes, SoNode(Int32(ARRAY), SO_F64, Int32(1), Int32(0), C_NULL, Int64(-3) #= SO_LEN_UNCHECKED =#,
+                           sofs(framerate(x)), 0, 0, 0, 0, size(data, 1), 0, 0.0, 0.0, 0.0, 0.0, pointer(data), C_NULL,
+                           1, size(data, 1)))
+    inner = Int32(length(lw.nodes) - 1)
+    kids = Int32[inner]
+    push!(lw.keep, kids)
+    push!(lw.nodes, SoNode(Int32(PAD), SO_F64, Int32(1), Int32(1), pointer(kids), LEN_INF, sofs(framerate(x)),
+                           2 #= zero =#, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL, C_NULL, 0, 0))
+    Int32(length(lw.nodes) - 1)
+end
 function lower_node!(lw, x::SignalFunction)
     code = x.fn === sin ? 0 : x.fn === cos ? 1 : x.fn === identity ? 2 :
         error("Signal($(x.fn)) is an opaque closure: materialise it with the stock sink first")
@@ -144,6 +202,11 @@ function lower_node!(lw, x::FilteredSignal)
             push_node!(lw, x, RESAMPLE; kids=Int32[c], i0=1, i1=32, d0=Float64(x.fn.ratio),
                        p0=pointer(h), i2=length(h), i3=x.blocksize)
         end
+    elseif (hobj = x.fn(framerate(x))) isa PolynomialRatio && length(coefa(hobj)) == 1
+        # Filt(x,h) with FIR coefficients (RawFilterFn, src/filters.jl:89-97): RESAMPLE kind SO_RS_FIR
+        h = Float64.(coefb(hobj) ./ coefa(hobj)[1])
+        push!(lw.keep, h)
+        push_node!(lw, x, RESAMPLE; kids=Int32[c], i0=2, i1=1, l0=1, l1=1, p0=pointer(h), i2=length(h), i3=x.blocksize)
     else                                            # reference src/filters.jl:10-11,94
         f = convert(SecondOrderSections, x.fn(framerate(x)))
         sos = Float64[c for b in f.biquads for c in (b.b0, b.b1, b.b2, 1.0, b.a1, b.a2)]
@@ -159,6 +222,7 @@ check(st) = st == 0 || error(unsafe_string(ccall((:so_last_error, libsigops), Cs
 # The method the engine plugs into: reference src/sink.jl:225-226 dispatch point.
 function SignalOperators.sink!(result::HIPSink{T}, x, ::IsSignal) where T
     lw = Lowering()
+    demand!(lw.need, x, size(result, 1))
     root = lower!(lw, x)
     desc = Ref(SoOutDesc(sodtype(T), size(result, 2), size(result, 1), 1, size(result, 1), 0, 0))
     plan = Ref{Ptr{Cvoid}}(C_NULL)
