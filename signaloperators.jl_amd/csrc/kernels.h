@@ -10,6 +10,10 @@ void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, cons
 // returns number of kernel launches
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
                const SosGeom& g, const SosCoefs& cf, hipStream_t st);
+// SOS IIR whose state pass was done by the resampler in front (vper: [nch][nper][16])
+int launch_sos_prestate(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
+                        double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,
+                        hipStream_t st);
 // single-pass SOS IIR (the caller zeroes `sync` on the stream before every launch)
 void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
                         int* sync, double* vpub, int dtype, hipStream_t st);

@@ -857,6 +857,76 @@ static void launch_sos_ns(const void* x, void* y, double* v, double* s0, const d
     }
 }
 
+// The state pass already done by the resampler in front (k_resample_periodic's state waves):
+// vper[ch][period][16] holds the zero-state end-of-period states; a chunk is pt periods:
+//   v_chunk = sum_{p<pt} Q^(pt-1-p) v_p,  Q = A^Ls   (Horner, Q in LDS)
+template <int NS>
+__global__ __launch_bounds__(kBlock) void k_sos_combine(const double* __restrict__ vper, int64_t nper,
+                                                        const double* __restrict__ qmat, int pt, SosGeom g,
+                                                        double* __restrict__ v) {
+    constexpr int D = 2 * NS;
+    __shared__ double q[D * D];
+    if ((int)threadIdx.x < D * D) q[threadIdx.x] = qmat[threadIdx.x];
+    __syncthreads();
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t nseq = (int64_t)g.nchunks * g.nch;
+    if (tid >= nseq) return;
+    const int k = (int)(tid % g.nchunks), ch = (int)(tid / g.nchunks);
+    if ((int64_t)(k + 1) * pt > nper) return;  // (an incomplete last chunk: its end state is never used)
+    double acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.0;
+    const double* vp = vper + ((int64_t)ch * nper + (int64_t)k * pt) * 16;
+    const int64_t half = (int64_t)g.nch * nper * 16;  // the second state wave's partial sums
+    for (int p = 0; p < pt; ++p, vp += 16) {
+        double t[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double a = vp[r] + vp[half + r];
+#pragma unroll
+            for (int d = 0; d < D; ++d) a = fma(q[r * D + d], acc[d], a);
+            t[r] = a;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = t[d];
+    }
+    double* o = v + ((int64_t)ch * g.nchunks + k) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] = acc[d];
+}
+
+template <int NS, typename T>
+static void launch_sos_pre_t(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
+                             double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,
+                             hipStream_t st) {
+    const int64_t nseq = (int64_t)g.nchunks * g.nch;
+    hipLaunchKernelGGL((k_sos_combine<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, vper, nper,
+                       qmat, pt, g, v);
+    hipLaunchKernelGGL((k_sos_scan<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v, mpow, g, s0);
+    hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       (const T*)x, (T*)y, (const double*)s0, (double*)nullptr, g, cf);
+}
+
+// IIR with the state pass precomputed (returns the number of launches)
+int launch_sos_prestate(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
+                        double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,
+                        hipStream_t st) {
+    if (g.n <= 0) return 0;
+#define SO_PRE(NS_)                                                                                             \
+    case NS_:                                                                                                   \
+        if (g.in_dtype == SO_F32) launch_sos_pre_t<NS_, float>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st); \
+        else launch_sos_pre_t<NS_, double>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);                    \
+        break;
+    switch (cf.nsec) {
+        SO_PRE(1) SO_PRE(2) SO_PRE(3) SO_PRE(4) SO_PRE(5) SO_PRE(6) SO_PRE(7)
+    default:
+        if (g.in_dtype == SO_F32) launch_sos_pre_t<8, float>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);
+        else launch_sos_pre_t<8, double>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);
+    }
+#undef SO_PRE
+    return 3;
+}
+
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
                const SosGeom& g, const SosCoefs& cf, hipStream_t st) {
     if (g.n <= 0) return 0;
@@ -1991,7 +2061,11 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // Signal(sin))`: the product is a Float64 signal, so it cannot be formed in the Float32 tile).  The
 // tile ring holds the raw Float32 samples (LDS-DMA, like a plain Float32 source), the gain ring is
 // three deep and the compute waves multiply while they fetch the A operand: (double)x * F[frame].
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false>
+// ST (state waves): the stage's only consumer is an SOS filter and the last two loader waves
+// compute its chunk states from the staged tiles (see RsPeriodic::nstate).  A separate
+// instantiation: the state waves' 24 tap registers must not raise the register budget (and with
+// it, spills) of the kernels that do not use them.
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -2020,6 +2094,18 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const int* src = reinterpret_cast<const int*>(gsrc.ctl);
         int* dst = reinterpret_cast<int*>(&sctl);
         for (int i = threadIdx.x; i < (int)(sizeof(RsCtl) / 4); i += blockDim.x) dst[i] = src[i];
+    }
+    if (ST && g.nstate > 0) {
+        // the state waves' window can reach frames of a slot no tile has written yet: zero the ring
+        // once (whatever bits LDS holds at kernel start must not meet a zero tap as NaN)
+        const int nq = (int)(((size_t)S * bufsz * sizeof(T)) / 8);
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) lds_raw[i] = 0.0;
+        // ... and their taps live in LDS, [4*ksw][10] behind the gain ring (registers would be 48 per
+        // lane across the whole loader loop -- spilled, measured 3.5 ms; L2 costs a dependent
+        // round trip per k-step group while the chip streams, 1.56 ms)
+        double* wl = lds_raw + ((size_t)S * bufsz * sizeof(T) + 7) / 8 + (size_t)(GA ? 3 : 2) * g.fslots * g.fpitch +
+                     (g.ftwo ? kRsTwoDoubles : 0);
+        for (int i = threadIdx.x; i < 4 * g.ksw * 10; i += blockDim.x) wl[i] = g.wtab[(size_t)(i / 10) * 16 + (i % 10)];
     }
     __syncthreads();
     const RsCtl& ctl = sctl;
@@ -2247,18 +2333,22 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         // Loader waves are numbered so that those on the SIMDs with the fewest compute waves come
         // first (waves go to SIMD wave&3): the first chunks of a tile are the full ones, and a
         // loader wave next to three MFMA-issuing waves runs ~30 % slower than one next to two.
+        // (g.nstate: the last nstate loader waves are the IIR state waves; they copy nothing)
+        const int nldr = nwaves - (ST ? g.nstate : 0);  // waves [nc, nldr) load
+        const bool swave = wave >= nldr;
         int lidx = 0;
         {
             auto ncomp_on = [&](int w) { return (nc - (w & 3) + 3) >> 2; };  // compute waves on w's SIMD
             const int mine = ncomp_on(wave);
-            for (int w = nc; w < nwaves; ++w) {
+            for (int w = nc; w < nldr; ++w) {
                 const int other = ncomp_on(w);
                 if (other < mine || (other == mine && w < wave)) ++lidx;
             }
+            if (swave) lidx = 1 << 20;
         }
         // g.nload > 0: only the first nload loader waves (those on the least loaded SIMDs) copy and
         // modify; the others just keep the barrier count
-        const int nactive = g.nload > 0 && g.nload < nwaves - nc ? g.nload : nwaves - nc;
+        const int nactive = g.nload > 0 && g.nload < nldr - nc ? g.nload : nldr - nc;
         const int lthr = nactive * 64;
         const int ltid = (lidx < nactive ? lidx * 64 : (1 << 30)) + lane;
         const int llane = lane;
@@ -2273,6 +2363,18 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         if (!(g.pad & 16)) __builtin_amdgcn_s_setprio(3);
         const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));  // byte address of the ring
         const uint32_t lane16 = (uint32_t)llane * 16u;                            // per-lane byte offset in a chunk
+        // state waves: row offsets of the A operands, first slot of this wave's half of the window
+        constexpr int kSwK = 24;  // k-steps per state wave (planner: 2 * kSwK * 4 >= staged span of a row)
+        int srow[kRsQ];
+        int swk0 = 0;
+        if constexpr (ST) {
+            swk0 = swave ? (wave - nldr) * kSwK * 4 : 0;
+#pragma unroll
+            for (int q = 0; q < kRsQ; ++q) {
+                const int rho = 16 * q + (lane & 15);
+                srow[q] = (rho >> g.ptshift) * g.lds_pitch + (rho & (g.pt - 1)) * (int)g.M + (lane >> 4);
+            }
+        }
         const int A = S - 2;  // tiles in flight beyond the one being retired
         int cnt0 = 0, cnt1 = 0;  // DMA instructions of the youngest / second youngest issued tile
         auto issue = [&](const TilePos& p, int slot, int tr_it) {
@@ -2367,6 +2469,57 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             if (!live) break;  // (the compute waves' last barrier)
             issue(pn, sn, it);
             rs_stamp(g, wave, it, 3);
+            if constexpr (ST) if (swave) {
+                // ---- IIR state pass on tile `it` (published by the barrier above, slot sr) ----
+                // Y[32 rows x 16] = X[32 x 4*ksh] * wtab[4*ksh x 16] over this wave's HALF of the staged
+                // span (the other state wave takes the other half; k_sos_combine adds the two): the
+                // taps sit in registers for the whole kernel like the compute waves' (streamed from
+                // L2 they cost ~1000 cycles per dependent round while the chip streams: measured
+                // 1.56 ms for the kernel), the A operands come from LDS one k-step ahead.
+                const int sh = (int)(pr.xb & (kAlign - 1));
+                const T* __restrict__ cur = lds + sr * bufsz + sh + swk0;
+                const double* __restrict__ wl = fbase + (size_t)kFDepth * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0) +
+                                                (size_t)(swk0 + (lane >> 4)) * 10 + ((lane & 15) < 10 ? (lane & 15) : 0);
+                v4d acc[kRsQ];
+#pragma unroll
+                for (int q = 0; q < kRsQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                double abuf[2][kRsQ], bbuf[2];
+                bbuf[0] = wl[0];
+#pragma unroll
+                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = (double)cur[srow[q]];
+#pragma unroll
+                for (int s = 0; s < kSwK; ++s) {
+                    if (s + 1 < kSwK) {
+#pragma unroll
+                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = (double)cur[srow[q] + 4 * (s + 1)];
+                        bbuf[(s + 1) & 1] = wl[40 * (s + 1)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < kRsQ; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], bbuf[s & 1], acc[q], 0, 0, 0);
+                }
+                // Eight stores, no waits between them: every address is ONE per-lane base plus a
+                // wave-uniform offset (an address computed per store spilled and reloaded from scratch
+                // here, and a scratch reload waits vmcnt(0) -- i.e. for the previous STORE: 12 000 cycles
+                // per tile, measured).  Rows (lane>>4)+4i+16q are (period (lane>>4)&(pt-1)..., channel ...).
+                // Row (lane>>4) + 4i + 16q of the result is (period kq + (4i mod pt), channel (16q + 4i) / pt),
+                // kq = lane >> 4 (no carry: kq < 4 <= pt): the per-lane part of the address is ONE pointer.
+                constexpr int PT = kRsRows / CT;
+                const int kq = lane >> 4;
+                const int64_t nper = g.nperiods;
+                double* vl = g.vper + ((size_t)(wave - nldr) * (size_t)g.nch + (size_t)((int)pr.tc * CT)) * (size_t)nper * 16 +
+                             (size_t)(pr.tx * PT + kq) * 16 + (lane & 15);
+                const int plim = (int)(nper - pr.tx * PT < PT ? nper - pr.tx * PT : PT);  // periods of this tile inside the signal
+#pragma unroll
+                for (int q = 0; q < kRsQ; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        constexpr int kDummy = 0;
+                        (void)kDummy;
+                        const int ppi = (4 * i) % PT, cci = (16 * q + 4 * i) / PT;  // compile-time after unrolling
+                        if (kq + ppi < plim) vl[((size_t)cci * (size_t)nper + (size_t)ppi) * 16] = acc[q][i];
+                    }
+            }
             f_duty(pf, fbw(it), it & 1);  // gains of tile it+2
             rs_stamp(g, wave, it, 4);
             tile_next(pf);
@@ -2494,19 +2647,31 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
-    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)(GA ? 3 : 2) * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0)) * 8;  // + static RsCtl
+    size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)(GA ? 3 : 2) * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0) +
+                  (ST ? (size_t)4 * g.ksw * 10 : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
+}
+
+// ST instantiations: Float64, 14 k-steps, one group per compute wave, state waves on
+template <int CT>
+static int launch_rp_st(void* y, const double* tab, const int* jend, const RsPeriodic& g,
+                        const RsGlobalTables& gsrc, hipStream_t st) {
+    const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+    if (g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga) return -1;
+    if (g.ftwo) launch_rp_k<double, CT, 14, 1, true, double, false, true>(y, tab, jend, g, gsrc, st);
+    else launch_rp_k<double, CT, 14, 1, false, double, false, true>(y, tab, jend, g, gsrc, st);
+    return 0;
 }
 
 // GA instantiations: Float32 tiles, Float64 arithmetic and (unless the sink buffer is Float32) result
@@ -2557,6 +2722,13 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
+    if (g.nstate > 0) {
+        switch (g.ct) {
+        case 8: return launch_rp_st<8>(y, tab, jend, g, gsrc, st);
+        case 4: return launch_rp_st<4>(y, tab, jend, g, gsrc, st);
+        default: return -1;
+        }
+    }
     if (g.ga) {
         switch (g.ct) {
         case 8: return launch_rp_ga<8>(y, tab, jend, g, gsrc, st);

@@ -149,6 +149,18 @@ struct Stage {
     int tab_buf = -1, jend_buf = -1;
     std::vector<double> tab_host;
     std::vector<int> jend_host;
+    // periodic variant: per-period positions (kept for the fused IIR state pass)
+    std::vector<int64_t> per_j;
+    std::vector<int> per_p;
+    std::vector<double> per_a;
+    int jend_last = 0;
+    // fused IIR state pass (this resampler computes its SOS consumer's chunk states)
+    int wtab_buf = -1, vper_buf = -1;
+    std::vector<double> wtab_host;
+    // ... and on the SOS side: the resampler stage that provides vper, Q = A^Ls
+    int pre_stage = -1;
+    int qmat_buf = -1;
+    std::vector<double> qmat_host;
     // outputs DSP.jl's phase accumulator positions differently (recomputed by k_resample_fix)
     std::vector<RsFix> fix_host;
     int fix_buf = -1;
@@ -338,6 +350,7 @@ struct Plan {
     void push_pw_step(int idx);
     int add_leaf(const Expr& e);
     void count_array(int ni);
+    void fuse_state_passes();
     void finalize();
     void release();
 };
@@ -1670,7 +1683,9 @@ void Plan::process_stage(int sid) {
             // on a 16-byte boundary (vector loads) whenever pt*M is a multiple of 4
             int jlo = jend[0] - (kw - 1);
             jlo -= ((jlo % 4) + 4) % 4;
-            const int64_t tile_len = (pt - 1) * Ms + jend[ngroups - 1] - jlo + 1;
+            // (+0..3 frames: a row's staged span is a whole number of MFMA k-steps, which the fused IIR
+            //  state pass walks from jlo to the end)
+            const int64_t tile_len = (pt - 1) * Ms + (jend[ngroups - 1] - jlo + 1 + 3) / 4 * 4;
             // tiles are kept in LDS in the sample type and staged from the 128-byte aligned frame
             // below their first input (+15 / +31 frames); rows are 16-byte multiples for LDS-DMA
             const int64_t esz_t = (int64_t)dsize(N.dtype), vfr = 16 / esz_t;
@@ -1723,6 +1738,10 @@ void Plan::process_stage(int sid) {
                 if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rp.pad = std::atoi(ev);  // ablation knob
                 if (const char* ev = std::getenv("SIGOPS_RS_NLOAD")) rp.nload = std::max(1, std::atoi(ev));  // tuning knob
                 stages[sid].periodic = true;
+                stages[sid].per_j = jr;
+                stages[sid].per_p = pr;
+                stages[sid].per_a = ar;
+                stages[sid].jend_last = jend[ngroups - 1];
                 stages[sid].rp = rp;
                 stages[sid].tab_host = tab;
                 stages[sid].jend_host = jend;
@@ -2425,6 +2444,150 @@ RsCtl Plan::make_ctl(const Stage& S) const {
 }
 
 // ---------------------------------------------------------------------------
+// Resampler -> IIR: fold the IIR's state pass into the resampler.
+// The three-pass K2 reads its input twice; when that input is the output of a periodic resampler
+// stage and nothing else reads it, the first read can go: a chunk's zero-state end state is linear
+// in the resampler's INPUT,  v = sum_r G[r] y[r],  y[r] = sum_k Tap_r[k] x[j_r - k]
+//                              = sum_i W[i] x[i],   W = G . Tap   (D x window of one period),
+// and the resampler has that window staged in LDS anyway.  Two of its loader waves become state
+// waves (k_resample_periodic): one MFMA pass over the window per period row, written as
+// vper[ch][period][16]; K2 then combines pt periods into a chunk (k_sos_combine), scans and runs
+// its output pass.  (Reference: the same filt! at src/filters.jl:252-255; values differ from the
+// sequential recurrence by rounding of the start states, ~1e-16 relative.)
+// Opt-in (SIGOPS_FUSE_STATE=1).  Measured on the north-star pipeline (28.8 M x 8, order 10): K2 1.13 ->
+// 0.90 ms and its traffic 5.57 -> ~4.1 GB, but the two state waves' 48 MFMAs per tile are the
+// resampler's critical path (tile period 9 800 -> 12 200 cycles): K3 0.72 -> 0.90 ms.  Break-even
+// (1.79 vs 1.76-1.83 ms), so the three-pass form stays the default.
+void Plan::fuse_state_passes() {
+    if (!std::getenv("SIGOPS_FUSE_STATE")) return;
+    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+        Stage& S2 = stages[i2];
+        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.groups.size() != 1 || S2.in_buf < 0 ||
+            S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.nchunks <= 1)
+            continue;
+        int i3 = -1;
+        for (size_t j = 0; j < stages.size(); ++j)
+            if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
+        if (i3 < 0 || i3 == alias_stage) continue;
+        Stage& S3 = stages[i3];
+        const RsPeriodic& rp0 = S3.rp;
+        if (!S3.periodic || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
+            rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
+            (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
+            continue;  // (the instantiations with state waves: kernels.hip launch_rp_st)
+        // nothing else may read the intermediate
+        bool other = false;
+        for (auto& L : leaves)
+            if (L.buf == S2.in_buf) other = true;
+        for (size_t j = 0; j < stages.size(); ++j) {
+            if (j != i2 && stages[j].in_buf == S2.in_buf) other = true;
+            for (auto& c : stages[j].carriers)
+                if (c.buf == S2.in_buf) other = true;
+        }
+        if (other) continue;
+        const SosCoefs& cf = S2.groups[0];
+        const int D = 2 * cf.nsec;
+        const int64_t Ls = rp0.L, L = (int64_t)rp0.pt * Ls;
+        if (L < 32 || L > 16384) continue;
+        // chunk geometry with L = pt periods
+        const double tol = std::ldexp(1.0, -70);
+        Mat A = sos_state_matrix(cf);
+        Mat M = matpow(A, L, D), cur = ident(D);
+        std::vector<double> mp;
+        int K = 0;
+        bool ok = true;
+        for (;;) {
+            mp.insert(mp.end(), cur.begin(), cur.end());
+            ++K;
+            cur = matmul(cur, M, D);
+            if (maxabs(cur) < tol) break;
+            if (K >= 64) {
+                ok = false;
+                break;
+            }
+        }
+        const int64_t nchunks = (S2.need + L - 1) / L;
+        if (!ok || nchunks <= 1) continue;
+        // W = G . Tap over the staged span [jlo, jlo + 4*ksw) of a period row
+        const so_node_t& nd3 = nodes[S3.node].nd;
+        const double* h = (const double*)nd3.p0;
+        const int hlen = nd3.i2, nphi = S3.rg.nphi, taps = S3.rg.taps;
+        const int jlo = rp0.jlo;
+        const int ksw = 2 * 24;  // two state waves x kSwK k-steps (kernels.hip)
+        if ((S3.jend_last - jlo + 1 + 3) / 4 > ksw) continue;  // the staged span of a row must fit
+        // (window slots beyond the span have zero taps; there a row's window runs into the next
+        //  row's staged frames or the slot's slack -- finite values: the kernel zeroes its LDS ring
+        //  once at start when it has state waves, and 0 x finite is 0)
+        std::vector<double> G((size_t)Ls * D, 0.0);  // G[r] = A^(Ls-1-r) B1
+        {
+            std::vector<double> st_(D, 0.0);
+            double y = 1.0;
+            for (int f = 0; f < cf.nsec; ++f) {  // one DF2T step with x = 1 from zero state
+                const double xi = y;
+                y = st_[2 * f] + cf.b0[f] * xi;
+                st_[2 * f] = st_[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
+                st_[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
+            }
+            for (int64_t r = Ls - 1; r >= 0; --r) {
+                for (int d = 0; d < D; ++d) G[(size_t)r * D + d] = st_[d];
+                std::vector<double> nx(D, 0.0);
+                for (int a = 0; a < D; ++a)
+                    for (int b = 0; b < D; ++b) nx[a] += A[(size_t)a * D + b] * st_[b];
+                st_ = nx;
+            }
+        }
+        std::vector<double> wt((size_t)4 * ksw * 16, 0.0);
+        for (int64_t r = 0; r < Ls; ++r)
+            for (int age = 0; age < taps; ++age) {
+                const int64_t rel = S3.per_j[r] - age - jlo;  // input slot of this tap
+                if (rel < 0 || rel >= 4 * ksw) {
+                    ok = false;  // (cannot happen: the span covers every tap of the period)
+                    continue;
+                }
+                const int64_t hi = S3.per_p[r] + (int64_t)nphi * age;
+                const double hv = hi < hlen ? h[hi] : 0.0;
+                const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                const double tv = hv + S3.per_a[r] * dv;
+                for (int d = 0; d < D; ++d) wt[(size_t)rel * 16 + d] += G[(size_t)r * D + d] * tv;
+            }
+        if (!ok) continue;
+        // LDS: the taps ([4*ksw][10] doubles) go behind the gain ring; keep at least three tile slots
+        {
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            const size_t tile_bytes = (size_t)rp0.ct * rp0.lds_pitch * 8;
+            const size_t fbytes = (size_t)2 * rp0.fslots * rp0.fpitch * 8 + (rp0.ftwo ? kRsTwoDoubles * 8 : 0);
+            const size_t wbytes = (size_t)4 * ksw * 10 * 8;
+            if (fbytes + wbytes + 3 * tile_bytes > avail) continue;
+            S3.rp.nslots = (int)std::min<size_t>(S3.rp.nslots, (avail - fbytes - wbytes) / tile_bytes);
+        }
+        // commit: resampler side
+        S3.rp.nstate = 2;
+        S3.rp.ksw = ksw;
+        S3.wtab_host = wt;
+        S3.wtab_buf = raw_buf(wt.size() * 8);
+        S3.vper_buf = raw_buf((size_t)2 * nodes[S3.node].nch * rp0.nperiods * 16 * 8);
+        // ... and the IIR side
+        S2.pre_stage = i3;
+        S2.qmat_host = matpow(A, Ls, D);
+        S2.qmat_buf = raw_buf(S2.qmat_host.size() * 8);
+        S2.sg.chunk = L;
+        S2.sg.nchunks = (int)nchunks;
+        S2.sg.kterms = K;
+        S2.mpow_host.assign(1, mp);
+        if (S2.mpow_buf >= 0) bufs[S2.mpow_buf].bytes = std::max<size_t>(8, mp.size() * 8);
+        else S2.mpow_buf = raw_buf(mp.size() * 8);
+        const size_t vb = (size_t)nchunks * S2.sg.nch * 2 * kMaxSec * 8;
+        if (S2.v_buf >= 0) bufs[S2.v_buf].bytes = vb;
+        else S2.v_buf = raw_buf(vb);
+        if (S2.s0_buf >= 0) bufs[S2.s0_buf].bytes = vb;
+        else S2.s0_buf = raw_buf(vb);
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr, "[sigops] IIR state pass fused into the resampler: chunk %lld frames, K=%d, window %d inputs\n",
+                         (long long)L, K, 4 * ksw);
+    }
+}
+
+// ---------------------------------------------------------------------------
 void Plan::finalize() {
     // size stage output buffers now that every need is known
     for (size_t si = 0; si < stages.size(); ++si) {
@@ -2529,11 +2692,15 @@ void Plan::finalize() {
     }
     for (auto& S : stages) {
         if (S.need <= 0) continue;
+        if (S.kind == ST_SOS && S.qmat_buf >= 0)
+            HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_SOS && S.onepass)
             HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.wtab_buf >= 0)
+                HIPCHECK(hipMemcpy(bufs[S.wtab_buf].d, S.wtab_host.data(), S.wtab_host.size() * 8, hipMemcpyHostToDevice));
             if (S.tiled) {
                 HIPCHECK(hipMemcpy(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8, hipMemcpyHostToDevice));
                 HIPCHECK(hipMemcpy(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8, hipMemcpyHostToDevice));
@@ -2756,6 +2923,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         }
         int rootstep = -1;
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
+        P->fuse_state_passes();
         P->finalize();
         if (rootstep >= 0) P->push_pw_step(rootstep);
         P->plan_lanes();
@@ -2886,7 +3054,14 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                            (int*)sb.d, (double*)P->bufs[S.one_vpub_buf].d, N.dtype, st);
                         nl += 1;
                     }
-                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass; ++gi) {
+                    if (S.pre_stage >= 0) {
+                        const Stage& S3 = P->stages[S.pre_stage];
+                        nl += launch_sos_prestate(inp, ob.d, (const double*)P->bufs[S3.vper_buf].d, S3.rp.nperiods,
+                                                  (const double*)P->bufs[S.qmat_buf].d, S3.rp.pt, (double*)P->bufs[S.v_buf].d,
+                                                  (double*)P->bufs[S.s0_buf].d, (const double*)P->bufs[S.mpow_buf].d, g,
+                                                  S.groups[0], st);
+                    }
+                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosGeom gg = g;
                         if (gi > 0) gg.in_pitch = ob.pitch;
@@ -2909,6 +3084,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rp.in_pitch = in_pitch;
                         rp.out_pitch = ob.pitch;
                         rp.out_f32 = s.idx == P->alias_stage && P->alias_narrow;
+                        if (rp.nstate > 0) {
+                            rp.wtab = (const double*)P->bufs[S.wtab_buf].d;
+                            rp.vper = (double*)P->bufs[S.vper_buf].d;
+                        }
                         const int64_t al = 16 / (int64_t)esz;
                         rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
                         static long long* d_trace = nullptr;  // SIGOPS_RS_TRACE tuning aid

@@ -256,7 +256,14 @@ struct RsPeriodic {
     int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
     int32_t out_f32;    // fp64 kernel storing into a Float32 result (`sink` of a Float64 signal into Float32)
     int32_t ga;         // GA instantiation: Float32 tiles, the gain multiplied at the A operand; lds_pitch in floats
-    int32_t pad2;
+    // Fused IIR state pass (the stage's only consumer is an SOS filter): the last nstate (= 2) loader
+    // waves multiply every row's staged window [jlo, jlo + 4*ksw) by wtab = (G . Tap), the filter's
+    // zero-state end-of-period state as a linear function of the resampler's INPUT, and write
+    // vper[ch][period][16] (components 0..D-1 valid) -- what k_sos_tiled<.,.,false> would have
+    // computed by reading the resampled signal once more.
+    int32_t nstate, ksw;
+    const double* wtab;  // [4*ksw][16]
+    double* vper;
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
 };

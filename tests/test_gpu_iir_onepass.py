@@ -118,3 +118,20 @@ def test_linearity_at_full_length():
     assert np.abs(got0 - h).max() < 1e-12
     assert np.abs(got1 + 2.0 * h).max() < 1e-12
     assert float(res[:d0, :].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nch,n,fo", [(8, 300_000, 48.0), (4, 120_000, 48.0), (8, 40_000, 96.0)])
+def test_state_pass_fused_into_the_resampler(nch, n, fo, monkeypatch):
+    """SIGOPS_FUSE_STATE=1: a periodic resampler whose only consumer is an SOS filter computes the
+    filter's per-period zero-state end states with two state waves (v = (G.Tap) x on the staged
+    LDS tile); K2 then runs combine + scan + output pass only.  Same values as the three-pass form
+    and as the oracle (Mix fused into the resampler's staging, as in the north-star pipeline)."""
+    x = _x(11, n, nch)
+    tree = (so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(x, 44.1 * so.kHz)) | so.Until(n * so.frames)
+            | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(fo * so.kHz))
+    monkeypatch.delenv("SIGOPS_SOS_ONEPASS", raising=False)
+    plain = so.sink(tree)[0]
+    monkeypatch.setenv("SIGOPS_FUSE_STATE", "1")
+    fused = so.sink(tree)[0]
+    assert relerr(fused, plain) < 1e-12
+    assert relerr(fused, oracle_sink(tree)) < 1e-9
