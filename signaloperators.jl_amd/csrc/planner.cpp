@@ -111,6 +111,7 @@ struct Stage {
     int64_t need = 0;  // output frames [0,need)
     bool processed = false;
     int out_buf = -1, in_buf = -1, aux_buf = -1;
+    int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)
     // input source (after processing): either a materialised buffer or a direct view
     const void* in_ptr = nullptr;  // direct device pointer (nullptr -> in_buf)
     int in_array_node = -1;
@@ -220,6 +221,8 @@ struct Plan {
     DOp* d_ops = nullptr;
     DLeaf* d_leaves = nullptr;
     int out_stage_buf = -1;  // device staging for a host result
+    int out_alias_buf = -1;  // pseudo buffer standing for the result (leaves of in-place root pieces point at it)
+    void try_window_alias(std::vector<Piece>& rootp);
     int alias_stage = -1;    // stage whose kernel writes the final output directly
     bool alias_narrow = false;  // ... rounding its Float64 values to the Float32 result
     bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
@@ -2444,6 +2447,126 @@ RsCtl Plan::make_ctl(const Stage& S) const {
 }
 
 // ---------------------------------------------------------------------------
+// Window aliasing.  When the root of the tree is `Append` / `Ramp` / `Amplify(number)` ... over
+// whole stage outputs (config 4: Append of Mix |> Filt |> Ramp scenes; any Append of filtered or
+// resampled children), the root pointwise launch used to copy every stage buffer into the result:
+// a read and a write of the whole output for nothing.  Here a stage whose buffer is read by root
+// pieces only, 1:1 (same channel, frame + constant offset, every frame exactly once), writes its
+// window of the result itself; identity pieces disappear and the remaining ones (ramp edges,
+// gains) run IN PLACE on the result (element-wise with the same index on both sides).
+void Plan::try_window_alias(std::vector<Piece>& rootp) {
+    if (std::getenv("SIGOPS_NO_WINDOW_ALIAS") || out.frame_stride != 1 || interleaved_host || out.nframes <= 0) return;
+    if (out.is_device && out.nch > 1 && out.chan_stride < out.nframes) return;
+    // stage buffers loaded by each root piece
+    auto loads_of = [&](int e, std::vector<int>& ls) {
+        std::vector<int> stk{e};
+        while (!stk.empty()) {
+            const int x = stk.back();
+            stk.pop_back();
+            if (x < 0) continue;
+            const Expr& ex = exprs[x];
+            if (ex.op == E_LOAD && ex.leaf.buf >= 0) ls.push_back(x);
+            if (ex.op >= E_ADD) {
+                stk.push_back(ex.a);
+                if (ex.op <= E_DIV) stk.push_back(ex.b);
+            }
+        }
+    };
+    struct Use { std::vector<size_t> pieces; bool bad = false; int64_t off = 0; };
+    std::map<int, Use> uses;  // buffer -> root pieces
+    for (size_t pi = 0; pi < rootp.size(); ++pi) {
+        const Piece& p = rootp[pi];
+        if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
+        std::vector<int> ls;
+        loads_of(p.e, ls);
+        std::set<int> bufs_here;
+        for (int x : ls) bufs_here.insert(exprs[x].leaf.buf);
+        for (int x : ls) {
+            const DLeaf& L = exprs[x].leaf;
+            Use& u = uses[L.buf];
+            const bool plain = L.mode == LM_PLAIN && L.sf == 1 && L.sc == 1 && L.dc == 0 && L.fstride == 1 && L.cstride == -1 &&
+                               L.dtype == out.dtype && p.r.c0 == 0 && p.r.c1 == out.nch && bufs_here.size() == 1 && ls.size() == 1;
+            if (!plain) u.bad = true;
+            if (u.pieces.empty()) u.off = -L.df;
+            else if (u.off != -L.df) u.bad = true;
+            u.pieces.push_back(pi);
+        }
+    }
+    std::vector<char> drop(rootp.size(), 0);
+    bool any = false;
+    for (auto& kv : uses) {
+        const int b = kv.first;
+        Use& u = kv.second;
+        if (u.bad || u.off < 0) continue;
+        int sid = -1;
+        for (size_t i = 0; i < stages.size(); ++i)
+            if (stages[i].out_buf == b) sid = (int)i;
+        if (sid < 0) continue;
+        Stage& S = stages[sid];
+        const Node& N = nodes[S.node];
+        if (S.kind == ST_NORM || S.need <= 0 || N.dtype != out.dtype || N.nch != out.nch || bufs[b].dtype != out.dtype) continue;
+        // every frame of the stage exactly once, in a window that starts at frame 0 of the stage
+        std::vector<std::pair<int64_t, int64_t>> iv;
+        for (size_t pi : u.pieces) iv.emplace_back(rootp[pi].r.a - u.off, rootp[pi].r.b - u.off);
+        std::sort(iv.begin(), iv.end());
+        int64_t at = 0;
+        bool cover = true;
+        for (auto& x : iv) {
+            if (x.first != at) cover = false;
+            at = x.second;
+        }
+        if (!cover || at != S.need || u.off + S.need > out.nframes) continue;
+        // no other reader of the buffer
+        bool other = false;
+        for (auto& L : leaves)
+            if (L.buf == b) other = true;
+        for (auto& S2 : stages) {
+            if (S2.in_buf == b) other = true;
+            for (auto& c : S2.carriers)
+                if (c.buf == b) other = true;
+        }
+        if (other) continue;
+        // commit
+        if (out_alias_buf < 0) {
+            Buf ob;
+            ob.frames = out.nframes;
+            ob.nch = out.nch;
+            ob.dtype = out.dtype;
+            ob.pitch = out.is_device ? (out.nch == 1 ? std::max<int64_t>(out.chan_stride, out.nframes) : out.chan_stride) : out.nframes;
+            ob.bytes = 0;
+            ob.external = true;
+            bufs.push_back(ob);
+            out_alias_buf = (int)bufs.size() - 1;
+        }
+        S.win_off = u.off;
+        any = true;
+        for (size_t pi : u.pieces) {
+            Expr& top = exprs[rootp[pi].e];
+            if (top.op == E_LOAD) {
+                drop[pi] = 1;  // the stage has written these frames
+                continue;
+            }
+            std::vector<int> ls;
+            loads_of(rootp[pi].e, ls);
+            for (int x : ls) {  // in place on the result
+                exprs[x].leaf.buf = out_alias_buf;
+                exprs[x].leaf.df = 0;
+            }
+        }
+    }
+    if (!any) return;
+    std::vector<Piece> keep;
+    for (size_t pi = 0; pi < rootp.size(); ++pi)
+        if (!drop[pi]) keep.push_back(rootp[pi]);
+    rootp.swap(keep);
+    if (std::getenv("SIGOPS_DEBUG_PLAN")) {
+        int n = 0;
+        for (auto& S : stages) n += S.win_off >= 0;
+        std::fprintf(stderr, "[sigops] window aliasing: %d stage(s) write the result themselves, %zu root piece(s) left\n", n, rootp.size());
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Resampler -> IIR: fold the IIR's state pass into the resampler.
 // The three-pass K2 reads its input twice; when that input is the output of a periodic resampler
 // stage and nothing else reads it, the first read can go: a chunk's zero-state end state is linear
@@ -2468,7 +2591,7 @@ void Plan::fuse_state_passes() {
         int i3 = -1;
         for (size_t j = 0; j < stages.size(); ++j)
             if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
-        if (i3 < 0 || i3 == alias_stage) continue;
+        if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
         Stage& S3 = stages[i3];
         const RsPeriodic& rp0 = S3.rp;
         if (!S3.periodic || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
@@ -2592,7 +2715,7 @@ void Plan::finalize() {
     // size stage output buffers now that every need is known
     for (size_t si = 0; si < stages.size(); ++si) {
         Stage& S = stages[si];
-        if (S.out_buf >= 0 && (int)si == alias_stage) {
+        if (S.out_buf >= 0 && ((int)si == alias_stage || S.win_off >= 0)) {
             bufs[S.out_buf].external = true;  // the kernel writes the final output directly
             bufs[S.out_buf].bytes = 0;
             continue;
@@ -2639,6 +2762,10 @@ void Plan::finalize() {
         scratch += (int64_t)b.bytes;
     }
     stats.scratch_bytes = scratch;
+    if (out_alias_buf >= 0 && !out.is_device) {
+        bufs[out_alias_buf].d = bufs[out_stage_buf].d;
+        bufs[out_alias_buf].pitch = bufs[out_stage_buf].pitch;
+    }
     // patch leaves
     for (size_t i = 0; i < leaves.size(); ++i) {
         DLeaf& L = leaves[i];
@@ -2776,6 +2903,9 @@ void Plan::plan_lanes() {
             const PwStep& w = pw[st.idx];
             piece_reads(w, rd[i]);
             wr[i].insert(w.out_buf >= 0 ? w.out_buf : kFinal);
+            if (w.out_buf < 0)  // the root launch runs in place on the windows stages have written
+                for (size_t k = 0; k < stages.size(); ++k)
+                    if (stages[k].win_off >= 0) rd[i].insert(-100 - (int)k);
         } else {
             const Stage& S = stages[st.idx];
             if (S.in_buf >= 0) rd[i].insert(S.in_buf);
@@ -2788,7 +2918,8 @@ void Plan::plan_lanes() {
                 for (int k = 0; k < c.nslots; ++k)
                     if (leaves[c.slot_leaf[k]].buf >= 0) rd[i].insert(leaves[c.slot_leaf[k]].buf);
             }
-            wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
+            if (S.win_off >= 0) wr[i].insert(-100 - st.idx);  // its own window of the result
+            else wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
             if (S.kind == ST_NORM) {  // reads its own output buffer, writes the rms scalar
                 rd[i].insert(S.out_buf);
                 if (S.rms_buf >= 0) wr[i].insert(S.rms_buf);
@@ -2922,6 +3053,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             }
         }
         int rootstep = -1;
+        if (P->alias_stage < 0) P->try_window_alias(rootp);
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
         P->fuse_state_passes();
         P->finalize();
@@ -2950,6 +3082,14 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 HIPCHECK(hipEventCreate(&e));
                 P->events.push_back(e);
             }
+        }
+        if (P->out_alias_buf >= 0 && P->out.is_device && P->bufs[P->out_alias_buf].d != outp) {
+            // in-place root pieces read the result: point their leaves at this execute's buffer
+            P->bufs[P->out_alias_buf].d = outp;
+            for (auto& L : P->leaves)
+                if (L.buf == P->out_alias_buf) L.base = outp;
+            if (P->d_leaves)
+                HIPCHECK(hipMemcpyAsync(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice, st));
         }
         int launches = 0;
         // (profiling times the steps one after the other on the caller's stream)
@@ -3030,6 +3170,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         ob.d = P->bufs[P->out_stage_buf].d;
                         ob.pitch = P->bufs[P->out_stage_buf].pitch;
                     }
+                } else if (S.win_off >= 0) {  // ... or its window of it
+                    const Buf& ab = P->bufs[P->out_alias_buf];
+                    ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
+                    ob.pitch = ab.pitch;
                 }
                 if (S.kind == ST_SOS) {
                     SosGeom g = S.sg;
