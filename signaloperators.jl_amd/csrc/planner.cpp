@@ -70,6 +70,8 @@ struct Node {
     Len len;
     int dtype, nch;
     double fs;
+    int64_t short_skip = 0;  // > 0: evaluating this node skips more frames than a child below has
+    int64_t checked_upto = 0;  // frames [0, checked_upto) have been lowered for their errors (check_frames)
 };
 
 // ---- expressions -------------------------------------------------------------
@@ -338,6 +340,8 @@ struct Plan {
                                int force_dtype);
     int stage_for(int ni, int kind);
     void use_stage(Stage& S, const Rect& r, const Map& m);
+    int dry = 0;  // > 0: lower() only looks for the errors evaluating those frames raises (no stages, no buffers)
+    void check_frames(int ni, int64_t upto);
     void process_stage(int sid);
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
@@ -411,8 +415,10 @@ void Plan::build_nodes(const so_node_t* in, int n) {
             Node& c = kid(0);
             if (isinf_(c.len)) N.len = c.len;
             else {
-                if (nd.l0 > c.len.n)
-                    fail(SO_ERR_LENGTH, "Signal is too short to skip " + std::to_string(nd.l0) + " frames");
+                // The reference raises this from After's first nextblock (src/cutting.jl:160-181), i.e.
+                // only when the node is evaluated: an After inside a Mix / Amplify whose result has
+                // no frames is never asked for a block.  Recorded here, raised by lower() / plan_create.
+                if (nd.l0 > c.len.n) N.short_skip = nd.l0;
                 N.len = Len{LK_FIN, std::min(std::max<int64_t>(c.len.n - nd.l0, 0), c.len.n)};
             }
             N.nch = c.nch;
@@ -520,6 +526,8 @@ void Plan::build_nodes(const so_node_t* in, int n) {
         }
         default: fail(SO_ERR_INVALID, "unknown node kind " + std::to_string(nd.kind));
         }
+        // nodes that ask their (first) child for a block whenever they are asked for one themselves
+        if (!N.short_skip && !N.kids.empty() && nd.kind != SO_NODE_MAP) N.short_skip = nodes[N.kids[0]].short_skip;
         if (N.dtype == SO_I64 && nd.kind != SO_NODE_CONST && nd.kind != SO_NODE_UNTIL &&
             nd.kind != SO_NODE_AFTER && nd.kind != SO_NODE_PAD && nd.kind != SO_NODE_APPEND &&
             nd.kind != SO_NODE_MAP)
@@ -560,6 +568,28 @@ void Plan::use_stage(Stage& S, const Rect& r, const Map& m) {
     int64_t hi = m.sf ? r.b + m.df : m.df + 1;
     if (S.processed && hi > S.need) fail(SO_ERR_RUNTIME, "internal: stage need raised after processing");
     S.need = std::max(S.need, hi);
+}
+
+// Frames the reference evaluates although nobody uses their values -- what `After` skips
+// (src/cutting.jl:160-173 pulls the skipped blocks through the whole tree below it) and what a
+// filter reads ahead of the frames asked for (src/filters.jl:221-262: whole blocks of `blocksize`
+// input frames) -- raise the same errors there as used frames do.  Lower them for the errors only.
+void Plan::check_frames(int ni, int64_t upto) {
+    Node& C = nodes[ni];
+    const int64_t hi = isinf_(C.len) ? upto : std::min(upto, C.len.n);
+    if (hi <= C.checked_upto || hi >= BIG) return;
+    const int64_t lo = C.checked_upto;
+    C.checked_upto = hi;
+    ++dry;
+    try {
+        (void)lower(ni, Rect{lo, hi, 0, C.nch}, Map{1, 0, 1, 0});
+    } catch (const PlanError& e) {
+        --dry;
+        // (frames the engine never computes cannot run into its own limits)
+        if (e.status == SO_ERR_UNSUPPORTED || e.status == SO_ERR_RUNTIME) return;
+        throw;
+    }
+    --dry;
 }
 
 static DLeaf mk_leafmap(const Map& m) {
@@ -713,6 +743,10 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
     if (r.a >= r.b || r.c0 >= r.c1) return out;
     Node& N = nodes[ni];
     const so_node_t& nd = N.nd;
+    if (nd.kind == SO_NODE_MAP || nd.kind == SO_NODE_APPEND)  // frames wanted: every child is evaluated
+        for (int k : N.kids)
+            if (nodes[k].short_skip)
+                fail(SO_ERR_LENGTH, "Signal is too short to skip " + std::to_string(nodes[k].short_skip) + " frames");
     switch (nd.kind) {
     case SO_NODE_ARRAY: {
         Expr e;
@@ -724,7 +758,7 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
         e.leaf.dtype = N.dtype;
         e.array_node = ni;
         e.mono = (m.sc == 0);
-        count_array(ni);
+        if (!dry) count_array(ni);
         out.push_back({r, add_expr(e)});
         return out;
     }
@@ -744,7 +778,9 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
         return out;
     }
     case SO_NODE_UNTIL: return lower(N.kids[0], r, m);
-    case SO_NODE_AFTER: return lower(N.kids[0], r, Map{m.sf, m.df + std::max<int64_t>(0, nd.l0), m.sc, m.dc});
+    case SO_NODE_AFTER:
+        if (nd.l0 > 0) check_frames(N.kids[0], nd.l0);
+        return lower(N.kids[0], r, Map{m.sf, m.df + std::max<int64_t>(0, nd.l0), m.sc, m.dc});
     case SO_NODE_PAD:
         return lower_padded(N.kids[0], nd.i0, nd.d0, (const double*)nd.p0, r, m, true);
     case SO_NODE_APPEND: {  // reference src/appending.jl:92-110
@@ -786,7 +822,7 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
             if (Ntot >= BIG) B = BIG;
             else {
                 B = Ntot - R;
-                if (B < 0) fail(SO_ERR_UNSUPPORTED, "RampOff longer than the signal is undefined in the reference (src/ramps.jl:79-80)");
+                if (B < 0) fail(SO_ERR_INVALID, "RampOff longer than the signal is undefined in the reference (src/ramps.jl:79-80)");
             }
         }
         auto region = [&](Rect rr, bool first) {
@@ -884,6 +920,18 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
     case SO_NODE_RESAMPLE:
     case SO_NODE_NORMPOWER: {
         int kind = nd.kind == SO_NODE_FILT_SOS ? ST_SOS : nd.kind == SO_NODE_RESAMPLE ? ST_RESAMPLE : ST_NORM;
+        if (dry) {  // the frames of the child this node's frames [0, F) are made of
+            const Node& C = nodes[N.kids[0]];
+            const int64_t F = m.sf ? r.b + m.df : m.df + 1;
+            int64_t Fc = BIG;
+            if (kind == ST_SOS) Fc = (F + std::max(1, nd.i1) - 1) / std::max(1, nd.i1) * std::max(1, nd.i1);
+            else if (kind == ST_RESAMPLE && N.fs > 0 && C.fs > 0) Fc = (int64_t)std::ceil((double)F * C.fs / N.fs) + 1;
+            if (kind == ST_NORM && isinf_(N.len))
+                fail(SO_ERR_LENGTH, "Cannot normalize an infinite-length signal. Please use `Until` to take a prefix of the signal");
+            check_frames(N.kids[0], Fc);
+            out.push_back({r, mk_const(0.0, N.dtype)});
+            return out;
+        }
         int sid = stage_for(ni, kind);
         if (kind == ST_NORM) {
             if (isinf_(N.len))
@@ -2098,6 +2146,10 @@ void Plan::process_stage(int sid) {
     // lower the child over the frames this stage consumes
     std::vector<Piece> ps;
     if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, 0, 1, 0});
+    if (stages[sid].kind == ST_SOS && in_frames > 0) {  // the reference filters whole blocks of its input
+        const int64_t bs = std::max(1, N.nd.i1);
+        check_frames(child, (in_frames + bs - 1) / bs * bs);
+    }
     Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
     S.in_frames = in_frames;
     int in_dtype = S.kind == ST_NORM ? N.dtype : C.dtype;
@@ -2903,7 +2955,9 @@ void Plan::plan_lanes() {
             const PwStep& w = pw[st.idx];
             piece_reads(w, rd[i]);
             wr[i].insert(w.out_buf >= 0 ? w.out_buf : kFinal);
-            if (w.out_buf < 0)  // the root launch runs in place on the windows stages have written
+            // the root launch runs in place on the windows stages have written, and so does any
+            // sub-expression of it that was materialised into a temporary first
+            if (w.out_buf < 0 || (out_alias_buf >= 0 && rd[i].count(out_alias_buf)))
                 for (size_t k = 0; k < stages.size(); ++k)
                     if (stages[k].win_off >= 0) rd[i].insert(-100 - (int)k);
         } else {
@@ -3010,6 +3064,8 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             fail(SO_ERR_LENGTH, "Signal is too short to fill buffer of length " + std::to_string(out->nframes) + ".");
         if (R.nch != out->nch)
             fail(SO_ERR_CHANNELS, "signal has " + std::to_string(R.nch) + " channels, buffer has " + std::to_string(out->nch) + " (the host applies ToChannels, reference src/sink.jl:164)");
+        if (R.short_skip)  // the sink asks the root for a block even when the result is empty (src/sink.jl:225-226)
+            fail(SO_ERR_LENGTH, "Signal is too short to skip " + std::to_string(R.short_skip) + " frames");
         std::vector<Piece> rootp;
         if (out->nframes > 0) rootp = P->lower(root, Rect{0, out->nframes, 0, out->nch}, Map{1, 0, 1, 0});
         // stages: largest node index first (all users of a stage have larger indices)

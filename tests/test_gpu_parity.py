@@ -403,3 +403,41 @@ def test_float32_normpower_reduction_order():
     y = np.asfortranarray(rng.standard_normal((100_000, 2)).astype(np.float32))
     t2 = so.Signal(y, 1 * so.kHz) | so.Normpower
     assert relerr(so.sink(t2)[0], oracle_sink(t2)) < 5e-7
+
+
+def _both_raise(tree):
+    with pytest.raises(so.ErrorException) as want:
+        oracle_sink(tree)
+    with pytest.raises(so.ErrorException) as got:
+        so.sink(tree)
+    assert str(got.value)[:40] == str(want.value)[:40]
+
+
+def test_errors_in_frames_nobody_uses():
+    """The reference evaluates the frames `After` skips and the whole input blocks a filter reads
+    (src/cutting.jl:160-173, src/filters.jl:221-262): errors raised there are raised by the engine too."""
+    rng = np.random.default_rng(12)
+    tone = so.Signal(so.sin, 8 * so.kHz, ω=16 * so.Hz) | so.Until(120 * so.frames)
+    # After skips the mirror-padded region of something that is not an array
+    _both_raise(so.Pad(tone, so.mirror) | so.Until(420 * so.frames) | so.After(300 * so.frames))
+    # ... also through a Pad / Until / After chain and a channel map on top
+    _both_raise(so.Pad(tone, so.mirror) | so.Until(420 * so.frames) | so.Pad(2.5) | so.Until(1056 * so.frames)
+                | so.After(729 * so.frames) | so.ToChannels(3))
+    # a filter reads its input in blocks of 4096 frames: the padding is evaluated although 13 outputs are used
+    x = so.Signal(np.asfortranarray(rng.standard_normal((279, 3))), 100 * so.Hz) | so.Amplify(0.5)
+    _both_raise(so.Pad(x, so.cycle) | so.Until(388 * so.frames) | so.Filt(so.Lowpass, 20 * so.Hz) | so.Until(13 * so.frames))
+    # the same trees without the offending padding are fine
+    ok = so.Pad(x, so.zero) | so.Until(388 * so.frames) | so.Filt(so.Lowpass, 20 * so.Hz) | so.Until(13 * so.frames)
+    assert relerr(so.sink(ok, so.Array), oracle_sink(ok)) < 1e-9
+
+
+def test_after_longer_than_a_child_that_is_never_evaluated():
+    """`After` raises from its first block (src/cutting.jl:174-181): inside a Mix whose result is empty
+    nobody asks for one; at the root of the tree the sink always does (src/sink.jl:225-226)."""
+    short = so.Signal(so.sin, 6 * so.kHz, ω=24 * so.Hz) | so.Until(4 * so.frames) | so.After(7 * so.frames)
+    tree = so.Ramp(short, 5 * so.frames)
+    want = oracle_sink(tree)
+    got = so.sink(tree, so.Array)
+    assert got.shape == want.shape == (0, 1)
+    _both_raise(short)
+    _both_raise(so.Append(short, so.Signal(np.ones(5), 6 * so.kHz)))

@@ -39,6 +39,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             tree = tree2(rng, nch, int(rng.integers(0, 4)), info)
         except Exception as e:
             print('GEN', seed, i, str(e)[:120]); continue
+        try:
+            if so.nframes(tree) == 0: continue
+        except Exception:
+            pass
         from sigops_amd import lowering as _lw
         try:
             _L = _lw.lower(tree)
