@@ -105,12 +105,16 @@ struct Buf {
     size_t bytes = 0;
     void* d = nullptr;
     bool external = false;  // aliases a user/device leaf pointer
+    int64_t frame0 = 0;     // stage buffers: node frame stored at position 0 (Stage::base)
 };
 
 enum { ST_SOS, ST_RESAMPLE, ST_NORM };
 struct Stage {
     int kind, node;
     int64_t need = 0;  // output frames [0,need)
+    int64_t lo = (int64_t)1 << 62;  // first frame anybody reads
+    int64_t base = 0;  // first frame the stage computes (warm start, see process_stage): its buffer holds [base, need)
+    int64_t in_base = 0;  // first frame of the child the stage consumes
     bool processed = false;
     int out_buf = -1, in_buf = -1, aux_buf = -1;
     int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)
@@ -568,6 +572,9 @@ void Plan::use_stage(Stage& S, const Rect& r, const Map& m) {
     int64_t hi = m.sf ? r.b + m.df : m.df + 1;
     if (S.processed && hi > S.need) fail(SO_ERR_RUNTIME, "internal: stage need raised after processing");
     S.need = std::max(S.need, hi);
+    const int64_t lo = m.sf ? r.a + m.df : m.df;
+    if (S.processed && lo < S.base) fail(SO_ERR_RUNTIME, "internal: stage read before its first frame after processing");
+    S.lo = std::min(S.lo, std::max<int64_t>(lo, 0));
 }
 
 // Frames the reference evaluates although nobody uses their values -- what `After` skips
@@ -1996,6 +2003,29 @@ void Plan::process_stage(int sid) {
             cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
             groups.push_back(cf);
         }
+        // ---- warm start: frames before the first one anybody reads (After, a later window of a
+        //      stream) matter only through the filter state, and what a state contributes has decayed
+        //      below 2^-70 after W frames: start from zero state W frames early instead of at frame 0.
+        //      (The reference filters the skipped frames, src/cutting.jl:160-173; same values.) ----
+        if (stages[sid].lo < need && stages[sid].lo >= 8192 && !std::getenv("SIGOPS_NO_WARM_START")) {
+            int64_t Wd = 0;
+            for (auto& cf : groups) {
+                const int D = 2 * cf.nsec;
+                Mat P = sos_state_matrix(cf);
+                int64_t w = 1;
+                while (maxabs(P) >= std::ldexp(1.0, -70) && w < ((int64_t)1 << 40)) {
+                    P = matmul(P, P, D);
+                    w <<= 1;
+                }
+                Wd += w;  // (groups are cascaded: decay times add up at worst)
+            }
+            if (stages[sid].lo - Wd >= 4096) {
+                const int64_t base = (stages[sid].lo - Wd) / 64 * 64;
+                stages[sid].base = stages[sid].in_base = base;
+                need -= base;  // local frames from here on
+                in_frames = need;
+            }
+        }
         // ---- single pass (one read, one write): wave tiles in time order with a look-back over the
         //      zero-state end states of the kt previous tiles (see k_sos_onepass) ----
         // Opt-in (SIGOPS_SOS_ONEPASS=1): its HBM traffic is the algorithmic minimum, but on MI355X it
@@ -2145,11 +2175,14 @@ void Plan::process_stage(int sid) {
 
     // lower the child over the frames this stage consumes
     std::vector<Piece> ps;
-    if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, 0, 1, 0});
+    const int64_t in_base = stages[sid].in_base;
+    if (in_base > 0) check_frames(child, in_base);
+    if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, in_base, 1, 0});
     if (stages[sid].kind == ST_SOS && in_frames > 0) {  // the reference filters whole blocks of its input
         const int64_t bs = std::max(1, N.nd.i1);
-        check_frames(child, (in_frames + bs - 1) / bs * bs);
+        check_frames(child, (in_base + in_frames + bs - 1) / bs * bs);
     }
+    if (stages[sid].out_buf >= 0) bufs[stages[sid].out_buf].frame0 = stages[sid].base;
     Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
     S.in_frames = in_frames;
     int in_dtype = S.kind == ST_NORM ? N.dtype : C.dtype;
@@ -2637,7 +2670,7 @@ void Plan::fuse_state_passes() {
     if (!std::getenv("SIGOPS_FUSE_STATE")) return;
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {
         Stage& S2 = stages[i2];
-        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.groups.size() != 1 || S2.in_buf < 0 ||
+        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.base > 0 || S2.groups.size() != 1 || S2.in_buf < 0 ||
             S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.nchunks <= 1)
             continue;
         int i3 = -1;
@@ -2774,8 +2807,8 @@ void Plan::finalize() {
         }
         if (S.out_buf >= 0) {
             Buf& b = bufs[S.out_buf];
-            b.frames = S.need;
-            b.pitch = std::max<int64_t>(64, (S.need + 63) / 64 * 64);
+            b.frames = S.need - S.base;
+            b.pitch = std::max<int64_t>(64, (S.need - S.base + 63) / 64 * 64);
             b.bytes = (size_t)b.pitch * (size_t)std::max(b.nch, 1) * dsize(b.dtype);
         }
     }
@@ -2827,6 +2860,7 @@ void Plan::finalize() {
         } else if (L.buf >= 0) {
             L.base = bufs[L.buf].d;
             if (L.cstride == -1) L.cstride = bufs[L.buf].pitch;
+            L.df -= bufs[L.buf].frame0;  // (stage buffers that start at a later frame: once, here)
         }
     }
     for (auto& S : stages) {
@@ -2839,6 +2873,7 @@ void Plan::finalize() {
             } else if (c.buf >= 0) {
                 c.base = bufs[c.buf].d;
                 if (c.cstride == -1) c.cstride = bufs[c.buf].pitch;
+                c.df -= bufs[c.buf].frame0;
             } else {
                 c.base = nullptr;  // generated piece
                 c.cstride = 0;
@@ -2913,9 +2948,9 @@ void Plan::finalize() {
         const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
-        if (S.kind == ST_SOS) st.bytes = 2 * S.need * S.sg.nch * esz;
+        if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
         else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
-        else st.bytes = S.need * nodes[S.node].nch * esz;
+        else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
         steps.push_back(st);
     }
     stats.n_stages = (int)order.size() + 1;
@@ -3214,7 +3249,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     in_pitch = N.nch == 1 ? 0 : S.in_pitch;
                 } else {
                     Buf& b = P->bufs[S.in_buf];
-                    inp = (const char*)b.d + (size_t)S.in_offset * esz;
+                    inp = (const char*)b.d + (size_t)(S.in_offset - b.frame0) * esz;
                     in_pitch = b.pitch;
                 }
                 Buf ob = P->bufs[S.out_buf];
