@@ -1319,17 +1319,49 @@ static Mat matpow(Mat A, int64_t e, int D) {
 // `prev[r]` marks those period positions so that the kernels' tap tables are built with the
 // accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
 // goes to the fix-up list (k_resample_fix).
-static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
                                           std::vector<uint8_t>& prev, std::vector<RsFix>& fix);
+
+// state of the accumulator before output m (a later window of the same resampler resumes from the
+// nearest one instead of replaying from output 0)
+struct AccCheckpoint {
+    int64_t m, xb;
+    double acc;
+};
+struct AccKey {
+    double delta, c0, hsum;
+    int64_t c0i, L, M;
+    int32_t nphi, taps, exact, hlen;
+    bool operator==(const AccKey& o) const { return std::memcmp(this, &o, sizeof(AccKey)) == 0; }
+};
+static std::mutex g_acc_mu;
+static std::vector<std::pair<AccKey, std::vector<AccCheckpoint>>> g_acc_checkpoints;
+static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
+    AccKey k;
+    std::memset(&k, 0, sizeof k);
+    k.delta = g.delta;
+    k.c0 = g.c0;
+    k.c0i = g.c0i;
+    k.L = g.L;
+    k.M = g.M;
+    k.nphi = g.nphi;
+    k.taps = g.taps;
+    k.exact = g.exact;
+    k.hlen = hlen;
+    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    return k;
+}
 
 // The replay is sequential by nature (~5 ns per output: 160 ms for config 3's 28.8 M outputs) and
 // depends only on the geometry, so a process keeps the last few results (plans of the same
 // resampler -- a bench's second workload, a re-created plan -- get it for free).
+// Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate, and the
+// fix-up list comes back in the window's own coordinates (output m - from, input j - from/L*M).
 static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
-                                     std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
+                                     std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from = 0) {
     struct Key {
         double delta, c0, hsum;
-        int64_t c0i, L, M, need;
+        int64_t c0i, L, M, need, from;
         int32_t nphi, taps, exact, hlen, bake;
         bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
     };
@@ -1348,6 +1380,7 @@ static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen,
     k.L = g.L;
     k.M = g.M;
     k.need = need;
+    k.from = from;
     k.nphi = g.nphi;
     k.taps = g.taps;
     k.exact = g.exact;
@@ -1368,13 +1401,13 @@ static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen,
                 return;
             }
     }
-    replay_phase_accumulator_impl(g, h, hlen, need, bake, prev, fix);
+    replay_phase_accumulator_impl(g, h, hlen, from, need, bake, prev, fix);
     std::lock_guard<std::mutex> lock(mu);
     if (cache.size() >= 8) cache.erase(cache.begin());
     cache.push_back(Entry{k, prev, fix});
 }
 
-static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
                                           std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
     prev.clear();
     fix.clear();
@@ -1413,7 +1446,27 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     struct Rec { int64_t m, qa; double alpha; };
     std::vector<Rec> rec;
     std::vector<int8_t> memo((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
-    for (int64_t m = 0; m < need; ++m) {
+    int64_t m0 = 0;
+    const AccKey ckey = acc_key(g, h, hlen);
+    std::vector<AccCheckpoint> made;
+    if (from > 0) {  // resume from the nearest checkpoint at or before the window
+        std::lock_guard<std::mutex> lock(g_acc_mu);
+        for (auto& e : g_acc_checkpoints)
+            if (e.first == ckey)
+                for (auto& c : e.second)
+                    if (c.m <= from && c.m > m0) {
+                        m0 = c.m;
+                        xb = c.xb;
+                        acc = c.acc;
+                    }
+        if (exact) {
+            const __int128 Nn = (__int128)m0 * ((int64_t)nphi * g.M);
+            qe = g.c0i + (int64_t)(Nn / L);
+            fe = (int64_t)(Nn % L);
+        }
+    }
+    for (int64_t m = m0; m < need; ++m) {
+        if (m == from || (m > m0 && (m & ((1 << 22) - 1)) == 0)) made.push_back(AccCheckpoint{m, xb, acc});
         const int pi = (int)acc;  // floor: acc >= 1
         const int64_t qa = xb + pi - 1;
         double qe_frac = 0.0;
@@ -1434,7 +1487,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                 if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
                 differ = mm != 0;
             } else differ = taps_differ(qa, alpha, qe, ae);
-            if (differ) rec.push_back(Rec{m, qa, alpha});
+            if (differ && m >= from) rec.push_back(Rec{m, qa, alpha});
         }
         if (exact) {
             qe += dq;
@@ -1465,6 +1518,24 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
             }
         }
     }
+    made.push_back(AccCheckpoint{need, xb, acc});
+    {
+        std::lock_guard<std::mutex> lock(g_acc_mu);
+        std::vector<AccCheckpoint>* store = nullptr;
+        for (auto& e : g_acc_checkpoints)
+            if (e.first == ckey) store = &e.second;
+        if (!store) {
+            if (g_acc_checkpoints.size() >= 8) g_acc_checkpoints.erase(g_acc_checkpoints.begin());
+            g_acc_checkpoints.emplace_back(ckey, std::vector<AccCheckpoint>{});
+            store = &g_acc_checkpoints.back().second;
+        }
+        for (auto& c : made) {
+            bool have = false;
+            for (auto& o : *store) have = have || o.m == c.m;
+            if (!have) store->push_back(c);
+        }
+        if (store->size() > 256) store->erase(store->begin(), store->begin() + (store->size() - 256));
+    }
     auto exact_q = [&](int64_t m) {
         const int64_t Nn = m * ((int64_t)nphi * g.M);
         return g.c0i + Nn / L;
@@ -1478,7 +1549,8 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
         prev.assign(L, 0);
         bool any = false;
         for (int64_t r = 0; r < L; ++r) {
-            const int64_t occ = need > r ? (need - 1 - r) / L + 1 : 0;
+            // (occurrences of period position r in [from, need); `from` is a multiple of L)
+            const int64_t occ = need - from > r ? (need - from - 1 - r) / L + 1 : 0;
             if (occ > 0 && 2 * cnt[r] > occ) prev[r] = 1, any = true;
         }
         if (!any) prev.clear();
@@ -1489,7 +1561,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
         for (int64_t r = 0; r < L; ++r) {
             if (!prev[r]) continue;
             size_t k = 0;
-            for (int64_t m = r; m < need; m += L) {  // outputs at a baked position
+            for (int64_t m = from + r; m < need; m += L) {  // outputs at a baked position
                 while (k < rec.size() && rec[k].m < m) ++k;
                 if (k < rec.size() && rec[k].m == m) continue;  // deviates: baked, or listed below
                 const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
@@ -1504,6 +1576,13 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
         for (const Rec& r : rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
     }
     std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
+    if (from > 0) {
+        const int64_t jin = exact ? from / L * g.M : 0;
+        for (auto& f : fix) {
+            f.m -= from;
+            f.j -= jin;
+        }
+    }
 }
 
 // integer frame rates: the arbitrary-rate kernel's rate is the exact rational fs_out/fs_in
@@ -1630,6 +1709,24 @@ void Plan::process_stage(int sid) {
         g.m0 = 0;
         g.n_out = need;
         if (g.arbitrary) rs_detect_exact(g, nd.fs, C.fs, nd.d0);
+        // ---- warm start (see the IIR's below): the resampler is an FIR filter, so outputs from a
+        //      whole number of periods before the first frame anybody reads on are the same whether
+        //      the stage starts there or at frame 0, except the first few (their taps reach before
+        //      the first input staged), which nobody reads either ----
+        int64_t rbase = 0;
+        if ((!g.arbitrary || g.exact) && stages[sid].lo >= 8192 && stages[sid].lo < need &&
+            !std::getenv("SIGOPS_NO_WARM_START")) {
+            const int64_t margin = (g.taps + 2 + g.M - 1) / g.M + 1;  // periods
+            int64_t k = stages[sid].lo / g.L - margin;
+            k = k / 16 * 16;  // (16 M inputs: the first staged input stays 128-byte aligned)
+            if (k > 0 && k * g.L >= 4096) {
+                rbase = k * g.L;
+                stages[sid].base = rbase;
+                stages[sid].in_base = k * g.M;
+                need -= rbase;
+                g.n_out = need;
+            }
+        }
         // newest input of the last needed output
         int64_t jl;
         if (g.arbitrary && g.exact) {
@@ -1640,7 +1737,7 @@ void Plan::process_stage(int sid) {
             jl = (int64_t)std::floor(q) / g.nphi;
         } else jl = (g.c0i + (need - 1) * g.M) / g.L;
         int64_t nin = jl + 2;  // +1 slack: host rounding of q may differ from the device's at ties
-        if (!isinf_(C.len)) nin = std::min(nin, C.len.n);
+        if (!isinf_(C.len)) nin = std::min(nin, C.len.n - stages[sid].in_base);
         g.n_in = nin;
         in_frames = nin;
         // polyphase tables: pfb[p][k] = h[p + nphi*k]; dpfb from dh = [diff(h);0]
@@ -1662,7 +1759,7 @@ void Plan::process_stage(int sid) {
         if (g.arbitrary && !std::getenv("SIGOPS_RS_EXACT")) {
             // (period positions can only be baked into the tap tables of the periodic / row-tiled
             //  kernels: short outputs go to the thread-per-output kernel and list every deviation)
-            replay_phase_accumulator(g, (const double*)nd.p0, hlen, need, g.exact && need >= 2048, wrap, stages[sid].fix_host);
+            replay_phase_accumulator(g, (const double*)nd.p0, hlen, rbase + need, g.exact && need >= 2048, wrap, stages[sid].fix_host, rbase);
         }
         // position of period output r as the tap tables see it: the closed form, or the
         // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
@@ -1981,7 +2078,8 @@ void Plan::process_stage(int sid) {
             }
         }
         if (!wrap.empty() && !stages[sid].periodic && !stages[sid].rows)  // no tap table took the baked positions
-            replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, need, false, wrap, stages[sid].fix_host);
+            replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, stages[sid].base + need, false, wrap, stages[sid].fix_host,
+                                     stages[sid].base);
         if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
     } else if (stages[sid].kind == ST_SOS) {
         if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);

@@ -205,6 +205,44 @@ def sink(x, to=None, *, device=0, rng=None):
     return res if to is Array else (res, x.fs)
 
 
+def stream(x, blocksize, to=None, *, device=0):
+    """Iterate over the frames of `x` in blocks of `blocksize` frames (the last one may be shorter;
+    an infinite signal never stops): block k is `sink(x |> After(k*blocksize frames) |>
+    Until(blocksize frames), to)`, which is what the reference's own sink loop -- `sink!(buffer, x,
+    block)` with the block it returned last time, src/sink.jl:227-241 -- writes into successive
+    buffers.  Results do not depend on `blocksize` (the reference's `blocksize` contract,
+    src/filters.jl:3).  Stateful stages do not start over for every block: a filter starts a decay
+    time before the block and a resampler a few periods before it (warm start), and the
+    resampler's DSP.jl phase accumulator resumes from the previous block's end.  Host arrays of the
+    tree are uploaded once.  `Normpower` needs its whole child for every block and `randn` leaves
+    draw new numbers for every block: neither is meant for streaming."""
+    from . import lowering as LW
+    from .units import frames
+
+    x = S._assignal(x)
+    blocksize = int(blocksize)
+    if blocksize <= 0:
+        S.error("stream: blocksize must be positive")
+    n = S.nframes(x)
+    if n is None:
+        S.error("Unknown number of frames in signal.")
+    finite = not S.isknowninf(n)
+    if to is None:
+        to = _refineroot(x)
+    cache = {"device": f"cuda:{device}"}
+    pos = 0
+    while not finite or pos < n:
+        m = blocksize if not finite else min(blocksize, n - pos)
+        blk = S.Until(S.After(x, pos * frames) if pos else x, m * frames)
+        prev, LW._device_cache = LW._device_cache, cache
+        try:
+            res = sink(blk, to, device=device)
+        finally:
+            LW._device_cache = prev
+        yield res
+        pos += m
+
+
 def filt(b, a, x, si=None, *, device=0):
     """DSP.filt(b, a, x::AbstractSignal[, si]) (reference src/filters.jl:68-79): the signal is sunk
     (HIP engine) and filtered with direct-form coefficients.  FIR (a scalar / [a0]) and orders <= 2

@@ -132,8 +132,26 @@ class Lowered:
         return self
 
 
+# so.stream(): host arrays of the tree are uploaded once and every block's plan reads the device
+# copy (id(ArraySig) -> torch tensor); None outside a stream
+_device_cache = None
+
+
 def _array_fields(x):
     d = x.data
+    if _device_cache is not None and not S._is_torch(d) and d.dtype in (np.float32, np.float64) and d.size:
+        t = _device_cache.get(id(x))
+        if t is None:
+            import torch
+
+            dev = _device_cache["device"]
+            if d.ndim == 1:
+                t = torch.from_numpy(np.ascontiguousarray(d)).to(dev)
+            else:  # planar on the device: channels contiguous in time
+                t = torch.from_numpy(np.ascontiguousarray(d.T)).to(dev).t()
+            _device_cache[id(x)] = t
+            _device_cache.setdefault("keep", []).append(x)
+        d = t
     if S._is_torch(d):
         ptr = d.data_ptr()
         st = d.stride()

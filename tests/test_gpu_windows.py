@@ -62,3 +62,117 @@ def test_float32_and_mixed_consumers():
     _check(so.Mix(f | so.After(60000 * so.frames), f | so.After(30000 * so.frames) | so.Until(20000 * so.frames)))
     # under an Append, next to an unfiltered child
     _check(so.Append(y | so.Until(5000 * so.frames), f | so.After(70000 * so.frames)))
+
+
+@pytest.mark.parametrize("nch", [1, 2, 8])
+@pytest.mark.parametrize("rates", [(44100, 48000), (44100, 16000), (8000, 16000), (12000, 8000)])
+def test_resample_then_after(nch, rates):
+    fi, fo = rates
+    rng = np.random.default_rng(31 + nch)
+    x = so.Signal(_noise(rng, 100000, nch), fi * so.Hz)
+    n_out = so.nframes(x | so.ToFramerate(fo * so.Hz))
+    skip = int(0.8 * n_out) + 7
+    _check(x | so.ToFramerate(fo * so.Hz) | so.After(skip * so.frames))
+    # a short window in the middle (the thread-per-output kernel)
+    _check(x | so.ToFramerate(fo * so.Hz) | so.After((skip // 2) * so.frames) | so.Until(500 * so.frames))
+
+
+def test_pipeline_window():
+    """the north-star pipeline, a window near its end"""
+    rng = np.random.default_rng(41)
+    n = 300000
+    x = so.Signal(_noise(rng, n, 8), 44.1 * so.kHz)
+    tree = (so.Mix(so.Signal(so.sin, ω=1 * so.kHz), x) | so.Until(n * so.frames)
+            | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz))
+    _check(tree | so.After(250000 * so.frames) | so.Until(60000 * so.frames))
+    _check(tree | so.After(250001 * so.frames))
+
+
+def test_fir_and_gain_under_a_window():
+    rng = np.random.default_rng(42)
+    x = so.Signal(_noise(rng, 70000, 2), 44.1 * so.kHz)
+    h = np.hanning(33) / np.hanning(33).sum()
+    _check(so.Filt(x, h) | so.After(60000 * so.frames))
+    env = so.Signal(so.sin, ω=5 * so.Hz)
+    _check(x | so.Amplify(env) | so.Until(70000 * so.frames) | so.ToFramerate(48 * so.kHz) | so.After(65000 * so.frames))
+
+
+def test_warm_start_really_skips_work():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(43)
+    n = 400000
+    x = so.Signal(_noise(rng, n, 2), 44.1 * so.kHz)
+    tree = so.ToChannels(x | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz) | so.After(400000 * so.frames), 2)
+    m = so.nframes(tree)
+    out = torch.empty((2, m), dtype=torch.float64, device="cuda")
+
+    def work():
+        p = so.Plan(tree, (m, 2), np.float64, (1, m), True, device=0)
+        p.set_profiling(True)
+        p.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        b = sum(s["algorithmic_bytes"] for s in p.steps())
+        p.close()
+        return b
+
+    warm = work()
+    os.environ["SIGOPS_NO_WARM_START"] = "1"
+    try:
+        cold = work()
+    finally:
+        os.environ.pop("SIGOPS_NO_WARM_START", None)
+    assert warm < 0.25 * cold
+
+
+def _stream_matches(tree, blocksize, tol=1e-12):
+    whole = so.sink(tree, so.Array)
+    blocks = list(so.stream(tree, blocksize, so.Array))
+    assert all(b.shape[0] == blocksize for b in blocks[:-1]) and 0 < blocks[-1].shape[0] <= blocksize
+    got = np.concatenate(blocks, axis=0)
+    assert got.shape == whole.shape and got.dtype == whole.dtype
+    assert relerr(got, whole) <= tol
+    return got
+
+
+@pytest.mark.parametrize("blocksize", [10007, 65536])
+def test_stream_pipeline_blocks_concatenate_to_the_whole(blocksize):
+    rng = np.random.default_rng(51)
+    n = 200000
+    x = so.Signal(_noise(rng, n, 8), 44.1 * so.kHz)
+    tree = (so.Mix(so.Signal(so.sin, ω=1 * so.kHz), x) | so.Until(n * so.frames)
+            | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz))
+    got = _stream_matches(tree, blocksize)
+    assert relerr(got, oracle_sink(tree)) <= 1e-9
+
+
+def test_stream_structural_trees_are_bit_exact():
+    rng = np.random.default_rng(52)
+    a = so.Signal(_noise(rng, 7001, 2), 8 * so.kHz)
+    b = so.Signal(_noise(rng, 3333, 2), 8 * so.kHz)
+    tree = so.Append(a | so.After(11 * so.frames), so.Pad(b, so.mirror) | so.Until(9000 * so.frames)) | so.Ramp(100 * so.frames)
+    whole = so.sink(tree, so.Array)
+    got = np.concatenate(list(so.stream(tree, 1000, so.Array)), axis=0)
+    assert np.array_equal(got, whole)
+
+
+def test_stream_filtered_children_under_append_and_device_blocks():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(53)
+    kids = [so.Signal(_noise(rng, n, 2), 44.1 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) | so.Ramp(5 * so.ms)
+            for n in (30001, 50000, 41111)]
+    tree = so.Append(*kids)
+    whole = so.sink(tree, so.Array)
+    blocks = [b for b, fs in so.stream(tree, 25000, "torch")]
+    assert all(b.is_cuda for b in blocks)
+    got = np.concatenate([b.cpu().numpy() for b in blocks], axis=0)
+    assert relerr(got, whole) <= 1e-12
+
+
+def test_stream_of_an_infinite_signal():
+    import itertools
+
+    tree = so.Signal(so.sin, 44.1 * so.kHz, ω=440 * so.Hz) | so.Filt(so.Highpass, 100 * so.Hz) | so.ToFramerate(48 * so.kHz)
+    blocks = list(itertools.islice(so.stream(tree, 48000, so.Array), 4))
+    whole = so.sink(tree | so.Until(4 * 48000 * so.frames), so.Array)
+    # (a 100 Hz high-pass at 48 kHz: large, slowly decaying states; chunk scan and warm start both cut at 2^-70 of them)
+    assert relerr(np.concatenate(blocks, axis=0), whole) <= 1e-10

@@ -188,3 +188,16 @@ def test_product_fails_loudly_without_a_gpu():
         pytest.skip("a HIP device is visible")
     with pytest.raises(ErrorException, match="no HIP device"):
         so.sink(Mix(Signal(np.ones((4, 1)), 10 * Hz), 1))
+
+
+def test_stream_of_plain_data_yields_consecutive_slices():
+    """so.stream: block k = sink(x |> After(k*blocksize) |> Until(blocksize)); for raw arrays that is the
+    reference's aliasing time slice (src/sink.jl:65-69), no device involved"""
+    import sigops_amd as so
+
+    data = np.asfortranarray(np.arange(20.0).reshape(10, 2))
+    blocks = list(so.stream(so.Signal(data, 10 * so.Hz), 4, so.Array))
+    assert [b.shape[0] for b in blocks] == [4, 4, 2]
+    assert np.array_equal(np.concatenate(blocks, axis=0), data)
+    with pytest.raises(so.ErrorException):
+        next(so.stream(so.Signal(data, 10 * so.Hz), 0))
