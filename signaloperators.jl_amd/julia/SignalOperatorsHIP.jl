@@ -240,4 +240,20 @@ function SignalOperators.sink!(result::HIPSink{T}, x, ::IsSignal) where T
     nothing
 end
 
+# Block-by-block evaluation (the Python mirror's `so.stream`): block k is the sink of
+# `x |> After(k*blocksize frames) |> Until(blocksize frames)`.  Stateful stages of a later block start a
+# decay time (IIR) / a few periods (resampler) before it instead of at frame 0 -- the planner's warm
+# start, DESIGN.md section 2 -- so the work per block does not grow with its position.
+function sink_blocks(f, x, blocksize::Integer; T=Float64)
+    n, pos = nframes(x), 0
+    while isinf(n) || pos < n
+        m = isinf(n) ? blocksize : min(blocksize, n - pos)
+        blk = Until(pos == 0 ? x : After(x, pos * frames), m * frames)
+        result = HIPSink{T}(Array{T}(undef, m, nchannels(x)))
+        SignalOperators.sink!(result, blk, SignalOperators.SignalTrait(blk))
+        f(result.data)
+        pos += m
+    end
+end
+
 end # module
