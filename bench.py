@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the sink hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload ns|config3|config4|config5]
+    python bench.py --gpus N --steps K --warmup W [--workload ns|config3|config4|config5|ns_time]
 
 Default workload (the pipeline the metric and north_star name, at config 3's size):
     Mix(Signal(sin, ω=1kHz), Signal(noise[26 460 000 x 8], 44.1 kHz)) |> Until(600 s)
@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="ns", choices=["ns", "config3", "config4", "config5"])
+    ap.add_argument("--workload", default="ns", choices=["ns", "config3", "config4", "config5", "ns_time"])
     ap.add_argument("--seconds", type=float, default=600.0, help="signal duration (600 = full config)")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
@@ -242,7 +242,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the sink engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if args.workload in ("config4", "config5"):
+    if args.workload in ("config4", "config5", "ns_time"):
         import bench_multi
 
         return bench_multi.run(args, so, torch, dist, rank, local_rank, world, dev)

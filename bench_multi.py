@@ -1,4 +1,5 @@
-"""Multi-GPU workloads of bench.py (`--workload config4|config5`), BASELINE.json configs[3] and [4].
+"""Multi-GPU workloads of bench.py (`--workload config4|config5|ns_time`), BASELINE.json configs[3] and [4]
+and the headline pipeline cut along time.
 
 config4  Append of 64 independent 60 s scenes (Mix(sin, noise[2 646 000 x 2]) |> Filt(Bandstop) |> Ramp),
          44.1 kHz, sharded in contiguous blocks of scenes over the ranks (reference: Append children
@@ -47,25 +48,63 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
     esz = 8 if args.dtype == "f64" else 4
     stream = torch.cuda.current_stream().cuda_stream
     steps, warmup = args.steps, args.warmup
-    if args.workload == "config4":
-        nscenes, nch = 64, 2
-        n = int(round(args.seconds / 10.0 * 44100)) if args.seconds != 600.0 else 2_646_000  # 60 s scenes
-        lo, hi = sharding.block_range(nscenes, rank, world)
-        trees = []
+    # measurement aid on a one-GPU box: evaluate the shard rank R of W would get, without a process group
+    # (SIGOPS_BENCH_AS=R/W; compute-only time of that rank, no gather)
+    import os
+
+    if world == 1 and os.environ.get("SIGOPS_BENCH_AS"):
+        r_, w_ = os.environ["SIGOPS_BENCH_AS"].split("/")
+        shard_rank, shard_world = int(r_), int(w_)
+    else:
+        shard_rank, shard_world = rank, world
+    if args.workload in ("config4", "ns_time"):
         keep = []
-        for k in range(lo, hi):
+        if args.workload == "config4":
+            nscenes, nch = 64, 2
+            n = int(round(args.seconds / 10.0 * 44100)) if args.seconds != 600.0 else 2_646_000  # 60 s scenes
+            lo, hi = sharding.block_range(nscenes, shard_rank, shard_world)
+            trees = []
+            for k in range(lo, hi):
+                g = torch.Generator(device=dev)
+                g.manual_seed(1983 + k)
+                nz = torch.randn((nch, n), dtype=tdt, device=dev, generator=g)
+                keep.append(nz)
+                trees.append(scene(so, nz.t(), k, n))
+            counts = [(sharding.block_range(nscenes, r, shard_world)[1] - sharding.block_range(nscenes, r, shard_world)[0]) * n
+                      for r in range(shard_world)]
+            total = nscenes * n
+            sub = None if not trees else (trees[0] if len(trees) == 1 else so.Append(*trees))
+            label = ("config4: Append of 64 scenes (Mix(sin,noise[%d x 2]) |> Filt(Bandstop 0.5-2kHz) |> Ramp(10ms)) "
+                     "@44.1kHz |> sink, scenes sharded over ranks, RCCL all-gather of the device slabs" % n)
+            par = f"append-shard x{world}, all_gather_into_tensor (device to device)"
+            extra = {"scenes_per_rank": hi - lo}
+        else:
+            # ONE north-star pipeline cut along time (sharding.shard_time): every rank evaluates its range of
+            # the output from a warm start (no filter state is handed over), slabs all-gathered.  Every rank
+            # holds the whole synthetic input (same seed); it reads only its own range of it.
+            from bench import tree_ns
+
+            nch = 8
+            n_in = int(round(args.seconds * 44100))
             g = torch.Generator(device=dev)
-            g.manual_seed(1983 + k)
-            nz = torch.randn((nch, n), dtype=tdt, device=dev, generator=g)
+            g.manual_seed(1983)
+            nz = torch.randn((nch, n_in), dtype=tdt, device=dev, generator=g)
             keep.append(nz)
-            trees.append(scene(so, nz.t(), k, n))
-        counts = [(sharding.block_range(nscenes, r, world)[1] - sharding.block_range(nscenes, r, world)[0]) * n
-                  for r in range(world)]
-        width, count, total = max(counts), counts[rank], nscenes * n
+            whole = tree_ns(so, nz.t(), n_in)
+            total = so.nframes(whole)
+            align = 160 * 16
+            parts = [sharding.shard_time(whole, r, shard_world, align) for r in range(shard_world)]
+            counts = [p[2] for p in parts]
+            sub = parts[shard_rank][0]
+            label = ("north-star pipeline Mix(sin 1kHz, noise[%d x 8]) |> Filt(Bandstop) |> ToFramerate(48kHz) |> sink, "
+                     "ONE signal cut along time over the ranks (warm starts, no state hand-off), RCCL all-gather" % n_in)
+            par = f"time-shard x{world}, all_gather_into_tensor (device to device)"
+            extra = {"in_frames": n_in}
+        width, count = max(counts), counts[shard_rank]
         slab = torch.zeros((nch, width), dtype=tdt, device=dev)
         plan = None
-        if trees:
-            sub = trees[0] if len(trees) == 1 else so.Append(*trees)
+        plan_ms = None
+        if sub is not None and count > 0:
             res = slab.t()[:count]
             t0 = time.perf_counter()
             plan = so.Plan(so.ToChannels(sub, nch), (count, nch), ndt, (res.stride(0), res.stride(1)), True, device=local_rank)
@@ -93,18 +132,17 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
         st = plan.stats() if plan is not None else {}
         if rank == 0:
             ms_g, ms_c = el_g / steps * 1e3, el_c / steps * 1e3
-            algo = 2 * esz * total * nch
+            algo = 2 * esz * total * nch if args.workload == "config4" else st.get("algorithmic_bytes", 0) * world
+            cfg = {"workload": label, "out_frames": total, "channels": nch, "parallelism": par,
+                   "compute_only_ms": ms_c, "compute_only_frames_per_s": total / (ms_c * 1e-3),
+                   "gather_ms": ms_g - ms_c, "launches_per_step": st.get("n_launches"), "plan_create_ms": plan_ms}
+            cfg.update(extra)
+            if shard_world != world:
+                cfg["measured_as"] = f"rank {shard_rank} of {shard_world} on one GPU: its shard only ({count} frames), no gather"
             print(json.dumps({
                 "metric": METRIC, "value": total / (ms_g * 1e-3), "unit": "frames/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": ms_g, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": "config4: Append of 64 scenes (Mix(sin,noise[%d x 2]) |> Filt(Bandstop 0.5-2kHz) |> Ramp(10ms)) "
-                                       "@44.1kHz |> sink, scenes sharded over ranks, RCCL all-gather of the device slabs" % n,
-                           "out_frames": total, "channels": nch, "scenes_per_rank": hi - lo,
-                           "parallelism": f"append-shard x{world}, all_gather_into_tensor (device to device)",
-                           "compute_only_ms": ms_c, "compute_only_frames_per_s": total / (ms_c * 1e-3),
-                           "gather_ms": ms_g - ms_c, "launches_per_step": st.get("n_launches"),
-                           "plan_create_ms": plan_ms if plan is not None else None},
+                "dtype": args.dtype, "data": "synthetic", "config": cfg,
                 "algorithmic_bytes_per_step": algo,
                 "roofline": {"bound": "hbm", "achieved": algo / (ms_c * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": algo / (ms_c * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,

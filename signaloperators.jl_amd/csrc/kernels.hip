@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const int r = j * 4 + rsub;
-                if (t0 + col < rowlen[w][r])
+                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= g.store_lo)
                     y[(int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col] = (T)tl[r * (kTT + 1) + col];
             }
             __builtin_amdgcn_wave_barrier();

@@ -231,6 +231,7 @@ struct Plan {
     void try_window_alias(std::vector<Piece>& rootp);
     int alias_stage = -1;    // stage whose kernel writes the final output directly
     bool alias_narrow = false;  // ... rounding its Float64 values to the Float32 result
+    int64_t alias_skip = 0;     // ... from its local frame alias_skip on (an IIR's warm-up frames are not stored)
     bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
     std::vector<char> host_tmp;
     bool profiling = false;
@@ -3224,15 +3225,20 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             const Expr& e = P->exprs[re];
             const bool narrowing = e.leaf.dtype == SO_F64 && out->dtype == SO_F32 && !std::getenv("SIGOPS_NO_NARROW_STORE");
             if (e.op == E_LOAD && e.leaf.buf >= 0 && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 &&
-                e.leaf.df == 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && (e.leaf.dtype == out->dtype || narrowing)) {
+                e.leaf.df >= 0 && e.leaf.sc == 1 && e.leaf.dc == 0 && (e.leaf.dtype == out->dtype || narrowing)) {
                 for (size_t i = 0; i < P->stages.size(); ++i)
                     if (P->stages[i].out_buf == e.leaf.buf && P->stages[i].kind != ST_NORM &&
-                        P->stages[i].need == out->nframes &&
+                        P->stages[i].need == out->nframes + e.leaf.df &&
+                        // (a window of the stage: the three-pass IIR can leave out the frames before it)
+                        (e.leaf.df == 0 || (P->stages[i].kind == ST_SOS && P->stages[i].groups.size() == 1 &&
+                                            !P->stages[i].onepass && e.leaf.dtype == out->dtype && out->frame_stride == 1 &&
+                                            e.leaf.df >= P->stages[i].base && !std::getenv("SIGOPS_NO_WINDOW_ALIAS"))) &&
                         (e.leaf.dtype == out->dtype || (P->stages[i].kind == ST_RESAMPLE && P->stages[i].periodic &&
                                                         P->stages[i].rp.ct >= 4 &&
                                                         (P->stages[i].rp.ngroups + P->stages[i].rp.ncompute - 1) / P->stages[i].rp.ncompute == 1)))
                         P->alias_stage = (int)i;
                 P->alias_narrow = P->alias_stage >= 0 && e.leaf.dtype != out->dtype;
+                if (P->alias_stage >= 0) P->alias_skip = e.leaf.df - P->stages[P->alias_stage].base;
                 if (P->alias_stage >= 0)
                     for (auto& L : P->leaves)  // any other consumer of that buffer forbids aliasing
                         if (L.buf == e.leaf.buf) P->alias_stage = -1;
@@ -3359,6 +3365,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         ob.d = P->bufs[P->out_stage_buf].d;
                         ob.pitch = P->bufs[P->out_stage_buf].pitch;
                     }
+                    // (local frame alias_skip is the result's frame 0; earlier frames are not stored)
+                    ob.d = (char*)ob.d - (size_t)P->alias_skip * esz;
                 } else if (S.win_off >= 0) {  // ... or its window of it
                     const Buf& ab = P->bufs[P->out_alias_buf];
                     ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
@@ -3368,6 +3376,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     SosGeom g = S.sg;
                     g.in_pitch = in_pitch;
                     g.out_pitch = ob.pitch;
+                    g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;

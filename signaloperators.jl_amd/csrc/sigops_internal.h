@@ -142,6 +142,7 @@ struct SosGeom {
     int32_t in_dtype, out_dtype;
     int32_t pad;
     int64_t in_pitch, out_pitch;  // elements between channels
+    int64_t store_lo;             // pass 3 stores frames >= store_lo only (warm-up frames of a windowed result)
 };
 
 // Single-pass variant (k_sos_onepass): one read and one write of the signal.  A WAVE owns a tile of

@@ -8,6 +8,11 @@ collective:
       -> contiguous blocks of children per rank, each rank writes its own time range;
   * channels are independent for every hot-path node except Normpower / ToChannels(1)
       -> contiguous channel slabs per rank.
+A third axis needs no hand-off of filter state either:
+  * time.  A stateful stage asked for frames [a, b) only starts a decay time (IIR) or a few periods
+    (resampler) before a (the planner's warm start), so ONE long signal is cut
+    into contiguous time ranges, one per rank, each evaluated as `x |> After(a) |> Until(b-a)`
+    (not for Normpower, whose rms needs the whole signal on every rank).
 The only exchange step is the optional final gather of the result (uneven sizes ->
 all_gather of padded slabs).
 """
@@ -38,6 +43,25 @@ def shard_append(x, rank, world):
         return None, start, 0
     sub = kids[lo] if hi - lo == 1 else S._Append(list(kids[lo:hi]))
     return sub, start, count
+
+
+def shard_time(x, rank, world, align=1):
+    """-> (x restricted to this rank's contiguous time range or None, first frame, frames); range
+    boundaries are multiples of `align` frames"""
+    from .units import frames
+
+    x = S._assignal(x)
+    n = S.nframes(x)
+    if n is None or S.isknowninf(n):
+        raise S.ErrorException("shard_time needs a signal of known, finite length")
+    n = int(n)
+    units = -(-n // align)
+    lo, hi = block_range(units, rank, world)
+    a, b = min(lo * align, n), min(hi * align, n)
+    if b <= a:
+        return None, a, 0
+    sub = x if a == 0 else S.After(x, a * frames)
+    return (sub if b == n and a == 0 else S.Until(sub, (b - a) * frames)), a, b - a
 
 
 def shard_channels(x, rank, world):
@@ -71,19 +95,30 @@ def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, 
     [nframes x nch] result is assembled on the device -- no host hop anywhere.  Returns a
     column-major torch tensor on every rank when gather=True, else (local_slab, start).
     `compute` (tests: the CPU oracle under gloo) switches to the NumPy path."""
+    return _sink_ranges(x, shard_append, rank, world, gather, compute, device)
+
+
+def sink_time_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, align=1):
+    """Evaluate ONE signal with its time axis cut into contiguous ranges, one per rank (see the module
+    docstring); same result layout and gather as `sink_append_sharded`."""
+    x = S._assignal(x)
+    return _sink_ranges(x, lambda y, r, w: shard_time(y, r, w, align), rank, world, gather, compute, device)
+
+
+def _sink_ranges(x, shard, rank, world, gather, compute, device):
     rank, world = _dist_info(rank, world)
-    sub, start, count = shard_append(x, rank, world)
+    sub, start, count = shard(x, rank, world)
     nch = x.nch
     dt = S.float_type(x.dtype)
+    counts = [shard(x, r, world)[2] for r in range(world)]
     if compute is not None:
-        return _sink_append_sharded_host(x, sub, start, count, rank, world, gather, compute, device)
+        return _sink_ranges_host(x, sub, start, count, counts, rank, world, gather, compute, device)
     import torch
     import torch.distributed as dist
 
     from .engine import sink_into
 
     tdt = torch.float32 if dt == S.F32 else torch.float64
-    counts = [shard_append(x, r, world)[2] for r in range(world)]
     width = max(counts) if gather and world > 1 else count
     slab = torch.zeros((nch, max(width, 1)), dtype=tdt, device=f"cuda:{device}")
     if sub is not None and count > 0:
@@ -168,7 +203,7 @@ def _gather_channels_host(local, nch, n, dt, world, device):
     return full
 
 
-def _sink_append_sharded_host(x, sub, start, count, rank, world, gather, compute, device):
+def _sink_ranges_host(x, sub, start, count, counts, rank, world, gather, compute, device):
     """NumPy path (a caller-supplied `compute`, e.g. the CPU oracle in the gloo tests)"""
     import torch.distributed as dist
 
@@ -180,7 +215,6 @@ def _sink_append_sharded_host(x, sub, start, count, rank, world, gather, compute
     import torch
 
     total = int(S.nframes(x))
-    counts = [shard_append(x, r, world)[2] for r in range(world)]
     width = max(counts)
     pad = np.zeros((width, nch), dtype=dt)
     pad[:count] = local

@@ -112,3 +112,48 @@ def test_append_sharding_world_size_2_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
     codes = [p.wait(timeout=300) for p in procs]
     assert codes == [0, 0]
+
+
+def test_shard_time_ranges():
+    x = so.Signal(np.arange(1003.0), 1 * so.kHz) | so.Filt(so.Lowpass, 100 * so.Hz)
+    got = []
+    for r in range(3):
+        sub, start, count = sharding.shard_time(x, r, 3, align=100)
+        assert start % 100 == 0 and (sub is None) == (count == 0)
+        if sub is not None:
+            assert so.nframes(sub) == count
+        got.append((start, count))
+    assert got == [(0, 400), (400, 400), (800, 203)]
+    assert sharding.shard_time(x, 5, 8, align=500)[2] == 0  # more ranks than ranges
+
+
+WORKER_T = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+import sigops_amd as so
+from sigops_amd import sharding
+from oracle_bridge import oracle_sink
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+x0 = np.asfortranarray(np.random.default_rng(4).standard_normal((30001, 2)))
+x = so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(x0, 44.1 * so.kHz)) | so.Until(30001 * so.frames) \
+    | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz)
+# the oracle evaluates each rank's `After(a) |> Until(n)` by running the skipped frames through the filters:
+# one signal cut along time, identical to the unsharded sink
+full = sharding.sink_time_sharded(x, compute=oracle_sink)
+want = oracle_sink(x)
+ok = full.shape == want.shape and float(np.abs(full - want).max()) <= 1e-12
+local, start = sharding.sink_time_sharded(x, compute=oracle_sink, gather=False, align=160)
+ok = ok and start % 160 == 0 and float(np.abs(local - want[start:start + local.shape[0]]).max()) <= 1e-12
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_time_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker_t.py"
+    script.write_text(WORKER_T)
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0]
