@@ -1,0 +1,363 @@
+// DSP.jl phase accumulator replay for the arbitrary-rate resampler (see the comment below) and the
+// host-only position diagnostics of the C-ABI (so_resample_positions).
+#include "plan_impl.h"
+
+namespace so {
+
+// ---------------------------------------------------------------------------
+// DSP.jl FIRArbitrary positions (reference call sites
+// src/reformatting.jl:92-98 `setphase!(self, timedelay(self))`, src/filters.jl:252-255 `filt!`):
+//     ϕAcc += Δ;  if ϕAcc > Nϕ:  xIdx += div(ϕAcc-1, Nϕ);  ϕAcc = mod(ϕAcc-1, Nϕ) + 1
+//     ϕIdx = floor(ϕAcc);  α = ϕAcc - ϕIdx
+// once per output, in Float64.  The sequence is data independent and does not depend on the
+// block size (xIdx is carried as inputDeficit), so it is replayed here once per plan and compared
+// with the kernels' closed-form rule.  At a tie (closed-form α == 0) accumulated rounding error
+// leaves the accumulator a hair below the integer: (previous phase, α ≈ 1).  The interpolated
+// taps h + α·dh are continuous there EXCEPT (a) across the wrap (ϕIdx = Nϕ, α ≈ 1, xIdx not
+// advanced: the tap h[0] of the next input is dropped) and (b) at the filter's last tap
+// (dh = [diff(h); 0] ends in 0, not -h[end]) -- differences of ~1e-3 of a sample.  For a rational
+// pattern (integer frame rates) both happen at the same place of (nearly) every period:
+// `prev[r]` marks those period positions so that the kernels' tap tables are built with the
+// accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
+// goes to the fix-up list (k_resample_fix).
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
+                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix);
+
+// state of the accumulator before output m (a later window of the same resampler resumes from the
+// nearest one instead of replaying from output 0)
+struct AccCheckpoint {
+    int64_t m, xb;
+    double acc;
+};
+struct AccKey {
+    double delta, c0, hsum;
+    int64_t c0i, L, M;
+    int32_t nphi, taps, exact, hlen;
+    bool operator==(const AccKey& o) const { return std::memcmp(this, &o, sizeof(AccKey)) == 0; }
+};
+static std::mutex g_acc_mu;
+static std::vector<std::pair<AccKey, std::vector<AccCheckpoint>>> g_acc_checkpoints;
+static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
+    AccKey k;
+    std::memset(&k, 0, sizeof k);
+    k.delta = g.delta;
+    k.c0 = g.c0;
+    k.c0i = g.c0i;
+    k.L = g.L;
+    k.M = g.M;
+    k.nphi = g.nphi;
+    k.taps = g.taps;
+    k.exact = g.exact;
+    k.hlen = hlen;
+    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    return k;
+}
+
+// The replay is sequential by nature (~5 ns per output: 160 ms for config 3's 28.8 M outputs) and
+// depends only on the geometry, so a process keeps the last few results (plans of the same
+// resampler -- a bench's second workload, a re-created plan -- get it for free).
+// Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate, and the
+// fix-up list comes back in the window's own coordinates (output m - from, input j - from/L*M).
+void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
+                                     std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from) {
+    struct Key {
+        double delta, c0, hsum;
+        int64_t c0i, L, M, need, from;
+        int32_t nphi, taps, exact, hlen, bake;
+        bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
+    };
+    struct Entry {
+        Key k;
+        std::vector<uint8_t> prev;
+        std::vector<RsFix> fix;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    Key k;
+    std::memset(&k, 0, sizeof k);
+    k.delta = g.delta;
+    k.c0 = g.c0;
+    k.c0i = g.c0i;
+    k.L = g.L;
+    k.M = g.M;
+    k.need = need;
+    k.from = from;
+    k.nphi = g.nphi;
+    k.taps = g.taps;
+    k.exact = g.exact;
+    k.hlen = hlen;
+    k.bake = bake;
+    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    if (!g.arbitrary || need <= 0) {
+        prev.clear();
+        fix.clear();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& e : cache)
+            if (e.k == k) {
+                prev = e.prev;
+                fix = e.fix;
+                return;
+            }
+    }
+    replay_phase_accumulator_impl(g, h, hlen, from, need, bake, prev, fix);
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    cache.push_back(Entry{k, prev, fix});
+}
+
+static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
+                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
+    prev.clear();
+    fix.clear();
+    if (!g.arbitrary || need <= 0) return;
+    const int nphi = g.nphi, taps = g.taps;
+    const double dnphi = (double)nphi;
+    const bool pow2 = (nphi & (nphi - 1)) == 0;
+    const double inv = 1.0 / dnphi;
+    double hmax = 0.0;
+    for (int i = 0; i < hlen; ++i) hmax = std::max(hmax, std::fabs(h[i]));
+    auto tap = [&](int64_t q, double alpha, int64_t k) -> double {  // tap applied to input (q/nphi - k)
+        if (k < 0 || k >= taps) return 0.0;
+        const int64_t hi = q % nphi + (int64_t)nphi * k;
+        const double hv = hi < hlen ? h[hi] : 0.0;
+        const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+        return hv + alpha * dv;
+    };
+    // do the two positions give different taps (beyond the interpolation's own continuity)?
+    auto taps_differ = [&](int64_t qa, double aa, int64_t qe, double ae) {
+        const int64_t ja = qa / nphi, je = qe / nphi, dj = je - ja;
+        if (std::llabs(dj) > 1) return true;
+        double d = 0.0;
+        for (int64_t k = -1; k <= taps; ++k) d = std::max(d, std::fabs(tap(qa, aa, k) - tap(qe, ae, k + dj)));
+        return d > 4e-6 * hmax;  // (positions within 1e-6 of each other move a tap by < 1e-6*|dh|)
+    };
+    // setphase!(kernel, τ), τ = (hLen-1)/(2Nϕ)
+    const double tau = (double)(hlen - 1) / 2.0 / dnphi;
+    const double w = std::floor(tau), fr = tau - w;
+    int64_t xb = (int64_t)std::llround(w) * nphi;  // (xIdx-1)*Nϕ, xIdx = inputDeficit = 1 + w
+    double acc = fr * dnphi + 1.0;
+    const double delta = g.delta;
+    // closed-form rule of the kernels
+    const bool exact = g.exact != 0;
+    const int64_t L = g.L, dq = exact ? ((int64_t)nphi * g.M) / L : 0, dfr = exact ? ((int64_t)nphi * g.M) % L : 0;
+    int64_t qe = g.c0i, fe = 0;
+    struct Rec { int64_t m, qa; double alpha; };
+    std::vector<Rec> rec;
+    std::vector<int8_t> memo((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
+    int64_t m0 = 0;
+    const AccKey ckey = acc_key(g, h, hlen);
+    std::vector<AccCheckpoint> made;
+    if (from > 0) {  // resume from the nearest checkpoint at or before the window
+        std::lock_guard<std::mutex> lock(g_acc_mu);
+        for (auto& e : g_acc_checkpoints)
+            if (e.first == ckey)
+                for (auto& c : e.second)
+                    if (c.m <= from && c.m > m0) {
+                        m0 = c.m;
+                        xb = c.xb;
+                        acc = c.acc;
+                    }
+        if (exact) {
+            const __int128 Nn = (__int128)m0 * ((int64_t)nphi * g.M);
+            qe = g.c0i + (int64_t)(Nn / L);
+            fe = (int64_t)(Nn % L);
+        }
+    }
+    for (int64_t m = m0; m < need; ++m) {
+        if (m == from || (m > m0 && (m & ((1 << 22) - 1)) == 0)) made.push_back(AccCheckpoint{m, xb, acc});
+        const int pi = (int)acc;  // floor: acc >= 1
+        const int64_t qa = xb + pi - 1;
+        double qe_frac = 0.0;
+        if (!exact) {
+            const double t = (double)m * delta;  // two separately rounded operations, like rs_pos
+            const double q = g.c0 + t;
+            const double fl = std::floor(q);
+            qe = (int64_t)fl;
+            qe_frac = q - fl;
+        }
+        if (qa != qe) {
+            const double alpha = acc - (double)pi;
+            const double ae = exact ? (double)fe / (double)L : qe_frac;
+            bool differ;
+            const bool tie = exact && fe == 0 && std::llabs(qa - qe) == 1 && (alpha < 1e-6 || alpha > 1.0 - 1e-6);
+            if (tie) {
+                int8_t& mm = memo[(size_t)(qe % nphi) * 4 + (qa > qe ? 2 : 0) + (alpha > 0.5 ? 1 : 0)];
+                if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
+                differ = mm != 0;
+            } else differ = taps_differ(qa, alpha, qe, ae);
+            if (differ && m >= from) rec.push_back(Rec{m, qa, alpha});
+        }
+        if (exact) {
+            qe += dq;
+            fe += dfr;
+            if (fe >= L) {
+                fe -= L;
+                ++qe;
+            }
+        }
+        acc += delta;
+        if (acc > dnphi) {
+            // xIdx += div(ϕAcc-1, Nϕ); ϕAcc = mod(ϕAcc-1, Nϕ) + 1.  (ϕAcc-1 and the remainder are
+            // exact, the final +1 rounds: the same real number as ϕAcc - k·Nϕ rounded once)
+            const double a1 = acc - 1.0;
+            if (a1 < dnphi) {
+                // k == 0: unchanged
+            } else if (a1 < 2.0 * dnphi) {
+                xb += nphi;
+                acc -= dnphi;
+            } else if (pow2) {
+                const double k = std::floor(a1 * inv);
+                xb += (int64_t)k * nphi;
+                acc -= k * dnphi;
+            } else {
+                const double k = std::floor(a1 / dnphi);
+                xb += (int64_t)k * nphi;
+                acc = std::fmod(a1, dnphi) + 1.0;
+            }
+        }
+    }
+    made.push_back(AccCheckpoint{need, xb, acc});
+    {
+        std::lock_guard<std::mutex> lock(g_acc_mu);
+        std::vector<AccCheckpoint>* store = nullptr;
+        for (auto& e : g_acc_checkpoints)
+            if (e.first == ckey) store = &e.second;
+        if (!store) {
+            if (g_acc_checkpoints.size() >= 8) g_acc_checkpoints.erase(g_acc_checkpoints.begin());
+            g_acc_checkpoints.emplace_back(ckey, std::vector<AccCheckpoint>{});
+            store = &g_acc_checkpoints.back().second;
+        }
+        for (auto& c : made) {
+            bool have = false;
+            for (auto& o : *store) have = have || o.m == c.m;
+            if (!have) store->push_back(c);
+        }
+        if (store->size() > 256) store->erase(store->begin(), store->begin() + (store->size() - 256));
+    }
+    auto exact_q = [&](int64_t m) {
+        const int64_t Nn = m * ((int64_t)nphi * g.M);
+        return g.c0i + Nn / L;
+    };
+    auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
+    if (bake && exact && L <= 65536) {
+        // majority per period position among the deviations of the form (fine position - 1, α ≈ 1)
+        std::vector<int64_t> cnt(L, 0);
+        for (const Rec& r : rec)
+            if (baked(r)) cnt[r.m % L]++;
+        prev.assign(L, 0);
+        bool any = false;
+        for (int64_t r = 0; r < L; ++r) {
+            // (occurrences of period position r in [from, need); `from` is a multiple of L)
+            const int64_t occ = need - from > r ? (need - from - 1 - r) / L + 1 : 0;
+            if (occ > 0 && 2 * cnt[r] > occ) prev[r] = 1, any = true;
+        }
+        if (!any) prev.clear();
+    }
+    // fix-up list: deviations the tables do not already contain + outputs at baked positions
+    // where the accumulator agreed with the closed form after all
+    if (!prev.empty()) {
+        for (int64_t r = 0; r < L; ++r) {
+            if (!prev[r]) continue;
+            size_t k = 0;
+            for (int64_t m = from + r; m < need; m += L) {  // outputs at a baked position
+                while (k < rec.size() && rec[k].m < m) ++k;
+                if (k < rec.size() && rec[k].m == m) continue;  // deviates: baked, or listed below
+                const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
+                fix.push_back(RsFix{m, q / nphi, (int32_t)(q % nphi), 0, (double)(Nn % L) / (double)L});
+            }
+        }
+        for (const Rec& r : rec) {
+            if (prev[r.m % L] && baked(r)) continue;  // what the tables contain
+            fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
+        }
+    } else {
+        for (const Rec& r : rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
+    }
+    std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
+    if (from > 0) {
+        const int64_t jin = exact ? from / L * g.M : 0;
+        for (auto& f : fix) {
+            f.m -= from;
+            f.j -= jin;
+        }
+    }
+}
+
+// integer frame rates: the arbitrary-rate kernel's rate is the exact rational fs_out/fs_in
+void rs_detect_exact(RsGeom& g, double fo, double fi, double rate) {
+    if (fo == std::floor(fo) && fi == std::floor(fi) && fo >= 1 && fi >= 1 && fo < 2147483648.0 &&
+        fi < 2147483648.0 && fo / fi == rate) {
+        int64_t a = (int64_t)fo, b = (int64_t)fi;
+        while (b) {
+            int64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        int64_t Lx = (int64_t)fo / a, Mx = (int64_t)fi / a;
+        if (Lx <= 8192 && Mx <= 1048576) {
+            g.exact = 1;
+            g.L = Lx;
+            g.M = Mx;
+        }
+    }
+}
+
+// Diagnostics (host only): the (newest input, phase, alpha) the arbitrary-rate resampler kernels
+// use for outputs [0,n_out) -- closed form, baked period positions and fix-up list combined.
+int resample_positions(double fs_in, double fs_out, double rate, int nphi, const double* h, int hlen,
+                       int64_t n_out, int64_t* jo, int32_t* po, double* ao, int64_t* nfix, int64_t* nbaked) {
+    RsGeom g{};
+    g.arbitrary = 1;
+    g.nphi = nphi;
+    g.delta = (double)nphi / rate;
+    g.c0 = (double)(hlen - 1) / 2.0;
+    g.c0i = (hlen - 1) / 2;
+    g.taps = (hlen + nphi - 1) / nphi;
+    rs_detect_exact(g, fs_out, fs_in, rate);
+    std::vector<uint8_t> prev;
+    std::vector<RsFix> fix;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!std::getenv("SIGOPS_RS_EXACT")) replay_phase_accumulator(g, h, hlen, n_out, g.exact && n_out >= 2048, prev, fix);
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] phase accumulator replay: %lld outputs, %.1f ms\n", (long long)n_out,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    for (int64_t m = 0; m < n_out; ++m) {
+        int64_t qi;
+        double alpha;
+        if (g.exact) {
+            const int64_t Nn = m * ((int64_t)nphi * g.M);
+            qi = g.c0i + Nn / g.L;
+            alpha = (double)(Nn % g.L) / (double)g.L;
+            if (!prev.empty() && prev[m % g.L]) {
+                qi -= 1;
+                alpha = 1.0;
+            }
+        } else {
+            const double t = (double)m * g.delta;
+            const double q = g.c0 + t;
+            const double fl = std::floor(q);
+            qi = (int64_t)fl;
+            alpha = q - fl;
+        }
+        jo[m] = qi / nphi;
+        po[m] = (int32_t)(qi % nphi);
+        ao[m] = alpha;
+    }
+    for (const RsFix& f : fix) {
+        jo[f.m] = f.j;
+        po[f.m] = f.p;
+        ao[f.m] = f.alpha;
+    }
+    if (nfix) *nfix = (int64_t)fix.size();
+    if (nbaked) {
+        *nbaked = 0;
+        for (uint8_t b : prev) *nbaked += b;
+    }
+    return SO_OK;
+}
+
+
+}  // namespace so

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["kernels.hip", "planner.cpp", "design.cpp", "capi.cpp"]
+SRCS = ["kernels.hip", "planner.cpp", "stages.cpp", "accumulator.cpp", "executor.cpp", "design.cpp", "capi.cpp"]
 OUT = os.path.join(HERE, "libsigops.so")
 
 
@@ -13,7 +13,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = SRCS + ["kernels.h", "plan.h", "sigops_internal.h", "../../include/sigops.h", "build.py"]
+    deps = SRCS + ["kernels.h", "plan.h", "plan_impl.h", "sigops_internal.h", "../../include/sigops.h", "build.py"]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 

@@ -1,0 +1,721 @@
+// Executor: buffer allocation and table upload (finalize), multi-stream lanes, launches, HIP-graph
+// replay, so_plan_set_array, statistics.
+#include "plan_impl.h"
+
+namespace so {
+
+// ---------------------------------------------------------------------------
+void Plan::finalize() {
+    // size stage output buffers now that every need is known
+    for (size_t si = 0; si < stages.size(); ++si) {
+        Stage& S = stages[si];
+        if (S.out_buf >= 0 && ((int)si == alias_stage || S.win_off >= 0)) {
+            bufs[S.out_buf].external = true;  // the kernel writes the final output directly
+            bufs[S.out_buf].bytes = 0;
+            continue;
+        }
+        if (S.out_buf >= 0) {
+            Buf& b = bufs[S.out_buf];
+            b.frames = S.need - S.base;
+            b.pitch = std::max<int64_t>(64, (S.need - S.base + 63) / 64 * 64);
+            b.bytes = (size_t)b.pitch * (size_t)std::max(b.nch, 1) * dsize(b.dtype);
+        }
+    }
+    // host array leaves get a device copy (the leaves of pointwise programs, the carriers of fused
+    // resampler sources and the direct sources of stages go through the same validation)
+    auto stage_host_array = [&](int an) {
+        if (an < 0) return;
+        const so_node_t& nd = nodes[an].nd;
+        if (nd.i0 || array_buf.count(an)) return;  // device-resident, or already staged
+        if (nd.s0 < 0 || nd.s1 < 0) fail(SO_ERR_UNSUPPORTED, "negative strides on host arrays are not supported");
+        const size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
+        const int b = raw_buf(extent * dsize(nd.dtype));
+        array_buf[an] = b;
+        host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
+    };
+    for (size_t i = 0; i < leaves.size(); ++i) stage_host_array(leaf_array_node[i]);
+    for (auto& S : stages) {
+        for (auto& c : S.carriers) stage_host_array(c.array_node);
+        stage_host_array(S.in_array_node);
+    }
+    if (!out.is_device && out.nframes > 0) {
+        Buf b;
+        b.frames = out.nframes;
+        b.pitch = out.nframes;
+        b.nch = out.nch;
+        b.dtype = out.dtype;
+        b.bytes = (size_t)out.nframes * out.nch * dsize(out.dtype);
+        bufs.push_back(b);
+        out_stage_buf = (int)bufs.size() - 1;
+    }
+    // allocate
+    int64_t scratch = 0;
+    for (auto& b : bufs) {
+        if (b.external) continue;
+        HIPCHECK(hipMalloc(&b.d, std::max<size_t>(b.bytes, 64)));
+        scratch += (int64_t)b.bytes;
+    }
+    stats.scratch_bytes = scratch;
+    if (out_alias_buf >= 0 && !out.is_device) {
+        bufs[out_alias_buf].d = bufs[out_stage_buf].d;
+        bufs[out_alias_buf].pitch = bufs[out_stage_buf].pitch;
+    }
+    // patch leaves
+    for (size_t i = 0; i < leaves.size(); ++i) {
+        DLeaf& L = leaves[i];
+        int an = leaf_array_node[i];
+        if (an >= 0) {
+            L.base = nodes[an].nd.i0 ? array_ptr[an] : bufs[array_buf[an]].d;
+        } else if (L.buf >= 0) {
+            L.base = bufs[L.buf].d;
+            if (L.cstride == -1) L.cstride = bufs[L.buf].pitch;
+            L.df -= bufs[L.buf].frame0;  // (stage buffers that start at a later frame: once, here)
+        }
+    }
+    for (auto& S : stages) {
+        if (S.carriers.empty()) continue;
+        for (auto& c : S.carriers) {
+            if (c.array_node >= 0) {
+                const so_node_t& nd = nodes[c.array_node].nd;
+                if (!nd.i0 && !array_buf.count(c.array_node)) fail(SO_ERR_RUNTIME, "internal: carrier array without device copy");
+                c.base = nd.i0 ? array_ptr[c.array_node] : bufs[array_buf[c.array_node]].d;
+            } else if (c.buf >= 0) {
+                c.base = bufs[c.buf].d;
+                if (c.cstride == -1) c.cstride = bufs[c.buf].pitch;
+                c.df -= bufs[c.buf].frame0;
+            } else {
+                c.base = nullptr;  // generated piece
+                c.cstride = 0;
+            }
+            const int64_t V = 16 / (int64_t)dsize(c.dtype);
+            c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
+        }
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            for (auto& c : S.carriers)
+                std::fprintf(stderr, "[sigops] carrier [%lld,%lld) base=%p cstride=%lld df=%lld dtype=%d vec_ok=%d nsteps=%d frame_len=%d depth=%d\n",
+                             (long long)c.a, (long long)c.b, c.base, (long long)c.cstride, (long long)c.df, c.dtype, c.vec_ok, c.nsteps, c.frame_len, c.depth);
+        HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
+        {
+            const RsCtl ctl = make_ctl(S);
+            HIPCHECK(hipMemcpy(bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice));
+        }
+    }
+    // upload tables
+    if (!pieces.empty()) {
+        HIPCHECK(hipMalloc(&d_pieces, pieces.size() * sizeof(DPiece)));
+        HIPCHECK(hipMemcpy(d_pieces, pieces.data(), pieces.size() * sizeof(DPiece), hipMemcpyHostToDevice));
+    }
+    if (!ops.empty()) {
+        HIPCHECK(hipMalloc(&d_ops, ops.size() * sizeof(DOp)));
+        HIPCHECK(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DOp), hipMemcpyHostToDevice));
+    }
+    if (!leaves.empty()) {
+        HIPCHECK(hipMalloc(&d_leaves, leaves.size() * sizeof(DLeaf)));
+        HIPCHECK(hipMemcpy(d_leaves, leaves.data(), leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice));
+    }
+    for (auto& S : stages) {
+        if (S.need <= 0) continue;
+        if (S.kind == ST_SOS && S.qmat_buf >= 0)
+            HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
+        if (S.kind == ST_SOS && S.onepass)
+            HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
+        if (S.kind == ST_RESAMPLE) {
+            HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.wtab_buf >= 0)
+                HIPCHECK(hipMemcpy(bufs[S.wtab_buf].d, S.wtab_host.data(), S.wtab_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.tiled) {
+                HIPCHECK(hipMemcpy(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8, hipMemcpyHostToDevice));
+            }
+            if (S.fix_buf >= 0)
+                HIPCHECK(hipMemcpy(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix), hipMemcpyHostToDevice));
+            if (S.periodic || S.rows) {
+                HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
+            }
+            if (S.rows && !S.mtab_host.empty()) {
+                HIPCHECK(hipMemcpy(bufs[S.mtab_buf].d, S.mtab_host.data(), S.mtab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4, hipMemcpyHostToDevice));
+            }
+        } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
+            size_t msz = 0;
+            for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
+            for (size_t gi = 0; gi < S.mpow_host.size(); ++gi)
+                HIPCHECK(hipMemcpy((char*)bufs[S.mpow_buf].d + gi * msz * 8, S.mpow_host[gi].data(),
+                                   S.mpow_host[gi].size() * 8, hipMemcpyHostToDevice));
+        }
+    }
+    // step list: stages in increasing node order (children first), then the root program
+    std::vector<int> order;
+    for (size_t i = 0; i < stages.size(); ++i)
+        if (stages[i].need > 0) order.push_back((int)i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
+    for (int sid : order) {
+        Stage& S = stages[sid];
+        if (S.pw_step >= 0) push_pw_step(S.pw_step);
+        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
+        Step st{1, sid, nm, 0};
+        int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
+        if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
+        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
+        else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
+        steps.push_back(st);
+    }
+    stats.n_stages = (int)order.size() + 1;
+    stats.algorithmic_bytes = algo_bytes + out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
+    int64_t h2d = 0;
+    for (auto& h : host_leaves) h2d += (int64_t)h.bytes;
+    stats.h2d_bytes = h2d;
+    stats.d2h_bytes = out.is_device ? 0 : out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
+}
+
+// Dependencies between steps from the plan buffers they read and write, then a lane (stream)
+// per step: a step continues on the lane of its latest dependency, a step without
+// dependencies opens the next lane (round robin over at most 8).
+void Plan::plan_lanes() {
+    const int n = (int)steps.size();
+    step_deps.assign(n, {});
+    step_lane.assign(n, 0);
+    step_signals.assign(n, 0);
+    nlanes = 1;
+    if (n < 3 || std::getenv("SIGOPS_SINGLE_STREAM")) return;
+    const int kFinal = -2;
+    std::vector<std::set<int>> rd(n), wr(n);
+    auto piece_reads = [&](const PwStep& w, std::set<int>& out) {
+        for (int pi = w.piece0; pi < w.piece0 + w.npieces; ++pi) {
+            const DPiece& P = pieces[pi];
+            for (int k = 0; k < P.frame_len + P.samp_len; ++k) {
+                const DOp& o = k < P.frame_len ? ops[P.frame_pc + k] : ops[P.samp_pc + (k - P.frame_len)];
+                if ((o.code == OP_LOAD || o.code == OP_SCALAR) && o.arg >= 0 && o.arg < (int)leaves.size() &&
+                    leaves[o.arg].buf >= 0)
+                    out.insert(leaves[o.arg].buf);
+            }
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        const Step& st = steps[i];
+        if (st.kind == 0) {
+            const PwStep& w = pw[st.idx];
+            piece_reads(w, rd[i]);
+            wr[i].insert(w.out_buf >= 0 ? w.out_buf : kFinal);
+            // the root launch runs in place on the windows stages have written, and so does any
+            // sub-expression of it that was materialised into a temporary first
+            if (w.out_buf < 0 || (out_alias_buf >= 0 && rd[i].count(out_alias_buf)))
+                for (size_t k = 0; k < stages.size(); ++k)
+                    if (stages[k].win_off >= 0) rd[i].insert(-100 - (int)k);
+        } else {
+            const Stage& S = stages[st.idx];
+            if (S.in_buf >= 0) rd[i].insert(S.in_buf);
+            for (auto& c : S.carriers) {
+                if (c.buf >= 0) rd[i].insert(c.buf);
+                for (int k = 0; k < c.frame_len; ++k) {
+                    const DOp& o = ops[c.frame_pc + k];
+                    if ((o.code == OP_LOAD || o.code == OP_SCALAR) && leaves[o.arg].buf >= 0) rd[i].insert(leaves[o.arg].buf);
+                }
+                for (int k = 0; k < c.nslots; ++k)
+                    if (leaves[c.slot_leaf[k]].buf >= 0) rd[i].insert(leaves[c.slot_leaf[k]].buf);
+            }
+            if (S.win_off >= 0) wr[i].insert(-100 - st.idx);  // its own window of the result
+            else wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
+            if (S.kind == ST_NORM) {  // reads its own output buffer, writes the rms scalar
+                rd[i].insert(S.out_buf);
+                if (S.rms_buf >= 0) wr[i].insert(S.rms_buf);
+            }
+        }
+    }
+    auto meets = [](const std::set<int>& a, const std::set<int>& b) {
+        for (int x : a)
+            if (b.count(x)) return true;
+        return false;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (meets(rd[i], wr[j]) || meets(wr[i], wr[j]) || meets(wr[i], rd[j])) step_deps[i].push_back(j);
+    int next = 0;
+    const int kMaxLanes = 8;
+    for (int i = 0; i < n; ++i) {
+        if (step_deps[i].empty()) {
+            step_lane[i] = next % kMaxLanes;
+            ++next;
+        } else step_lane[i] = step_lane[step_deps[i].back()];
+    }
+    step_lane[n - 1] = 0;  // the last step (it produces the result) runs on the caller's stream
+    for (int i = 0; i < n; ++i) nlanes = std::max(nlanes, step_lane[i] + 1);
+    for (int i = 0; i < n; ++i)
+        for (int j : step_deps[i])
+            if (step_lane[j] != step_lane[i]) step_signals[j] = 1;
+    if (nlanes == 1) return;
+    lane_streams.assign(nlanes, nullptr);
+    for (int l = 1; l < nlanes; ++l) HIPCHECK(hipStreamCreateWithFlags(&lane_streams[l], hipStreamNonBlocking));
+    step_done.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) HIPCHECK(hipEventCreateWithFlags(&step_done[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+}
+
+void Plan::release() {
+    for (auto st_ : lane_streams)
+        if (st_) (void)hipStreamDestroy(st_);
+    lane_streams.clear();
+    for (auto e : step_done)
+        if (e) (void)hipEventDestroy(e);
+    step_done.clear();
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    ev_start = nullptr;
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
+    capture_stream = nullptr;
+    for (auto& b : bufs)
+        if (b.d && !b.external) (void)hipFree(b.d);
+    bufs.clear();
+    if (d_pieces) (void)hipFree(d_pieces);
+    if (d_ops) (void)hipFree(d_ops);
+    if (d_leaves) (void)hipFree(d_leaves);
+    for (auto e : events) (void)hipEventDestroy(e);
+    events.clear();
+}
+
+
+static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& err) {
+    try {
+        HIPCHECK(hipSetDevice(P->device));
+        hipStream_t st = (hipStream_t)stream;
+        if (P->out.nframes > 0 && !outp) fail(SO_ERR_INVALID, "so_plan_execute: null output");
+        for (auto& h : P->host_leaves)
+            if (h.bytes) HIPCHECK(hipMemcpyAsync(P->bufs[h.buf].d, P->array_ptr[h.node], h.bytes, hipMemcpyHostToDevice, st));
+        if (P->profiling && P->events.size() < 2 * P->steps.size()) {
+            while (P->events.size() < 2 * P->steps.size()) {
+                hipEvent_t e;
+                HIPCHECK(hipEventCreate(&e));
+                P->events.push_back(e);
+            }
+        }
+        if (P->out_alias_buf >= 0 && P->out.is_device && P->bufs[P->out_alias_buf].d != outp) {
+            // in-place root pieces read the result: point their leaves at this execute's buffer
+            P->bufs[P->out_alias_buf].d = outp;
+            for (auto& L : P->leaves)
+                if (L.buf == P->out_alias_buf) L.base = outp;
+            if (P->d_leaves)
+                HIPCHECK(hipMemcpyAsync(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice, st));
+        }
+        int launches = 0;
+        // (profiling times the steps one after the other on the caller's stream)
+        const bool lanes = P->nlanes > 1 && !P->profiling && !std::getenv("SIGOPS_RS_TRACE");
+        hipStream_t const main_st = st;
+        std::vector<char> lane_started(P->nlanes, 0);
+        if (lanes) HIPCHECK(hipEventRecord(P->ev_start, main_st));  // after the H2D copies / earlier work
+        for (size_t si = 0; si < P->steps.size(); ++si) {
+            Step& s = P->steps[si];
+            const int ln = lanes ? P->step_lane[si] : 0;
+            hipStream_t st = ln == 0 ? main_st : P->lane_streams[ln];  // shadows the caller's stream
+            if (lanes) {
+                if (ln != 0 && !lane_started[ln]) {
+                    HIPCHECK(hipStreamWaitEvent(st, P->ev_start, 0));
+                    lane_started[ln] = 1;
+                }
+                for (int d : P->step_deps[si])
+                    if (P->step_lane[d] != ln) HIPCHECK(hipStreamWaitEvent(st, P->step_done[d], 0));
+            }
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si], st));
+            if (s.kind == 0) {
+                PwStep& w = P->pw[s.idx];
+                OutView ov{};
+                if (w.nblocks <= 0) {
+                    // empty rectangle (zero-frame sink): nothing to launch
+                } else if (w.out_buf >= 0) {
+                    Buf& b = P->bufs[w.out_buf];
+                    ov.base = b.d;
+                    ov.fstride = 1;
+                    ov.cstride = b.pitch;
+                    ov.dtype = b.dtype;
+                } else if (P->out.is_device) {
+                    ov.base = outp;
+                    ov.fstride = P->out.frame_stride;
+                    ov.cstride = P->out.chan_stride;
+                    ov.dtype = P->out.dtype;
+                } else {
+                    Buf& b = P->bufs[P->out_stage_buf];
+                    ov.base = b.d;
+                    ov.fstride = P->interleaved_host ? P->out.nch : 1;
+                    ov.cstride = P->interleaved_host ? 1 : b.pitch;
+                    ov.dtype = b.dtype;
+                }
+                if (w.nblocks > 0) {
+                    static const int il_scalar = std::getenv("SIGOPS_K1_ILSCALAR") ? 1 : 0;  // ablation knob
+                    ov.pad = il_scalar;
+                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st, w.chain,
+                                     w.il || (ov.fstride > 1 && ov.cstride == 1));
+                    s.launches = 1;
+                    launches++;
+                }
+            } else {
+                Stage& S = P->stages[s.idx];
+                Node& N = P->nodes[S.node];
+                size_t esz = dsize(N.dtype);
+                const char* inp;
+                int64_t in_pitch;
+                if (S.kind == ST_RESAMPLE && S.periodic) {
+                    inp = nullptr;  // the periodic kernel reads through its carriers
+                    in_pitch = 0;
+                } else if (S.in_array_node >= 0) {
+                    const so_node_t& nd = P->nodes[S.in_array_node].nd;
+                    const char* base = nd.i0 ? (const char*)P->array_ptr[S.in_array_node]
+                                             : (const char*)P->bufs[P->array_buf[S.in_array_node]].d;
+                    inp = base + (size_t)S.in_offset * esz;
+                    in_pitch = N.nch == 1 ? 0 : S.in_pitch;
+                } else {
+                    Buf& b = P->bufs[S.in_buf];
+                    inp = (const char*)b.d + (size_t)(S.in_offset - b.frame0) * esz;
+                    in_pitch = b.pitch;
+                }
+                Buf ob = P->bufs[S.out_buf];
+                if (s.idx == P->alias_stage) {  // write the sink buffer directly
+                    if (P->out.is_device) {
+                        ob.d = outp;
+                        ob.pitch = N.nch == 1 ? std::max<int64_t>(P->out.chan_stride, S.need) : P->out.chan_stride;
+                    } else {
+                        ob.d = P->bufs[P->out_stage_buf].d;
+                        ob.pitch = P->bufs[P->out_stage_buf].pitch;
+                    }
+                    // (local frame alias_skip is the result's frame 0; earlier frames are not stored)
+                    ob.d = (char*)ob.d - (size_t)P->alias_skip * esz;
+                } else if (S.win_off >= 0) {  // ... or its window of it
+                    const Buf& ab = P->bufs[P->out_alias_buf];
+                    ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
+                    ob.pitch = ab.pitch;
+                }
+                if (S.kind == ST_SOS) {
+                    SosGeom g = S.sg;
+                    g.in_pitch = in_pitch;
+                    g.out_pitch = ob.pitch;
+                    g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
+                    size_t msz = 0;
+                    for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
+                    int nl = 0;
+                    for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {
+                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
+                        SosOne o = S.so1;
+                        o.in_pitch = gi == 0 ? in_pitch : ob.pitch;
+                        o.out_pitch = ob.pitch;
+                        const int64_t al = 16 / (int64_t)esz;
+                        o.vec_in = ((uintptr_t)x % 16 == 0) && (o.in_pitch % al == 0);
+                        o.vec_out = ((uintptr_t)ob.d % 16 == 0) && (o.out_pitch % al == 0);
+                        Buf& sb = P->bufs[S.one_sync_buf];
+                        Buf& vb = P->bufs[S.one_vpub_buf];
+                        HIPCHECK(hipMemsetAsync(sb.d, 0, sb.bytes, st));     // ticket counter
+                        HIPCHECK(hipMemsetAsync(vb.d, 0xff, vb.bytes, st));  // "not published yet"
+                        launch_sos_onepass(x, ob.d, o, S.groups[gi], (const double*)P->bufs[S.one_tabs_buf].d + S.one_tabs_off[gi],
+                                           (int*)sb.d, (double*)P->bufs[S.one_vpub_buf].d, N.dtype, st);
+                        nl += 1;
+                    }
+                    if (S.pre_stage >= 0) {
+                        const Stage& S3 = P->stages[S.pre_stage];
+                        nl += launch_sos_prestate(inp, ob.d, (const double*)P->bufs[S3.vper_buf].d, S3.rp.nperiods,
+                                                  (const double*)P->bufs[S.qmat_buf].d, S3.rp.pt, (double*)P->bufs[S.v_buf].d,
+                                                  (double*)P->bufs[S.s0_buf].d, (const double*)P->bufs[S.mpow_buf].d, g,
+                                                  S.groups[0], st);
+                    }
+                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0; ++gi) {
+                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
+                        SosGeom gg = g;
+                        if (gi > 0) gg.in_pitch = ob.pitch;
+                        // frames beyond the child's end are zero (Pad(x.signal,zero), reference
+                        // src/filters.jl:240): the materialised input covers them; a direct
+                        // source always has in_frames == need
+                        nl += launch_sos(x, ob.d, S.v_buf >= 0 ? (double*)P->bufs[S.v_buf].d : nullptr,
+                                         S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr,
+                                         S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
+                                         gg, S.groups[gi], st);
+                    }
+                    s.launches = nl;
+                    launches += nl;
+                } else if (S.kind == ST_RESAMPLE) {
+                    RsGeom g = S.rg;
+                    g.in_pitch = in_pitch;
+                    g.out_pitch = ob.pitch;
+                    if (S.periodic) {
+                        RsPeriodic rp = S.rp;
+                        rp.in_pitch = in_pitch;
+                        rp.out_pitch = ob.pitch;
+                        rp.out_f32 = s.idx == P->alias_stage && P->alias_narrow;
+                        if (rp.nstate > 0) {
+                            rp.wtab = (const double*)P->bufs[S.wtab_buf].d;
+                            rp.vper = (double*)P->bufs[S.vper_buf].d;
+                        }
+                        const int64_t al = 16 / (int64_t)esz;
+                        rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
+                        static long long* d_trace = nullptr;  // SIGOPS_RS_TRACE tuning aid
+                        const bool tracing = std::getenv("SIGOPS_RS_TRACE") != nullptr;
+                        const size_t trace_n = (size_t)16 * kRsTraceIters * kRsTraceStamps;
+                        if (tracing) {
+                            if (!d_trace) HIPCHECK(hipMalloc(&d_trace, trace_n * 8));
+                            HIPCHECK(hipMemsetAsync(d_trace, 0, trace_n * 8, st));
+                            rp.trace = d_trace;
+                        }
+                        if (launch_resample_periodic(ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                                     (const int*)P->bufs[S.jend_buf].d, rp, N.dtype,
+                                                     RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves},
+                                                     st) != 0)
+                            fail(SO_ERR_RUNTIME, "internal: no periodic resampler instantiation for this geometry");
+                        if (tracing) {
+                            std::vector<long long> tr(trace_n);
+                            HIPCHECK(hipStreamSynchronize(st));
+                            HIPCHECK(hipMemcpy(tr.data(), d_trace, trace_n * 8, hipMemcpyDeviceToHost));
+                            long long t0 = 0;
+                            for (size_t i = 0; i < trace_n; ++i)
+                                if (tr[i] && (!t0 || tr[i] < t0)) t0 = tr[i];
+                            for (int w = 0; w < rp.nwaves; ++w)
+                                for (int it = 0; it < kRsTraceIters; ++it) {
+                                    const long long* q = &tr[((size_t)w * kRsTraceIters + it) * kRsTraceStamps];
+                                    if (!q[0]) continue;
+                                    std::fprintf(stderr, "[rs-trace] %s w%02d it%02d", w < rp.ncompute ? "C" : "L", w, it);
+                                    for (int k = 0; k < kRsTraceStamps; ++k)
+                                        std::fprintf(stderr, " %lld", q[k] ? q[k] - t0 : -1);
+                                    std::fprintf(stderr, "\n");
+                                }
+                        }
+                    } else if (S.rows) {
+                        RsRows rr = S.rr;
+                        rr.in_pitch = in_pitch;
+                        rr.out_pitch = ob.pitch;
+                        launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                             (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
+                                             (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
+                    } else if (S.tiled) {
+                        RsTiled rt = S.rt;
+                        rt.g.in_pitch = in_pitch;
+                        rt.g.out_pitch = ob.pitch;
+                        launch_resample_tiled(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
+                                              (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
+                    } else
+                        launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
+                                        (const double*)P->bufs[S.dpfb_buf].d, g, st);
+                    s.launches = 1;
+                    launches++;
+                    if (S.fix_buf >= 0) {  // the outputs DSP.jl's phase accumulator places differently
+                        RsFixArgs fa{};
+                        fa.fix = (const RsFix*)P->bufs[S.fix_buf].d;
+                        fa.nfix = (int64_t)S.fix_host.size();
+                        fa.pfb = (const double*)P->bufs[S.pfb_buf].d;
+                        fa.dpfb = (const double*)P->bufs[S.dpfb_buf].d;
+                        fa.n_in = g.n_in;
+                        fa.taps = g.taps;
+                        fa.nch = N.nch;
+                        fa.stage_dtype = N.dtype;
+                        fa.out_dtype = (s.idx == P->alias_stage && P->alias_narrow) ? SO_F32 : N.dtype;
+                        if (S.periodic) {
+                            fa.car = (const DCarrier*)P->bufs[S.car_buf].d;
+                            fa.ncar = (int)S.carriers.size();
+                            fa.ops = P->d_ops;
+                            fa.leaves = P->d_leaves;
+                        } else {
+                            fa.x = inp;
+                            fa.in_pitch = in_pitch;
+                            fa.in_dtype = N.dtype;
+                        }
+                        fa.y = ob.d;
+                        fa.out_pitch = ob.pitch;
+                        launch_resample_fix(fa, st);
+                        s.launches++;
+                        launches++;
+                    }
+                } else {
+                    launch_rms(ob.d, N.dtype, S.need, N.nch, ob.pitch, (double*)P->bufs[S.partial_buf].d,
+                               S.nparts, (double*)P->bufs[S.rms_buf].d, st);
+                    s.launches = 2;
+                    launches += 2;
+                }
+            }
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si + 1], st));
+            if (lanes && (P->step_signals[si] || (ln != 0 && si + 1 == P->steps.size())))
+                HIPCHECK(hipEventRecord(P->step_done[si], st));
+        }
+        if (lanes) {
+            // join: everything the side lanes did is ordered before what follows on the caller's
+            // stream (the last step of every side lane signals; wait for the last step per lane)
+            std::vector<int> last(P->nlanes, -1);
+            for (size_t si = 0; si < P->steps.size(); ++si) last[P->step_lane[si]] = (int)si;
+            for (int l = 1; l < P->nlanes; ++l)
+                if (last[l] >= 0) {
+                    if (!P->step_signals[last[l]]) HIPCHECK(hipEventRecord(P->step_done[last[l]], P->lane_streams[l]));
+                    HIPCHECK(hipStreamWaitEvent(main_st, P->step_done[last[l]], 0));
+                }
+        }
+        HIPCHECK(hipGetLastError());
+        P->stats.n_launches = launches;
+        if (!P->out.is_device && P->out.nframes > 0) {
+            Buf& b = P->bufs[P->out_stage_buf];
+            size_t esz = dsize(P->out.dtype);
+            bool planar = P->out.frame_stride == 1 && (P->out.nch == 1 || P->out.chan_stride == P->out.nframes);
+            if (planar || P->interleaved_host) {
+                HIPCHECK(hipMemcpyAsync(outp, b.d, b.bytes, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            } else {
+                P->host_tmp.resize(b.bytes);
+                HIPCHECK(hipMemcpyAsync(P->host_tmp.data(), b.d, b.bytes, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                for (int c = 0; c < P->out.nch; ++c)
+                    for (int64_t f = 0; f < P->out.nframes; ++f)
+                        std::memcpy((char*)outp + (size_t)(f * P->out.frame_stride + c * P->out.chan_stride) * esz,
+                                    P->host_tmp.data() + (size_t)(c * P->out.nframes + f) * esz, esz);
+            }
+        } else if (!P->host_leaves.empty() || P->profiling) {
+            HIPCHECK(hipStreamSynchronize(st));
+        }
+        if (P->profiling) {
+            HIPCHECK(hipStreamSynchronize(st));
+            double total = 0, best = -1;
+            for (size_t si = 0; si < P->steps.size(); ++si) {
+                float ms = 0;
+                HIPCHECK(hipEventElapsedTime(&ms, P->events[2 * si], P->events[2 * si + 1]));
+                P->steps[si].ms = ms;
+                total += ms;
+                if (ms > best) {
+                    best = ms;
+                    P->stats.dominant_kernel_ms = ms;
+                    P->stats.dominant_kernel_bytes = P->steps[si].bytes;
+                    std::snprintf(P->stats.dominant_kernel, sizeof P->stats.dominant_kernel, "%s", P->steps[si].name.c_str());
+                }
+            }
+            P->stats.last_exec_ms = total;
+        }
+    } catch (const PlanError& e) {
+        err = e.msg;
+        return e.status;
+    }
+    return SO_OK;
+}
+
+// so_plan_execute.  Plans with many small launches (config 4: 33 launches and ~40 event
+// operations per execute) are host-bound, so from the second execute with the same result
+// pointer on, the whole multi-stream launch sequence is replayed from a captured HIP graph.
+int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
+    DeviceGuard guard(P->device);
+    const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
+                          !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
+    if (!eligible) return plan_execute_direct(P, outp, stream, err);
+    hipStream_t st = (hipStream_t)stream;
+    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch) {
+        if (hipSetDevice(P->device) == hipSuccess && hipGraphLaunch(P->graph_exec, st) == hipSuccess) return SO_OK;
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(P->graph_exec);  // fall back to direct launches for good
+        P->graph_exec = nullptr;
+        P->graph_failed = true;
+    }
+    if (P->graph_failed || P->last_out != outp || P->last_epoch != P->array_epoch) {
+        // first execute for this result / these arrays: plain launches (also performs the
+        // one-time function attribute calls, which must not happen inside a capture)
+        P->last_out = outp;
+        P->last_epoch = P->array_epoch;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    if (P->graph_exec) {
+        (void)hipGraphExecDestroy(P->graph_exec);
+        P->graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    // capture on a stream of our own (the caller's may be the legacy default stream, which cannot
+    // be captured); the graph is then launched on the caller's stream
+    if (!P->capture_stream && hipStreamCreateWithFlags(&P->capture_stream, hipStreamNonBlocking) != hipSuccess)
+        P->capture_stream = nullptr;
+    if (!P->capture_stream || hipSetDevice(P->device) != hipSuccess ||
+        hipStreamBeginCapture(P->capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        P->graph_failed = true;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    const int rc = plan_execute_direct(P, outp, (void*)P->capture_stream, err);
+    const hipError_t ec = hipStreamEndCapture(P->capture_stream, &graph);
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] graph capture: rc=%d end=%d (%s) graph=%p err=%s\n", rc, (int)ec, hipGetErrorString(ec), (void*)graph, err.c_str());
+    if (rc != SO_OK || ec != hipSuccess || !graph ||
+        hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        P->graph_exec = nullptr;
+        P->graph_failed = true;
+        return rc != SO_OK ? rc : plan_execute_direct(P, outp, stream, err);
+    }
+    (void)hipGraphDestroy(graph);
+    P->graph_out = outp;
+    P->graph_epoch = P->array_epoch;
+    if (hipGraphLaunch(P->graph_exec, st) != hipSuccess) {
+        (void)hipGetLastError();
+        P->graph_failed = true;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    return SO_OK;
+}
+
+int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& err) {
+    if (node_index < 0 || node_index >= (int)P->nodes.size() || P->nodes[node_index].nd.kind != SO_NODE_ARRAY) {
+        err = "so_plan_set_array: not an ARRAY node";
+        return SO_ERR_INVALID;
+    }
+    DeviceGuard guard(P->device);
+    P->array_ptr[node_index] = data;
+    P->array_epoch++;  // invalidates a captured launch graph
+    if (P->nodes[node_index].nd.i0) {  // device leaf: patch the leaf table
+        bool changed = false;
+        for (size_t i = 0; i < P->leaves.size(); ++i)
+            if (P->leaf_array_node[i] == node_index) {
+                P->leaves[i].base = data;
+                changed = true;
+            }
+        if (changed && P->d_leaves)
+            if (hipMemcpy(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice) != hipSuccess) {
+                err = "so_plan_set_array: leaf upload failed";
+                return SO_ERR_RUNTIME;
+            }
+        // carriers of fused resampler stages (by value at launch + a device copy for the slow path)
+        for (auto& S : P->stages) {
+            bool touched = false;
+            for (auto& c : S.carriers)
+                if (c.array_node == node_index) {
+                    c.base = data;
+                    const int64_t V = 16 / (int64_t)dsize(c.dtype);
+                    c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
+                    touched = true;
+                }
+            if (touched) {
+                const RsCtl ctl = P->make_ctl(S);
+                if (hipMemcpy(P->bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(P->bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice) != hipSuccess) {
+                    err = "so_plan_set_array: carrier upload failed";
+                    return SO_ERR_RUNTIME;
+                }
+            }
+        }
+    }
+    return SO_OK;
+}
+
+int64_t plan_nframes(const Plan* P) {
+    const Node& R = P->nodes[P->root];
+    return isinf_(R.len) ? SO_LEN_INF : R.len.n;
+}
+void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
+void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
+int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
+    if (info && index >= 0 && index < (int)P->steps.size()) {
+        const Step& s = P->steps[index];
+        std::memset(info, 0, sizeof *info);
+        std::snprintf(info->name, sizeof info->name, "%s", s.name.c_str());
+        info->algorithmic_bytes = s.bytes;
+        info->ms = s.ms;
+        info->launches = s.launches;
+    }
+    return (int)P->steps.size();
+}
+void plan_destroy(Plan* P) {
+    if (!P) return;
+    {
+        DeviceGuard guard(P->device);
+        P->release();
+    }
+    delete P;
+}
+
+
+}  // namespace so

@@ -9,363 +9,9 @@
 // Index-only nodes (Until/After/Pad/Extend/Append/Ramp regions, channel maps) never
 // reach the device: they become piece boundaries and leaf index offsets.  Stateful
 // nodes (Filt IIR, resampler, Normpower) become *stages* with device buffers.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <set>
-#include <string>
-#include <vector>
-
-#include "kernels.h"
-#include "plan.h"
-#include "sigops_internal.h"
+#include "plan_impl.h"
 
 namespace so {
-
-namespace {
-
-struct PlanError {
-    int status;
-    std::string msg;
-};
-[[noreturn]] void fail(int status, const std::string& msg) { throw PlanError{status, msg}; }
-
-#define HIPCHECK(expr)                                                                         \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            fail(SO_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));           \
-    } while (0)
-
-// ---- lengths (reference src/inflen.jl, src/signal.jl:28-37, src/numbers.jl:5-9) ----
-enum { LK_FIN, LK_INF, LK_EXT, LK_NUMEXT };
-struct Len {
-    int k;
-    int64_t n;
-};
-constexpr int64_t BIG = (int64_t)1 << 62;
-inline bool isinf_(Len l) { return l.k != LK_FIN; }
-inline int64_t clean(Len l) { return l.k == LK_FIN ? l.n : BIG; }
-
-inline int promote(int a, int b) {
-    if (a == SO_F64 || b == SO_F64) return SO_F64;
-    if (a == SO_F32 || b == SO_F32) return SO_F32;
-    return SO_I64;
-}
-inline int float_of(int t) { return t == SO_I64 ? SO_F64 : t; }
-inline double roundto(int t, double v) { return t == SO_F32 ? (double)(float)v : v; }
-inline size_t dsize(int t) { return t == SO_F32 ? 4 : 8; }
-
-struct Node {
-    so_node_t nd;
-    std::vector<int> kids;
-    Len len;
-    int dtype, nch;
-    double fs;
-    int64_t short_skip = 0;  // > 0: evaluating this node skips more frames than a child below has
-    int64_t checked_upto = 0;  // frames [0, checked_upto) have been lowered for their errors (check_frames)
-};
-
-// ---- expressions -------------------------------------------------------------
-enum { E_CONST, E_LOAD, E_SCALAR, E_FUNC, E_RAMP, E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_ROUND32, E_RETYPE };
-struct Expr {
-    int op;
-    int dtype;
-    int a = -1, b = -1;
-    DLeaf leaf{};
-    int array_node = -1;  // E_LOAD of an ARRAY node (for so_plan_set_array)
-    bool mono = true, heavy = false;
-};
-struct Map {
-    int sf;
-    int64_t df;
-    int sc;
-    int64_t dc;
-};
-struct Rect {
-    int64_t a, b;
-    int c0, c1;
-};
-struct Piece {
-    Rect r;
-    int e;
-};
-
-struct Buf {
-    int64_t frames = 0, pitch = 0;
-    int nch = 0, dtype = SO_F64;
-    size_t bytes = 0;
-    void* d = nullptr;
-    bool external = false;  // aliases a user/device leaf pointer
-    int64_t frame0 = 0;     // stage buffers: node frame stored at position 0 (Stage::base)
-};
-
-enum { ST_SOS, ST_RESAMPLE, ST_NORM };
-struct Stage {
-    int kind, node;
-    int64_t need = 0;  // output frames [0,need)
-    int64_t lo = (int64_t)1 << 62;  // first frame anybody reads
-    int64_t base = 0;  // first frame the stage computes (warm start, see process_stage): its buffer holds [base, need)
-    int64_t in_base = 0;  // first frame of the child the stage consumes
-    bool processed = false;
-    int out_buf = -1, in_buf = -1, aux_buf = -1;
-    int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)
-    // input source (after processing): either a materialised buffer or a direct view
-    const void* in_ptr = nullptr;  // direct device pointer (nullptr -> in_buf)
-    int in_array_node = -1;
-    int64_t in_offset = 0;  // elements (direct)
-    int64_t in_pitch = 0, in_frames = 0;
-    int pw_step = -1;  // pointwise step materialising the input
-    std::vector<DCarrier> carriers;  // periodic resampler: input expressed as carriers
-    int car_buf = -1;
-    int ctl_buf = -1;  // device copy of the RsCtl control block
-    // SOS
-    std::vector<SosCoefs> groups;
-    SosGeom sg{};
-    int mpow_buf = -1, v_buf = -1, s0_buf = -1;
-    std::vector<std::vector<double>> mpow_host;  // per group
-    // single-pass kernel (k_sos_onepass)
-    bool onepass = false;
-    SosOne so1{};
-    int one_tabs_buf = -1, one_sync_buf = -1, one_vpub_buf = -1;
-    std::vector<double> one_tabs_host;    // per group: [nlev + kt][D*D]
-    std::vector<size_t> one_tabs_off;     // doubles
-    // resample
-    RsGeom rg{};
-    int pfb_buf = -1, dpfb_buf = -1;
-    std::vector<double> pfb_host, dpfb_host;
-    bool periodic = false;
-    RsPeriodic rp{};
-    bool tiled = false;  // tiled resampler without a period (k_resample_tiled)
-    RsTiled rt{};
-    int pfbt_buf = -1, dpfbt_buf = -1;
-    std::vector<double> pfbt_host, dpfbt_host;
-    bool rows = false;  // row-tiled resampler (k_resample_rows)
-    RsRows rr{};
-    int mtab_buf = -1, mjend_buf = -1;
-    std::vector<double> mtab_host;
-    std::vector<int> mjend_host;
-    int tab_buf = -1, jend_buf = -1;
-    std::vector<double> tab_host;
-    std::vector<int> jend_host;
-    // periodic variant: per-period positions (kept for the fused IIR state pass)
-    std::vector<int64_t> per_j;
-    std::vector<int> per_p;
-    std::vector<double> per_a;
-    int jend_last = 0;
-    // fused IIR state pass (this resampler computes its SOS consumer's chunk states)
-    int wtab_buf = -1, vper_buf = -1;
-    std::vector<double> wtab_host;
-    // ... and on the SOS side: the resampler stage that provides vper, Q = A^Ls
-    int pre_stage = -1;
-    int qmat_buf = -1;
-    std::vector<double> qmat_host;
-    // outputs DSP.jl's phase accumulator positions differently (recomputed by k_resample_fix)
-    std::vector<RsFix> fix_host;
-    int fix_buf = -1;
-    // norm
-    int partial_buf = -1, rms_buf = -1;
-    int nparts = 0;
-};
-
-struct PwStep {
-    int piece0 = 0, npieces = 0;
-    int64_t nblocks = 0;
-    int out_buf = -1;  // -1: final output
-    int64_t bytes = 0;
-    bool deep = false;  // some piece needs the 4-deep interpreter
-    bool chain = false;  // some piece takes k_pointwise's chain path
-    bool il = false;     // ... with an interleaved leaf (the LDS-transposing instantiation)
-    std::vector<int> pre;  // pointwise steps that materialise sub-expressions this one reads (run first)
-};
-
-struct Step {
-    int kind;  // 0 pointwise, 1 stage kernel
-    int idx;
-    std::string name;
-    int64_t bytes = 0;
-    double ms = 0;
-    int launches = 0;
-};
-
-struct HostLeaf {
-    int node;
-    const void* src;
-    size_t bytes;
-    int buf;
-};
-
-}  // namespace
-
-struct Plan {
-    int device = 0;
-    std::vector<Node> nodes;
-    int root = -1;
-    so_out_desc_t out{};
-    std::vector<Expr> exprs;
-    std::vector<Buf> bufs;
-    std::map<int, int> stage_of_node;
-    std::vector<Stage> stages;
-    std::vector<PwStep> pw;
-    std::vector<Step> steps;
-    std::vector<DPiece> pieces;
-    std::vector<DOp> ops;
-    std::vector<DLeaf> leaves;
-    std::vector<int> leaf_array_node;  // per leaf: ARRAY node or -1
-    std::vector<HostLeaf> host_leaves;
-    std::map<int, int> array_buf;  // ARRAY node -> buf id (host arrays: device copy)
-    std::map<int, const void*> array_ptr;  // current data pointer per ARRAY node
-    DPiece* d_pieces = nullptr;
-    DOp* d_ops = nullptr;
-    DLeaf* d_leaves = nullptr;
-    int out_stage_buf = -1;  // device staging for a host result
-    int out_alias_buf = -1;  // pseudo buffer standing for the result (leaves of in-place root pieces point at it)
-    void try_window_alias(std::vector<Piece>& rootp);
-    int alias_stage = -1;    // stage whose kernel writes the final output directly
-    bool alias_narrow = false;  // ... rounding its Float64 values to the Float32 result
-    int64_t alias_skip = 0;     // ... from its local frame alias_skip on (an IIR's warm-up frames are not stored)
-    bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
-    std::vector<char> host_tmp;
-    bool profiling = false;
-    std::vector<hipEvent_t> events;
-    // independent step chains (Append children, Mix operands with their own filters ...) run on
-    // separate HIP streams: the small latency-bound kernels of different chains overlap
-    std::vector<std::vector<int>> step_deps;  // per step: earlier steps it must wait for
-    std::vector<int> step_lane;               // per step: 0 = the caller's stream
-    std::vector<char> step_signals;           // per step: a later step on another lane waits for it
-    int nlanes = 1;
-    std::vector<hipStream_t> lane_streams;  // [1..nlanes)
-    std::vector<hipEvent_t> step_done;
-    hipEvent_t ev_start = nullptr;
-    void plan_lanes();
-    // captured launch sequence (see plan_execute)
-    hipGraphExec_t graph_exec = nullptr;
-    hipStream_t capture_stream = nullptr;
-    const void* graph_out = nullptr;
-    const void* last_out = nullptr;
-    int64_t array_epoch = 0, graph_epoch = -1, last_epoch = -1;
-    bool graph_failed = false;
-    so_stats_t stats{};
-    int64_t algo_bytes = 0;
-    std::map<int, bool> array_counted;
-
-    // ---- helpers ---------------------------------------------------------
-    int add_expr(const Expr& e) {
-        exprs.push_back(e);
-        return (int)exprs.size() - 1;
-    }
-    int new_buf(int64_t frames, int nch, int dtype) {
-        Buf b;
-        b.frames = frames;
-        b.pitch = (frames + 63) / 64 * 64;
-        if (b.pitch == 0) b.pitch = 64;
-        b.nch = nch;
-        b.dtype = dtype;
-        b.bytes = (size_t)b.pitch * (size_t)std::max(nch, 1) * dsize(dtype);
-        bufs.push_back(b);
-        return (int)bufs.size() - 1;
-    }
-    int raw_buf(size_t bytes) {
-        Buf b;
-        b.bytes = std::max<size_t>(bytes, 8);
-        b.dtype = SO_F64;
-        bufs.push_back(b);
-        return (int)bufs.size() - 1;
-    }
-
-    int mk_const(double v, int dtype) {
-        Expr e;
-        e.op = E_CONST;
-        e.dtype = dtype;
-        e.leaf.v0 = v;
-        e.leaf.buf = -1;
-        return add_expr(e);
-    }
-    int mk_un(int op, int a, int dtype) {
-        Expr e;
-        e.op = op;
-        e.dtype = dtype;
-        e.a = a;
-        e.mono = exprs[a].mono;
-        e.heavy = exprs[a].heavy;
-        return add_expr(e);
-    }
-    bool is_const(int e, double v) const { return exprs[e].op == E_CONST && exprs[e].leaf.v0 == v; }
-    int mk_bin(int op, int a, int b) {
-        int ta = exprs[a].dtype, tb = exprs[b].dtype;
-        int t = promote(ta, tb);
-        if (op == E_DIV && t == SO_I64) t = SO_F64;
-        // x*1 == x exactly (ramp flat regions, reference src/ramps.jl:56-59)
-        if (op == E_MUL && is_const(b, 1.0)) return t == ta ? a : mk_un(E_RETYPE, a, t);
-        if (op == E_MUL && is_const(a, 1.0)) return t == tb ? b : mk_un(E_RETYPE, b, t);
-        if (exprs[a].op == E_CONST && exprs[b].op == E_CONST) {
-            double x = exprs[a].leaf.v0, y = exprs[b].leaf.v0, r;
-            switch (op) {
-            case E_ADD: r = x + y; break;
-            case E_SUB: r = x - y; break;
-            case E_MUL: r = x * y; break;
-            default: r = x / y;
-            }
-            return mk_const(roundto(t, r), t);
-        }
-        Expr e;
-        e.op = op;
-        e.dtype = t;
-        e.a = a;
-        e.b = b;
-        e.mono = exprs[a].mono && exprs[b].mono;
-        e.heavy = exprs[a].heavy || exprs[b].heavy;
-        return add_expr(e);
-    }
-
-    // ---- model -----------------------------------------------------------
-    void build_nodes(const so_node_t* in, int n);
-    Len map_maxlen(Len x, Len y) const {
-        if (x.k == LK_NUMEXT && y.k == LK_NUMEXT) return x;
-        if (x.k == LK_INF || y.k == LK_INF) return Len{LK_INF, 0};
-        int64_t a = x.k == LK_NUMEXT ? 0 : x.n, b = y.k == LK_NUMEXT ? 0 : y.n;
-        return Len{LK_FIN, std::max(a, b)};
-    }
-
-    // ---- lowering --------------------------------------------------------
-    std::vector<Piece> lower(int ni, Rect r, Map m);
-    std::vector<Piece> lower_padded(int ni, int padkind, double padvalue, const double* padvec,
-                                    Rect r, Map m, bool always_pad);
-    std::vector<Piece> pad_pieces(int child, int padkind, double padvalue, const double* padvec,
-                                  Rect r, Map m);
-    std::vector<Piece> combine(const std::vector<std::vector<Piece>>& kids, Rect r, int op,
-                               int force_dtype);
-    int stage_for(int ni, int kind);
-    void use_stage(Stage& S, const Rect& r, const Map& m);
-    int dry = 0;  // > 0: lower() only looks for the errors evaluating those frames raises (no stages, no buffers)
-    void check_frames(int ni, int64_t upto);
-    void process_stage(int sid);
-    int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
-    bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
-    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false);
-    RsCtl make_ctl(const Stage& S) const;
-    void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
-             bool allow_hoist);
-    int depth(int e) const;
-    int frame_slots(int e) const;
-    int shift_expr(int e, int64_t a, int c0);
-    int materialise(int e, const Rect& r, std::vector<int>& pre);
-    int legalise(int e, const Rect& r, std::vector<int>& pre);
-    void push_pw_step(int idx);
-    int add_leaf(const Expr& e);
-    void count_array(int ni);
-    void fuse_state_passes();
-    void finalize();
-    void release();
-};
 
 // ===========================================================================
 void Plan::build_nodes(const so_node_t* in, int n) {
@@ -1241,1394 +887,6 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
 
 // The C-ABI entry points run on the plan's device and leave the caller's current device as they
 // found it (a single process may drive several GPUs).
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-        else prev = -1;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-// ---------------------------------------------------------------------------
-// small dense matrices for the SOS state propagation
-using Mat = std::vector<double>;
-static Mat matmul(const Mat& a, const Mat& b, int D) {
-    Mat c((size_t)D * D, 0.0);
-    for (int i = 0; i < D; ++i)
-        for (int k = 0; k < D; ++k) {
-            double v = a[(size_t)i * D + k];
-            if (v == 0.0) continue;
-            for (int j = 0; j < D; ++j) c[(size_t)i * D + j] += v * b[(size_t)k * D + j];
-        }
-    return c;
-}
-static double maxabs(const Mat& a) {
-    double m = 0;
-    for (double v : a) m = std::max(m, std::fabs(v));
-    return m;
-}
-static Mat ident(int D) {
-    Mat m((size_t)D * D, 0.0);
-    for (int i = 0; i < D; ++i) m[(size_t)i * D + i] = 1.0;
-    return m;
-}
-// one zero-input DF2T step applied to each unit state: columns of the state matrix A
-static Mat sos_state_matrix(const SosCoefs& cf) {
-    int ns = cf.nsec, D = 2 * ns;
-    Mat A((size_t)D * D, 0.0);
-    for (int col = 0; col < D; ++col) {
-        std::vector<double> s(D, 0.0);
-        s[col] = 1.0;
-        double y = 0.0;
-        for (int f = 0; f < ns; ++f) {
-            double xi = y;
-            y = s[2 * f] + cf.b0[f] * xi;
-            s[2 * f] = s[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
-            s[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
-        }
-        for (int r = 0; r < D; ++r) A[(size_t)r * D + col] = s[r];
-    }
-    return A;
-}
-static Mat matpow(Mat A, int64_t e, int D) {
-    Mat R = ident(D);
-    while (e > 0) {
-        if (e & 1) R = matmul(R, A, D);
-        e >>= 1;
-        if (e) A = matmul(A, A, D);
-    }
-    return R;
-}
-
-// ---------------------------------------------------------------------------
-// DSP.jl FIRArbitrary positions (reference call sites
-// src/reformatting.jl:92-98 `setphase!(self, timedelay(self))`, src/filters.jl:252-255 `filt!`):
-//     ϕAcc += Δ;  if ϕAcc > Nϕ:  xIdx += div(ϕAcc-1, Nϕ);  ϕAcc = mod(ϕAcc-1, Nϕ) + 1
-//     ϕIdx = floor(ϕAcc);  α = ϕAcc - ϕIdx
-// once per output, in Float64.  The sequence is data independent and does not depend on the
-// block size (xIdx is carried as inputDeficit), so it is replayed here once per plan and compared
-// with the kernels' closed-form rule.  At a tie (closed-form α == 0) accumulated rounding error
-// leaves the accumulator a hair below the integer: (previous phase, α ≈ 1).  The interpolated
-// taps h + α·dh are continuous there EXCEPT (a) across the wrap (ϕIdx = Nϕ, α ≈ 1, xIdx not
-// advanced: the tap h[0] of the next input is dropped) and (b) at the filter's last tap
-// (dh = [diff(h); 0] ends in 0, not -h[end]) -- differences of ~1e-3 of a sample.  For a rational
-// pattern (integer frame rates) both happen at the same place of (nearly) every period:
-// `prev[r]` marks those period positions so that the kernels' tap tables are built with the
-// accumulator's (fine position - 1, α = 1) there; every other deviation that changes the taps
-// goes to the fix-up list (k_resample_fix).
-static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
-                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix);
-
-// state of the accumulator before output m (a later window of the same resampler resumes from the
-// nearest one instead of replaying from output 0)
-struct AccCheckpoint {
-    int64_t m, xb;
-    double acc;
-};
-struct AccKey {
-    double delta, c0, hsum;
-    int64_t c0i, L, M;
-    int32_t nphi, taps, exact, hlen;
-    bool operator==(const AccKey& o) const { return std::memcmp(this, &o, sizeof(AccKey)) == 0; }
-};
-static std::mutex g_acc_mu;
-static std::vector<std::pair<AccKey, std::vector<AccCheckpoint>>> g_acc_checkpoints;
-static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
-    AccKey k;
-    std::memset(&k, 0, sizeof k);
-    k.delta = g.delta;
-    k.c0 = g.c0;
-    k.c0i = g.c0i;
-    k.L = g.L;
-    k.M = g.M;
-    k.nphi = g.nphi;
-    k.taps = g.taps;
-    k.exact = g.exact;
-    k.hlen = hlen;
-    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
-    return k;
-}
-
-// The replay is sequential by nature (~5 ns per output: 160 ms for config 3's 28.8 M outputs) and
-// depends only on the geometry, so a process keeps the last few results (plans of the same
-// resampler -- a bench's second workload, a re-created plan -- get it for free).
-// Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate, and the
-// fix-up list comes back in the window's own coordinates (output m - from, input j - from/L*M).
-static void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
-                                     std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from = 0) {
-    struct Key {
-        double delta, c0, hsum;
-        int64_t c0i, L, M, need, from;
-        int32_t nphi, taps, exact, hlen, bake;
-        bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
-    };
-    struct Entry {
-        Key k;
-        std::vector<uint8_t> prev;
-        std::vector<RsFix> fix;
-    };
-    static std::mutex mu;
-    static std::vector<Entry> cache;
-    Key k;
-    std::memset(&k, 0, sizeof k);
-    k.delta = g.delta;
-    k.c0 = g.c0;
-    k.c0i = g.c0i;
-    k.L = g.L;
-    k.M = g.M;
-    k.need = need;
-    k.from = from;
-    k.nphi = g.nphi;
-    k.taps = g.taps;
-    k.exact = g.exact;
-    k.hlen = hlen;
-    k.bake = bake;
-    for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
-    if (!g.arbitrary || need <= 0) {
-        prev.clear();
-        fix.clear();
-        return;
-    }
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        for (auto& e : cache)
-            if (e.k == k) {
-                prev = e.prev;
-                fix = e.fix;
-                return;
-            }
-    }
-    replay_phase_accumulator_impl(g, h, hlen, from, need, bake, prev, fix);
-    std::lock_guard<std::mutex> lock(mu);
-    if (cache.size() >= 8) cache.erase(cache.begin());
-    cache.push_back(Entry{k, prev, fix});
-}
-
-static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int hlen, int64_t from, int64_t need, bool bake,
-                                          std::vector<uint8_t>& prev, std::vector<RsFix>& fix) {
-    prev.clear();
-    fix.clear();
-    if (!g.arbitrary || need <= 0) return;
-    const int nphi = g.nphi, taps = g.taps;
-    const double dnphi = (double)nphi;
-    const bool pow2 = (nphi & (nphi - 1)) == 0;
-    const double inv = 1.0 / dnphi;
-    double hmax = 0.0;
-    for (int i = 0; i < hlen; ++i) hmax = std::max(hmax, std::fabs(h[i]));
-    auto tap = [&](int64_t q, double alpha, int64_t k) -> double {  // tap applied to input (q/nphi - k)
-        if (k < 0 || k >= taps) return 0.0;
-        const int64_t hi = q % nphi + (int64_t)nphi * k;
-        const double hv = hi < hlen ? h[hi] : 0.0;
-        const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
-        return hv + alpha * dv;
-    };
-    // do the two positions give different taps (beyond the interpolation's own continuity)?
-    auto taps_differ = [&](int64_t qa, double aa, int64_t qe, double ae) {
-        const int64_t ja = qa / nphi, je = qe / nphi, dj = je - ja;
-        if (std::llabs(dj) > 1) return true;
-        double d = 0.0;
-        for (int64_t k = -1; k <= taps; ++k) d = std::max(d, std::fabs(tap(qa, aa, k) - tap(qe, ae, k + dj)));
-        return d > 4e-6 * hmax;  // (positions within 1e-6 of each other move a tap by < 1e-6*|dh|)
-    };
-    // setphase!(kernel, τ), τ = (hLen-1)/(2Nϕ)
-    const double tau = (double)(hlen - 1) / 2.0 / dnphi;
-    const double w = std::floor(tau), fr = tau - w;
-    int64_t xb = (int64_t)std::llround(w) * nphi;  // (xIdx-1)*Nϕ, xIdx = inputDeficit = 1 + w
-    double acc = fr * dnphi + 1.0;
-    const double delta = g.delta;
-    // closed-form rule of the kernels
-    const bool exact = g.exact != 0;
-    const int64_t L = g.L, dq = exact ? ((int64_t)nphi * g.M) / L : 0, dfr = exact ? ((int64_t)nphi * g.M) % L : 0;
-    int64_t qe = g.c0i, fe = 0;
-    struct Rec { int64_t m, qa; double alpha; };
-    std::vector<Rec> rec;
-    std::vector<int8_t> memo((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
-    int64_t m0 = 0;
-    const AccKey ckey = acc_key(g, h, hlen);
-    std::vector<AccCheckpoint> made;
-    if (from > 0) {  // resume from the nearest checkpoint at or before the window
-        std::lock_guard<std::mutex> lock(g_acc_mu);
-        for (auto& e : g_acc_checkpoints)
-            if (e.first == ckey)
-                for (auto& c : e.second)
-                    if (c.m <= from && c.m > m0) {
-                        m0 = c.m;
-                        xb = c.xb;
-                        acc = c.acc;
-                    }
-        if (exact) {
-            const __int128 Nn = (__int128)m0 * ((int64_t)nphi * g.M);
-            qe = g.c0i + (int64_t)(Nn / L);
-            fe = (int64_t)(Nn % L);
-        }
-    }
-    for (int64_t m = m0; m < need; ++m) {
-        if (m == from || (m > m0 && (m & ((1 << 22) - 1)) == 0)) made.push_back(AccCheckpoint{m, xb, acc});
-        const int pi = (int)acc;  // floor: acc >= 1
-        const int64_t qa = xb + pi - 1;
-        double qe_frac = 0.0;
-        if (!exact) {
-            const double t = (double)m * delta;  // two separately rounded operations, like rs_pos
-            const double q = g.c0 + t;
-            const double fl = std::floor(q);
-            qe = (int64_t)fl;
-            qe_frac = q - fl;
-        }
-        if (qa != qe) {
-            const double alpha = acc - (double)pi;
-            const double ae = exact ? (double)fe / (double)L : qe_frac;
-            bool differ;
-            const bool tie = exact && fe == 0 && std::llabs(qa - qe) == 1 && (alpha < 1e-6 || alpha > 1.0 - 1e-6);
-            if (tie) {
-                int8_t& mm = memo[(size_t)(qe % nphi) * 4 + (qa > qe ? 2 : 0) + (alpha > 0.5 ? 1 : 0)];
-                if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
-                differ = mm != 0;
-            } else differ = taps_differ(qa, alpha, qe, ae);
-            if (differ && m >= from) rec.push_back(Rec{m, qa, alpha});
-        }
-        if (exact) {
-            qe += dq;
-            fe += dfr;
-            if (fe >= L) {
-                fe -= L;
-                ++qe;
-            }
-        }
-        acc += delta;
-        if (acc > dnphi) {
-            // xIdx += div(ϕAcc-1, Nϕ); ϕAcc = mod(ϕAcc-1, Nϕ) + 1.  (ϕAcc-1 and the remainder are
-            // exact, the final +1 rounds: the same real number as ϕAcc - k·Nϕ rounded once)
-            const double a1 = acc - 1.0;
-            if (a1 < dnphi) {
-                // k == 0: unchanged
-            } else if (a1 < 2.0 * dnphi) {
-                xb += nphi;
-                acc -= dnphi;
-            } else if (pow2) {
-                const double k = std::floor(a1 * inv);
-                xb += (int64_t)k * nphi;
-                acc -= k * dnphi;
-            } else {
-                const double k = std::floor(a1 / dnphi);
-                xb += (int64_t)k * nphi;
-                acc = std::fmod(a1, dnphi) + 1.0;
-            }
-        }
-    }
-    made.push_back(AccCheckpoint{need, xb, acc});
-    {
-        std::lock_guard<std::mutex> lock(g_acc_mu);
-        std::vector<AccCheckpoint>* store = nullptr;
-        for (auto& e : g_acc_checkpoints)
-            if (e.first == ckey) store = &e.second;
-        if (!store) {
-            if (g_acc_checkpoints.size() >= 8) g_acc_checkpoints.erase(g_acc_checkpoints.begin());
-            g_acc_checkpoints.emplace_back(ckey, std::vector<AccCheckpoint>{});
-            store = &g_acc_checkpoints.back().second;
-        }
-        for (auto& c : made) {
-            bool have = false;
-            for (auto& o : *store) have = have || o.m == c.m;
-            if (!have) store->push_back(c);
-        }
-        if (store->size() > 256) store->erase(store->begin(), store->begin() + (store->size() - 256));
-    }
-    auto exact_q = [&](int64_t m) {
-        const int64_t Nn = m * ((int64_t)nphi * g.M);
-        return g.c0i + Nn / L;
-    };
-    auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
-    if (bake && exact && L <= 65536) {
-        // majority per period position among the deviations of the form (fine position - 1, α ≈ 1)
-        std::vector<int64_t> cnt(L, 0);
-        for (const Rec& r : rec)
-            if (baked(r)) cnt[r.m % L]++;
-        prev.assign(L, 0);
-        bool any = false;
-        for (int64_t r = 0; r < L; ++r) {
-            // (occurrences of period position r in [from, need); `from` is a multiple of L)
-            const int64_t occ = need - from > r ? (need - from - 1 - r) / L + 1 : 0;
-            if (occ > 0 && 2 * cnt[r] > occ) prev[r] = 1, any = true;
-        }
-        if (!any) prev.clear();
-    }
-    // fix-up list: deviations the tables do not already contain + outputs at baked positions
-    // where the accumulator agreed with the closed form after all
-    if (!prev.empty()) {
-        for (int64_t r = 0; r < L; ++r) {
-            if (!prev[r]) continue;
-            size_t k = 0;
-            for (int64_t m = from + r; m < need; m += L) {  // outputs at a baked position
-                while (k < rec.size() && rec[k].m < m) ++k;
-                if (k < rec.size() && rec[k].m == m) continue;  // deviates: baked, or listed below
-                const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
-                fix.push_back(RsFix{m, q / nphi, (int32_t)(q % nphi), 0, (double)(Nn % L) / (double)L});
-            }
-        }
-        for (const Rec& r : rec) {
-            if (prev[r.m % L] && baked(r)) continue;  // what the tables contain
-            fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
-        }
-    } else {
-        for (const Rec& r : rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
-    }
-    std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
-    if (from > 0) {
-        const int64_t jin = exact ? from / L * g.M : 0;
-        for (auto& f : fix) {
-            f.m -= from;
-            f.j -= jin;
-        }
-    }
-}
-
-// integer frame rates: the arbitrary-rate kernel's rate is the exact rational fs_out/fs_in
-static void rs_detect_exact(RsGeom& g, double fo, double fi, double rate) {
-    if (fo == std::floor(fo) && fi == std::floor(fi) && fo >= 1 && fi >= 1 && fo < 2147483648.0 &&
-        fi < 2147483648.0 && fo / fi == rate) {
-        int64_t a = (int64_t)fo, b = (int64_t)fi;
-        while (b) {
-            int64_t t = a % b;
-            a = b;
-            b = t;
-        }
-        int64_t Lx = (int64_t)fo / a, Mx = (int64_t)fi / a;
-        if (Lx <= 8192 && Mx <= 1048576) {
-            g.exact = 1;
-            g.L = Lx;
-            g.M = Mx;
-        }
-    }
-}
-
-// Diagnostics (host only): the (newest input, phase, alpha) the arbitrary-rate resampler kernels
-// use for outputs [0,n_out) -- closed form, baked period positions and fix-up list combined.
-int resample_positions(double fs_in, double fs_out, double rate, int nphi, const double* h, int hlen,
-                       int64_t n_out, int64_t* jo, int32_t* po, double* ao, int64_t* nfix, int64_t* nbaked) {
-    RsGeom g{};
-    g.arbitrary = 1;
-    g.nphi = nphi;
-    g.delta = (double)nphi / rate;
-    g.c0 = (double)(hlen - 1) / 2.0;
-    g.c0i = (hlen - 1) / 2;
-    g.taps = (hlen + nphi - 1) / nphi;
-    rs_detect_exact(g, fs_out, fs_in, rate);
-    std::vector<uint8_t> prev;
-    std::vector<RsFix> fix;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (!std::getenv("SIGOPS_RS_EXACT")) replay_phase_accumulator(g, h, hlen, n_out, g.exact && n_out >= 2048, prev, fix);
-    if (std::getenv("SIGOPS_DEBUG_PLAN"))
-        std::fprintf(stderr, "[sigops] phase accumulator replay: %lld outputs, %.1f ms\n", (long long)n_out,
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    for (int64_t m = 0; m < n_out; ++m) {
-        int64_t qi;
-        double alpha;
-        if (g.exact) {
-            const int64_t Nn = m * ((int64_t)nphi * g.M);
-            qi = g.c0i + Nn / g.L;
-            alpha = (double)(Nn % g.L) / (double)g.L;
-            if (!prev.empty() && prev[m % g.L]) {
-                qi -= 1;
-                alpha = 1.0;
-            }
-        } else {
-            const double t = (double)m * g.delta;
-            const double q = g.c0 + t;
-            const double fl = std::floor(q);
-            qi = (int64_t)fl;
-            alpha = q - fl;
-        }
-        jo[m] = qi / nphi;
-        po[m] = (int32_t)(qi % nphi);
-        ao[m] = alpha;
-    }
-    for (const RsFix& f : fix) {
-        jo[f.m] = f.j;
-        po[f.m] = f.p;
-        ao[f.m] = f.alpha;
-    }
-    if (nfix) *nfix = (int64_t)fix.size();
-    if (nbaked) {
-        *nbaked = 0;
-        for (uint8_t b : prev) *nbaked += b;
-    }
-    return SO_OK;
-}
-
-// Can this periodic resampler stage run the GA instantiation (Float32 tiles, Float64 gain at the A
-// operand)?  Geometry the instantiations cover, and the LDS budget with three gain arrays.
-static bool ga_fits(const Stage& S, int stage_dtype) {
-    if (!S.periodic || stage_dtype != SO_F64 || std::getenv("SIGOPS_RS_NOGA")) return false;
-    const RsPeriodic& rp = S.rp;
-    const int gper = (rp.ngroups + rp.ncompute - 1) / std::max(1, rp.ncompute);
-    if (rp.kw != 56 || gper != 1 || !(rp.ct == 8 || rp.ct == 4)) return false;
-    const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
-    const size_t pitch4 = (size_t)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
-    const size_t tile_bytes = (size_t)rp.ct * pitch4 * 4;
-    const size_t fpitch = (size_t)((rp.tile_len + 16 + 1) & ~1);
-    const bool ok = 3 * fpitch * 8 + kRsTwoDoubles * 8 + 2 * tile_bytes <= avail;
-    if (std::getenv("SIGOPS_DEBUG_PLAN"))
-        std::fprintf(stderr, "[sigops] GA geometry: kw=%d gper=%d ct=%d tile_len=%d -> %s\n", rp.kw, gper, rp.ct, rp.tile_len, ok ? "fits" : "no");
-    return ok;
-}
-
-void Plan::process_stage(int sid) {
-    // NOTE: `stages` may grow while lowering the child; re-take references after.
-    int ni = stages[sid].node;
-    Node& N = nodes[ni];
-    const so_node_t& nd = N.nd;
-    int child = N.kids[0];
-    Node& C = nodes[child];
-    int64_t need = stages[sid].need;
-    stages[sid].processed = true;
-    if (need <= 0) return;
-
-    int64_t in_frames = need;
-    if (stages[sid].kind == ST_RESAMPLE) {
-        RsGeom g{};
-        g.arbitrary = nd.i0 == SO_RS_ARBITRARY;
-        int hlen = nd.i2;
-        g.nphi = g.arbitrary ? nd.i1 : (int)nd.l0;
-        if (g.nphi < 1) fail(SO_ERR_INVALID, "resampler: bad phase count");
-        g.L = nd.l0;
-        g.M = nd.l1;
-        const bool plain_fir = nd.i0 == SO_RS_FIR;  // Filt(x,h): ratio 1, causal, no delay compensation
-        if (plain_fir) {
-            g.nphi = 1;
-            g.L = g.M = 1;
-        }
-        if (!g.arbitrary && (g.L < 1 || g.M < 1)) fail(SO_ERR_INVALID, "resampler: bad ratio");
-        g.delta = g.arbitrary ? (double)g.nphi / nd.d0 : 0.0;
-        g.c0 = plain_fir ? 0.0 : (double)(hlen - 1) / 2.0;
-        g.c0i = plain_fir ? 0 : (hlen - 1) / 2;
-        g.taps = (hlen + g.nphi - 1) / g.nphi;
-        g.nch = N.nch;
-        g.m0 = 0;
-        g.n_out = need;
-        if (g.arbitrary) rs_detect_exact(g, nd.fs, C.fs, nd.d0);
-        // ---- warm start (see the IIR's below): the resampler is an FIR filter, so outputs from a
-        //      whole number of periods before the first frame anybody reads on are the same whether
-        //      the stage starts there or at frame 0, except the first few (their taps reach before
-        //      the first input staged), which nobody reads either ----
-        int64_t rbase = 0;
-        if ((!g.arbitrary || g.exact) && stages[sid].lo >= 8192 && stages[sid].lo < need &&
-            !std::getenv("SIGOPS_NO_WARM_START")) {
-            const int64_t margin = (g.taps + 2 + g.M - 1) / g.M + 1;  // periods
-            int64_t k = stages[sid].lo / g.L - margin;
-            k = k / 16 * 16;  // (16 M inputs: the first staged input stays 128-byte aligned)
-            if (k > 0 && k * g.L >= 4096) {
-                rbase = k * g.L;
-                stages[sid].base = rbase;
-                stages[sid].in_base = k * g.M;
-                need -= rbase;
-                g.n_out = need;
-            }
-        }
-        // newest input of the last needed output
-        int64_t jl;
-        if (g.arbitrary && g.exact) {
-            int64_t Nn = (need - 1) * ((int64_t)g.nphi * g.M);
-            jl = (g.c0i + Nn / g.L) / g.nphi;
-        } else if (g.arbitrary) {
-            double q = g.c0 + (double)(need - 1) * g.delta;
-            jl = (int64_t)std::floor(q) / g.nphi;
-        } else jl = (g.c0i + (need - 1) * g.M) / g.L;
-        int64_t nin = jl + 2;  // +1 slack: host rounding of q may differ from the device's at ties
-        if (!isinf_(C.len)) nin = std::min(nin, C.len.n - stages[sid].in_base);
-        g.n_in = nin;
-        in_frames = nin;
-        // polyphase tables: pfb[p][k] = h[p + nphi*k]; dpfb from dh = [diff(h);0]
-        const double* h = (const double*)nd.p0;
-        stages[sid].pfb_host.assign((size_t)g.nphi * g.taps, 0.0);
-        stages[sid].dpfb_host.assign((size_t)g.nphi * g.taps, 0.0);
-        for (int p = 0; p < g.nphi; ++p)
-            for (int k = 0; k < g.taps; ++k) {
-                int64_t hi = p + (int64_t)g.nphi * k;
-                stages[sid].pfb_host[(size_t)p * g.taps + k] = hi < hlen ? h[hi] : 0.0;
-                stages[sid].dpfb_host[(size_t)p * g.taps + k] = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
-            }
-        stages[sid].pfb_buf = raw_buf(stages[sid].pfb_host.size() * 8);
-        stages[sid].dpfb_buf = raw_buf(stages[sid].dpfb_host.size() * 8);
-        g.in_dtype = g.out_dtype = N.dtype;
-        stages[sid].rg = g;
-        // reference positions: DSP.jl's phase accumulator (SIGOPS_RS_EXACT=1 keeps the closed form)
-        std::vector<uint8_t> wrap;
-        if (g.arbitrary && !std::getenv("SIGOPS_RS_EXACT")) {
-            // (period positions can only be baked into the tap tables of the periodic / row-tiled
-            //  kernels: short outputs go to the thread-per-output kernel and list every deviation)
-            replay_phase_accumulator(g, (const double*)nd.p0, hlen, rbase + need, g.exact && need >= 2048, wrap, stages[sid].fix_host, rbase);
-        }
-        // position of period output r as the tap tables see it: the closed form, or the
-        // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
-        auto wrap_at = [&](int64_t r) { return !wrap.empty() && wrap[r % g.L]; };
-        // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
-        if ((!g.arbitrary || g.exact) && need >= 2048) {
-            constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
-            const int64_t Lb = g.L, Mb = g.M;
-            // (8 channels per tile when possible: per-frame gains of a fused source are evaluated
-            //  once per tile row-group, and 8 rows give every loader wave exactly one chunk)
-            int ct = 1;
-            for (int c : {8, 4, 2})
-                if (N.nch % c == 0) {
-                    ct = c;
-                    break;
-                }
-            if (const char* ev = std::getenv("SIGOPS_RS_CT")) {  // tuning knob
-                int c = std::atoi(ev);
-                if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
-            }
-            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in kernels.hip)
-            // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
-            // (b) a tile (pt super-periods) covers ~1100 input frames per channel
-            int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
-            int64_t t = std::max<int64_t>(1, 1100 / (pt * Mb));
-            t = std::max<int64_t>(tmin, t / tmin * tmin);
-            if (Lb * t > 4096) t = std::max<int64_t>(1, 4096 / Lb);
-            const int64_t Ls = Lb * t, Ms = Mb * t;
-            auto pos = [&](int64_t r, int64_t& j, int& p, double& alpha) {
-                int64_t qi;
-                if (g.arbitrary) {
-                    int64_t Nn = r * ((int64_t)g.nphi * Mb);
-                    qi = g.c0i + Nn / Lb;
-                    alpha = (double)(Nn % Lb) / (double)Lb;
-                } else {
-                    qi = g.c0i + r * Mb;
-                    alpha = 0.0;
-                }
-                if (wrap_at(r)) {
-                    qi -= 1;
-                    alpha = 1.0;
-                }
-                j = qi / g.nphi;
-                p = (int)(qi % g.nphi);
-            };
-            std::vector<int64_t> jr(Ls);
-            std::vector<int> pr(Ls);
-            std::vector<double> ar(Ls);
-            for (int64_t r = 0; r < Ls; ++r) pos(r, jr[r], pr[r], ar[r]);
-            const int ngroups = (int)((Ls + RM - 1) / RM);
-            int64_t maxspan = 0;
-            std::vector<int> jend(ngroups);
-            for (int gi = 0; gi < ngroups; ++gi) {
-                int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
-                jend[gi] = (int)jr[r1 - 1];
-                maxspan = std::max(maxspan, jr[r1 - 1] - jr[r0]);
-            }
-            // k-steps: smallest instantiated KS covering taps + span (tab is zero padded);
-            // compute waves: one (or two) groups each, taps stay in registers
-            int kw = 0, ncomp = 0, gper = 0;
-            {
-                const int ksneed = (g.taps + (int)maxspan + 3) / 4;
-                gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
-                if (const char* ev = std::getenv("SIGOPS_RS_GPER")) gper = std::atoi(ev);  // tuning knob
-                const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14};
-                if (gper == 1) {
-                    for (int k : ks1)
-                        if (!kw && k >= ksneed) kw = 4 * k;
-                } else if (gper == 2 || gper == 3) {
-                    for (int k : ks2)
-                        if (!kw && k >= ksneed) kw = 4 * k;
-                }
-                if (kw) ncomp = (ngroups + gper - 1) / gper;
-            }
-            // first staged input, rounded down to a multiple of 4 frames so that tiles start
-            // on a 16-byte boundary (vector loads) whenever pt*M is a multiple of 4
-            int jlo = jend[0] - (kw - 1);
-            jlo -= ((jlo % 4) + 4) % 4;
-            // (+0..3 frames: a row's staged span is a whole number of MFMA k-steps, which the fused IIR
-            //  state pass walks from jlo to the end)
-            const int64_t tile_len = (pt - 1) * Ms + (jend[ngroups - 1] - jlo + 1 + 3) / 4 * 4;
-            // tiles are kept in LDS in the sample type and staged from the 128-byte aligned frame
-            // below their first input (+15 / +31 frames); rows are 16-byte multiples for LDS-DMA
-            const int64_t esz_t = (int64_t)dsize(N.dtype), vfr = 16 / esz_t;
-            int64_t pitch = (tile_len + (128 / esz_t - 1) + 2 * vfr + vfr - 1) / vfr * vfr;
-            size_t lds_bytes = ((size_t)ct * pitch * esz_t + 7) / 8 * 8;
-            size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
-            // LDS ring: as many tile slots as fit in 160 KiB, at most 4 (2 tiles in flight
-            // beyond the one being retired), at least 2 (plain double buffering)
-            int nslots = (int)std::min<size_t>(4, (160 * 1024 - sizeof(RsCtl) - 64) / std::max<size_t>(1, lds_bytes));
-            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) nslots = std::min(nslots, std::max(2, std::atoi(ev)));
-            if (kw && nslots >= 2 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
-                const double* h = (const double*)nd.p0;
-                std::vector<double> tab((size_t)ngroups * kw * RM, 0.0);
-                for (int gi = 0; gi < ngroups; ++gi) {
-                    int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
-                    for (int64_t r = r0; r < r1; ++r)
-                        for (int kk = 0; kk < kw; ++kk) {
-                            int64_t rel = jend[gi] - (kw - 1) + kk;  // input index of slot kk
-                            int64_t age = jr[r] - rel;               // tap age for output r
-                            if (age < 0 || age >= g.taps) continue;
-                            int64_t hi = pr[r] + (int64_t)g.nphi * age;
-                            double hv = hi < hlen ? h[hi] : 0.0;
-                            double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
-                            tab[((size_t)gi * kw + kk) * RM + (r - r0)] = hv + ar[r] * dv;
-                        }
-                }
-                RsPeriodic rp{};
-                rp.n_in = g.n_in;
-                rp.n_out = need;
-                rp.L = Ls;
-                rp.M = Ms;
-                rp.nperiods = (need + Ls - 1) / Ls;
-                rp.pt = pt;
-                rp.ct = ct;
-                rp.ngroups = ngroups;
-                rp.kw = kw;
-                rp.tile_len = (int)tile_len;
-                rp.lds_pitch = (int)pitch;
-                rp.jlo = jlo;
-                rp.nch = N.nch;
-                rp.ptshift = pt == 32 ? 5 : pt == 16 ? 4 : pt == 8 ? 3 : 2;
-                rp.nslots = nslots;
-                // persistent kernel: 16 waves per workgroup (8 when a wave owns three groups and
-                // needs the registers), one workgroup per CU; the waves that do not compute load
-                rp.nwaves = gper >= 3 ? 8 : 16;
-                rp.ncompute = ncomp;
-                rp.grid = 256;
-                if (const char* ev = std::getenv("SIGOPS_RS_NWAVES")) rp.nwaves = std::max(2, std::min(16, std::atoi(ev)));
-                if (const char* ev = std::getenv("SIGOPS_RS_GRID")) rp.grid = std::max(1, std::atoi(ev));
-                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rp.pad = std::atoi(ev);  // ablation knob
-                if (const char* ev = std::getenv("SIGOPS_RS_NLOAD")) rp.nload = std::max(1, std::atoi(ev));  // tuning knob
-                stages[sid].periodic = true;
-                stages[sid].per_j = jr;
-                stages[sid].per_p = pr;
-                stages[sid].per_a = ar;
-                stages[sid].jend_last = jend[ngroups - 1];
-                stages[sid].rp = rp;
-                stages[sid].tab_host = tab;
-                stages[sid].jend_host = jend;
-                stages[sid].tab_buf = raw_buf(tab.size() * 8);
-                stages[sid].jend_buf = raw_buf(jend.size() * 4);
-            }
-        }
-        // ---- row-tiled variant: rational rates the MFMA kernel's geometry does not cover -------
-        if (!stages[sid].periodic && (!g.arbitrary || g.exact) && need >= 2048 && g.m0 == 0 &&
-            !std::getenv("SIGOPS_RS_NOROWS")) {
-            const int64_t Lb = g.L, Mb = g.M;
-            const double* h = (const double*)nd.p0;
-            std::vector<int> jr(Lb);
-            std::vector<double> ctab((size_t)Lb * g.taps, 0.0);
-            int64_t jmin = INT64_MAX, jmax = INT64_MIN;
-            for (int64_t r = 0; r < Lb; ++r) {
-                int64_t qi;
-                double alpha = 0.0;
-                if (g.arbitrary) {
-                    const int64_t Nn = r * ((int64_t)g.nphi * Mb);
-                    qi = g.c0i + Nn / Lb;
-                    alpha = (double)(Nn % Lb) / (double)Lb;
-                } else qi = g.c0i + r * Mb;
-                if (wrap_at(r)) {
-                    qi -= 1;
-                    alpha = 1.0;
-                }
-                const int64_t j = qi / g.nphi;
-                const int p = (int)(qi % g.nphi);
-                jr[r] = (int)j;
-                jmin = std::min(jmin, j - (g.taps - 1));
-                jmax = std::max(jmax, j);
-                for (int k = 0; k < g.taps; ++k) {
-                    const int64_t hi = p + (int64_t)g.nphi * k;
-                    const double hv = hi < hlen ? h[hi] : 0.0;
-                    const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
-                    ctab[(size_t)r * g.taps + k] = hv + alpha * dv;
-                }
-            }
-            const int64_t esz_t = (int64_t)dsize(N.dtype);
-            int best_ct = 0, best_pb = 0;
-            int64_t best_pitch = 0, best_len = 0;
-            size_t rr_max_lds = 150 * 1024;
-            if (const char* ev = std::getenv("SIGOPS_RR_MAXLDS")) rr_max_lds = (size_t)std::atoi(ev) * 1024;  // tuning knob
-            // tile choice: the largest row count whose tile fits; two workgroups per CU (tiles of at
-            // most 75 KB) overlap one's staging with the other's MFMAs (config 5: 0.77 -> 0.66 ms),
-            // so that budget is tried first as long as it still gives an MFMA-able tile (>= 16 rows)
-            const bool lds_forced = std::getenv("SIGOPS_RR_MAXLDS") != nullptr;
-            for (int pass = 0; pass < 2 && !best_ct; ++pass) {
-                const size_t budget = lds_forced ? rr_max_lds : (pass == 0 ? (size_t)75 * 1024 : rr_max_lds);
-                for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
-                    if (pass == 0 && !lds_forced && rows < 16) break;
-                    for (int ct : {8, 4, 2, 1}) {
-                        if (best_ct || N.nch % ct || rows % ct) continue;
-                        const int pb = rows / ct;
-                        const int64_t tile_len = (pb - 1) * Mb + (jmax - jmin + 1);
-                        const int64_t pitch = (tile_len + 3) | 1;  // odd: rows fall on different LDS banks
-                        if ((size_t)ct * pitch * esz_t <= budget && tile_len < (1 << 30)) {
-                            best_ct = ct;
-                            best_pb = pb;
-                            best_pitch = pitch;
-                            best_len = tile_len;
-                            rr_max_lds = budget;
-                        }
-                    }
-                }
-            }
-            // MFMA path: groups of 16 phases against a [kw x 16] tap block (rows = 16, 32 or 64)
-            std::vector<double> mtab;
-            std::vector<int> mjend;
-            int kw_m = 0, ngroups_m = 0;
-            if (best_ct && (best_ct * best_pb) % 16 == 0 && !std::getenv("SIGOPS_RS_NOROWS_MFMA")) {
-                const int64_t jmin_scalar = jmin;
-                ngroups_m = (int)((Lb + 15) / 16);
-                mjend.resize(ngroups_m);
-                int64_t maxspan = 0;
-                for (int gi = 0; gi < ngroups_m; ++gi) {
-                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
-                    mjend[gi] = jr[r1 - 1];
-                    maxspan = std::max<int64_t>(maxspan, jr[r1 - 1] - jr[r0]);
-                }
-                kw_m = (int)((g.taps + maxspan + 3) / 4 * 4);
-                mtab.assign((size_t)ngroups_m * kw_m * 16, 0.0);
-                for (int gi = 0; gi < ngroups_m; ++gi) {
-                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
-                    jmin = std::min<int64_t>(jmin, mjend[gi] - (kw_m - 1));
-                    for (int64_t r = r0; r < r1; ++r)
-                        for (int kk = 0; kk < kw_m; ++kk) {
-                            const int64_t age = jr[r] - (mjend[gi] - (kw_m - 1) + kk);
-                            if (age >= 0 && age < g.taps)
-                                mtab[((size_t)gi * kw_m + kk) * 16 + (r - r0)] = ctab[(size_t)r * g.taps + age];
-                        }
-                }
-                // the window of a group may start a few frames before the oldest tap: re-size the tile
-                const int64_t tile_len = (best_pb - 1) * Mb + (jmax - jmin + 1);
-                const int64_t pitch = (tile_len + 3) | 1;
-                if ((size_t)best_ct * pitch * esz_t <= rr_max_lds + 2048) {
-                    best_len = tile_len;
-                    best_pitch = pitch;
-                } else {
-                    kw_m = 0;
-                    mtab.clear();
-                    jmin = jmin_scalar;
-                }
-            }
-            if (best_ct && jmin > INT32_MIN && jmax < INT32_MAX && (size_t)Lb * g.taps * 8 <= (64u << 20)) {
-                RsRows rr{};
-                rr.kw = kw_m;
-                rr.ngroups = ngroups_m;
-                rr.pbshift = 0;
-                while ((1 << rr.pbshift) < best_pb) ++rr.pbshift;  // pb is a power of two
-                stages[sid].mtab_host = mtab;
-                stages[sid].mjend_host = mjend;
-                stages[sid].mtab_buf = raw_buf(std::max<size_t>(mtab.size(), 1) * 8);
-                stages[sid].mjend_buf = raw_buf(std::max<size_t>(mjend.size(), 1) * 4);
-                rr.n_in = g.n_in;
-                rr.n_out = need;
-                rr.L = Lb;
-                rr.M = Mb;
-                rr.nperiods = (need + Lb - 1) / Lb;
-                rr.taps = g.taps;
-                rr.ct = best_ct;
-                rr.pb = best_pb;
-                rr.jlo = (int)jmin;
-                rr.tile_len = (int)best_len;
-                rr.pitch = (int)best_pitch;
-                rr.nch = N.nch;
-                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rr.debug = std::atoi(ev);  // ablation knob
-                rr.threads = 1024;
-                if (const char* ev = std::getenv("SIGOPS_RR_THREADS")) rr.threads = std::max(64, std::min(1024, std::atoi(ev) / 64 * 64));  // tuning knob
-                stages[sid].rows = true;
-                stages[sid].rr = rr;
-                stages[sid].tab_host = ctab;
-                stages[sid].jend_host = jr;
-                stages[sid].tab_buf = raw_buf(ctab.size() * 8);
-                stages[sid].jend_buf = raw_buf(jr.size() * 4);
-            }
-        }
-        // ---- tiled variant for everything else that is long enough (no period to exploit) ----
-        if (!stages[sid].periodic && !stages[sid].rows && need >= 2048 && !std::getenv("SIGOPS_RS_NOTILED")) {
-            const int64_t esz_t = (int64_t)dsize(N.dtype);
-            const size_t tabs = (size_t)2 * g.taps * g.nphi * 8;
-            int ct = 1;
-            for (int c : {8, 4, 2})
-                if (N.nch % c == 0) {
-                    ct = c;
-                    break;
-                }
-            // inputs per output (fine-grid step / Nphi), for sizing the tile
-            const double step = g.arbitrary ? g.delta / g.nphi : (double)g.M / (double)g.L;
-            for (; ct >= 1; ct >>= 1) {
-                if (N.nch % ct) continue;
-                // two workgroups per CU when the tables allow it (their staging and arithmetic overlap)
-                size_t budget = tabs <= (size_t)24 * 1024 ? (size_t)78 * 1024 - tabs : (size_t)150 * 1024 - std::min<size_t>(tabs, 150 * 1024);
-                int64_t tile_in = (int64_t)(budget / ((size_t)ct * esz_t));
-                int64_t tile_out = (int64_t)std::floor((double)(tile_in - g.taps - 4) / step);
-                tile_out = std::min<int64_t>(tile_out, 4096);
-                if (tabs <= (size_t)100 * 1024 && tile_out >= 128) {
-                    RsTiled rt{};
-                    rt.g = g;
-                    rt.ct = ct;
-                    rt.tile_out = (int32_t)tile_out;
-                    rt.tile_in = (int32_t)tile_in;
-                    rt.pitch = (int32_t)(tile_in | 1);
-                    rt.ntiles = (need + tile_out - 1) / tile_out;
-                    stages[sid].tiled = true;
-                    stages[sid].rt = rt;
-                    stages[sid].pfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
-                    stages[sid].dpfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
-                    for (int p = 0; p < g.nphi; ++p)
-                        for (int k = 0; k < g.taps; ++k) {
-                            stages[sid].pfbt_host[(size_t)k * g.nphi + p] = stages[sid].pfb_host[(size_t)p * g.taps + k];
-                            stages[sid].dpfbt_host[(size_t)k * g.nphi + p] = stages[sid].dpfb_host[(size_t)p * g.taps + k];
-                        }
-                    stages[sid].pfbt_buf = raw_buf(stages[sid].pfbt_host.size() * 8);
-                    stages[sid].dpfbt_buf = raw_buf(stages[sid].dpfbt_host.size() * 8);
-                    break;
-                }
-            }
-        }
-        if (!wrap.empty() && !stages[sid].periodic && !stages[sid].rows)  // no tap table took the baked positions
-            replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, stages[sid].base + need, false, wrap, stages[sid].fix_host,
-                                     stages[sid].base);
-        if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
-    } else if (stages[sid].kind == ST_SOS) {
-        if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
-        int nsec = nd.i0;
-        const double* sos = (const double*)nd.p0;
-        std::vector<SosCoefs> groups;
-        for (int s0 = 0; s0 < nsec; s0 += kMaxSec) {
-            SosCoefs cf{};
-            cf.nsec = std::min(kMaxSec, nsec - s0);
-            for (int f = 0; f < cf.nsec; ++f) {
-                const double* b = sos + 6 * (s0 + f);
-                if (b[3] != 1.0) fail(SO_ERR_INVALID, "SOS rows must be normalised (a0 == 1)");
-                cf.b0[f] = b[0];
-                cf.b1[f] = b[1];
-                cf.b2[f] = b[2];
-                cf.a1[f] = b[4];
-                cf.a2[f] = b[5];
-            }
-            cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
-            groups.push_back(cf);
-        }
-        // ---- warm start: frames before the first one anybody reads (After, a later window of a
-        //      stream) matter only through the filter state, and what a state contributes has decayed
-        //      below 2^-70 after W frames: start from zero state W frames early instead of at frame 0.
-        //      (The reference filters the skipped frames, src/cutting.jl:160-173; same values.) ----
-        if (stages[sid].lo < need && stages[sid].lo >= 8192 && !std::getenv("SIGOPS_NO_WARM_START")) {
-            int64_t Wd = 0;
-            for (auto& cf : groups) {
-                const int D = 2 * cf.nsec;
-                Mat P = sos_state_matrix(cf);
-                int64_t w = 1;
-                while (maxabs(P) >= std::ldexp(1.0, -70) && w < ((int64_t)1 << 40)) {
-                    P = matmul(P, P, D);
-                    w <<= 1;
-                }
-                Wd += w;  // (groups are cascaded: decay times add up at worst)
-            }
-            if (stages[sid].lo - Wd >= 4096) {
-                const int64_t base = (stages[sid].lo - Wd) / 64 * 64;
-                stages[sid].base = stages[sid].in_base = base;
-                need -= base;  // local frames from here on
-                in_frames = need;
-            }
-        }
-        // ---- single pass (one read, one write): wave tiles in time order with a look-back over the
-        //      zero-state end states of the kt previous tiles (see k_sos_onepass) ----
-        // Opt-in (SIGOPS_SOS_ONEPASS=1): its HBM traffic is the algorithmic minimum, but on MI355X it
-        // is bound by fp64 vector work and dependent chains at two waves per SIMD (28.8 M x 8, order
-        // 10: 1.7 ms against 1.13 ms for the three-pass form, which streams at ~5 TB/s) -- DESIGN.md.
-        if (need >= 4096 && std::getenv("SIGOPS_SOS_ONEPASS") && !std::getenv("SIGOPS_SOS_3PASS")) {
-            SosOne o{};
-            const int tf = 64 * kSosLc;
-            o.n = need;
-            o.nch = N.nch;
-            o.ntiles = (int)((need + tf - 1) / tf);
-            o.nlev = 6;
-            o.bt = std::min(4, N.nch);
-            if (const char* ev = std::getenv("SIGOPS_SOS_BT")) o.bt = std::max(1, std::min(4, std::atoi(ev)));  // tuning knob
-            if (const char* ev = std::getenv("SIGOPS_SOS_DEBUG")) o.debug = std::atoi(ev);  // ablation knob
-            const double tol1 = std::ldexp(1.0, -70);
-            bool ok = (int64_t)o.ntiles * o.nch < (1 << 30);
-            // look-back depth: first kt with ||(A^tf)^kt|| < 2^-70, the same for every group
-            int kt = 1;
-            std::vector<Mat> As, Ts;
-            for (auto& cf : groups) {
-                const int D = 2 * cf.nsec;
-                Mat A = sos_state_matrix(cf);
-                Mat T = matpow(A, tf, D);
-                As.push_back(A);
-                Ts.push_back(T);
-                Mat cur = T;
-                int k = 1;
-                while (ok && !(maxabs(cur) < tol1)) {
-                    cur = matmul(cur, T, D);
-                    if (++k > 64) ok = false;  // a pole this close to the unit circle: three-pass form
-                }
-                kt = std::max(kt, k);
-            }
-            if (ok) {
-                o.kt = kt;
-                std::vector<double> tabs;
-                std::vector<size_t> offs;
-                for (size_t gi = 0; gi < groups.size(); ++gi) {
-                    const int D = 2 * groups[gi].nsec;
-                    offs.push_back(tabs.size());
-                    Mat P = matpow(As[gi], kSosLc, D);  // M = A^lc, then M^2, M^4, ...
-                    for (int lev = 0; lev < o.nlev; ++lev) {
-                        tabs.insert(tabs.end(), P.begin(), P.end());
-                        P = matmul(P, P, D);
-                    }
-                    Mat cur = ident(D);
-                    for (int j = 0; j < kt; ++j) {  // (A^tf)^j
-                        tabs.insert(tabs.end(), cur.begin(), cur.end());
-                        cur = matmul(cur, Ts[gi], D);
-                    }
-                }
-                stages[sid].onepass = true;
-                stages[sid].so1 = o;
-                stages[sid].one_tabs_host = tabs;
-                stages[sid].one_tabs_off = offs;
-                stages[sid].one_tabs_buf = raw_buf(tabs.size() * 8);
-                stages[sid].one_sync_buf = raw_buf(64);
-                stages[sid].one_vpub_buf = raw_buf((size_t)o.ntiles * o.nch * 2 * kMaxSec * 8);
-            }
-        }
-        // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
-        SosGeom g{};
-        g.n = need;
-        g.nch = N.nch;
-        const double tol = std::ldexp(1.0, -70);
-        // chunk length: as many sequences (chunks x channels) as the machine can hold; every
-        // pass is latency-bound per sequence, so shorter chunks win down to L = 64 (sweep on
-        // config 2: L=64 0.205 ms, 128 0.208, 256 0.293, 512 0.531)
-        int64_t target = 262144 / std::max(1, N.nch);
-        int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
-        int64_t L = (need + nchunks - 1) / nchunks;
-        if (const char* ev = std::getenv("SIGOPS_SOS_CHUNK")) {  // tuning knob
-            L = std::max(32, std::atoi(ev));
-        }
-        L = (L + 31) / 32 * 32;
-        std::vector<std::vector<double>> mp;
-        int K = 1;
-        int64_t W = BIG;
-        for (;;) {
-            nchunks = (need + L - 1) / L;
-            mp.clear();
-            K = 1;
-            W = 0;
-            if (nchunks <= 1) break;
-            bool ok = true;
-            for (auto& cf : groups) {
-                int D = 2 * cf.nsec;
-                Mat A = sos_state_matrix(cf);
-                // W: first power of two with ||A^W|| < tol (pass-1 warm-up length)
-                Mat P = A;
-                int64_t w = 1;
-                while (maxabs(P) >= tol && w < ((int64_t)1 << 40)) {
-                    P = matmul(P, P, D);
-                    w <<= 1;
-                }
-                W = std::max(W, w);
-                Mat M = matpow(A, L, D);
-                std::vector<double> pw_((size_t)D * D, 0.0);
-                Mat cur = ident(D);
-                std::vector<double> all;
-                int k = 0;
-                for (;;) {
-                    all.insert(all.end(), cur.begin(), cur.end());
-                    ++k;
-                    cur = matmul(cur, M, D);
-                    if (maxabs(cur) < tol) break;
-                    if (k >= 64) {
-                        ok = false;
-                        break;
-                    }
-                }
-                if (!ok) break;
-                K = std::max(K, k);
-                mp.push_back(all);
-            }
-            if (ok) break;
-            L *= 2;  // slower-decaying filter: fewer, longer chunks
-        }
-        // every group is scanned with the same K (pad shorter tables with zeros)
-        for (size_t gi = 0; gi < mp.size(); ++gi) {
-            int D = 2 * groups[gi].nsec;
-            mp[gi].resize((size_t)K * D * D, 0.0);
-        }
-        g.chunk = L;
-        g.nchunks = (int)nchunks;
-        g.warm = W;
-        g.kterms = K;
-        g.in_dtype = g.out_dtype = N.dtype;
-        stages[sid].groups = groups;
-        stages[sid].mpow_host = mp;
-        if (nchunks > 1 && !stages[sid].onepass) {
-            size_t msz = 0;
-            for (auto& v : mp) msz = std::max(msz, v.size());
-            stages[sid].mpow_buf = raw_buf(msz * 8 * groups.size());
-            stages[sid].v_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
-            stages[sid].s0_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
-        }
-        stages[sid].sg = g;
-    } else {  // ST_NORM
-        in_frames = need;
-        int64_t total = need * N.nch;
-        int nparts = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + kBlock * 8 - 1) / (kBlock * 8)));
-        stages[sid].nparts = nparts;
-        stages[sid].partial_buf = raw_buf((size_t)nparts * 8);
-    }
-
-    // lower the child over the frames this stage consumes
-    std::vector<Piece> ps;
-    const int64_t in_base = stages[sid].in_base;
-    if (in_base > 0) check_frames(child, in_base);
-    if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, in_base, 1, 0});
-    if (stages[sid].kind == ST_SOS && in_frames > 0) {  // the reference filters whole blocks of its input
-        const int64_t bs = std::max(1, N.nd.i1);
-        check_frames(child, (in_base + in_frames + bs - 1) / bs * bs);
-    }
-    if (stages[sid].out_buf >= 0) bufs[stages[sid].out_buf].frame0 = stages[sid].base;
-    Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
-    S.in_frames = in_frames;
-    int in_dtype = S.kind == ST_NORM ? N.dtype : C.dtype;
-    if (S.kind != ST_NORM && float_of(C.dtype) != N.dtype) fail(SO_ERR_INVALID, "filter dtype mismatch");
-    if (S.kind != ST_NORM && C.dtype == SO_I64) in_dtype = SO_F64;
-    // direct source: a single plain contiguous load of the right type
-    bool direct = false;
-    if (S.kind != ST_NORM && ps.size() == 1) {
-        const Expr& e = exprs[ps[0].e];
-        if (e.op == E_LOAD && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 && e.leaf.sc == 1 &&
-            e.leaf.fstride == 1 && e.leaf.dtype == in_dtype && e.leaf.df >= 0 && e.leaf.dc >= 0 &&
-            (e.leaf.cstride > 0 || e.leaf.cstride == -1 || N.nch == 1)) {
-            direct = true;
-            S.in_array_node = e.array_node;
-            S.in_buf = e.leaf.buf;  // stage buffer or -1 (array)
-            S.in_offset = e.leaf.df;
-            S.in_pitch = e.leaf.cstride;  // -1: pitch of in_buf
-            if (e.array_node >= 0) {
-                // element offset = df*fstride + dc*cstride
-                S.in_offset = e.leaf.df + e.leaf.dc * std::max<int64_t>(e.leaf.cstride, 0);
-            } else {
-                if (e.leaf.dc != 0) direct = false;
-            }
-        }
-    }
-    if (S.kind == ST_NORM) {
-        // materialise the child straight into `vals` (the stage's own output buffer)
-        S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
-        S.in_buf = S.out_buf;
-        S.in_pitch = -1;
-    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype))) {
-        // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
-        // staging, no intermediate in HBM
-        S.in_buf = -1;
-        S.in_array_node = -1;
-        if (S.carriers[0].pad_) {
-            // GA instantiation: Float32 tiles (pitch in floats, 16-byte rows, 128-byte aligned start),
-            // three gain arrays, no in-place work for the loaders
-            RsPeriodic& rp = S.rp;
-            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
-            rp.ga = 1;
-            rp.lds_pitch = (int)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
-            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 4;
-            rp.fslots = 1;
-            rp.fpitch = (rp.tile_len + 16 + 1) & ~1;
-            const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
-            const bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases &&
-                             (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
-            rp.ftwo = two ? 1 : 0;
-            const size_t fbytes = (size_t)3 * rp.fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
-            rp.nslots = (int)std::min<size_t>(4, (avail - fbytes) / tile_bytes);
-            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) rp.nslots = std::min(rp.nslots, std::max(2, std::atoi(ev)));
-            rp.nload = 0;
-        } else {
-        // gain ring: two LDS arrays [slots][tile frames] next to the tile ring, if at least two
-        // tile slots still fit (see k_resample_periodic)
-            RsPeriodic& rp = S.rp;
-            const int ns0 = S.carriers[0].nslots;
-            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * dsize(N.dtype);
-            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
-            const int fpitch = (rp.tile_len + 16 + 1) & ~1;
-            // slot 0 (the only one) a sine generator: the kernel's two-level evaluation (TWO)
-            bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases && ns0 == 1 && N.dtype == SO_F64 &&
-                       (rp.ngroups + rp.ncompute - 1) / rp.ncompute == 1;
-            if (two) {
-                const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
-                two = (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
-            }
-            const size_t fbytes = (size_t)2 * ns0 * fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
-            if (ns0 > 0 && S.carriers[0].nsteps > 0 && !std::getenv("SIGOPS_RS_NOFRING") &&
-                fbytes + 2 * tile_bytes <= avail) {
-                rp.fslots = ns0;
-                rp.fpitch = fpitch;
-                rp.ftwo = two ? 1 : 0;
-                // the in-place multiply is vector-ALU work next to the MFMAs: keep it off the
-                // SIMDs that carry the most compute waves (10 compute waves: loaders 10,11,14,15
-                // on SIMD 2/3 copy and modify, 12,13 only keep the barrier count; measured
-                // 0.790 -> 0.780 ms on config 3, three alternating runs each)
-                if (!std::getenv("SIGOPS_RS_NLOAD")) {
-                    auto ncomp_on = [&](int w) { return (rp.ncompute - (w & 3) + 3) >> 2; };
-                    int minc = 1 << 30, cnt = 0;
-                    for (int w = rp.ncompute; w < rp.nwaves; ++w) minc = std::min(minc, ncomp_on(w));
-                    for (int w = rp.ncompute; w < rp.nwaves; ++w) cnt += ncomp_on(w) == minc;
-                    if (cnt >= 2) rp.nload = cnt;
-                }
-                rp.nslots = (int)std::min<size_t>(rp.nslots, (avail - fbytes) / tile_bytes);
-            }
-        }
-    } else if (!direct) {
-        S.in_buf = new_buf(in_frames, N.nch, in_dtype);
-        S.in_pitch = -1;
-        S.in_array_node = -1;
-        S.in_offset = 0;
-        S.pw_step = emit_pointwise(ps, S.in_buf, in_dtype);
-    }
-    if (S.kind == ST_RESAMPLE && S.periodic && S.carriers.empty()) {
-        // plain source (direct array / stage buffer / materialised input): one 0-step carrier
-        DCarrier c{};
-        c.a = 0;
-        c.b = in_frames;
-        c.dtype = in_dtype;
-        c.array_node = S.in_array_node;
-        c.buf = S.in_array_node >= 0 ? -1 : S.in_buf;
-        c.df = S.in_offset;
-        c.cstride = S.in_array_node >= 0 ? (N.nch == 1 ? 0 : S.in_pitch) : -1;  // -1: buffer pitch
-        S.carriers.push_back(c);
-    }
-    if (!S.carriers.empty()) {
-        S.car_buf = raw_buf(S.carriers.size() * sizeof(DCarrier));
-        S.ctl_buf = raw_buf(sizeof(RsCtl));
-    }
-}
-
-// e == carrier load combined with channel-independent operands by a short chain of ops?
-bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
-    const Expr e = exprs[ei];
-    auto add_step = [&](int op, int mono_expr, bool flip, bool round32) {
-        if (C.nsteps >= 4) return false;
-        int slot = 0;
-        if (mono_expr >= 0) {
-            auto it = std::find(monos.begin(), monos.end(), mono_expr);
-            if (it == monos.end()) {
-                if ((int)monos.size() >= kMaxFrameSlots) return false;
-                monos.push_back(mono_expr);
-                slot = (int)monos.size() - 1;
-            } else slot = (int)(it - monos.begin());
-        }
-        C.op[C.nsteps] = op;
-        C.arg[C.nsteps] = slot | (flip ? 0x100 : 0) | (round32 ? 0x200 : 0);
-        C.nsteps++;
-        return true;
-    };
-    if (e.mono && C.nsteps == 0 && C.base == nullptr && C.buf == -1 && C.array_node == -1) {
-        // channel-independent piece (generator, constant, padding value): no array at all,
-        // the value is a per-frame slot
-        C.dtype = e.dtype == SO_F32 ? SO_F32 : SO_F64;
-        return add_step(OP_LOADF, ei, false, false);
-    }
-    switch (e.op) {
-    case E_LOAD: {
-        const DLeaf& L = e.leaf;
-        if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1) return false;
-        if (e.array_node < 0 && L.dc != 0) return false;
-        if (L.dc < 0) return false;
-        C.dtype = L.dtype;
-        C.array_node = e.array_node;
-        C.buf = e.array_node >= 0 ? -1 : L.buf;
-        C.cstride = L.cstride;  // -1: buffer pitch (patched in finalize)
-        C.df = L.df + (e.array_node >= 0 ? L.dc * L.cstride : 0);
-        if (e.array_node >= 0) count_array(e.array_node);
-        return true;
-    }
-    case E_RETYPE: return match_carrier(e.a, C, monos);
-    case E_ROUND32: return match_carrier(e.a, C, monos) && add_step(OP_ROUND32, -1, false, true);
-    case E_NEG: return match_carrier(e.a, C, monos) && add_step(OP_NEG, -1, false, false);
-    case E_ADD:
-    case E_SUB:
-    case E_MUL:
-    case E_DIV: {
-        int oc = e.op == E_ADD ? OP_ADD : e.op == E_SUB ? OP_SUB : e.op == E_MUL ? OP_MUL : OP_DIV;
-        bool r32 = e.dtype == SO_F32;
-        if (exprs[e.b].mono) {
-            DCarrier c2 = C;
-            std::vector<int> m2 = monos;
-            if (match_carrier(e.a, c2, m2)) {
-                C = c2;
-                monos = m2;
-                return add_step(oc, e.b, false, r32);
-            }
-        }
-        if (exprs[e.a].mono) {
-            DCarrier c2 = C;
-            std::vector<int> m2 = monos;
-            if (match_carrier(e.b, c2, m2)) {
-                C = c2;
-                monos = m2;
-                return add_step(oc, e.a, true, r32);
-            }
-        }
-        return false;
-    }
-    default: return false;
-    }
-}
-
-bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out, bool allow_ga) {
-    std::vector<Piece> ps = ps_in;
-    for (auto& p : ps)
-        if (p.r.c0 != 0 || p.r.c1 != nch) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 1); return false; }
-    std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
-    std::vector<DCarrier> cs;
-    std::vector<std::vector<int>> monos_all;
-    for (auto& p : ps) {
-        DCarrier c{};
-        c.buf = -1;
-        c.array_node = -1;
-        std::vector<int> monos;
-        if (!match_carrier(p.e, c, monos)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 2); return false; }
-        c.a = p.r.a;
-        c.b = p.r.b;
-        cs.push_back(c);
-        monos_all.push_back(monos);
-    }
-    // compile the per-frame programs; everything must fit the kernel-argument control block
-    if (cs.size() > (size_t)kCtlCar) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 3); return false; }
-    // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
-    // staging path, ~6x slower than a K1 pass + the LDS-DMA fast path), so steps on fp32 data
-    // are materialised by K1 instead of fused
-    // ... except the commonest case, ONE Float32 array times ONE Float64 per-frame gain (`Amplify(x32,
-    // Signal(sin))`, a Float64 product): the kernel's GA instantiation keeps the raw Float32 tile
-    // and multiplies at the A operand (allow_ga: the caller has checked geometry and LDS budget)
-    // Further carriers may only be generated pieces whose value is that same gain (the tail of an
-    // infinite `Amplify`: the array's padding `one` times the gain): staged as 1.0f.
-    bool ga = false;
-    if (allow_ga && !cs.empty() && cs[0].dtype == SO_F32 && cs[0].nsteps == 1 && cs[0].op[0] == OP_MUL &&
-        !(cs[0].arg[0] & 0x200) && (cs[0].array_node >= 0 || cs[0].buf >= 0) && monos_all[0].size() == 1) {
-        ga = true;
-        for (size_t i = 1; i < cs.size(); ++i)
-            if (cs[i].base != nullptr || cs[i].array_node >= 0 || cs[i].buf >= 0 || cs[i].nsteps != 1 ||
-                cs[i].op[0] != OP_LOADF || (cs[i].arg[0] & 0x300) || monos_all[i].size() != 1 || cs[i].dtype != SO_F64)
-                ga = false;
-    }
-    if (std::getenv("SIGOPS_DEBUG_PLAN") && !cs.empty())
-        std::fprintf(stderr, "[sigops] carriers=%zu allow_ga=%d dtype=%d nsteps=%d op=%d arg=%#x monos=%zu -> ga=%d\n", cs.size(), (int)allow_ga,
-                     cs[0].dtype, cs[0].nsteps, cs[0].op[0], cs[0].arg[0], monos_all[0].size(), (int)ga);
-    for (auto& c : cs)
-        if (!ga && c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
-    std::vector<std::vector<DOp>> fcodes(cs.size());
-    size_t nops_total = 0;
-    std::set<int> leafset;
-    const size_t leaves_before = leaves.size();
-    for (size_t i = 0; i < cs.size(); ++i) {
-        DCarrier& c = cs[i];
-        std::vector<DOp>& fcode = fcodes[i];
-        int dmax = 2;
-        c.nslots = (int)monos_all[i].size();
-        for (size_t k = 0; k < monos_all[i].size(); ++k) {
-            // closed form for the kernel's hot loop: a single leaf, optionally rounded to
-            // Float32; compound per-frame expressions are not fused
-            int ei = monos_all[i][k], r32 = 0;
-            for (;;) {
-                const Expr& ex = exprs[ei];
-                if (ex.op == E_RETYPE) ei = ex.a;
-                else if (ex.op == E_ROUND32) { r32 = 0x100; ei = ex.a; }
-                // `0 + g` / `g + 0`: the zero-padded tail of a `Mix` operand under a generator (the
-                // sum differs from g only in the sign of a zero)
-                else if (ex.op == E_ADD && is_const(ex.a, 0.0)) ei = ex.b;
-                else if ((ex.op == E_ADD || ex.op == E_SUB) && is_const(ex.b, 0.0)) ei = ex.a;  // (g - 0 == g exactly)
-                else break;
-            }
-            const int eop = exprs[ei].op;
-            const int kind = eop == E_CONST ? OP_CONST : eop == E_SCALAR ? OP_SCALAR : eop == E_FUNC ? OP_FUNC : eop == E_RAMP ? OP_RAMP : -1;
-            if (kind < 0) {
-                leaves.resize(leaves_before);
-                leaf_array_node.resize(leaves_before);
-                { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 5); return false; }
-            }
-            c.slot_leaf[k] = add_leaf(exprs[ei]);
-            c.slot_kind[k] = kind | r32;
-            leafset.insert(c.slot_leaf[k]);
-            std::map<int, int> none;
-            gen(monos_all[i][k], fcode, none, fcode, false);
-            fcode.push_back(DOp{OP_STOREF, (int)k});
-            dmax = std::max(dmax, depth(monos_all[i][k]));
-        }
-        c.depth = dmax;
-        nops_total += fcode.size();
-        for (auto& o : fcode)
-            if (o.code <= OP_RAMP) leafset.insert(o.arg);
-        // the in-kernel frame interpreter is the 2-deep one
-        if (dmax > 2 || nops_total > (size_t)kCtlOps || leafset.size() > (size_t)kCtlLeaves) {
-            leaves.resize(leaves_before);  // drop what gen() appended
-            leaf_array_node.resize(leaves_before);
-            { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 6); return false; }
-        }
-    }
-    // commit
-    for (size_t i = 0; i < cs.size(); ++i) {
-        cs[i].frame_pc = (int)ops.size();
-        cs[i].frame_len = (int)fcodes[i].size();
-        ops.insert(ops.end(), fcodes[i].begin(), fcodes[i].end());
-    }
-    if (ga) {
-        // the generated pieces must be exactly carrier 0's gain
-        auto same_leaf = [&](int a, int b) {
-            const DLeaf &x = leaves[a], &y = leaves[b];
-            return x.base == y.base && x.fstride == y.fstride && x.cstride == y.cstride && x.df == y.df && x.dc == y.dc &&
-                   x.modn == y.modn && x.v0 == y.v0 && x.v1 == y.v1 && x.v2 == y.v2 && x.sf == y.sf && x.sc == y.sc &&
-                   x.dtype == y.dtype && x.mode == y.mode && x.flag == y.flag && x.buf == y.buf;
-        };
-        for (size_t i = 1; i < cs.size(); ++i)
-            if (cs[i].slot_kind[0] != cs[0].slot_kind[0] || !same_leaf(cs[i].slot_leaf[0], cs[0].slot_leaf[0])) ga = false;
-        if (!ga) {
-            leaves.resize(leaves_before);
-            leaf_array_node.resize(leaves_before);
-            ops.resize(ops.size() - nops_total);
-            if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 7);
-            return false;
-        }
-        // the staging code copies the raw samples (1.0f for the generated pieces); the multiply
-        // happens at the A operand
-        for (size_t i = 0; i < cs.size(); ++i) {
-            cs[i].pad_ = i == 0 ? 1 : 2;
-            cs[i].nsteps = 0;
-            cs[i].dtype = SO_F32;
-        }
-    }
-    out = cs;
-    return true;
-}
-
-// Kernel-argument control block of a periodic resampler stage: carriers with their frame
-// programs and leaves re-indexed into the block (built per execute from the patched tables).
-RsCtl Plan::make_ctl(const Stage& S) const {
-    RsCtl ctl{};
-    std::map<int, int> leafmap;
-    for (const DCarrier& c0 : S.carriers) {
-        if (ctl.ncar >= kCtlCar) throw PlanError{SO_ERR_RUNTIME, "internal: carrier control block overflow"};
-        DCarrier c = c0;
-        c.frame_pc = ctl.nops;
-        for (int k = 0; k < c0.frame_len; ++k) {
-            DOp o = ops[c0.frame_pc + k];
-            if (o.code <= OP_RAMP) {
-                auto it = leafmap.find(o.arg);
-                if (it == leafmap.end()) {
-                    if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
-                    ctl.leaves[ctl.nleaves] = leaves[o.arg];
-                    it = leafmap.emplace(o.arg, ctl.nleaves++).first;
-                }
-                o.arg = it->second;
-            }
-            if (ctl.nops >= kCtlOps) throw PlanError{SO_ERR_RUNTIME, "internal: op control block overflow"};
-            ctl.ops[ctl.nops++] = o;
-        }
-        for (int k = 0; k < c0.nslots; ++k) {
-            auto it = leafmap.find(c0.slot_leaf[k]);
-            if (it == leafmap.end()) {
-                if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
-                ctl.leaves[ctl.nleaves] = leaves[c0.slot_leaf[k]];
-                it = leafmap.emplace(c0.slot_leaf[k], ctl.nleaves++).first;
-            }
-            c.slot_leaf[k] = it->second;
-        }
-        ctl.car[ctl.ncar++] = c;
-    }
-    return ctl;
-}
 
 // ---------------------------------------------------------------------------
 // Window aliasing.  When the root of the tree is `Append` / `Ramp` / `Amplify(number)` ... over
@@ -2750,421 +1008,6 @@ void Plan::try_window_alias(std::vector<Piece>& rootp) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Resampler -> IIR: fold the IIR's state pass into the resampler.
-// The three-pass K2 reads its input twice; when that input is the output of a periodic resampler
-// stage and nothing else reads it, the first read can go: a chunk's zero-state end state is linear
-// in the resampler's INPUT,  v = sum_r G[r] y[r],  y[r] = sum_k Tap_r[k] x[j_r - k]
-//                              = sum_i W[i] x[i],   W = G . Tap   (D x window of one period),
-// and the resampler has that window staged in LDS anyway.  Two of its loader waves become state
-// waves (k_resample_periodic): one MFMA pass over the window per period row, written as
-// vper[ch][period][16]; K2 then combines pt periods into a chunk (k_sos_combine), scans and runs
-// its output pass.  (Reference: the same filt! at src/filters.jl:252-255; values differ from the
-// sequential recurrence by rounding of the start states, ~1e-16 relative.)
-// Opt-in (SIGOPS_FUSE_STATE=1).  Measured on the north-star pipeline (28.8 M x 8, order 10): K2 1.13 ->
-// 0.90 ms and its traffic 5.57 -> ~4.1 GB, but the two state waves' 48 MFMAs per tile are the
-// resampler's critical path (tile period 9 800 -> 12 200 cycles): K3 0.72 -> 0.90 ms.  Break-even
-// (1.79 vs 1.76-1.83 ms), so the three-pass form stays the default.
-void Plan::fuse_state_passes() {
-    if (!std::getenv("SIGOPS_FUSE_STATE")) return;
-    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
-        Stage& S2 = stages[i2];
-        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.base > 0 || S2.groups.size() != 1 || S2.in_buf < 0 ||
-            S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.nchunks <= 1)
-            continue;
-        int i3 = -1;
-        for (size_t j = 0; j < stages.size(); ++j)
-            if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
-        if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
-        Stage& S3 = stages[i3];
-        const RsPeriodic& rp0 = S3.rp;
-        if (!S3.periodic || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
-            rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
-            (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
-            continue;  // (the instantiations with state waves: kernels.hip launch_rp_st)
-        // nothing else may read the intermediate
-        bool other = false;
-        for (auto& L : leaves)
-            if (L.buf == S2.in_buf) other = true;
-        for (size_t j = 0; j < stages.size(); ++j) {
-            if (j != i2 && stages[j].in_buf == S2.in_buf) other = true;
-            for (auto& c : stages[j].carriers)
-                if (c.buf == S2.in_buf) other = true;
-        }
-        if (other) continue;
-        const SosCoefs& cf = S2.groups[0];
-        const int D = 2 * cf.nsec;
-        const int64_t Ls = rp0.L, L = (int64_t)rp0.pt * Ls;
-        if (L < 32 || L > 16384) continue;
-        // chunk geometry with L = pt periods
-        const double tol = std::ldexp(1.0, -70);
-        Mat A = sos_state_matrix(cf);
-        Mat M = matpow(A, L, D), cur = ident(D);
-        std::vector<double> mp;
-        int K = 0;
-        bool ok = true;
-        for (;;) {
-            mp.insert(mp.end(), cur.begin(), cur.end());
-            ++K;
-            cur = matmul(cur, M, D);
-            if (maxabs(cur) < tol) break;
-            if (K >= 64) {
-                ok = false;
-                break;
-            }
-        }
-        const int64_t nchunks = (S2.need + L - 1) / L;
-        if (!ok || nchunks <= 1) continue;
-        // W = G . Tap over the staged span [jlo, jlo + 4*ksw) of a period row
-        const so_node_t& nd3 = nodes[S3.node].nd;
-        const double* h = (const double*)nd3.p0;
-        const int hlen = nd3.i2, nphi = S3.rg.nphi, taps = S3.rg.taps;
-        const int jlo = rp0.jlo;
-        const int ksw = 2 * 24;  // two state waves x kSwK k-steps (kernels.hip)
-        if ((S3.jend_last - jlo + 1 + 3) / 4 > ksw) continue;  // the staged span of a row must fit
-        // (window slots beyond the span have zero taps; there a row's window runs into the next
-        //  row's staged frames or the slot's slack -- finite values: the kernel zeroes its LDS ring
-        //  once at start when it has state waves, and 0 x finite is 0)
-        std::vector<double> G((size_t)Ls * D, 0.0);  // G[r] = A^(Ls-1-r) B1
-        {
-            std::vector<double> st_(D, 0.0);
-            double y = 1.0;
-            for (int f = 0; f < cf.nsec; ++f) {  // one DF2T step with x = 1 from zero state
-                const double xi = y;
-                y = st_[2 * f] + cf.b0[f] * xi;
-                st_[2 * f] = st_[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
-                st_[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
-            }
-            for (int64_t r = Ls - 1; r >= 0; --r) {
-                for (int d = 0; d < D; ++d) G[(size_t)r * D + d] = st_[d];
-                std::vector<double> nx(D, 0.0);
-                for (int a = 0; a < D; ++a)
-                    for (int b = 0; b < D; ++b) nx[a] += A[(size_t)a * D + b] * st_[b];
-                st_ = nx;
-            }
-        }
-        std::vector<double> wt((size_t)4 * ksw * 16, 0.0);
-        for (int64_t r = 0; r < Ls; ++r)
-            for (int age = 0; age < taps; ++age) {
-                const int64_t rel = S3.per_j[r] - age - jlo;  // input slot of this tap
-                if (rel < 0 || rel >= 4 * ksw) {
-                    ok = false;  // (cannot happen: the span covers every tap of the period)
-                    continue;
-                }
-                const int64_t hi = S3.per_p[r] + (int64_t)nphi * age;
-                const double hv = hi < hlen ? h[hi] : 0.0;
-                const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
-                const double tv = hv + S3.per_a[r] * dv;
-                for (int d = 0; d < D; ++d) wt[(size_t)rel * 16 + d] += G[(size_t)r * D + d] * tv;
-            }
-        if (!ok) continue;
-        // LDS: the taps ([4*ksw][10] doubles) go behind the gain ring; keep at least three tile slots
-        {
-            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
-            const size_t tile_bytes = (size_t)rp0.ct * rp0.lds_pitch * 8;
-            const size_t fbytes = (size_t)2 * rp0.fslots * rp0.fpitch * 8 + (rp0.ftwo ? kRsTwoDoubles * 8 : 0);
-            const size_t wbytes = (size_t)4 * ksw * 10 * 8;
-            if (fbytes + wbytes + 3 * tile_bytes > avail) continue;
-            S3.rp.nslots = (int)std::min<size_t>(S3.rp.nslots, (avail - fbytes - wbytes) / tile_bytes);
-        }
-        // commit: resampler side
-        S3.rp.nstate = 2;
-        S3.rp.ksw = ksw;
-        S3.wtab_host = wt;
-        S3.wtab_buf = raw_buf(wt.size() * 8);
-        S3.vper_buf = raw_buf((size_t)2 * nodes[S3.node].nch * rp0.nperiods * 16 * 8);
-        // ... and the IIR side
-        S2.pre_stage = i3;
-        S2.qmat_host = matpow(A, Ls, D);
-        S2.qmat_buf = raw_buf(S2.qmat_host.size() * 8);
-        S2.sg.chunk = L;
-        S2.sg.nchunks = (int)nchunks;
-        S2.sg.kterms = K;
-        S2.mpow_host.assign(1, mp);
-        if (S2.mpow_buf >= 0) bufs[S2.mpow_buf].bytes = std::max<size_t>(8, mp.size() * 8);
-        else S2.mpow_buf = raw_buf(mp.size() * 8);
-        const size_t vb = (size_t)nchunks * S2.sg.nch * 2 * kMaxSec * 8;
-        if (S2.v_buf >= 0) bufs[S2.v_buf].bytes = vb;
-        else S2.v_buf = raw_buf(vb);
-        if (S2.s0_buf >= 0) bufs[S2.s0_buf].bytes = vb;
-        else S2.s0_buf = raw_buf(vb);
-        if (std::getenv("SIGOPS_DEBUG_PLAN"))
-            std::fprintf(stderr, "[sigops] IIR state pass fused into the resampler: chunk %lld frames, K=%d, window %d inputs\n",
-                         (long long)L, K, 4 * ksw);
-    }
-}
-
-// ---------------------------------------------------------------------------
-void Plan::finalize() {
-    // size stage output buffers now that every need is known
-    for (size_t si = 0; si < stages.size(); ++si) {
-        Stage& S = stages[si];
-        if (S.out_buf >= 0 && ((int)si == alias_stage || S.win_off >= 0)) {
-            bufs[S.out_buf].external = true;  // the kernel writes the final output directly
-            bufs[S.out_buf].bytes = 0;
-            continue;
-        }
-        if (S.out_buf >= 0) {
-            Buf& b = bufs[S.out_buf];
-            b.frames = S.need - S.base;
-            b.pitch = std::max<int64_t>(64, (S.need - S.base + 63) / 64 * 64);
-            b.bytes = (size_t)b.pitch * (size_t)std::max(b.nch, 1) * dsize(b.dtype);
-        }
-    }
-    // host array leaves get a device copy (the leaves of pointwise programs, the carriers of fused
-    // resampler sources and the direct sources of stages go through the same validation)
-    auto stage_host_array = [&](int an) {
-        if (an < 0) return;
-        const so_node_t& nd = nodes[an].nd;
-        if (nd.i0 || array_buf.count(an)) return;  // device-resident, or already staged
-        if (nd.s0 < 0 || nd.s1 < 0) fail(SO_ERR_UNSUPPORTED, "negative strides on host arrays are not supported");
-        const size_t extent = nd.l0 > 0 ? (size_t)((nd.l0 - 1) * nd.s0 + (int64_t)(nd.nch - 1) * nd.s1 + 1) : 0;
-        const int b = raw_buf(extent * dsize(nd.dtype));
-        array_buf[an] = b;
-        host_leaves.push_back(HostLeaf{an, nd.p0, extent * dsize(nd.dtype), b});
-    };
-    for (size_t i = 0; i < leaves.size(); ++i) stage_host_array(leaf_array_node[i]);
-    for (auto& S : stages) {
-        for (auto& c : S.carriers) stage_host_array(c.array_node);
-        stage_host_array(S.in_array_node);
-    }
-    if (!out.is_device && out.nframes > 0) {
-        Buf b;
-        b.frames = out.nframes;
-        b.pitch = out.nframes;
-        b.nch = out.nch;
-        b.dtype = out.dtype;
-        b.bytes = (size_t)out.nframes * out.nch * dsize(out.dtype);
-        bufs.push_back(b);
-        out_stage_buf = (int)bufs.size() - 1;
-    }
-    // allocate
-    int64_t scratch = 0;
-    for (auto& b : bufs) {
-        if (b.external) continue;
-        HIPCHECK(hipMalloc(&b.d, std::max<size_t>(b.bytes, 64)));
-        scratch += (int64_t)b.bytes;
-    }
-    stats.scratch_bytes = scratch;
-    if (out_alias_buf >= 0 && !out.is_device) {
-        bufs[out_alias_buf].d = bufs[out_stage_buf].d;
-        bufs[out_alias_buf].pitch = bufs[out_stage_buf].pitch;
-    }
-    // patch leaves
-    for (size_t i = 0; i < leaves.size(); ++i) {
-        DLeaf& L = leaves[i];
-        int an = leaf_array_node[i];
-        if (an >= 0) {
-            L.base = nodes[an].nd.i0 ? array_ptr[an] : bufs[array_buf[an]].d;
-        } else if (L.buf >= 0) {
-            L.base = bufs[L.buf].d;
-            if (L.cstride == -1) L.cstride = bufs[L.buf].pitch;
-            L.df -= bufs[L.buf].frame0;  // (stage buffers that start at a later frame: once, here)
-        }
-    }
-    for (auto& S : stages) {
-        if (S.carriers.empty()) continue;
-        for (auto& c : S.carriers) {
-            if (c.array_node >= 0) {
-                const so_node_t& nd = nodes[c.array_node].nd;
-                if (!nd.i0 && !array_buf.count(c.array_node)) fail(SO_ERR_RUNTIME, "internal: carrier array without device copy");
-                c.base = nd.i0 ? array_ptr[c.array_node] : bufs[array_buf[c.array_node]].d;
-            } else if (c.buf >= 0) {
-                c.base = bufs[c.buf].d;
-                if (c.cstride == -1) c.cstride = bufs[c.buf].pitch;
-                c.df -= bufs[c.buf].frame0;
-            } else {
-                c.base = nullptr;  // generated piece
-                c.cstride = 0;
-            }
-            const int64_t V = 16 / (int64_t)dsize(c.dtype);
-            c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
-        }
-        if (std::getenv("SIGOPS_DEBUG_PLAN"))
-            for (auto& c : S.carriers)
-                std::fprintf(stderr, "[sigops] carrier [%lld,%lld) base=%p cstride=%lld df=%lld dtype=%d vec_ok=%d nsteps=%d frame_len=%d depth=%d\n",
-                             (long long)c.a, (long long)c.b, c.base, (long long)c.cstride, (long long)c.df, c.dtype, c.vec_ok, c.nsteps, c.frame_len, c.depth);
-        HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
-        {
-            const RsCtl ctl = make_ctl(S);
-            HIPCHECK(hipMemcpy(bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice));
-        }
-    }
-    // upload tables
-    if (!pieces.empty()) {
-        HIPCHECK(hipMalloc(&d_pieces, pieces.size() * sizeof(DPiece)));
-        HIPCHECK(hipMemcpy(d_pieces, pieces.data(), pieces.size() * sizeof(DPiece), hipMemcpyHostToDevice));
-    }
-    if (!ops.empty()) {
-        HIPCHECK(hipMalloc(&d_ops, ops.size() * sizeof(DOp)));
-        HIPCHECK(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DOp), hipMemcpyHostToDevice));
-    }
-    if (!leaves.empty()) {
-        HIPCHECK(hipMalloc(&d_leaves, leaves.size() * sizeof(DLeaf)));
-        HIPCHECK(hipMemcpy(d_leaves, leaves.data(), leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice));
-    }
-    for (auto& S : stages) {
-        if (S.need <= 0) continue;
-        if (S.kind == ST_SOS && S.qmat_buf >= 0)
-            HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
-        if (S.kind == ST_SOS && S.onepass)
-            HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
-        if (S.kind == ST_RESAMPLE) {
-            HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
-            HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
-            if (S.wtab_buf >= 0)
-                HIPCHECK(hipMemcpy(bufs[S.wtab_buf].d, S.wtab_host.data(), S.wtab_host.size() * 8, hipMemcpyHostToDevice));
-            if (S.tiled) {
-                HIPCHECK(hipMemcpy(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8, hipMemcpyHostToDevice));
-            }
-            if (S.fix_buf >= 0)
-                HIPCHECK(hipMemcpy(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix), hipMemcpyHostToDevice));
-            if (S.periodic || S.rows) {
-                HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
-            }
-            if (S.rows && !S.mtab_host.empty()) {
-                HIPCHECK(hipMemcpy(bufs[S.mtab_buf].d, S.mtab_host.data(), S.mtab_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4, hipMemcpyHostToDevice));
-            }
-        } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
-            size_t msz = 0;
-            for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
-            for (size_t gi = 0; gi < S.mpow_host.size(); ++gi)
-                HIPCHECK(hipMemcpy((char*)bufs[S.mpow_buf].d + gi * msz * 8, S.mpow_host[gi].data(),
-                                   S.mpow_host[gi].size() * 8, hipMemcpyHostToDevice));
-        }
-    }
-    // step list: stages in increasing node order (children first), then the root program
-    std::vector<int> order;
-    for (size_t i = 0; i < stages.size(); ++i)
-        if (stages[i].need > 0) order.push_back((int)i);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
-    for (int sid : order) {
-        Stage& S = stages[sid];
-        if (S.pw_step >= 0) push_pw_step(S.pw_step);
-        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
-        Step st{1, sid, nm, 0};
-        int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
-        if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
-        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
-        else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
-        steps.push_back(st);
-    }
-    stats.n_stages = (int)order.size() + 1;
-    stats.algorithmic_bytes = algo_bytes + out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
-    int64_t h2d = 0;
-    for (auto& h : host_leaves) h2d += (int64_t)h.bytes;
-    stats.h2d_bytes = h2d;
-    stats.d2h_bytes = out.is_device ? 0 : out.nframes * (int64_t)out.nch * (int64_t)dsize(out.dtype);
-}
-
-// Dependencies between steps from the plan buffers they read and write, then a lane (stream)
-// per step: a step continues on the lane of its latest dependency, a step without
-// dependencies opens the next lane (round robin over at most 8).
-void Plan::plan_lanes() {
-    const int n = (int)steps.size();
-    step_deps.assign(n, {});
-    step_lane.assign(n, 0);
-    step_signals.assign(n, 0);
-    nlanes = 1;
-    if (n < 3 || std::getenv("SIGOPS_SINGLE_STREAM")) return;
-    const int kFinal = -2;
-    std::vector<std::set<int>> rd(n), wr(n);
-    auto piece_reads = [&](const PwStep& w, std::set<int>& out) {
-        for (int pi = w.piece0; pi < w.piece0 + w.npieces; ++pi) {
-            const DPiece& P = pieces[pi];
-            for (int k = 0; k < P.frame_len + P.samp_len; ++k) {
-                const DOp& o = k < P.frame_len ? ops[P.frame_pc + k] : ops[P.samp_pc + (k - P.frame_len)];
-                if ((o.code == OP_LOAD || o.code == OP_SCALAR) && o.arg >= 0 && o.arg < (int)leaves.size() &&
-                    leaves[o.arg].buf >= 0)
-                    out.insert(leaves[o.arg].buf);
-            }
-        }
-    };
-    for (int i = 0; i < n; ++i) {
-        const Step& st = steps[i];
-        if (st.kind == 0) {
-            const PwStep& w = pw[st.idx];
-            piece_reads(w, rd[i]);
-            wr[i].insert(w.out_buf >= 0 ? w.out_buf : kFinal);
-            // the root launch runs in place on the windows stages have written, and so does any
-            // sub-expression of it that was materialised into a temporary first
-            if (w.out_buf < 0 || (out_alias_buf >= 0 && rd[i].count(out_alias_buf)))
-                for (size_t k = 0; k < stages.size(); ++k)
-                    if (stages[k].win_off >= 0) rd[i].insert(-100 - (int)k);
-        } else {
-            const Stage& S = stages[st.idx];
-            if (S.in_buf >= 0) rd[i].insert(S.in_buf);
-            for (auto& c : S.carriers) {
-                if (c.buf >= 0) rd[i].insert(c.buf);
-                for (int k = 0; k < c.frame_len; ++k) {
-                    const DOp& o = ops[c.frame_pc + k];
-                    if ((o.code == OP_LOAD || o.code == OP_SCALAR) && leaves[o.arg].buf >= 0) rd[i].insert(leaves[o.arg].buf);
-                }
-                for (int k = 0; k < c.nslots; ++k)
-                    if (leaves[c.slot_leaf[k]].buf >= 0) rd[i].insert(leaves[c.slot_leaf[k]].buf);
-            }
-            if (S.win_off >= 0) wr[i].insert(-100 - st.idx);  // its own window of the result
-            else wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
-            if (S.kind == ST_NORM) {  // reads its own output buffer, writes the rms scalar
-                rd[i].insert(S.out_buf);
-                if (S.rms_buf >= 0) wr[i].insert(S.rms_buf);
-            }
-        }
-    }
-    auto meets = [](const std::set<int>& a, const std::set<int>& b) {
-        for (int x : a)
-            if (b.count(x)) return true;
-        return false;
-    };
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < i; ++j)
-            if (meets(rd[i], wr[j]) || meets(wr[i], wr[j]) || meets(wr[i], rd[j])) step_deps[i].push_back(j);
-    int next = 0;
-    const int kMaxLanes = 8;
-    for (int i = 0; i < n; ++i) {
-        if (step_deps[i].empty()) {
-            step_lane[i] = next % kMaxLanes;
-            ++next;
-        } else step_lane[i] = step_lane[step_deps[i].back()];
-    }
-    step_lane[n - 1] = 0;  // the last step (it produces the result) runs on the caller's stream
-    for (int i = 0; i < n; ++i) nlanes = std::max(nlanes, step_lane[i] + 1);
-    for (int i = 0; i < n; ++i)
-        for (int j : step_deps[i])
-            if (step_lane[j] != step_lane[i]) step_signals[j] = 1;
-    if (nlanes == 1) return;
-    lane_streams.assign(nlanes, nullptr);
-    for (int l = 1; l < nlanes; ++l) HIPCHECK(hipStreamCreateWithFlags(&lane_streams[l], hipStreamNonBlocking));
-    step_done.assign(n, nullptr);
-    for (int i = 0; i < n; ++i) HIPCHECK(hipEventCreateWithFlags(&step_done[i], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-}
-
-void Plan::release() {
-    for (auto st_ : lane_streams)
-        if (st_) (void)hipStreamDestroy(st_);
-    lane_streams.clear();
-    for (auto e : step_done)
-        if (e) (void)hipEventDestroy(e);
-    step_done.clear();
-    if (ev_start) (void)hipEventDestroy(ev_start);
-    ev_start = nullptr;
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    graph_exec = nullptr;
-    if (capture_stream) (void)hipStreamDestroy(capture_stream);
-    capture_stream = nullptr;
-    for (auto& b : bufs)
-        if (b.d && !b.external) (void)hipFree(b.d);
-    bufs.clear();
-    if (d_pieces) (void)hipFree(d_pieces);
-    if (d_ops) (void)hipFree(d_ops);
-    if (d_leaves) (void)hipFree(d_leaves);
-    for (auto e : events) (void)hipEventDestroy(e);
-    events.clear();
-}
 
 // ===========================================================================
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
@@ -3264,444 +1107,5 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
     return P.release();
 }
 
-static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& err) {
-    try {
-        HIPCHECK(hipSetDevice(P->device));
-        hipStream_t st = (hipStream_t)stream;
-        if (P->out.nframes > 0 && !outp) fail(SO_ERR_INVALID, "so_plan_execute: null output");
-        for (auto& h : P->host_leaves)
-            if (h.bytes) HIPCHECK(hipMemcpyAsync(P->bufs[h.buf].d, P->array_ptr[h.node], h.bytes, hipMemcpyHostToDevice, st));
-        if (P->profiling && P->events.size() < 2 * P->steps.size()) {
-            while (P->events.size() < 2 * P->steps.size()) {
-                hipEvent_t e;
-                HIPCHECK(hipEventCreate(&e));
-                P->events.push_back(e);
-            }
-        }
-        if (P->out_alias_buf >= 0 && P->out.is_device && P->bufs[P->out_alias_buf].d != outp) {
-            // in-place root pieces read the result: point their leaves at this execute's buffer
-            P->bufs[P->out_alias_buf].d = outp;
-            for (auto& L : P->leaves)
-                if (L.buf == P->out_alias_buf) L.base = outp;
-            if (P->d_leaves)
-                HIPCHECK(hipMemcpyAsync(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice, st));
-        }
-        int launches = 0;
-        // (profiling times the steps one after the other on the caller's stream)
-        const bool lanes = P->nlanes > 1 && !P->profiling && !std::getenv("SIGOPS_RS_TRACE");
-        hipStream_t const main_st = st;
-        std::vector<char> lane_started(P->nlanes, 0);
-        if (lanes) HIPCHECK(hipEventRecord(P->ev_start, main_st));  // after the H2D copies / earlier work
-        for (size_t si = 0; si < P->steps.size(); ++si) {
-            Step& s = P->steps[si];
-            const int ln = lanes ? P->step_lane[si] : 0;
-            hipStream_t st = ln == 0 ? main_st : P->lane_streams[ln];  // shadows the caller's stream
-            if (lanes) {
-                if (ln != 0 && !lane_started[ln]) {
-                    HIPCHECK(hipStreamWaitEvent(st, P->ev_start, 0));
-                    lane_started[ln] = 1;
-                }
-                for (int d : P->step_deps[si])
-                    if (P->step_lane[d] != ln) HIPCHECK(hipStreamWaitEvent(st, P->step_done[d], 0));
-            }
-            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si], st));
-            if (s.kind == 0) {
-                PwStep& w = P->pw[s.idx];
-                OutView ov{};
-                if (w.nblocks <= 0) {
-                    // empty rectangle (zero-frame sink): nothing to launch
-                } else if (w.out_buf >= 0) {
-                    Buf& b = P->bufs[w.out_buf];
-                    ov.base = b.d;
-                    ov.fstride = 1;
-                    ov.cstride = b.pitch;
-                    ov.dtype = b.dtype;
-                } else if (P->out.is_device) {
-                    ov.base = outp;
-                    ov.fstride = P->out.frame_stride;
-                    ov.cstride = P->out.chan_stride;
-                    ov.dtype = P->out.dtype;
-                } else {
-                    Buf& b = P->bufs[P->out_stage_buf];
-                    ov.base = b.d;
-                    ov.fstride = P->interleaved_host ? P->out.nch : 1;
-                    ov.cstride = P->interleaved_host ? 1 : b.pitch;
-                    ov.dtype = b.dtype;
-                }
-                if (w.nblocks > 0) {
-                    static const int il_scalar = std::getenv("SIGOPS_K1_ILSCALAR") ? 1 : 0;  // ablation knob
-                    ov.pad = il_scalar;
-                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st, w.chain,
-                                     w.il || (ov.fstride > 1 && ov.cstride == 1));
-                    s.launches = 1;
-                    launches++;
-                }
-            } else {
-                Stage& S = P->stages[s.idx];
-                Node& N = P->nodes[S.node];
-                size_t esz = dsize(N.dtype);
-                const char* inp;
-                int64_t in_pitch;
-                if (S.kind == ST_RESAMPLE && S.periodic) {
-                    inp = nullptr;  // the periodic kernel reads through its carriers
-                    in_pitch = 0;
-                } else if (S.in_array_node >= 0) {
-                    const so_node_t& nd = P->nodes[S.in_array_node].nd;
-                    const char* base = nd.i0 ? (const char*)P->array_ptr[S.in_array_node]
-                                             : (const char*)P->bufs[P->array_buf[S.in_array_node]].d;
-                    inp = base + (size_t)S.in_offset * esz;
-                    in_pitch = N.nch == 1 ? 0 : S.in_pitch;
-                } else {
-                    Buf& b = P->bufs[S.in_buf];
-                    inp = (const char*)b.d + (size_t)(S.in_offset - b.frame0) * esz;
-                    in_pitch = b.pitch;
-                }
-                Buf ob = P->bufs[S.out_buf];
-                if (s.idx == P->alias_stage) {  // write the sink buffer directly
-                    if (P->out.is_device) {
-                        ob.d = outp;
-                        ob.pitch = N.nch == 1 ? std::max<int64_t>(P->out.chan_stride, S.need) : P->out.chan_stride;
-                    } else {
-                        ob.d = P->bufs[P->out_stage_buf].d;
-                        ob.pitch = P->bufs[P->out_stage_buf].pitch;
-                    }
-                    // (local frame alias_skip is the result's frame 0; earlier frames are not stored)
-                    ob.d = (char*)ob.d - (size_t)P->alias_skip * esz;
-                } else if (S.win_off >= 0) {  // ... or its window of it
-                    const Buf& ab = P->bufs[P->out_alias_buf];
-                    ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
-                    ob.pitch = ab.pitch;
-                }
-                if (S.kind == ST_SOS) {
-                    SosGeom g = S.sg;
-                    g.in_pitch = in_pitch;
-                    g.out_pitch = ob.pitch;
-                    g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
-                    size_t msz = 0;
-                    for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
-                    int nl = 0;
-                    for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {
-                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
-                        SosOne o = S.so1;
-                        o.in_pitch = gi == 0 ? in_pitch : ob.pitch;
-                        o.out_pitch = ob.pitch;
-                        const int64_t al = 16 / (int64_t)esz;
-                        o.vec_in = ((uintptr_t)x % 16 == 0) && (o.in_pitch % al == 0);
-                        o.vec_out = ((uintptr_t)ob.d % 16 == 0) && (o.out_pitch % al == 0);
-                        Buf& sb = P->bufs[S.one_sync_buf];
-                        Buf& vb = P->bufs[S.one_vpub_buf];
-                        HIPCHECK(hipMemsetAsync(sb.d, 0, sb.bytes, st));     // ticket counter
-                        HIPCHECK(hipMemsetAsync(vb.d, 0xff, vb.bytes, st));  // "not published yet"
-                        launch_sos_onepass(x, ob.d, o, S.groups[gi], (const double*)P->bufs[S.one_tabs_buf].d + S.one_tabs_off[gi],
-                                           (int*)sb.d, (double*)P->bufs[S.one_vpub_buf].d, N.dtype, st);
-                        nl += 1;
-                    }
-                    if (S.pre_stage >= 0) {
-                        const Stage& S3 = P->stages[S.pre_stage];
-                        nl += launch_sos_prestate(inp, ob.d, (const double*)P->bufs[S3.vper_buf].d, S3.rp.nperiods,
-                                                  (const double*)P->bufs[S.qmat_buf].d, S3.rp.pt, (double*)P->bufs[S.v_buf].d,
-                                                  (double*)P->bufs[S.s0_buf].d, (const double*)P->bufs[S.mpow_buf].d, g,
-                                                  S.groups[0], st);
-                    }
-                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0; ++gi) {
-                        const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
-                        SosGeom gg = g;
-                        if (gi > 0) gg.in_pitch = ob.pitch;
-                        // frames beyond the child's end are zero (Pad(x.signal,zero), reference
-                        // src/filters.jl:240): the materialised input covers them; a direct
-                        // source always has in_frames == need
-                        nl += launch_sos(x, ob.d, S.v_buf >= 0 ? (double*)P->bufs[S.v_buf].d : nullptr,
-                                         S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr,
-                                         S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
-                                         gg, S.groups[gi], st);
-                    }
-                    s.launches = nl;
-                    launches += nl;
-                } else if (S.kind == ST_RESAMPLE) {
-                    RsGeom g = S.rg;
-                    g.in_pitch = in_pitch;
-                    g.out_pitch = ob.pitch;
-                    if (S.periodic) {
-                        RsPeriodic rp = S.rp;
-                        rp.in_pitch = in_pitch;
-                        rp.out_pitch = ob.pitch;
-                        rp.out_f32 = s.idx == P->alias_stage && P->alias_narrow;
-                        if (rp.nstate > 0) {
-                            rp.wtab = (const double*)P->bufs[S.wtab_buf].d;
-                            rp.vper = (double*)P->bufs[S.vper_buf].d;
-                        }
-                        const int64_t al = 16 / (int64_t)esz;
-                        rp.vec_ok = ((uintptr_t)ob.d % 16 == 0) && (ob.pitch % al == 0) && (rp.L % al == 0);
-                        static long long* d_trace = nullptr;  // SIGOPS_RS_TRACE tuning aid
-                        const bool tracing = std::getenv("SIGOPS_RS_TRACE") != nullptr;
-                        const size_t trace_n = (size_t)16 * kRsTraceIters * kRsTraceStamps;
-                        if (tracing) {
-                            if (!d_trace) HIPCHECK(hipMalloc(&d_trace, trace_n * 8));
-                            HIPCHECK(hipMemsetAsync(d_trace, 0, trace_n * 8, st));
-                            rp.trace = d_trace;
-                        }
-                        if (launch_resample_periodic(ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                                     (const int*)P->bufs[S.jend_buf].d, rp, N.dtype,
-                                                     RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves},
-                                                     st) != 0)
-                            fail(SO_ERR_RUNTIME, "internal: no periodic resampler instantiation for this geometry");
-                        if (tracing) {
-                            std::vector<long long> tr(trace_n);
-                            HIPCHECK(hipStreamSynchronize(st));
-                            HIPCHECK(hipMemcpy(tr.data(), d_trace, trace_n * 8, hipMemcpyDeviceToHost));
-                            long long t0 = 0;
-                            for (size_t i = 0; i < trace_n; ++i)
-                                if (tr[i] && (!t0 || tr[i] < t0)) t0 = tr[i];
-                            for (int w = 0; w < rp.nwaves; ++w)
-                                for (int it = 0; it < kRsTraceIters; ++it) {
-                                    const long long* q = &tr[((size_t)w * kRsTraceIters + it) * kRsTraceStamps];
-                                    if (!q[0]) continue;
-                                    std::fprintf(stderr, "[rs-trace] %s w%02d it%02d", w < rp.ncompute ? "C" : "L", w, it);
-                                    for (int k = 0; k < kRsTraceStamps; ++k)
-                                        std::fprintf(stderr, " %lld", q[k] ? q[k] - t0 : -1);
-                                    std::fprintf(stderr, "\n");
-                                }
-                        }
-                    } else if (S.rows) {
-                        RsRows rr = S.rr;
-                        rr.in_pitch = in_pitch;
-                        rr.out_pitch = ob.pitch;
-                        launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                             (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
-                                             (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
-                    } else if (S.tiled) {
-                        RsTiled rt = S.rt;
-                        rt.g.in_pitch = in_pitch;
-                        rt.g.out_pitch = ob.pitch;
-                        launch_resample_tiled(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
-                                              (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
-                    } else
-                        launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
-                                        (const double*)P->bufs[S.dpfb_buf].d, g, st);
-                    s.launches = 1;
-                    launches++;
-                    if (S.fix_buf >= 0) {  // the outputs DSP.jl's phase accumulator places differently
-                        RsFixArgs fa{};
-                        fa.fix = (const RsFix*)P->bufs[S.fix_buf].d;
-                        fa.nfix = (int64_t)S.fix_host.size();
-                        fa.pfb = (const double*)P->bufs[S.pfb_buf].d;
-                        fa.dpfb = (const double*)P->bufs[S.dpfb_buf].d;
-                        fa.n_in = g.n_in;
-                        fa.taps = g.taps;
-                        fa.nch = N.nch;
-                        fa.stage_dtype = N.dtype;
-                        fa.out_dtype = (s.idx == P->alias_stage && P->alias_narrow) ? SO_F32 : N.dtype;
-                        if (S.periodic) {
-                            fa.car = (const DCarrier*)P->bufs[S.car_buf].d;
-                            fa.ncar = (int)S.carriers.size();
-                            fa.ops = P->d_ops;
-                            fa.leaves = P->d_leaves;
-                        } else {
-                            fa.x = inp;
-                            fa.in_pitch = in_pitch;
-                            fa.in_dtype = N.dtype;
-                        }
-                        fa.y = ob.d;
-                        fa.out_pitch = ob.pitch;
-                        launch_resample_fix(fa, st);
-                        s.launches++;
-                        launches++;
-                    }
-                } else {
-                    launch_rms(ob.d, N.dtype, S.need, N.nch, ob.pitch, (double*)P->bufs[S.partial_buf].d,
-                               S.nparts, (double*)P->bufs[S.rms_buf].d, st);
-                    s.launches = 2;
-                    launches += 2;
-                }
-            }
-            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si + 1], st));
-            if (lanes && (P->step_signals[si] || (ln != 0 && si + 1 == P->steps.size())))
-                HIPCHECK(hipEventRecord(P->step_done[si], st));
-        }
-        if (lanes) {
-            // join: everything the side lanes did is ordered before what follows on the caller's
-            // stream (the last step of every side lane signals; wait for the last step per lane)
-            std::vector<int> last(P->nlanes, -1);
-            for (size_t si = 0; si < P->steps.size(); ++si) last[P->step_lane[si]] = (int)si;
-            for (int l = 1; l < P->nlanes; ++l)
-                if (last[l] >= 0) {
-                    if (!P->step_signals[last[l]]) HIPCHECK(hipEventRecord(P->step_done[last[l]], P->lane_streams[l]));
-                    HIPCHECK(hipStreamWaitEvent(main_st, P->step_done[last[l]], 0));
-                }
-        }
-        HIPCHECK(hipGetLastError());
-        P->stats.n_launches = launches;
-        if (!P->out.is_device && P->out.nframes > 0) {
-            Buf& b = P->bufs[P->out_stage_buf];
-            size_t esz = dsize(P->out.dtype);
-            bool planar = P->out.frame_stride == 1 && (P->out.nch == 1 || P->out.chan_stride == P->out.nframes);
-            if (planar || P->interleaved_host) {
-                HIPCHECK(hipMemcpyAsync(outp, b.d, b.bytes, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-            } else {
-                P->host_tmp.resize(b.bytes);
-                HIPCHECK(hipMemcpyAsync(P->host_tmp.data(), b.d, b.bytes, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-                for (int c = 0; c < P->out.nch; ++c)
-                    for (int64_t f = 0; f < P->out.nframes; ++f)
-                        std::memcpy((char*)outp + (size_t)(f * P->out.frame_stride + c * P->out.chan_stride) * esz,
-                                    P->host_tmp.data() + (size_t)(c * P->out.nframes + f) * esz, esz);
-            }
-        } else if (!P->host_leaves.empty() || P->profiling) {
-            HIPCHECK(hipStreamSynchronize(st));
-        }
-        if (P->profiling) {
-            HIPCHECK(hipStreamSynchronize(st));
-            double total = 0, best = -1;
-            for (size_t si = 0; si < P->steps.size(); ++si) {
-                float ms = 0;
-                HIPCHECK(hipEventElapsedTime(&ms, P->events[2 * si], P->events[2 * si + 1]));
-                P->steps[si].ms = ms;
-                total += ms;
-                if (ms > best) {
-                    best = ms;
-                    P->stats.dominant_kernel_ms = ms;
-                    P->stats.dominant_kernel_bytes = P->steps[si].bytes;
-                    std::snprintf(P->stats.dominant_kernel, sizeof P->stats.dominant_kernel, "%s", P->steps[si].name.c_str());
-                }
-            }
-            P->stats.last_exec_ms = total;
-        }
-    } catch (const PlanError& e) {
-        err = e.msg;
-        return e.status;
-    }
-    return SO_OK;
-}
-
-// so_plan_execute.  Plans with many small launches (config 4: 33 launches and ~40 event
-// operations per execute) are host-bound, so from the second execute with the same result
-// pointer on, the whole multi-stream launch sequence is replayed from a captured HIP graph.
-int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
-    DeviceGuard guard(P->device);
-    const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
-                          !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
-    if (!eligible) return plan_execute_direct(P, outp, stream, err);
-    hipStream_t st = (hipStream_t)stream;
-    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch) {
-        if (hipSetDevice(P->device) == hipSuccess && hipGraphLaunch(P->graph_exec, st) == hipSuccess) return SO_OK;
-        (void)hipGetLastError();
-        (void)hipGraphExecDestroy(P->graph_exec);  // fall back to direct launches for good
-        P->graph_exec = nullptr;
-        P->graph_failed = true;
-    }
-    if (P->graph_failed || P->last_out != outp || P->last_epoch != P->array_epoch) {
-        // first execute for this result / these arrays: plain launches (also performs the
-        // one-time function attribute calls, which must not happen inside a capture)
-        P->last_out = outp;
-        P->last_epoch = P->array_epoch;
-        return plan_execute_direct(P, outp, stream, err);
-    }
-    if (P->graph_exec) {
-        (void)hipGraphExecDestroy(P->graph_exec);
-        P->graph_exec = nullptr;
-    }
-    hipGraph_t graph = nullptr;
-    // capture on a stream of our own (the caller's may be the legacy default stream, which cannot
-    // be captured); the graph is then launched on the caller's stream
-    if (!P->capture_stream && hipStreamCreateWithFlags(&P->capture_stream, hipStreamNonBlocking) != hipSuccess)
-        P->capture_stream = nullptr;
-    if (!P->capture_stream || hipSetDevice(P->device) != hipSuccess ||
-        hipStreamBeginCapture(P->capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-        (void)hipGetLastError();
-        P->graph_failed = true;
-        return plan_execute_direct(P, outp, stream, err);
-    }
-    const int rc = plan_execute_direct(P, outp, (void*)P->capture_stream, err);
-    const hipError_t ec = hipStreamEndCapture(P->capture_stream, &graph);
-    if (std::getenv("SIGOPS_DEBUG_PLAN"))
-        std::fprintf(stderr, "[sigops] graph capture: rc=%d end=%d (%s) graph=%p err=%s\n", rc, (int)ec, hipGetErrorString(ec), (void*)graph, err.c_str());
-    if (rc != SO_OK || ec != hipSuccess || !graph ||
-        hipGraphInstantiate(&P->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        if (graph) (void)hipGraphDestroy(graph);
-        P->graph_exec = nullptr;
-        P->graph_failed = true;
-        return rc != SO_OK ? rc : plan_execute_direct(P, outp, stream, err);
-    }
-    (void)hipGraphDestroy(graph);
-    P->graph_out = outp;
-    P->graph_epoch = P->array_epoch;
-    if (hipGraphLaunch(P->graph_exec, st) != hipSuccess) {
-        (void)hipGetLastError();
-        P->graph_failed = true;
-        return plan_execute_direct(P, outp, stream, err);
-    }
-    return SO_OK;
-}
-
-int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& err) {
-    if (node_index < 0 || node_index >= (int)P->nodes.size() || P->nodes[node_index].nd.kind != SO_NODE_ARRAY) {
-        err = "so_plan_set_array: not an ARRAY node";
-        return SO_ERR_INVALID;
-    }
-    DeviceGuard guard(P->device);
-    P->array_ptr[node_index] = data;
-    P->array_epoch++;  // invalidates a captured launch graph
-    if (P->nodes[node_index].nd.i0) {  // device leaf: patch the leaf table
-        bool changed = false;
-        for (size_t i = 0; i < P->leaves.size(); ++i)
-            if (P->leaf_array_node[i] == node_index) {
-                P->leaves[i].base = data;
-                changed = true;
-            }
-        if (changed && P->d_leaves)
-            if (hipMemcpy(P->d_leaves, P->leaves.data(), P->leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice) != hipSuccess) {
-                err = "so_plan_set_array: leaf upload failed";
-                return SO_ERR_RUNTIME;
-            }
-        // carriers of fused resampler stages (by value at launch + a device copy for the slow path)
-        for (auto& S : P->stages) {
-            bool touched = false;
-            for (auto& c : S.carriers)
-                if (c.array_node == node_index) {
-                    c.base = data;
-                    const int64_t V = 16 / (int64_t)dsize(c.dtype);
-                    c.vec_ok = ((uintptr_t)c.base % 16 == 0) && (c.cstride % V == 0);
-                    touched = true;
-                }
-            if (touched) {
-                const RsCtl ctl = P->make_ctl(S);
-                if (hipMemcpy(P->bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice) != hipSuccess ||
-                    hipMemcpy(P->bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice) != hipSuccess) {
-                    err = "so_plan_set_array: carrier upload failed";
-                    return SO_ERR_RUNTIME;
-                }
-            }
-        }
-    }
-    return SO_OK;
-}
-
-int64_t plan_nframes(const Plan* P) {
-    const Node& R = P->nodes[P->root];
-    return isinf_(R.len) ? SO_LEN_INF : R.len.n;
-}
-void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
-void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
-int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
-    if (info && index >= 0 && index < (int)P->steps.size()) {
-        const Step& s = P->steps[index];
-        std::memset(info, 0, sizeof *info);
-        std::snprintf(info->name, sizeof info->name, "%s", s.name.c_str());
-        info->algorithmic_bytes = s.bytes;
-        info->ms = s.ms;
-        info->launches = s.launches;
-    }
-    return (int)P->steps.size();
-}
-void plan_destroy(Plan* P) {
-    if (!P) return;
-    {
-        DeviceGuard guard(P->device);
-        P->release();
-    }
-    delete P;
-}
 
 }  // namespace so

@@ -1,0 +1,1176 @@
+// Stage setup: geometry and tables of the stateful stages (resampler variants, SOS IIR, Normpower),
+// carrier fusion of pointwise sources into the periodic resampler, and the optional fusion of the
+// IIR's state pass into the resampler in front of it.
+#include "plan_impl.h"
+
+namespace so {
+
+// ---------------------------------------------------------------------------
+// small dense matrices for the SOS state propagation
+Mat matmul(const Mat& a, const Mat& b, int D) {
+    Mat c((size_t)D * D, 0.0);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            double v = a[(size_t)i * D + k];
+            if (v == 0.0) continue;
+            for (int j = 0; j < D; ++j) c[(size_t)i * D + j] += v * b[(size_t)k * D + j];
+        }
+    return c;
+}
+double maxabs(const Mat& a) {
+    double m = 0;
+    for (double v : a) m = std::max(m, std::fabs(v));
+    return m;
+}
+Mat ident(int D) {
+    Mat m((size_t)D * D, 0.0);
+    for (int i = 0; i < D; ++i) m[(size_t)i * D + i] = 1.0;
+    return m;
+}
+// one zero-input DF2T step applied to each unit state: columns of the state matrix A
+Mat sos_state_matrix(const SosCoefs& cf) {
+    int ns = cf.nsec, D = 2 * ns;
+    Mat A((size_t)D * D, 0.0);
+    for (int col = 0; col < D; ++col) {
+        std::vector<double> s(D, 0.0);
+        s[col] = 1.0;
+        double y = 0.0;
+        for (int f = 0; f < ns; ++f) {
+            double xi = y;
+            y = s[2 * f] + cf.b0[f] * xi;
+            s[2 * f] = s[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
+            s[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
+        }
+        for (int r = 0; r < D; ++r) A[(size_t)r * D + col] = s[r];
+    }
+    return A;
+}
+Mat matpow(Mat A, int64_t e, int D) {
+    Mat R = ident(D);
+    while (e > 0) {
+        if (e & 1) R = matmul(R, A, D);
+        e >>= 1;
+        if (e) A = matmul(A, A, D);
+    }
+    return R;
+}
+
+
+// Can this periodic resampler stage run the GA instantiation (Float32 tiles, Float64 gain at the A
+// operand)?  Geometry the instantiations cover, and the LDS budget with three gain arrays.
+static bool ga_fits(const Stage& S, int stage_dtype) {
+    if (!S.periodic || stage_dtype != SO_F64 || std::getenv("SIGOPS_RS_NOGA")) return false;
+    const RsPeriodic& rp = S.rp;
+    const int gper = (rp.ngroups + rp.ncompute - 1) / std::max(1, rp.ncompute);
+    if (rp.kw != 56 || gper != 1 || !(rp.ct == 8 || rp.ct == 4)) return false;
+    const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+    const size_t pitch4 = (size_t)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
+    const size_t tile_bytes = (size_t)rp.ct * pitch4 * 4;
+    const size_t fpitch = (size_t)((rp.tile_len + 16 + 1) & ~1);
+    const bool ok = 3 * fpitch * 8 + kRsTwoDoubles * 8 + 2 * tile_bytes <= avail;
+    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+        std::fprintf(stderr, "[sigops] GA geometry: kw=%d gper=%d ct=%d tile_len=%d -> %s\n", rp.kw, gper, rp.ct, rp.tile_len, ok ? "fits" : "no");
+    return ok;
+}
+
+void Plan::process_stage(int sid) {
+    // NOTE: `stages` may grow while lowering the child; re-take references after.
+    int ni = stages[sid].node;
+    Node& N = nodes[ni];
+    const so_node_t& nd = N.nd;
+    int child = N.kids[0];
+    Node& C = nodes[child];
+    int64_t need = stages[sid].need;
+    stages[sid].processed = true;
+    if (need <= 0) return;
+
+    int64_t in_frames = need;
+    if (stages[sid].kind == ST_RESAMPLE) {
+        RsGeom g{};
+        g.arbitrary = nd.i0 == SO_RS_ARBITRARY;
+        int hlen = nd.i2;
+        g.nphi = g.arbitrary ? nd.i1 : (int)nd.l0;
+        if (g.nphi < 1) fail(SO_ERR_INVALID, "resampler: bad phase count");
+        g.L = nd.l0;
+        g.M = nd.l1;
+        const bool plain_fir = nd.i0 == SO_RS_FIR;  // Filt(x,h): ratio 1, causal, no delay compensation
+        if (plain_fir) {
+            g.nphi = 1;
+            g.L = g.M = 1;
+        }
+        if (!g.arbitrary && (g.L < 1 || g.M < 1)) fail(SO_ERR_INVALID, "resampler: bad ratio");
+        g.delta = g.arbitrary ? (double)g.nphi / nd.d0 : 0.0;
+        g.c0 = plain_fir ? 0.0 : (double)(hlen - 1) / 2.0;
+        g.c0i = plain_fir ? 0 : (hlen - 1) / 2;
+        g.taps = (hlen + g.nphi - 1) / g.nphi;
+        g.nch = N.nch;
+        g.m0 = 0;
+        g.n_out = need;
+        if (g.arbitrary) rs_detect_exact(g, nd.fs, C.fs, nd.d0);
+        // ---- warm start (see the IIR's below): the resampler is an FIR filter, so outputs from a
+        //      whole number of periods before the first frame anybody reads on are the same whether
+        //      the stage starts there or at frame 0, except the first few (their taps reach before
+        //      the first input staged), which nobody reads either ----
+        int64_t rbase = 0;
+        if ((!g.arbitrary || g.exact) && stages[sid].lo >= 8192 && stages[sid].lo < need &&
+            !std::getenv("SIGOPS_NO_WARM_START")) {
+            const int64_t margin = (g.taps + 2 + g.M - 1) / g.M + 1;  // periods
+            int64_t k = stages[sid].lo / g.L - margin;
+            k = k / 16 * 16;  // (16 M inputs: the first staged input stays 128-byte aligned)
+            if (k > 0 && k * g.L >= 4096) {
+                rbase = k * g.L;
+                stages[sid].base = rbase;
+                stages[sid].in_base = k * g.M;
+                need -= rbase;
+                g.n_out = need;
+            }
+        }
+        // newest input of the last needed output
+        int64_t jl;
+        if (g.arbitrary && g.exact) {
+            int64_t Nn = (need - 1) * ((int64_t)g.nphi * g.M);
+            jl = (g.c0i + Nn / g.L) / g.nphi;
+        } else if (g.arbitrary) {
+            double q = g.c0 + (double)(need - 1) * g.delta;
+            jl = (int64_t)std::floor(q) / g.nphi;
+        } else jl = (g.c0i + (need - 1) * g.M) / g.L;
+        int64_t nin = jl + 2;  // +1 slack: host rounding of q may differ from the device's at ties
+        if (!isinf_(C.len)) nin = std::min(nin, C.len.n - stages[sid].in_base);
+        g.n_in = nin;
+        in_frames = nin;
+        // polyphase tables: pfb[p][k] = h[p + nphi*k]; dpfb from dh = [diff(h);0]
+        const double* h = (const double*)nd.p0;
+        stages[sid].pfb_host.assign((size_t)g.nphi * g.taps, 0.0);
+        stages[sid].dpfb_host.assign((size_t)g.nphi * g.taps, 0.0);
+        for (int p = 0; p < g.nphi; ++p)
+            for (int k = 0; k < g.taps; ++k) {
+                int64_t hi = p + (int64_t)g.nphi * k;
+                stages[sid].pfb_host[(size_t)p * g.taps + k] = hi < hlen ? h[hi] : 0.0;
+                stages[sid].dpfb_host[(size_t)p * g.taps + k] = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+            }
+        stages[sid].pfb_buf = raw_buf(stages[sid].pfb_host.size() * 8);
+        stages[sid].dpfb_buf = raw_buf(stages[sid].dpfb_host.size() * 8);
+        g.in_dtype = g.out_dtype = N.dtype;
+        stages[sid].rg = g;
+        // reference positions: DSP.jl's phase accumulator (SIGOPS_RS_EXACT=1 keeps the closed form)
+        std::vector<uint8_t> wrap;
+        if (g.arbitrary && !std::getenv("SIGOPS_RS_EXACT")) {
+            // (period positions can only be baked into the tap tables of the periodic / row-tiled
+            //  kernels: short outputs go to the thread-per-output kernel and list every deviation)
+            replay_phase_accumulator(g, (const double*)nd.p0, hlen, rbase + need, g.exact && need >= 2048, wrap, stages[sid].fix_host, rbase);
+        }
+        // position of period output r as the tap tables see it: the closed form, or the
+        // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
+        auto wrap_at = [&](int64_t r) { return !wrap.empty() && wrap[r % g.L]; };
+        // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
+        if ((!g.arbitrary || g.exact) && need >= 2048) {
+            constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
+            const int64_t Lb = g.L, Mb = g.M;
+            // (8 channels per tile when possible: per-frame gains of a fused source are evaluated
+            //  once per tile row-group, and 8 rows give every loader wave exactly one chunk)
+            int ct = 1;
+            for (int c : {8, 4, 2})
+                if (N.nch % c == 0) {
+                    ct = c;
+                    break;
+                }
+            if (const char* ev = std::getenv("SIGOPS_RS_CT")) {  // tuning knob
+                int c = std::atoi(ev);
+                if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
+            }
+            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in kernels.hip)
+            // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
+            // (b) a tile (pt super-periods) covers ~1100 input frames per channel
+            int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
+            int64_t t = std::max<int64_t>(1, 1100 / (pt * Mb));
+            t = std::max<int64_t>(tmin, t / tmin * tmin);
+            if (Lb * t > 4096) t = std::max<int64_t>(1, 4096 / Lb);
+            const int64_t Ls = Lb * t, Ms = Mb * t;
+            auto pos = [&](int64_t r, int64_t& j, int& p, double& alpha) {
+                int64_t qi;
+                if (g.arbitrary) {
+                    int64_t Nn = r * ((int64_t)g.nphi * Mb);
+                    qi = g.c0i + Nn / Lb;
+                    alpha = (double)(Nn % Lb) / (double)Lb;
+                } else {
+                    qi = g.c0i + r * Mb;
+                    alpha = 0.0;
+                }
+                if (wrap_at(r)) {
+                    qi -= 1;
+                    alpha = 1.0;
+                }
+                j = qi / g.nphi;
+                p = (int)(qi % g.nphi);
+            };
+            std::vector<int64_t> jr(Ls);
+            std::vector<int> pr(Ls);
+            std::vector<double> ar(Ls);
+            for (int64_t r = 0; r < Ls; ++r) pos(r, jr[r], pr[r], ar[r]);
+            const int ngroups = (int)((Ls + RM - 1) / RM);
+            int64_t maxspan = 0;
+            std::vector<int> jend(ngroups);
+            for (int gi = 0; gi < ngroups; ++gi) {
+                int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
+                jend[gi] = (int)jr[r1 - 1];
+                maxspan = std::max(maxspan, jr[r1 - 1] - jr[r0]);
+            }
+            // k-steps: smallest instantiated KS covering taps + span (tab is zero padded);
+            // compute waves: one (or two) groups each, taps stay in registers
+            int kw = 0, ncomp = 0, gper = 0;
+            {
+                const int ksneed = (g.taps + (int)maxspan + 3) / 4;
+                gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
+                if (const char* ev = std::getenv("SIGOPS_RS_GPER")) gper = std::atoi(ev);  // tuning knob
+                const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14};
+                if (gper == 1) {
+                    for (int k : ks1)
+                        if (!kw && k >= ksneed) kw = 4 * k;
+                } else if (gper == 2 || gper == 3) {
+                    for (int k : ks2)
+                        if (!kw && k >= ksneed) kw = 4 * k;
+                }
+                if (kw) ncomp = (ngroups + gper - 1) / gper;
+            }
+            // first staged input, rounded down to a multiple of 4 frames so that tiles start
+            // on a 16-byte boundary (vector loads) whenever pt*M is a multiple of 4
+            int jlo = jend[0] - (kw - 1);
+            jlo -= ((jlo % 4) + 4) % 4;
+            // (+0..3 frames: a row's staged span is a whole number of MFMA k-steps, which the fused IIR
+            //  state pass walks from jlo to the end)
+            const int64_t tile_len = (pt - 1) * Ms + (jend[ngroups - 1] - jlo + 1 + 3) / 4 * 4;
+            // tiles are kept in LDS in the sample type and staged from the 128-byte aligned frame
+            // below their first input (+15 / +31 frames); rows are 16-byte multiples for LDS-DMA
+            const int64_t esz_t = (int64_t)dsize(N.dtype), vfr = 16 / esz_t;
+            int64_t pitch = (tile_len + (128 / esz_t - 1) + 2 * vfr + vfr - 1) / vfr * vfr;
+            size_t lds_bytes = ((size_t)ct * pitch * esz_t + 7) / 8 * 8;
+            size_t tab_bytes = (size_t)ngroups * kw * RM * 8;
+            // LDS ring: as many tile slots as fit in 160 KiB, at most 4 (2 tiles in flight
+            // beyond the one being retired), at least 2 (plain double buffering)
+            int nslots = (int)std::min<size_t>(4, (160 * 1024 - sizeof(RsCtl) - 64) / std::max<size_t>(1, lds_bytes));
+            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) nslots = std::min(nslots, std::max(2, std::atoi(ev)));
+            if (kw && nslots >= 2 && tab_bytes <= (16u << 20) && tile_len < (1 << 30)) {
+                const double* h = (const double*)nd.p0;
+                std::vector<double> tab((size_t)ngroups * kw * RM, 0.0);
+                for (int gi = 0; gi < ngroups; ++gi) {
+                    int64_t r0 = (int64_t)gi * RM, r1 = std::min<int64_t>(Ls, r0 + RM);
+                    for (int64_t r = r0; r < r1; ++r)
+                        for (int kk = 0; kk < kw; ++kk) {
+                            int64_t rel = jend[gi] - (kw - 1) + kk;  // input index of slot kk
+                            int64_t age = jr[r] - rel;               // tap age for output r
+                            if (age < 0 || age >= g.taps) continue;
+                            int64_t hi = pr[r] + (int64_t)g.nphi * age;
+                            double hv = hi < hlen ? h[hi] : 0.0;
+                            double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                            tab[((size_t)gi * kw + kk) * RM + (r - r0)] = hv + ar[r] * dv;
+                        }
+                }
+                RsPeriodic rp{};
+                rp.n_in = g.n_in;
+                rp.n_out = need;
+                rp.L = Ls;
+                rp.M = Ms;
+                rp.nperiods = (need + Ls - 1) / Ls;
+                rp.pt = pt;
+                rp.ct = ct;
+                rp.ngroups = ngroups;
+                rp.kw = kw;
+                rp.tile_len = (int)tile_len;
+                rp.lds_pitch = (int)pitch;
+                rp.jlo = jlo;
+                rp.nch = N.nch;
+                rp.ptshift = pt == 32 ? 5 : pt == 16 ? 4 : pt == 8 ? 3 : 2;
+                rp.nslots = nslots;
+                // persistent kernel: 16 waves per workgroup (8 when a wave owns three groups and
+                // needs the registers), one workgroup per CU; the waves that do not compute load
+                rp.nwaves = gper >= 3 ? 8 : 16;
+                rp.ncompute = ncomp;
+                rp.grid = 256;
+                if (const char* ev = std::getenv("SIGOPS_RS_NWAVES")) rp.nwaves = std::max(2, std::min(16, std::atoi(ev)));
+                if (const char* ev = std::getenv("SIGOPS_RS_GRID")) rp.grid = std::max(1, std::atoi(ev));
+                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rp.pad = std::atoi(ev);  // ablation knob
+                if (const char* ev = std::getenv("SIGOPS_RS_NLOAD")) rp.nload = std::max(1, std::atoi(ev));  // tuning knob
+                stages[sid].periodic = true;
+                stages[sid].per_j = jr;
+                stages[sid].per_p = pr;
+                stages[sid].per_a = ar;
+                stages[sid].jend_last = jend[ngroups - 1];
+                stages[sid].rp = rp;
+                stages[sid].tab_host = tab;
+                stages[sid].jend_host = jend;
+                stages[sid].tab_buf = raw_buf(tab.size() * 8);
+                stages[sid].jend_buf = raw_buf(jend.size() * 4);
+            }
+        }
+        // ---- row-tiled variant: rational rates the MFMA kernel's geometry does not cover -------
+        if (!stages[sid].periodic && (!g.arbitrary || g.exact) && need >= 2048 && g.m0 == 0 &&
+            !std::getenv("SIGOPS_RS_NOROWS")) {
+            const int64_t Lb = g.L, Mb = g.M;
+            const double* h = (const double*)nd.p0;
+            std::vector<int> jr(Lb);
+            std::vector<double> ctab((size_t)Lb * g.taps, 0.0);
+            int64_t jmin = INT64_MAX, jmax = INT64_MIN;
+            for (int64_t r = 0; r < Lb; ++r) {
+                int64_t qi;
+                double alpha = 0.0;
+                if (g.arbitrary) {
+                    const int64_t Nn = r * ((int64_t)g.nphi * Mb);
+                    qi = g.c0i + Nn / Lb;
+                    alpha = (double)(Nn % Lb) / (double)Lb;
+                } else qi = g.c0i + r * Mb;
+                if (wrap_at(r)) {
+                    qi -= 1;
+                    alpha = 1.0;
+                }
+                const int64_t j = qi / g.nphi;
+                const int p = (int)(qi % g.nphi);
+                jr[r] = (int)j;
+                jmin = std::min(jmin, j - (g.taps - 1));
+                jmax = std::max(jmax, j);
+                for (int k = 0; k < g.taps; ++k) {
+                    const int64_t hi = p + (int64_t)g.nphi * k;
+                    const double hv = hi < hlen ? h[hi] : 0.0;
+                    const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                    ctab[(size_t)r * g.taps + k] = hv + alpha * dv;
+                }
+            }
+            const int64_t esz_t = (int64_t)dsize(N.dtype);
+            int best_ct = 0, best_pb = 0;
+            int64_t best_pitch = 0, best_len = 0;
+            size_t rr_max_lds = 150 * 1024;
+            if (const char* ev = std::getenv("SIGOPS_RR_MAXLDS")) rr_max_lds = (size_t)std::atoi(ev) * 1024;  // tuning knob
+            // tile choice: the largest row count whose tile fits; two workgroups per CU (tiles of at
+            // most 75 KB) overlap one's staging with the other's MFMAs (config 5: 0.77 -> 0.66 ms),
+            // so that budget is tried first as long as it still gives an MFMA-able tile (>= 16 rows)
+            const bool lds_forced = std::getenv("SIGOPS_RR_MAXLDS") != nullptr;
+            for (int pass = 0; pass < 2 && !best_ct; ++pass) {
+                const size_t budget = lds_forced ? rr_max_lds : (pass == 0 ? (size_t)75 * 1024 : rr_max_lds);
+                for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
+                    if (pass == 0 && !lds_forced && rows < 16) break;
+                    for (int ct : {8, 4, 2, 1}) {
+                        if (best_ct || N.nch % ct || rows % ct) continue;
+                        const int pb = rows / ct;
+                        const int64_t tile_len = (pb - 1) * Mb + (jmax - jmin + 1);
+                        const int64_t pitch = (tile_len + 3) | 1;  // odd: rows fall on different LDS banks
+                        if ((size_t)ct * pitch * esz_t <= budget && tile_len < (1 << 30)) {
+                            best_ct = ct;
+                            best_pb = pb;
+                            best_pitch = pitch;
+                            best_len = tile_len;
+                            rr_max_lds = budget;
+                        }
+                    }
+                }
+            }
+            // MFMA path: groups of 16 phases against a [kw x 16] tap block (rows = 16, 32 or 64)
+            std::vector<double> mtab;
+            std::vector<int> mjend;
+            int kw_m = 0, ngroups_m = 0;
+            if (best_ct && (best_ct * best_pb) % 16 == 0 && !std::getenv("SIGOPS_RS_NOROWS_MFMA")) {
+                const int64_t jmin_scalar = jmin;
+                ngroups_m = (int)((Lb + 15) / 16);
+                mjend.resize(ngroups_m);
+                int64_t maxspan = 0;
+                for (int gi = 0; gi < ngroups_m; ++gi) {
+                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
+                    mjend[gi] = jr[r1 - 1];
+                    maxspan = std::max<int64_t>(maxspan, jr[r1 - 1] - jr[r0]);
+                }
+                kw_m = (int)((g.taps + maxspan + 3) / 4 * 4);
+                mtab.assign((size_t)ngroups_m * kw_m * 16, 0.0);
+                for (int gi = 0; gi < ngroups_m; ++gi) {
+                    const int64_t r0 = 16 * (int64_t)gi, r1 = std::min<int64_t>(Lb, r0 + 16);
+                    jmin = std::min<int64_t>(jmin, mjend[gi] - (kw_m - 1));
+                    for (int64_t r = r0; r < r1; ++r)
+                        for (int kk = 0; kk < kw_m; ++kk) {
+                            const int64_t age = jr[r] - (mjend[gi] - (kw_m - 1) + kk);
+                            if (age >= 0 && age < g.taps)
+                                mtab[((size_t)gi * kw_m + kk) * 16 + (r - r0)] = ctab[(size_t)r * g.taps + age];
+                        }
+                }
+                // the window of a group may start a few frames before the oldest tap: re-size the tile
+                const int64_t tile_len = (best_pb - 1) * Mb + (jmax - jmin + 1);
+                const int64_t pitch = (tile_len + 3) | 1;
+                if ((size_t)best_ct * pitch * esz_t <= rr_max_lds + 2048) {
+                    best_len = tile_len;
+                    best_pitch = pitch;
+                } else {
+                    kw_m = 0;
+                    mtab.clear();
+                    jmin = jmin_scalar;
+                }
+            }
+            if (best_ct && jmin > INT32_MIN && jmax < INT32_MAX && (size_t)Lb * g.taps * 8 <= (64u << 20)) {
+                RsRows rr{};
+                rr.kw = kw_m;
+                rr.ngroups = ngroups_m;
+                rr.pbshift = 0;
+                while ((1 << rr.pbshift) < best_pb) ++rr.pbshift;  // pb is a power of two
+                stages[sid].mtab_host = mtab;
+                stages[sid].mjend_host = mjend;
+                stages[sid].mtab_buf = raw_buf(std::max<size_t>(mtab.size(), 1) * 8);
+                stages[sid].mjend_buf = raw_buf(std::max<size_t>(mjend.size(), 1) * 4);
+                rr.n_in = g.n_in;
+                rr.n_out = need;
+                rr.L = Lb;
+                rr.M = Mb;
+                rr.nperiods = (need + Lb - 1) / Lb;
+                rr.taps = g.taps;
+                rr.ct = best_ct;
+                rr.pb = best_pb;
+                rr.jlo = (int)jmin;
+                rr.tile_len = (int)best_len;
+                rr.pitch = (int)best_pitch;
+                rr.nch = N.nch;
+                if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rr.debug = std::atoi(ev);  // ablation knob
+                rr.threads = 1024;
+                if (const char* ev = std::getenv("SIGOPS_RR_THREADS")) rr.threads = std::max(64, std::min(1024, std::atoi(ev) / 64 * 64));  // tuning knob
+                stages[sid].rows = true;
+                stages[sid].rr = rr;
+                stages[sid].tab_host = ctab;
+                stages[sid].jend_host = jr;
+                stages[sid].tab_buf = raw_buf(ctab.size() * 8);
+                stages[sid].jend_buf = raw_buf(jr.size() * 4);
+            }
+        }
+        // ---- tiled variant for everything else that is long enough (no period to exploit) ----
+        if (!stages[sid].periodic && !stages[sid].rows && need >= 2048 && !std::getenv("SIGOPS_RS_NOTILED")) {
+            const int64_t esz_t = (int64_t)dsize(N.dtype);
+            const size_t tabs = (size_t)2 * g.taps * g.nphi * 8;
+            int ct = 1;
+            for (int c : {8, 4, 2})
+                if (N.nch % c == 0) {
+                    ct = c;
+                    break;
+                }
+            // inputs per output (fine-grid step / Nphi), for sizing the tile
+            const double step = g.arbitrary ? g.delta / g.nphi : (double)g.M / (double)g.L;
+            for (; ct >= 1; ct >>= 1) {
+                if (N.nch % ct) continue;
+                // two workgroups per CU when the tables allow it (their staging and arithmetic overlap)
+                size_t budget = tabs <= (size_t)24 * 1024 ? (size_t)78 * 1024 - tabs : (size_t)150 * 1024 - std::min<size_t>(tabs, 150 * 1024);
+                int64_t tile_in = (int64_t)(budget / ((size_t)ct * esz_t));
+                int64_t tile_out = (int64_t)std::floor((double)(tile_in - g.taps - 4) / step);
+                tile_out = std::min<int64_t>(tile_out, 4096);
+                if (tabs <= (size_t)100 * 1024 && tile_out >= 128) {
+                    RsTiled rt{};
+                    rt.g = g;
+                    rt.ct = ct;
+                    rt.tile_out = (int32_t)tile_out;
+                    rt.tile_in = (int32_t)tile_in;
+                    rt.pitch = (int32_t)(tile_in | 1);
+                    rt.ntiles = (need + tile_out - 1) / tile_out;
+                    stages[sid].tiled = true;
+                    stages[sid].rt = rt;
+                    stages[sid].pfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
+                    stages[sid].dpfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
+                    for (int p = 0; p < g.nphi; ++p)
+                        for (int k = 0; k < g.taps; ++k) {
+                            stages[sid].pfbt_host[(size_t)k * g.nphi + p] = stages[sid].pfb_host[(size_t)p * g.taps + k];
+                            stages[sid].dpfbt_host[(size_t)k * g.nphi + p] = stages[sid].dpfb_host[(size_t)p * g.taps + k];
+                        }
+                    stages[sid].pfbt_buf = raw_buf(stages[sid].pfbt_host.size() * 8);
+                    stages[sid].dpfbt_buf = raw_buf(stages[sid].dpfbt_host.size() * 8);
+                    break;
+                }
+            }
+        }
+        if (!wrap.empty() && !stages[sid].periodic && !stages[sid].rows)  // no tap table took the baked positions
+            replay_phase_accumulator(stages[sid].rg, (const double*)nd.p0, nd.i2, stages[sid].base + need, false, wrap, stages[sid].fix_host,
+                                     stages[sid].base);
+        if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
+    } else if (stages[sid].kind == ST_SOS) {
+        if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
+        int nsec = nd.i0;
+        const double* sos = (const double*)nd.p0;
+        std::vector<SosCoefs> groups;
+        for (int s0 = 0; s0 < nsec; s0 += kMaxSec) {
+            SosCoefs cf{};
+            cf.nsec = std::min(kMaxSec, nsec - s0);
+            for (int f = 0; f < cf.nsec; ++f) {
+                const double* b = sos + 6 * (s0 + f);
+                if (b[3] != 1.0) fail(SO_ERR_INVALID, "SOS rows must be normalised (a0 == 1)");
+                cf.b0[f] = b[0];
+                cf.b1[f] = b[1];
+                cf.b2[f] = b[2];
+                cf.a1[f] = b[4];
+                cf.a2[f] = b[5];
+            }
+            cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
+            groups.push_back(cf);
+        }
+        // ---- warm start: frames before the first one anybody reads (After, a later window of a
+        //      stream) matter only through the filter state, and what a state contributes has decayed
+        //      below 2^-70 after W frames: start from zero state W frames early instead of at frame 0.
+        //      (The reference filters the skipped frames, src/cutting.jl:160-173; same values.) ----
+        if (stages[sid].lo < need && stages[sid].lo >= 8192 && !std::getenv("SIGOPS_NO_WARM_START")) {
+            int64_t Wd = 0;
+            for (auto& cf : groups) {
+                const int D = 2 * cf.nsec;
+                Mat P = sos_state_matrix(cf);
+                int64_t w = 1;
+                while (maxabs(P) >= std::ldexp(1.0, -70) && w < ((int64_t)1 << 40)) {
+                    P = matmul(P, P, D);
+                    w <<= 1;
+                }
+                Wd += w;  // (groups are cascaded: decay times add up at worst)
+            }
+            if (stages[sid].lo - Wd >= 4096) {
+                const int64_t base = (stages[sid].lo - Wd) / 64 * 64;
+                stages[sid].base = stages[sid].in_base = base;
+                need -= base;  // local frames from here on
+                in_frames = need;
+            }
+        }
+        // ---- single pass (one read, one write): wave tiles in time order with a look-back over the
+        //      zero-state end states of the kt previous tiles (see k_sos_onepass) ----
+        // Opt-in (SIGOPS_SOS_ONEPASS=1): its HBM traffic is the algorithmic minimum, but on MI355X it
+        // is bound by fp64 vector work and dependent chains at two waves per SIMD (28.8 M x 8, order
+        // 10: 1.7 ms against 1.13 ms for the three-pass form, which streams at ~5 TB/s) -- DESIGN.md.
+        if (need >= 4096 && std::getenv("SIGOPS_SOS_ONEPASS") && !std::getenv("SIGOPS_SOS_3PASS")) {
+            SosOne o{};
+            const int tf = 64 * kSosLc;
+            o.n = need;
+            o.nch = N.nch;
+            o.ntiles = (int)((need + tf - 1) / tf);
+            o.nlev = 6;
+            o.bt = std::min(4, N.nch);
+            if (const char* ev = std::getenv("SIGOPS_SOS_BT")) o.bt = std::max(1, std::min(4, std::atoi(ev)));  // tuning knob
+            if (const char* ev = std::getenv("SIGOPS_SOS_DEBUG")) o.debug = std::atoi(ev);  // ablation knob
+            const double tol1 = std::ldexp(1.0, -70);
+            bool ok = (int64_t)o.ntiles * o.nch < (1 << 30);
+            // look-back depth: first kt with ||(A^tf)^kt|| < 2^-70, the same for every group
+            int kt = 1;
+            std::vector<Mat> As, Ts;
+            for (auto& cf : groups) {
+                const int D = 2 * cf.nsec;
+                Mat A = sos_state_matrix(cf);
+                Mat T = matpow(A, tf, D);
+                As.push_back(A);
+                Ts.push_back(T);
+                Mat cur = T;
+                int k = 1;
+                while (ok && !(maxabs(cur) < tol1)) {
+                    cur = matmul(cur, T, D);
+                    if (++k > 64) ok = false;  // a pole this close to the unit circle: three-pass form
+                }
+                kt = std::max(kt, k);
+            }
+            if (ok) {
+                o.kt = kt;
+                std::vector<double> tabs;
+                std::vector<size_t> offs;
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    const int D = 2 * groups[gi].nsec;
+                    offs.push_back(tabs.size());
+                    Mat P = matpow(As[gi], kSosLc, D);  // M = A^lc, then M^2, M^4, ...
+                    for (int lev = 0; lev < o.nlev; ++lev) {
+                        tabs.insert(tabs.end(), P.begin(), P.end());
+                        P = matmul(P, P, D);
+                    }
+                    Mat cur = ident(D);
+                    for (int j = 0; j < kt; ++j) {  // (A^tf)^j
+                        tabs.insert(tabs.end(), cur.begin(), cur.end());
+                        cur = matmul(cur, Ts[gi], D);
+                    }
+                }
+                stages[sid].onepass = true;
+                stages[sid].so1 = o;
+                stages[sid].one_tabs_host = tabs;
+                stages[sid].one_tabs_off = offs;
+                stages[sid].one_tabs_buf = raw_buf(tabs.size() * 8);
+                stages[sid].one_sync_buf = raw_buf(64);
+                stages[sid].one_vpub_buf = raw_buf((size_t)o.ntiles * o.nch * 2 * kMaxSec * 8);
+            }
+        }
+        // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
+        SosGeom g{};
+        g.n = need;
+        g.nch = N.nch;
+        const double tol = std::ldexp(1.0, -70);
+        // chunk length: as many sequences (chunks x channels) as the machine can hold; every
+        // pass is latency-bound per sequence, so shorter chunks win down to L = 64 (sweep on
+        // config 2: L=64 0.205 ms, 128 0.208, 256 0.293, 512 0.531)
+        int64_t target = 262144 / std::max(1, N.nch);
+        int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
+        int64_t L = (need + nchunks - 1) / nchunks;
+        if (const char* ev = std::getenv("SIGOPS_SOS_CHUNK")) {  // tuning knob
+            L = std::max(32, std::atoi(ev));
+        }
+        L = (L + 31) / 32 * 32;
+        std::vector<std::vector<double>> mp;
+        int K = 1;
+        int64_t W = BIG;
+        for (;;) {
+            nchunks = (need + L - 1) / L;
+            mp.clear();
+            K = 1;
+            W = 0;
+            if (nchunks <= 1) break;
+            bool ok = true;
+            for (auto& cf : groups) {
+                int D = 2 * cf.nsec;
+                Mat A = sos_state_matrix(cf);
+                // W: first power of two with ||A^W|| < tol (pass-1 warm-up length)
+                Mat P = A;
+                int64_t w = 1;
+                while (maxabs(P) >= tol && w < ((int64_t)1 << 40)) {
+                    P = matmul(P, P, D);
+                    w <<= 1;
+                }
+                W = std::max(W, w);
+                Mat M = matpow(A, L, D);
+                std::vector<double> pw_((size_t)D * D, 0.0);
+                Mat cur = ident(D);
+                std::vector<double> all;
+                int k = 0;
+                for (;;) {
+                    all.insert(all.end(), cur.begin(), cur.end());
+                    ++k;
+                    cur = matmul(cur, M, D);
+                    if (maxabs(cur) < tol) break;
+                    if (k >= 64) {
+                        ok = false;
+                        break;
+                    }
+                }
+                if (!ok) break;
+                K = std::max(K, k);
+                mp.push_back(all);
+            }
+            if (ok) break;
+            L *= 2;  // slower-decaying filter: fewer, longer chunks
+        }
+        // every group is scanned with the same K (pad shorter tables with zeros)
+        for (size_t gi = 0; gi < mp.size(); ++gi) {
+            int D = 2 * groups[gi].nsec;
+            mp[gi].resize((size_t)K * D * D, 0.0);
+        }
+        g.chunk = L;
+        g.nchunks = (int)nchunks;
+        g.warm = W;
+        g.kterms = K;
+        g.in_dtype = g.out_dtype = N.dtype;
+        stages[sid].groups = groups;
+        stages[sid].mpow_host = mp;
+        if (nchunks > 1 && !stages[sid].onepass) {
+            size_t msz = 0;
+            for (auto& v : mp) msz = std::max(msz, v.size());
+            stages[sid].mpow_buf = raw_buf(msz * 8 * groups.size());
+            stages[sid].v_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
+            stages[sid].s0_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
+        }
+        stages[sid].sg = g;
+    } else {  // ST_NORM
+        in_frames = need;
+        int64_t total = need * N.nch;
+        int nparts = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + kBlock * 8 - 1) / (kBlock * 8)));
+        stages[sid].nparts = nparts;
+        stages[sid].partial_buf = raw_buf((size_t)nparts * 8);
+    }
+
+    // lower the child over the frames this stage consumes
+    std::vector<Piece> ps;
+    const int64_t in_base = stages[sid].in_base;
+    if (in_base > 0) check_frames(child, in_base);
+    if (in_frames > 0) ps = lower(child, Rect{0, in_frames, 0, N.nch}, Map{1, in_base, 1, 0});
+    if (stages[sid].kind == ST_SOS && in_frames > 0) {  // the reference filters whole blocks of its input
+        const int64_t bs = std::max(1, N.nd.i1);
+        check_frames(child, (in_base + in_frames + bs - 1) / bs * bs);
+    }
+    if (stages[sid].out_buf >= 0) bufs[stages[sid].out_buf].frame0 = stages[sid].base;
+    Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
+    S.in_frames = in_frames;
+    int in_dtype = S.kind == ST_NORM ? N.dtype : C.dtype;
+    if (S.kind != ST_NORM && float_of(C.dtype) != N.dtype) fail(SO_ERR_INVALID, "filter dtype mismatch");
+    if (S.kind != ST_NORM && C.dtype == SO_I64) in_dtype = SO_F64;
+    // direct source: a single plain contiguous load of the right type
+    bool direct = false;
+    if (S.kind != ST_NORM && ps.size() == 1) {
+        const Expr& e = exprs[ps[0].e];
+        if (e.op == E_LOAD && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 && e.leaf.sc == 1 &&
+            e.leaf.fstride == 1 && e.leaf.dtype == in_dtype && e.leaf.df >= 0 && e.leaf.dc >= 0 &&
+            (e.leaf.cstride > 0 || e.leaf.cstride == -1 || N.nch == 1)) {
+            direct = true;
+            S.in_array_node = e.array_node;
+            S.in_buf = e.leaf.buf;  // stage buffer or -1 (array)
+            S.in_offset = e.leaf.df;
+            S.in_pitch = e.leaf.cstride;  // -1: pitch of in_buf
+            if (e.array_node >= 0) {
+                // element offset = df*fstride + dc*cstride
+                S.in_offset = e.leaf.df + e.leaf.dc * std::max<int64_t>(e.leaf.cstride, 0);
+            } else {
+                if (e.leaf.dc != 0) direct = false;
+            }
+        }
+    }
+    if (S.kind == ST_NORM) {
+        // materialise the child straight into `vals` (the stage's own output buffer)
+        S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
+        S.in_buf = S.out_buf;
+        S.in_pitch = -1;
+    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype))) {
+        // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
+        // staging, no intermediate in HBM
+        S.in_buf = -1;
+        S.in_array_node = -1;
+        if (S.carriers[0].pad_) {
+            // GA instantiation: Float32 tiles (pitch in floats, 16-byte rows, 128-byte aligned start),
+            // three gain arrays, no in-place work for the loaders
+            RsPeriodic& rp = S.rp;
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            rp.ga = 1;
+            rp.lds_pitch = (int)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
+            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 4;
+            rp.fslots = 1;
+            rp.fpitch = (rp.tile_len + 16 + 1) & ~1;
+            const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
+            const bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases &&
+                             (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
+            rp.ftwo = two ? 1 : 0;
+            const size_t fbytes = (size_t)3 * rp.fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
+            rp.nslots = (int)std::min<size_t>(4, (avail - fbytes) / tile_bytes);
+            if (const char* ev = std::getenv("SIGOPS_RS_SLOTS")) rp.nslots = std::min(rp.nslots, std::max(2, std::atoi(ev)));
+            rp.nload = 0;
+        } else {
+        // gain ring: two LDS arrays [slots][tile frames] next to the tile ring, if at least two
+        // tile slots still fit (see k_resample_periodic)
+            RsPeriodic& rp = S.rp;
+            const int ns0 = S.carriers[0].nslots;
+            const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * dsize(N.dtype);
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            const int fpitch = (rp.tile_len + 16 + 1) & ~1;
+            // slot 0 (the only one) a sine generator: the kernel's two-level evaluation (TWO)
+            bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases && ns0 == 1 && N.dtype == SO_F64 &&
+                       (rp.ngroups + rp.ncompute - 1) / rp.ncompute == 1;
+            if (two) {
+                const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
+                two = (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;
+            }
+            const size_t fbytes = (size_t)2 * ns0 * fpitch * 8 + (two ? kRsTwoDoubles * 8 : 0);
+            if (ns0 > 0 && S.carriers[0].nsteps > 0 && !std::getenv("SIGOPS_RS_NOFRING") &&
+                fbytes + 2 * tile_bytes <= avail) {
+                rp.fslots = ns0;
+                rp.fpitch = fpitch;
+                rp.ftwo = two ? 1 : 0;
+                // the in-place multiply is vector-ALU work next to the MFMAs: keep it off the
+                // SIMDs that carry the most compute waves (10 compute waves: loaders 10,11,14,15
+                // on SIMD 2/3 copy and modify, 12,13 only keep the barrier count; measured
+                // 0.790 -> 0.780 ms on config 3, three alternating runs each)
+                if (!std::getenv("SIGOPS_RS_NLOAD")) {
+                    auto ncomp_on = [&](int w) { return (rp.ncompute - (w & 3) + 3) >> 2; };
+                    int minc = 1 << 30, cnt = 0;
+                    for (int w = rp.ncompute; w < rp.nwaves; ++w) minc = std::min(minc, ncomp_on(w));
+                    for (int w = rp.ncompute; w < rp.nwaves; ++w) cnt += ncomp_on(w) == minc;
+                    if (cnt >= 2) rp.nload = cnt;
+                }
+                rp.nslots = (int)std::min<size_t>(rp.nslots, (avail - fbytes) / tile_bytes);
+            }
+        }
+    } else if (!direct) {
+        S.in_buf = new_buf(in_frames, N.nch, in_dtype);
+        S.in_pitch = -1;
+        S.in_array_node = -1;
+        S.in_offset = 0;
+        S.pw_step = emit_pointwise(ps, S.in_buf, in_dtype);
+    }
+    if (S.kind == ST_RESAMPLE && S.periodic && S.carriers.empty()) {
+        // plain source (direct array / stage buffer / materialised input): one 0-step carrier
+        DCarrier c{};
+        c.a = 0;
+        c.b = in_frames;
+        c.dtype = in_dtype;
+        c.array_node = S.in_array_node;
+        c.buf = S.in_array_node >= 0 ? -1 : S.in_buf;
+        c.df = S.in_offset;
+        c.cstride = S.in_array_node >= 0 ? (N.nch == 1 ? 0 : S.in_pitch) : -1;  // -1: buffer pitch
+        S.carriers.push_back(c);
+    }
+    if (!S.carriers.empty()) {
+        S.car_buf = raw_buf(S.carriers.size() * sizeof(DCarrier));
+        S.ctl_buf = raw_buf(sizeof(RsCtl));
+    }
+}
+
+// e == carrier load combined with channel-independent operands by a short chain of ops?
+bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
+    const Expr e = exprs[ei];
+    auto add_step = [&](int op, int mono_expr, bool flip, bool round32) {
+        if (C.nsteps >= 4) return false;
+        int slot = 0;
+        if (mono_expr >= 0) {
+            auto it = std::find(monos.begin(), monos.end(), mono_expr);
+            if (it == monos.end()) {
+                if ((int)monos.size() >= kMaxFrameSlots) return false;
+                monos.push_back(mono_expr);
+                slot = (int)monos.size() - 1;
+            } else slot = (int)(it - monos.begin());
+        }
+        C.op[C.nsteps] = op;
+        C.arg[C.nsteps] = slot | (flip ? 0x100 : 0) | (round32 ? 0x200 : 0);
+        C.nsteps++;
+        return true;
+    };
+    if (e.mono && C.nsteps == 0 && C.base == nullptr && C.buf == -1 && C.array_node == -1) {
+        // channel-independent piece (generator, constant, padding value): no array at all,
+        // the value is a per-frame slot
+        C.dtype = e.dtype == SO_F32 ? SO_F32 : SO_F64;
+        return add_step(OP_LOADF, ei, false, false);
+    }
+    switch (e.op) {
+    case E_LOAD: {
+        const DLeaf& L = e.leaf;
+        if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1) return false;
+        if (e.array_node < 0 && L.dc != 0) return false;
+        if (L.dc < 0) return false;
+        C.dtype = L.dtype;
+        C.array_node = e.array_node;
+        C.buf = e.array_node >= 0 ? -1 : L.buf;
+        C.cstride = L.cstride;  // -1: buffer pitch (patched in finalize)
+        C.df = L.df + (e.array_node >= 0 ? L.dc * L.cstride : 0);
+        if (e.array_node >= 0) count_array(e.array_node);
+        return true;
+    }
+    case E_RETYPE: return match_carrier(e.a, C, monos);
+    case E_ROUND32: return match_carrier(e.a, C, monos) && add_step(OP_ROUND32, -1, false, true);
+    case E_NEG: return match_carrier(e.a, C, monos) && add_step(OP_NEG, -1, false, false);
+    case E_ADD:
+    case E_SUB:
+    case E_MUL:
+    case E_DIV: {
+        int oc = e.op == E_ADD ? OP_ADD : e.op == E_SUB ? OP_SUB : e.op == E_MUL ? OP_MUL : OP_DIV;
+        bool r32 = e.dtype == SO_F32;
+        if (exprs[e.b].mono) {
+            DCarrier c2 = C;
+            std::vector<int> m2 = monos;
+            if (match_carrier(e.a, c2, m2)) {
+                C = c2;
+                monos = m2;
+                return add_step(oc, e.b, false, r32);
+            }
+        }
+        if (exprs[e.a].mono) {
+            DCarrier c2 = C;
+            std::vector<int> m2 = monos;
+            if (match_carrier(e.b, c2, m2)) {
+                C = c2;
+                monos = m2;
+                return add_step(oc, e.a, true, r32);
+            }
+        }
+        return false;
+    }
+    default: return false;
+    }
+}
+
+bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out, bool allow_ga) {
+    std::vector<Piece> ps = ps_in;
+    for (auto& p : ps)
+        if (p.r.c0 != 0 || p.r.c1 != nch) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 1); return false; }
+    std::sort(ps.begin(), ps.end(), [](const Piece& a, const Piece& b) { return a.r.a < b.r.a; });
+    std::vector<DCarrier> cs;
+    std::vector<std::vector<int>> monos_all;
+    for (auto& p : ps) {
+        DCarrier c{};
+        c.buf = -1;
+        c.array_node = -1;
+        std::vector<int> monos;
+        if (!match_carrier(p.e, c, monos)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 2); return false; }
+        c.a = p.r.a;
+        c.b = p.r.b;
+        cs.push_back(c);
+        monos_all.push_back(monos);
+    }
+    // compile the per-frame programs; everything must fit the kernel-argument control block
+    if (cs.size() > (size_t)kCtlCar) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 3); return false; }
+    // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
+    // staging path, ~6x slower than a K1 pass + the LDS-DMA fast path), so steps on fp32 data
+    // are materialised by K1 instead of fused
+    // ... except the commonest case, ONE Float32 array times ONE Float64 per-frame gain (`Amplify(x32,
+    // Signal(sin))`, a Float64 product): the kernel's GA instantiation keeps the raw Float32 tile
+    // and multiplies at the A operand (allow_ga: the caller has checked geometry and LDS budget)
+    // Further carriers may only be generated pieces whose value is that same gain (the tail of an
+    // infinite `Amplify`: the array's padding `one` times the gain): staged as 1.0f.
+    bool ga = false;
+    if (allow_ga && !cs.empty() && cs[0].dtype == SO_F32 && cs[0].nsteps == 1 && cs[0].op[0] == OP_MUL &&
+        !(cs[0].arg[0] & 0x200) && (cs[0].array_node >= 0 || cs[0].buf >= 0) && monos_all[0].size() == 1) {
+        ga = true;
+        for (size_t i = 1; i < cs.size(); ++i)
+            if (cs[i].base != nullptr || cs[i].array_node >= 0 || cs[i].buf >= 0 || cs[i].nsteps != 1 ||
+                cs[i].op[0] != OP_LOADF || (cs[i].arg[0] & 0x300) || monos_all[i].size() != 1 || cs[i].dtype != SO_F64)
+                ga = false;
+    }
+    if (std::getenv("SIGOPS_DEBUG_PLAN") && !cs.empty())
+        std::fprintf(stderr, "[sigops] carriers=%zu allow_ga=%d dtype=%d nsteps=%d op=%d arg=%#x monos=%zu -> ga=%d\n", cs.size(), (int)allow_ga,
+                     cs[0].dtype, cs[0].nsteps, cs[0].op[0], cs[0].arg[0], monos_all[0].size(), (int)ga);
+    for (auto& c : cs)
+        if (!ga && c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
+    std::vector<std::vector<DOp>> fcodes(cs.size());
+    size_t nops_total = 0;
+    std::set<int> leafset;
+    const size_t leaves_before = leaves.size();
+    for (size_t i = 0; i < cs.size(); ++i) {
+        DCarrier& c = cs[i];
+        std::vector<DOp>& fcode = fcodes[i];
+        int dmax = 2;
+        c.nslots = (int)monos_all[i].size();
+        for (size_t k = 0; k < monos_all[i].size(); ++k) {
+            // closed form for the kernel's hot loop: a single leaf, optionally rounded to
+            // Float32; compound per-frame expressions are not fused
+            int ei = monos_all[i][k], r32 = 0;
+            for (;;) {
+                const Expr& ex = exprs[ei];
+                if (ex.op == E_RETYPE) ei = ex.a;
+                else if (ex.op == E_ROUND32) { r32 = 0x100; ei = ex.a; }
+                // `0 + g` / `g + 0`: the zero-padded tail of a `Mix` operand under a generator (the
+                // sum differs from g only in the sign of a zero)
+                else if (ex.op == E_ADD && is_const(ex.a, 0.0)) ei = ex.b;
+                else if ((ex.op == E_ADD || ex.op == E_SUB) && is_const(ex.b, 0.0)) ei = ex.a;  // (g - 0 == g exactly)
+                else break;
+            }
+            const int eop = exprs[ei].op;
+            const int kind = eop == E_CONST ? OP_CONST : eop == E_SCALAR ? OP_SCALAR : eop == E_FUNC ? OP_FUNC : eop == E_RAMP ? OP_RAMP : -1;
+            if (kind < 0) {
+                leaves.resize(leaves_before);
+                leaf_array_node.resize(leaves_before);
+                { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 5); return false; }
+            }
+            c.slot_leaf[k] = add_leaf(exprs[ei]);
+            c.slot_kind[k] = kind | r32;
+            leafset.insert(c.slot_leaf[k]);
+            std::map<int, int> none;
+            gen(monos_all[i][k], fcode, none, fcode, false);
+            fcode.push_back(DOp{OP_STOREF, (int)k});
+            dmax = std::max(dmax, depth(monos_all[i][k]));
+        }
+        c.depth = dmax;
+        nops_total += fcode.size();
+        for (auto& o : fcode)
+            if (o.code <= OP_RAMP) leafset.insert(o.arg);
+        // the in-kernel frame interpreter is the 2-deep one
+        if (dmax > 2 || nops_total > (size_t)kCtlOps || leafset.size() > (size_t)kCtlLeaves) {
+            leaves.resize(leaves_before);  // drop what gen() appended
+            leaf_array_node.resize(leaves_before);
+            { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 6); return false; }
+        }
+    }
+    // commit
+    for (size_t i = 0; i < cs.size(); ++i) {
+        cs[i].frame_pc = (int)ops.size();
+        cs[i].frame_len = (int)fcodes[i].size();
+        ops.insert(ops.end(), fcodes[i].begin(), fcodes[i].end());
+    }
+    if (ga) {
+        // the generated pieces must be exactly carrier 0's gain
+        auto same_leaf = [&](int a, int b) {
+            const DLeaf &x = leaves[a], &y = leaves[b];
+            return x.base == y.base && x.fstride == y.fstride && x.cstride == y.cstride && x.df == y.df && x.dc == y.dc &&
+                   x.modn == y.modn && x.v0 == y.v0 && x.v1 == y.v1 && x.v2 == y.v2 && x.sf == y.sf && x.sc == y.sc &&
+                   x.dtype == y.dtype && x.mode == y.mode && x.flag == y.flag && x.buf == y.buf;
+        };
+        for (size_t i = 1; i < cs.size(); ++i)
+            if (cs[i].slot_kind[0] != cs[0].slot_kind[0] || !same_leaf(cs[i].slot_leaf[0], cs[0].slot_leaf[0])) ga = false;
+        if (!ga) {
+            leaves.resize(leaves_before);
+            leaf_array_node.resize(leaves_before);
+            ops.resize(ops.size() - nops_total);
+            if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 7);
+            return false;
+        }
+        // the staging code copies the raw samples (1.0f for the generated pieces); the multiply
+        // happens at the A operand
+        for (size_t i = 0; i < cs.size(); ++i) {
+            cs[i].pad_ = i == 0 ? 1 : 2;
+            cs[i].nsteps = 0;
+            cs[i].dtype = SO_F32;
+        }
+    }
+    out = cs;
+    return true;
+}
+
+// Kernel-argument control block of a periodic resampler stage: carriers with their frame
+// programs and leaves re-indexed into the block (built per execute from the patched tables).
+RsCtl Plan::make_ctl(const Stage& S) const {
+    RsCtl ctl{};
+    std::map<int, int> leafmap;
+    for (const DCarrier& c0 : S.carriers) {
+        if (ctl.ncar >= kCtlCar) throw PlanError{SO_ERR_RUNTIME, "internal: carrier control block overflow"};
+        DCarrier c = c0;
+        c.frame_pc = ctl.nops;
+        for (int k = 0; k < c0.frame_len; ++k) {
+            DOp o = ops[c0.frame_pc + k];
+            if (o.code <= OP_RAMP) {
+                auto it = leafmap.find(o.arg);
+                if (it == leafmap.end()) {
+                    if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
+                    ctl.leaves[ctl.nleaves] = leaves[o.arg];
+                    it = leafmap.emplace(o.arg, ctl.nleaves++).first;
+                }
+                o.arg = it->second;
+            }
+            if (ctl.nops >= kCtlOps) throw PlanError{SO_ERR_RUNTIME, "internal: op control block overflow"};
+            ctl.ops[ctl.nops++] = o;
+        }
+        for (int k = 0; k < c0.nslots; ++k) {
+            auto it = leafmap.find(c0.slot_leaf[k]);
+            if (it == leafmap.end()) {
+                if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
+                ctl.leaves[ctl.nleaves] = leaves[c0.slot_leaf[k]];
+                it = leafmap.emplace(c0.slot_leaf[k], ctl.nleaves++).first;
+            }
+            c.slot_leaf[k] = it->second;
+        }
+        ctl.car[ctl.ncar++] = c;
+    }
+    return ctl;
+}
+
+
+// ---------------------------------------------------------------------------
+// Resampler -> IIR: fold the IIR's state pass into the resampler.
+// The three-pass K2 reads its input twice; when that input is the output of a periodic resampler
+// stage and nothing else reads it, the first read can go: a chunk's zero-state end state is linear
+// in the resampler's INPUT,  v = sum_r G[r] y[r],  y[r] = sum_k Tap_r[k] x[j_r - k]
+//                              = sum_i W[i] x[i],   W = G . Tap   (D x window of one period),
+// and the resampler has that window staged in LDS anyway.  Two of its loader waves become state
+// waves (k_resample_periodic): one MFMA pass over the window per period row, written as
+// vper[ch][period][16]; K2 then combines pt periods into a chunk (k_sos_combine), scans and runs
+// its output pass.  (Reference: the same filt! at src/filters.jl:252-255; values differ from the
+// sequential recurrence by rounding of the start states, ~1e-16 relative.)
+// Opt-in (SIGOPS_FUSE_STATE=1).  Measured on the north-star pipeline (28.8 M x 8, order 10): K2 1.13 ->
+// 0.90 ms and its traffic 5.57 -> ~4.1 GB, but the two state waves' 48 MFMAs per tile are the
+// resampler's critical path (tile period 9 800 -> 12 200 cycles): K3 0.72 -> 0.90 ms.  Break-even
+// (1.79 vs 1.76-1.83 ms), so the three-pass form stays the default.
+void Plan::fuse_state_passes() {
+    if (!std::getenv("SIGOPS_FUSE_STATE")) return;
+    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+        Stage& S2 = stages[i2];
+        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.base > 0 || S2.groups.size() != 1 || S2.in_buf < 0 ||
+            S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.nchunks <= 1)
+            continue;
+        int i3 = -1;
+        for (size_t j = 0; j < stages.size(); ++j)
+            if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
+        if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
+        Stage& S3 = stages[i3];
+        const RsPeriodic& rp0 = S3.rp;
+        if (!S3.periodic || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
+            rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
+            (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
+            continue;  // (the instantiations with state waves: kernels.hip launch_rp_st)
+        // nothing else may read the intermediate
+        bool other = false;
+        for (auto& L : leaves)
+            if (L.buf == S2.in_buf) other = true;
+        for (size_t j = 0; j < stages.size(); ++j) {
+            if (j != i2 && stages[j].in_buf == S2.in_buf) other = true;
+            for (auto& c : stages[j].carriers)
+                if (c.buf == S2.in_buf) other = true;
+        }
+        if (other) continue;
+        const SosCoefs& cf = S2.groups[0];
+        const int D = 2 * cf.nsec;
+        const int64_t Ls = rp0.L, L = (int64_t)rp0.pt * Ls;
+        if (L < 32 || L > 16384) continue;
+        // chunk geometry with L = pt periods
+        const double tol = std::ldexp(1.0, -70);
+        Mat A = sos_state_matrix(cf);
+        Mat M = matpow(A, L, D), cur = ident(D);
+        std::vector<double> mp;
+        int K = 0;
+        bool ok = true;
+        for (;;) {
+            mp.insert(mp.end(), cur.begin(), cur.end());
+            ++K;
+            cur = matmul(cur, M, D);
+            if (maxabs(cur) < tol) break;
+            if (K >= 64) {
+                ok = false;
+                break;
+            }
+        }
+        const int64_t nchunks = (S2.need + L - 1) / L;
+        if (!ok || nchunks <= 1) continue;
+        // W = G . Tap over the staged span [jlo, jlo + 4*ksw) of a period row
+        const so_node_t& nd3 = nodes[S3.node].nd;
+        const double* h = (const double*)nd3.p0;
+        const int hlen = nd3.i2, nphi = S3.rg.nphi, taps = S3.rg.taps;
+        const int jlo = rp0.jlo;
+        const int ksw = 2 * 24;  // two state waves x kSwK k-steps (kernels.hip)
+        if ((S3.jend_last - jlo + 1 + 3) / 4 > ksw) continue;  // the staged span of a row must fit
+        // (window slots beyond the span have zero taps; there a row's window runs into the next
+        //  row's staged frames or the slot's slack -- finite values: the kernel zeroes its LDS ring
+        //  once at start when it has state waves, and 0 x finite is 0)
+        std::vector<double> G((size_t)Ls * D, 0.0);  // G[r] = A^(Ls-1-r) B1
+        {
+            std::vector<double> st_(D, 0.0);
+            double y = 1.0;
+            for (int f = 0; f < cf.nsec; ++f) {  // one DF2T step with x = 1 from zero state
+                const double xi = y;
+                y = st_[2 * f] + cf.b0[f] * xi;
+                st_[2 * f] = st_[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
+                st_[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
+            }
+            for (int64_t r = Ls - 1; r >= 0; --r) {
+                for (int d = 0; d < D; ++d) G[(size_t)r * D + d] = st_[d];
+                std::vector<double> nx(D, 0.0);
+                for (int a = 0; a < D; ++a)
+                    for (int b = 0; b < D; ++b) nx[a] += A[(size_t)a * D + b] * st_[b];
+                st_ = nx;
+            }
+        }
+        std::vector<double> wt((size_t)4 * ksw * 16, 0.0);
+        for (int64_t r = 0; r < Ls; ++r)
+            for (int age = 0; age < taps; ++age) {
+                const int64_t rel = S3.per_j[r] - age - jlo;  // input slot of this tap
+                if (rel < 0 || rel >= 4 * ksw) {
+                    ok = false;  // (cannot happen: the span covers every tap of the period)
+                    continue;
+                }
+                const int64_t hi = S3.per_p[r] + (int64_t)nphi * age;
+                const double hv = hi < hlen ? h[hi] : 0.0;
+                const double dv = hi + 1 < hlen ? h[hi + 1] - h[hi] : 0.0;
+                const double tv = hv + S3.per_a[r] * dv;
+                for (int d = 0; d < D; ++d) wt[(size_t)rel * 16 + d] += G[(size_t)r * D + d] * tv;
+            }
+        if (!ok) continue;
+        // LDS: the taps ([4*ksw][10] doubles) go behind the gain ring; keep at least three tile slots
+        {
+            const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
+            const size_t tile_bytes = (size_t)rp0.ct * rp0.lds_pitch * 8;
+            const size_t fbytes = (size_t)2 * rp0.fslots * rp0.fpitch * 8 + (rp0.ftwo ? kRsTwoDoubles * 8 : 0);
+            const size_t wbytes = (size_t)4 * ksw * 10 * 8;
+            if (fbytes + wbytes + 3 * tile_bytes > avail) continue;
+            S3.rp.nslots = (int)std::min<size_t>(S3.rp.nslots, (avail - fbytes - wbytes) / tile_bytes);
+        }
+        // commit: resampler side
+        S3.rp.nstate = 2;
+        S3.rp.ksw = ksw;
+        S3.wtab_host = wt;
+        S3.wtab_buf = raw_buf(wt.size() * 8);
+        S3.vper_buf = raw_buf((size_t)2 * nodes[S3.node].nch * rp0.nperiods * 16 * 8);
+        // ... and the IIR side
+        S2.pre_stage = i3;
+        S2.qmat_host = matpow(A, Ls, D);
+        S2.qmat_buf = raw_buf(S2.qmat_host.size() * 8);
+        S2.sg.chunk = L;
+        S2.sg.nchunks = (int)nchunks;
+        S2.sg.kterms = K;
+        S2.mpow_host.assign(1, mp);
+        if (S2.mpow_buf >= 0) bufs[S2.mpow_buf].bytes = std::max<size_t>(8, mp.size() * 8);
+        else S2.mpow_buf = raw_buf(mp.size() * 8);
+        const size_t vb = (size_t)nchunks * S2.sg.nch * 2 * kMaxSec * 8;
+        if (S2.v_buf >= 0) bufs[S2.v_buf].bytes = vb;
+        else S2.v_buf = raw_buf(vb);
+        if (S2.s0_buf >= 0) bufs[S2.s0_buf].bytes = vb;
+        else S2.s0_buf = raw_buf(vb);
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr, "[sigops] IIR state pass fused into the resampler: chunk %lld frames, K=%d, window %d inputs\n",
+                         (long long)L, K, 4 * ksw);
+    }
+}
+
+
+}  // namespace so

@@ -1,6 +1,6 @@
 """Host logic of the engine's resampler positions (no GPU): so_resample_positions exposes the
 (newest input, phase, alpha) the HIP kernels use per output -- closed form + period positions
-baked from DSP.jl's phase accumulator + the sparse fix-up list (planner.cpp
+baked from DSP.jl's phase accumulator + the sparse fix-up list (csrc/accumulator.cpp
 replay_phase_accumulator).  Applying them in NumPy must reproduce the oracle's DEFAULT mode,
 which is the reference's FIRArbitrary algorithm (reference src/reformatting.jl:92-98,
 src/filters.jl:252-255)."""
