@@ -685,8 +685,15 @@ void Plan::gen(int ei, std::vector<DOp>& code, std::map<int, int>& hoisted,
         code.push_back(DOp{OP_ROUND32, 0});
         return;
     default: {
-        gen(e.a, code, hoisted, fcode, allow_hoist);
-        gen(e.b, code, hoisted, fcode, allow_hoist);
+        // `per-frame value (+|*) samples`: samples first (the same sum / product bit for bit), so that
+        // Mix(sin, x) and Amplify(gain, x) compile to the kernel's chain form like Mix(x, sin)
+        // (only when the per-frame operand is ONE opcode -- a hoisted slot or a constant -- so that the
+        //  stack depth depth() predicts for the original order still holds)
+        const Expr& ea = exprs[e.a];
+        const bool one_op = ea.op == E_CONST || (allow_hoist && ea.heavy && (hoisted.count(e.a) || (int)hoisted.size() < kMaxFrameSlots));
+        const bool swap = (e.op == E_ADD || e.op == E_MUL) && ea.mono && one_op && !exprs[e.b].mono;
+        gen(swap ? e.b : e.a, code, hoisted, fcode, allow_hoist);
+        gen(swap ? e.a : e.b, code, hoisted, fcode, allow_hoist);
         int oc = e.op == E_ADD ? OP_ADD : e.op == E_SUB ? OP_SUB : e.op == E_MUL ? OP_MUL : OP_DIV;
         code.push_back(DOp{oc, 0});
         if (e.dtype == SO_F32) code.push_back(DOp{OP_ROUND32, 0});  // Julia Float32 arithmetic
