@@ -879,6 +879,7 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
             int64_t want = (2048 + d.nblk_f - 1) / d.nblk_f;
             chc = (int)std::max<int64_t>(1, nchp / std::min<int64_t>(want, nchp));
         }
+        if (const char* ev = std::getenv("SIGOPS_K1_CHC")) chc = std::max(1, std::min(nchp, std::atoi(ev)));  // tuning knob
         d.chc = chc;
         int nbc = (nchp + chc - 1) / chc;
         d.block0 = blk;
