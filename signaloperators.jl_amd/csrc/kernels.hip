@@ -2867,8 +2867,57 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_final(const double* __restrict
     if (threadIdx.x == 0) rms[0] = sqrt(red[0] / count);
 }
 
+// Float32 signals: Julia reduces `mean(x -> float(x)^2, vals)` in Float32 -- pairwise over blocks of
+// 1024 values (Base.mapreduce_impl).  The same order as the oracle's restatement
+// (oracle/sigops_oracle.c, NORMPOWER): every block summed front to back in Float32 (separate
+// multiply and add), then neighbours folded level by level; rms = sqrt(sum / count) in Float32.
+__global__ __launch_bounds__(kBlock) void k_sumsq32_blocks(const float* __restrict__ x, int64_t n, int nch,
+                                                           int64_t pitch, float* __restrict__ part, int64_t nb) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nb) return;
+    const int64_t total = n * nch;
+    const int64_t e = (b + 1) * 1024 < total ? (b + 1) * 1024 : total;
+    int64_t i = b * 1024;
+    int64_t ch = i / n, f = i - ch * n;
+    float acc = 0.f;
+    for (; i < e; ++i) {
+        const float v = x[ch * pitch + f];
+        acc = __fadd_rn(acc, __fmul_rn(v, v));
+        if (++f == n) {
+            f = 0;
+            ++ch;
+        }
+    }
+    part[b] = acc;
+}
+__global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, float* __restrict__ b, int64_t nb,
+                                                         float count, double* __restrict__ rms) {
+    float* in = a;
+    float* out = b;
+    int64_t m = nb;
+    while (m > 1) {
+        const int64_t h = (m + 1) / 2;
+        for (int64_t i = threadIdx.x; i < m / 2; i += kBlock) out[i] = __fadd_rn(in[2 * i], in[2 * i + 1]);
+        if ((m & 1) && threadIdx.x == 0) out[m / 2] = in[m - 1];
+        __syncthreads();
+        float* t = in;
+        in = out;
+        out = t;
+        m = h;
+    }
+    if (threadIdx.x == 0) rms[0] = (double)sqrtf(__fdiv_rn(nb ? in[0] : 0.f, count));
+}
+
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
                 int nparts, double* rms, hipStream_t st) {
+    if (dtype == SO_F32) {
+        const int64_t nb = (n * nch + 1023) / 1024;
+        float* pa = (float*)partial;
+        hipLaunchKernelGGL(k_sumsq32_blocks, dim3((unsigned)((nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const float*)x, n, nch, pitch, pa, nb);
+        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nb, nb, (float)((double)n * (double)nch), rms);
+        return;
+    }
     if (dtype == SO_F32)
         hipLaunchKernelGGL((k_sumsq_partial<float>), dim3(nparts), dim3(kBlock), 0, st,
                            (const float*)x, n, nch, pitch, partial);

@@ -635,11 +635,23 @@ void Plan::process_stage(int sid) {
                     }
                 }
                 if (!ok) break;
+                if (k < 2) {  // (the scan kernel reads M itself, entry 1, whatever K is)
+                    all.insert(all.end(), cur.begin(), cur.end());
+                    k = 2;
+                }
                 K = std::max(K, k);
                 mp.push_back(all);
             }
             if (ok) break;
             L *= 2;  // slower-decaying filter: fewer, longer chunks
+        }
+        // Short signals are filtered without either cut (every earlier chunk enters the scan, the state
+        // pass runs over whole chunks): what has decayed below 2^-70 of an earlier peak -- the tail of a
+        // filter long after its input went silent -- then keeps the relative accuracy of the sequential
+        // recurrence, which a `Normpower` of such a tail makes visible (tools/tree_soak.py 1396/7).
+        if (nchunks > 1 && nchunks <= 64) {
+            K = std::max<int>(K, (int)nchunks);
+            W = std::max(W, L);
         }
         // every group is scanned with the same K (pad shorter tables with zeros)
         for (size_t gi = 0; gi < mp.size(); ++gi) {
@@ -666,7 +678,9 @@ void Plan::process_stage(int sid) {
         int64_t total = need * N.nch;
         int nparts = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + kBlock * 8 - 1) / (kBlock * 8)));
         stages[sid].nparts = nparts;
-        stages[sid].partial_buf = raw_buf((size_t)nparts * 8);
+        // (Float32: one Float32 partial per block of 1024 values, two copies for the pairwise fold)
+        const size_t nb32 = N.dtype == SO_F32 ? (size_t)((total + 1023) / 1024) : 0;
+        stages[sid].partial_buf = raw_buf(std::max((size_t)nparts * 8, 2 * nb32 * 4));
     }
 
     // lower the child over the frames this stage consumes
