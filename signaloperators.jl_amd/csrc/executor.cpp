@@ -379,7 +379,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         ob.pitch = P->bufs[P->out_stage_buf].pitch;
                     }
                     // (local frame alias_skip is the result's frame 0; earlier frames are not stored)
-                    ob.d = (char*)ob.d - (size_t)P->alias_skip * esz;
+                    ob.d = (char*)ob.d - (size_t)P->alias_skip * (P->alias_narrow ? dsize(P->out.dtype) : esz);
                 } else if (S.win_off >= 0) {  // ... or its window of it
                     const Buf& ab = P->bufs[P->out_alias_buf];
                     ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
@@ -390,6 +390,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     g.in_pitch = in_pitch;
                     g.out_pitch = ob.pitch;
                     g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
+                    if (s.idx == P->alias_stage && P->alias_narrow) g.out_dtype = SO_F32;
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;

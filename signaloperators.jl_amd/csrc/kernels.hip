@@ -768,8 +768,12 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const int r = j * 4 + rsub;
-                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= g.store_lo)
-                    y[(int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col] = (T)tl[r * (kTT + 1) + col];
+                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= g.store_lo) {
+                    const int64_t o = (int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col;
+                    // (a Float64 filter writing a Float32 result itself: `convert` on store, src/sink.jl:262-266)
+                    if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)tl[r * (kTT + 1) + col];
+                    else y[o] = (T)tl[r * (kTT + 1) + col];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -319,6 +319,32 @@ def test_float64_signal_into_float32_result(nch, leaf_dtype, fused):
     assert np.mean(res != w32) < 1e-3
 
 
+@pytest.mark.parametrize("nch", [1, 2, 8])
+@pytest.mark.parametrize("skip", [0, 30001])
+def test_float64_filter_into_float32_result(nch, skip):
+    """... and when the root is an IIR its pass 3 rounds in its own store (also for a window of it: the
+    warm-up frames in front are left out)"""
+    rng = np.random.default_rng(68)
+    n = 60000
+    x = np.asfortranarray(rng.standard_normal((n, nch)))
+    tree = so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(x, 44.1 * so.kHz)) | so.Until(n * so.frames) \
+        | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    if skip:
+        tree = tree | so.After(skip * so.frames)
+    want = oracle_sink(tree)
+    assert want.dtype == np.float64
+    res = np.full((so.nframes(tree), nch), np.nan, dtype=np.float32, order="F")
+    so.sink_into(res, tree)
+    w32 = want.astype(np.float32)
+    assert relerr(res.astype(np.float64), w32.astype(np.float64)) < 1e-7
+    assert np.mean(res != w32) < 1e-3
+    torch = pytest.importorskip("torch")
+    dev = torch.full((nch, so.nframes(tree) + 3), float("nan"), dtype=torch.float32, device="cuda")
+    so.sink_into(dev.t()[:so.nframes(tree)], tree)
+    assert np.array_equal(dev[:, :so.nframes(tree)].t().cpu().numpy(), res)
+    assert bool(torch.isnan(dev[:, so.nframes(tree):]).all())
+
+
 @pytest.mark.parametrize("nch,n,res_dt,gen", [(8, 300_000, np.float64, dict(ω=5 * so.Hz)), (4, 120_000, np.float64, dict(ω=440 * so.Hz, ϕ=0.3)),
                                              (8, 50_000, np.float32, dict(ω=5 * so.Hz)), (8, 9_000, np.float64, dict()),
                                              (4, 200_000, np.float32, dict(ω=50 * so.Hz))])
