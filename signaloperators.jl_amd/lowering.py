@@ -22,9 +22,20 @@ def _len_code(n):
     return int(n)
 
 
+_DESIGNS = {}  # (what, parameters) -> designed coefficients (designs are pure functions of their parameters)
+
+
 def design_iir(fn, fs):
     """FilterFn(fs): digitalfilter(design(args...,fs=fs),method) -> SOS
     (reference src/filters.jl:10-11,94) through the library's design entry point."""
+    key = ("iir", fn.design, tuple(fn.method), tuple(float(a) for a in fn.args), float(fs))
+    if key not in _DESIGNS:
+        _DESIGNS[key] = _design_iir(fn, fs)
+    sos, gain = _DESIGNS[key]
+    return sos.copy(), gain  # (callers own their copy)
+
+
+def _design_iir(fn, fs):
     L = K.lib()
     method = fn.method
     order = method[1]
@@ -44,6 +55,13 @@ def design_iir(fn, fs):
 
 def design_resample(ratio):
     """resample_filter(ratio) (reference src/reformatting.jl:93)"""
+    key = ("resample", ratio)
+    if key not in _DESIGNS:
+        _DESIGNS[key] = _design_resample(ratio)
+    return _DESIGNS[key].copy()
+
+
+def _design_resample(ratio):
     L = K.lib()
     n = C.c_int32(0)
     if isinstance(ratio, tuple):

@@ -103,6 +103,21 @@ class AbstractSignal:
     def nframes_helper(self):
         raise NotImplementedError
 
+    def __init_subclass__(cls, **kw):
+        # signals are immutable once built and their length is asked for again and again (every node of
+        # every lowering, every block of so.stream): remember it per object
+        super().__init_subclass__(**kw)
+        f = cls.__dict__.get("nframes_helper")
+        if f is not None and not getattr(f, "_memo", False):
+            def helper(self, _f=f):
+                d = self.__dict__
+                if "_nframes_memo" not in d:
+                    d["_nframes_memo"] = _f(self)
+                return d["_nframes_memo"]
+            helper._memo = True
+            helper.__doc__ = f.__doc__
+            cls.nframes_helper = helper
+
     def __or__(self, fn):  # x |> f
         if callable(fn):
             return fn(self)
