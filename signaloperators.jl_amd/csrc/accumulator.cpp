@@ -1,5 +1,7 @@
 // DSP.jl phase accumulator replay for the arbitrary-rate resampler (see the comment below) and the
 // host-only position diagnostics of the C-ABI (so_resample_positions).
+#include <thread>
+
 #include "plan_impl.h"
 
 namespace so {
@@ -93,7 +95,8 @@ void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_
         fix.clear();
         return;
     }
-    {
+    const bool nocache = std::getenv("SIGOPS_REPLAY_NOCACHE") != nullptr;  // (tests: compare replays, not cache hits)
+    if (!nocache) {
         std::lock_guard<std::mutex> lock(mu);
         for (auto& e : cache)
             if (e.k == k) {
@@ -143,14 +146,12 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     // closed-form rule of the kernels
     const bool exact = g.exact != 0;
     const int64_t L = g.L, dq = exact ? ((int64_t)nphi * g.M) / L : 0, dfr = exact ? ((int64_t)nphi * g.M) % L : 0;
-    int64_t qe = g.c0i, fe = 0;
     struct Rec { int64_t m, qa; double alpha; };
     std::vector<Rec> rec;
-    std::vector<int8_t> memo((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
     int64_t m0 = 0;
     const AccKey ckey = acc_key(g, h, hlen);
     std::vector<AccCheckpoint> made;
-    if (from > 0) {  // resume from the nearest checkpoint at or before the window
+    if (from > 0 && !std::getenv("SIGOPS_REPLAY_NOCACHE")) {  // resume from the nearest checkpoint at or before the window
         std::lock_guard<std::mutex> lock(g_acc_mu);
         for (auto& e : g_acc_checkpoints)
             if (e.first == ckey)
@@ -160,64 +161,157 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                         xb = c.xb;
                         acc = c.acc;
                     }
+    }
+    // outputs [ma, mb) from the accumulator state (xb, acc) before output ma; deviations of outputs
+    // >= from are appended to `out`; the state before output mb is left in (xb, acc)
+    auto run = [&](int64_t ma, int64_t mb, int64_t& xb, double& acc, std::vector<Rec>& out, std::vector<int8_t>& memo) {
+        int64_t qe = g.c0i, fe = 0;
         if (exact) {
-            const __int128 Nn = (__int128)m0 * ((int64_t)nphi * g.M);
+            const __int128 Nn = (__int128)ma * ((int64_t)nphi * g.M);
             qe = g.c0i + (int64_t)(Nn / L);
             fe = (int64_t)(Nn % L);
         }
+        for (int64_t m = ma; m < mb; ++m) {
+            const int pi = (int)acc;  // floor: acc >= 1
+            const int64_t qa = xb + pi - 1;
+            double qe_frac = 0.0;
+            if (!exact) {
+                const double t = (double)m * delta;  // two separately rounded operations, like rs_pos
+                const double q = g.c0 + t;
+                const double fl = std::floor(q);
+                qe = (int64_t)fl;
+                qe_frac = q - fl;
+            }
+            if (qa != qe) {
+                const double alpha = acc - (double)pi;
+                const double ae = exact ? (double)fe / (double)L : qe_frac;
+                bool differ;
+                const bool tie = exact && fe == 0 && std::llabs(qa - qe) == 1 && (alpha < 1e-6 || alpha > 1.0 - 1e-6);
+                if (tie) {
+                    int8_t& mm = memo[(size_t)(qe % nphi) * 4 + (qa > qe ? 2 : 0) + (alpha > 0.5 ? 1 : 0)];
+                    if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
+                    differ = mm != 0;
+                } else differ = taps_differ(qa, alpha, qe, ae);
+                if (differ && m >= from) out.push_back(Rec{m, qa, alpha});
+            }
+            if (exact) {
+                qe += dq;
+                fe += dfr;
+                if (fe >= L) {
+                    fe -= L;
+                    ++qe;
+                }
+            }
+            acc += delta;
+            if (acc > dnphi) {
+                // xIdx += div(ϕAcc-1, Nϕ); ϕAcc = mod(ϕAcc-1, Nϕ) + 1.  (ϕAcc-1 and the remainder are
+                // exact, the final +1 rounds: the same real number as ϕAcc - k·Nϕ rounded once)
+                const double a1 = acc - 1.0;
+                if (a1 < dnphi) {
+                    // k == 0: unchanged
+                } else if (a1 < 2.0 * dnphi) {
+                    xb += nphi;
+                    acc -= dnphi;
+                } else if (pow2) {
+                    const double k = std::floor(a1 * inv);
+                    xb += (int64_t)k * nphi;
+                    acc -= k * dnphi;
+                } else {
+                    const double k = std::floor(a1 / dnphi);
+                    xb += (int64_t)k * nphi;
+                    acc = std::fmod(a1, dnphi) + 1.0;
+                }
+            }
+        }
+    };
+    std::vector<int8_t> memo0((size_t)nphi * 4, -1);  // exact ties: (phase of qe, qa-qe, α snapped) -> differ?
+    made.push_back(AccCheckpoint{m0, xb, acc});
+    int64_t mcur = m0;
+    // ---- long replays of an exact rational rate, several threads.  The accumulator turns out to be
+    //      periodic up to a constant: ϕAcc(m + L) = ϕAcc(m) + δ bit for bit (δ ~ -2e-13 for 44.1 -> 48 kHz,
+    //      the same for 30 M outputs), xIdx(m + L) = xIdx(m) + M.  That PREDICTS the state before any
+    //      output; every thread replays its own range from the predicted state, and the prediction is
+    //      then VERIFIED: the state a range ends in must equal, bit for bit, the state the next range
+    //      started from -- so the concatenation is the sequential replay.  A range that fails the check
+    //      (and everything after it) is replayed sequentially from the true state. ----
+    const unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = (int)std::min<unsigned>(16, hw ? hw : 1);
+    if (const char* ev = std::getenv("SIGOPS_REPLAY_THREADS")) nthreads = std::max(1, std::atoi(ev));  // tuning knob
+    if (exact && nthreads > 1 && need - mcur >= ((int64_t)1 << 21) && L >= 2 && L <= 65536) {
+        // a phase that is not a tie of the closed form (its position is >= 1/L away from an integer:
+        // floor() there cannot depend on the drift) as range boundary
+        int64_t r0 = -1;
+        for (int64_t r = 1; r < L && r0 < 0; ++r)
+            if ((r * ((int64_t)nphi * g.M)) % L != 0) r0 = r;
+        const int64_t k0 = (mcur + L - 1) / L + 1;  // first whole period used as the reference
+        if (r0 >= 0 && (k0 + 2) * L + r0 < need) {
+            // sequentially up to the reference point and one period beyond it
+            const int64_t mref = k0 * L + r0;
+            run(mcur, mref, xb, acc, rec, memo0);
+            const int64_t xb1 = xb;
+            const double acc1 = acc;
+            run(mref, mref + L, xb, acc, rec, memo0);
+            const double dacc = acc - acc1;
+            const int64_t dxb = xb - xb1;
+            mcur = mref + L;
+            const int64_t periods = (need - mcur) / L;
+            const int nseg = (int)std::min<int64_t>(nthreads, periods / 4096);
+            if (nseg >= 2 && dxb == (int64_t)g.M * nphi) {
+                struct Seg {
+                    int64_t ma, mb, xb0, xb1;
+                    double acc0, acc1;
+                    std::vector<Rec> rec;
+                };
+                std::vector<Seg> seg(nseg);
+                for (int t = 0; t < nseg; ++t) {
+                    const int64_t ka = periods * t / nseg, kb = periods * (t + 1) / nseg;
+                    seg[t].ma = mcur + ka * L;
+                    seg[t].mb = t == nseg - 1 ? need : mcur + kb * L;
+                    // predicted state before output ma (ma = mref + (1 + ka) L)
+                    seg[t].xb0 = xb + ka * dxb;
+                    seg[t].acc0 = acc + (double)ka * dacc;
+                }
+                std::vector<std::thread> th;
+                for (int t = 0; t < nseg; ++t)
+                    th.emplace_back([&, t] {
+                        std::vector<int8_t> memo((size_t)nphi * 4, -1);
+                        int64_t x = seg[t].xb0;
+                        double a = seg[t].acc0;
+                        run(seg[t].ma, seg[t].mb, x, a, seg[t].rec, memo);
+                        seg[t].xb1 = x;
+                        seg[t].acc1 = a;
+                    });
+                for (auto& t : th) t.join();
+                int good = 0;  // ranges whose start state has been confirmed
+                for (int t = 0; t < nseg; ++t) {
+                    const bool ok = t == 0 ? (seg[0].xb0 == xb && std::memcmp(&seg[0].acc0, &acc, 8) == 0)
+                                           : (seg[t].xb0 == seg[t - 1].xb1 && std::memcmp(&seg[t].acc0, &seg[t - 1].acc1, 8) == 0);
+                    if (!ok) break;
+                    ++good;
+                }
+                for (int t = 0; t < good; ++t) {
+                    rec.insert(rec.end(), seg[t].rec.begin(), seg[t].rec.end());
+                    made.push_back(AccCheckpoint{seg[t].ma, seg[t].xb0, seg[t].acc0});
+                    xb = seg[t].xb1;
+                    acc = seg[t].acc1;
+                    mcur = seg[t].mb;
+                }
+                if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                    std::fprintf(stderr, "[sigops] accumulator replay: %d of %d ranges confirmed (period drift %.3e)\n", good, nseg, dacc);
+            }
+        }
     }
-    for (int64_t m = m0; m < need; ++m) {
-        if (m == from || (m > m0 && (m & ((1 << 22) - 1)) == 0)) made.push_back(AccCheckpoint{m, xb, acc});
-        const int pi = (int)acc;  // floor: acc >= 1
-        const int64_t qa = xb + pi - 1;
-        double qe_frac = 0.0;
-        if (!exact) {
-            const double t = (double)m * delta;  // two separately rounded operations, like rs_pos
-            const double q = g.c0 + t;
-            const double fl = std::floor(q);
-            qe = (int64_t)fl;
-            qe_frac = q - fl;
+    // the rest (everything, for short replays and rates without a period) in order
+    while (mcur < need) {
+        const int64_t mb = std::min<int64_t>(need, (mcur | (((int64_t)1 << 22) - 1)) + 1);
+        if (mcur <= from && from < mb && from != mcur) {
+            run(mcur, from, xb, acc, rec, memo0);
+            mcur = from;
         }
-        if (qa != qe) {
-            const double alpha = acc - (double)pi;
-            const double ae = exact ? (double)fe / (double)L : qe_frac;
-            bool differ;
-            const bool tie = exact && fe == 0 && std::llabs(qa - qe) == 1 && (alpha < 1e-6 || alpha > 1.0 - 1e-6);
-            if (tie) {
-                int8_t& mm = memo[(size_t)(qe % nphi) * 4 + (qa > qe ? 2 : 0) + (alpha > 0.5 ? 1 : 0)];
-                if (mm < 0) mm = taps_differ(qa, alpha > 0.5 ? 1.0 : 0.0, qe, 0.0) ? 1 : 0;
-                differ = mm != 0;
-            } else differ = taps_differ(qa, alpha, qe, ae);
-            if (differ && m >= from) rec.push_back(Rec{m, qa, alpha});
-        }
-        if (exact) {
-            qe += dq;
-            fe += dfr;
-            if (fe >= L) {
-                fe -= L;
-                ++qe;
-            }
-        }
-        acc += delta;
-        if (acc > dnphi) {
-            // xIdx += div(ϕAcc-1, Nϕ); ϕAcc = mod(ϕAcc-1, Nϕ) + 1.  (ϕAcc-1 and the remainder are
-            // exact, the final +1 rounds: the same real number as ϕAcc - k·Nϕ rounded once)
-            const double a1 = acc - 1.0;
-            if (a1 < dnphi) {
-                // k == 0: unchanged
-            } else if (a1 < 2.0 * dnphi) {
-                xb += nphi;
-                acc -= dnphi;
-            } else if (pow2) {
-                const double k = std::floor(a1 * inv);
-                xb += (int64_t)k * nphi;
-                acc -= k * dnphi;
-            } else {
-                const double k = std::floor(a1 / dnphi);
-                xb += (int64_t)k * nphi;
-                acc = std::fmod(a1, dnphi) + 1.0;
-            }
-        }
+        if (mcur == from) made.push_back(AccCheckpoint{mcur, xb, acc});
+        run(mcur, mb, xb, acc, rec, memo0);
+        mcur = mb;
+        if (mcur < need) made.push_back(AccCheckpoint{mcur, xb, acc});
     }
     made.push_back(AccCheckpoint{need, xb, acc});
     {

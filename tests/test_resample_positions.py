@@ -78,3 +78,19 @@ def test_closed_form_mode_is_the_opt_in(monkeypatch):
     with oracle_positions("exact"):
         want = oracle_sink(ToFramerate(Signal(F(x[:, None]), 44100 * Hz), 48000 * Hz))[:, 0]
     assert relerr(apply_positions(x, h, j, p, a), want) < 1e-12
+
+
+@pytest.mark.parametrize("fs_in,fs_out", [(44100, 48000), (44100, 16000), (48000, 44100), (8000, 11025)])
+def test_threaded_replay_is_the_sequential_replay(fs_in, fs_out, monkeypatch):
+    """Long replays of an exact rational rate run on several threads from PREDICTED accumulator states
+    (the accumulator is periodic up to a constant drift per period) and are verified range by range
+    against the state the previous range really ended in: same positions, same fix-up list as one
+    thread from output 0."""
+    n_out = 5_000_003
+    monkeypatch.setenv("SIGOPS_REPLAY_NOCACHE", "1")
+    monkeypatch.setenv("SIGOPS_REPLAY_THREADS", "1")
+    _, j1, p1, a1, nfix1, nb1 = engine_positions(fs_in, fs_out, n_out)
+    monkeypatch.setenv("SIGOPS_REPLAY_THREADS", "7")
+    _, j7, p7, a7, nfix7, nb7 = engine_positions(fs_in, fs_out, n_out)
+    assert (nfix1, nb1) == (nfix7, nb7)
+    assert np.array_equal(j1, j7) and np.array_equal(p1, p7) and np.array_equal(a1, a7)
