@@ -272,18 +272,24 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                     seg[t].acc0 = acc + (double)ka * dacc;
                 }
                 std::vector<std::thread> th;
-                for (int t = 0; t < nseg; ++t)
-                    th.emplace_back([&, t] {
-                        std::vector<int8_t> memo((size_t)nphi * 4, -1);
-                        int64_t x = seg[t].xb0;
-                        double a = seg[t].acc0;
-                        run(seg[t].ma, seg[t].mb, x, a, seg[t].rec, memo);
-                        seg[t].xb1 = x;
-                        seg[t].acc1 = a;
-                    });
+                int started = 0;
+                try {
+                    for (int t = 0; t < nseg; ++t) {
+                        th.emplace_back([&, t] {
+                            std::vector<int8_t> memo((size_t)nphi * 4, -1);
+                            int64_t x = seg[t].xb0;
+                            double a = seg[t].acc0;
+                            run(seg[t].ma, seg[t].mb, x, a, seg[t].rec, memo);
+                            seg[t].xb1 = x;
+                            seg[t].acc1 = a;
+                        });
+                        ++started;
+                    }
+                } catch (...) {  // (no more threads to be had: the ranges that did start still count)
+                }
                 for (auto& t : th) t.join();
                 int good = 0;  // ranges whose start state has been confirmed
-                for (int t = 0; t < nseg; ++t) {
+                for (int t = 0; t < started; ++t) {
                     const bool ok = t == 0 ? (seg[0].xb0 == xb && std::memcmp(&seg[0].acc0, &acc, 8) == 0)
                                            : (seg[t].xb0 == seg[t - 1].xb1 && std::memcmp(&seg[t].acc0, &seg[t - 1].acc1, 8) == 0);
                     if (!ok) break;
