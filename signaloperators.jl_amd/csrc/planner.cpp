@@ -1021,6 +1021,7 @@ void Plan::try_window_alias(std::vector<Piece>& rootp) {
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
                   int32_t device, int& status, std::string& err) {
     std::unique_ptr<Plan> P(new Plan());
+    const auto t_create0 = std::chrono::steady_clock::now();
     int prev_device = -1;
     (void)hipGetDevice(&prev_device);
     struct Restore {
@@ -1105,9 +1106,16 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         if (P->alias_stage < 0) P->try_window_alias(rootp);
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
         P->fuse_state_passes();
+        const auto t_lowered = std::chrono::steady_clock::now();
         P->finalize();
+        const auto t_final = std::chrono::steady_clock::now();
         if (rootstep >= 0) P->push_pw_step(rootstep);
         P->plan_lanes();
+        if (std::getenv("SIGOPS_DEBUG_PLAN")) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[sigops] plan_create: lowering and stage setup %.3f ms, allocation and uploads %.3f ms, lanes %.3f ms\n",
+                         ms(t_create0, t_lowered), ms(t_lowered, t_final), ms(t_final, std::chrono::steady_clock::now()));
+        }
     } catch (const PlanError& e) {
         status = e.status;
         err = e.msg;
