@@ -136,6 +136,8 @@ typedef enum so_rskind {
  *
  *  ARRAY     p0=data  l0=nframes  i0=is_device(0 host,1 HIP device ptr)
  *            s0=frame_stride s1=chan_stride (elements)   dtype=element type
+ *            l1=first resident frame (device arrays; 0 = all of it): p0 is the address frame 0 WOULD
+ *            have, frames [l1,l0) are in memory, reading an earlier one is SO_ERR_LENGTH
  *  CONST     d0=value  i0=literal type (so_dtype_t; SO_I64 promotes like Julia Int)
  *  FUNC      i0=so_fn_t  i1=has_omega  d0=omega(Hz)  d1=phi (cycles if has_omega
  *            else seconds, src/functions.jl:92-95)       fs = frame rate (required)

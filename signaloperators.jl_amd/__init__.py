@@ -13,7 +13,7 @@ from .signals import (  # noqa: F401
     PolynomialRatio,
 )
 from numpy import sin, cos  # noqa: F401  (Signal(sin), Signal(cos))
-from .engine import sink, sink_into, stream, Plan, Array, process_sink_params, _eager, filt, filt_into  # noqa: F401
+from .engine import sink, sink_into, stream, BlockStream, Plan, Array, process_sink_params, _eager, filt, filt_into  # noqa: F401
 from .arraytypes import SampleBuf, AxisArray, DimensionalArray  # noqa: F401
 from .lowering import lower, design_iir, design_resample  # noqa: F401
 from .wav import save_signal, load_signal  # noqa: F401

@@ -412,6 +412,14 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
         e.leaf.dtype = N.dtype;
         e.array_node = ni;
         e.mono = (m.sc == 0);
+        if (!dry && nd.l1 > 0) {
+            // a leaf of which only the frames >= l1 are resident (streams fed block by block keep a
+            // bounded tail of their input): nothing earlier may be read
+            const int64_t first = (m.sf > 0 ? r.a : m.sf < 0 ? r.b - 1 : 0) * m.sf + m.df;
+            if (first < nd.l1)
+                fail(SO_ERR_LENGTH, "frame " + std::to_string(first) + " of a streamed leaf is needed, but frames before " +
+                                        std::to_string(nd.l1) + " are no longer resident (raise the stream's history)");
+        }
         if (!dry) count_array(ni);
         out.push_back({r, add_expr(e)});
         return out;

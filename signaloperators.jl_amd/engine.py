@@ -243,6 +243,135 @@ def stream(x, blocksize, to=None, *, device=0):
         pos += m
 
 
+class BlockStream:
+    """Bounded-memory streaming of an UNBOUNDED input: `push(block)` takes the next frames of the input
+    signal and returns the output frames that have become final; `finish()` returns the rest.
+
+        bs = so.BlockStream(lambda x: x | so.Filt(so.Lowpass, 3*so.kHz) | so.ToFramerate(48*so.kHz),
+                            fs=44.1*so.kHz, nch=2)
+        for block in source: out = bs.push(block)      # torch tensors [frames x nch] on the device
+        tail = bs.finish()
+
+    `pipeline` builds the operator tree over the input signal (called once per block with a signal
+    that covers everything received so far).  Only the last `history` input frames stay in device
+    memory: the tree's array leaf is *virtual* -- its address is where frame 0 would be, its node
+    says which frames are resident (include/sigops.h, ARRAY l1) -- every block is the plan of
+    `tree |> After(emitted) |> Until(final - emitted)`, stateful stages start from warm starts a decay
+    time before the block, and the planner refuses to read a frame that is gone
+    ("raise the stream's history").  An output frame is final when every input frame it depends on
+    has arrived (the lowering's demand analysis: the newest input of the last output of every
+    resampler, `Filt` one to one).  Concatenated, the outputs are the sink of the pipeline over the
+    whole input.  Not streamable: `Normpower`, pads that index the end of the input, anything whose
+    early outputs depend on the input's total length."""
+
+    def __init__(self, pipeline, fs, nch=1, dtype=np.float64, history=1 << 16, device=0):
+        import torch
+
+        from .units import inHz
+
+        self.pipeline = pipeline
+        self.fs = inHz(fs)
+        self.nch = int(nch)
+        self.dtype = np.dtype(dtype)
+        self.tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        self.history = int(history)
+        self.device = device
+        self.dev = f"cuda:{device}"
+        self.cap = 0
+        self.buf = None  # [nch x cap] planar tail of the input
+        self.start = 0  # absolute frame stored at buf[:, 0]
+        self.received = 0
+        self.emitted = 0
+        self.closed = False
+
+    # -- resident tail ---------------------------------------------------------------------------
+    def _append(self, block):
+        import torch
+
+        if hasattr(block, "data_ptr"):
+            b = block.to(self.dev, self.tdt)
+        else:
+            b = torch.from_numpy(np.ascontiguousarray(np.asarray(block, dtype=self.dtype))).to(self.dev)
+        if b.dim() == 1:
+            b = b[:, None]
+        if b.shape[1] != self.nch:
+            S.error(f"BlockStream: blocks must have {self.nch} channel(s)")
+        m = int(b.shape[0])
+        have = self.received - self.start
+        if self.buf is None or have + m > self.cap:
+            keep = min(have, self.history)
+            cap = max(self.cap, 2 * (self.history + m))
+            nb = torch.empty((self.nch, cap), dtype=self.tdt, device=self.dev)
+            if keep:
+                nb[:, :keep] = self.buf[:, have - keep:have]
+            self.buf, self.cap = nb, cap
+            self.start = self.received - keep
+            have = keep
+        self.buf[:, have:have + m] = b.t()
+        self.received += m
+
+    def _tree(self):
+        esz = self.dtype.itemsize
+        leaf = S.ArraySig(np.empty((0, self.nch), dtype=self.dtype), self.fs)
+        leaf.n = self.received  # (no host data: the node is filled in from `virtual`)
+        guard = 64 if self.start > 0 else 0  # (vector loads may touch the aligned pair below a range)
+        leaf.virtual = (self.buf.data_ptr() - self.start * esz, 1, self.cap, self.start + guard)
+        return leaf, self.pipeline(leaf)
+
+    def _final_frames(self, leaf, tree, total):
+        """outputs whose inputs have all arrived: the largest n with demand(n) <= received"""
+        from .lowering import _demand
+
+        def needs(n):
+            out = {}
+            _demand(tree, n, out)
+            return out.get(id(leaf), (0, 0))[0]
+
+        lo, hi = self.emitted, total  # needs(lo) <= received
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if needs(mid) <= self.received - (0 if self.closed else 1):
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
+
+    def _emit(self):
+        import torch
+
+        from .units import frames
+
+        leaf, tree = self._tree()
+        total = S.nframes(tree)
+        if total is None or S.isknowninf(total):
+            S.error("BlockStream: the pipeline must have as many frames as its input decides")
+        upto = total if self.closed else self._final_frames(leaf, tree, int(total))
+        m = upto - self.emitted
+        nch_out = tree.nch
+        tdt = torch.float32 if tree.dtype == S.F32 else torch.float64
+        if m <= 0:
+            return torch.empty((0, nch_out), dtype=tdt, device=self.dev)
+        blk = S.Until(S.After(tree, self.emitted * frames) if self.emitted else tree, m * frames)
+        res = torch.empty((nch_out, m), dtype=tdt, device=self.dev).t()
+        sink_into(res, blk, device=self.device)
+        self.emitted = upto
+        return res
+
+    def push(self, block):
+        if self.closed:
+            S.error("BlockStream: finished")
+        self._append(block)
+        return self._emit()
+
+    def finish(self):
+        self.closed = True
+        if self.buf is None:
+            import torch
+
+            return torch.empty((0, self.nch), dtype=self.tdt, device=self.dev)
+        return self._emit()
+
+
 def filt(b, a, x, si=None, *, device=0):
     """DSP.filt(b, a, x::AbstractSignal[, si]) (reference src/filters.jl:68-79): the signal is sunk
     (HIP engine) and filtered with direct-form coefficients.  FIR (a scalar / [a0]) and orders <= 2

@@ -198,7 +198,11 @@ def _demand(x, n, out, skip=0):
             n0, s0 = out.get(id(x), (0, skip))
             out[id(x)] = (max(n0, n), min(s0, skip))
         return
-    if isinstance(x, (S.ArraySig, S.NumberSig, S.RampSignal)):
+    if isinstance(x, S.ArraySig):
+        n0, s0 = out.get(id(x), (0, skip))
+        out[id(x)] = (max(n0, n), min(s0, skip))
+        return
+    if isinstance(x, (S.NumberSig, S.RampSignal)):
         return
 
     def capped(c, m):
@@ -274,6 +278,9 @@ def lower(x, nframes_out=None, rng=None):
             ptr, fst, cst, dev = _array_fields(s)
             r = common(s, K.NODE_ARRAY)
             r.update(p0=ptr, l0=s.n, i0=dev, s0=fst, s1=cst)
+            if getattr(s, "virtual", None) is not None:  # a bounded resident tail of an unbounded input
+                vptr, vfst, vcst, first = s.virtual
+                r.update(p0=vptr, i0=1, s0=vfst, s1=vcst, l1=int(first))
             idx = lw.add(**r)
             lw.array_nodes.append((idx, s))
         elif isinstance(s, S.NumberSig):

@@ -197,6 +197,7 @@ class ArraySig(AbstractSignal):
         self.n = int(shape[0])
         self.dtype = np.dtype(dt)
         self.container = None  # SampleBuf / AxisArray / DimensionalArray class the data came in (root type)
+        self.virtual = None  # engine.BlockStream: (address frame 0 would have, frame stride, channel stride, first resident frame)
 
     def nframes_helper(self):
         return self.n

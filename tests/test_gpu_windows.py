@@ -199,3 +199,51 @@ def test_window_of_a_last_stage_is_written_by_the_stage_itself(last):
     want = oracle_sink(blk)
     assert relerr(out[:, :50000].t().cpu().numpy(), want) <= 1e-9
     assert bool(torch.isnan(out[:, 50000:]).all())
+
+
+def _push_all(bs, x, sizes):
+    outs, pos = [], 0
+    for m in sizes:
+        outs.append(bs.push(x[pos:pos + m]).cpu().numpy())
+        pos += m
+    assert pos == x.shape[0]
+    outs.append(bs.finish().cpu().numpy())
+    return np.concatenate(outs, axis=0), [o.shape[0] for o in outs]
+
+
+@pytest.mark.parametrize("name", ["pipeline", "filt", "down", "f32"])
+def test_block_stream_of_an_unbounded_input(name):
+    """so.BlockStream: input pushed block by block, a bounded tail of it resident; the outputs concatenate
+    to the sink of the pipeline over the whole input"""
+    rng = np.random.default_rng(71)
+    n, nch = 400000, 2
+    dt = np.float32 if name == "f32" else np.float64
+    x = rng.standard_normal((n, nch)).astype(dt)
+    pipes = {
+        "pipeline": lambda s: (so.Mix(so.Signal(so.sin, ω=1 * so.kHz), s) | so.Until(so.nframes(s) * so.frames)
+                               | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz)),
+        "filt": lambda s: s | so.Filt(so.Lowpass, 3 * so.kHz) | so.Amplify(0.5),
+        "down": lambda s: s | so.Filt(so.Lowpass, 4 * so.kHz) | so.ToFramerate(16 * so.kHz),
+        "f32": lambda s: s | so.ToFramerate(48 * so.kHz),
+    }
+    pipe = pipes[name]
+    whole = so.sink(pipe(so.Signal(np.asfortranarray(x), 44.1 * so.kHz)), so.Array)
+    sizes = [30000, 1, 70001, 44100, 9, 100000]
+    sizes.append(n - sum(sizes))
+    bs = so.BlockStream(pipe, 44.1 * so.kHz, nch=nch, dtype=dt, history=40000)
+    got, counts = _push_all(bs, x, sizes)
+    assert got.shape == whole.shape and got.dtype == whole.dtype
+    assert relerr(got, whole) <= (1e-6 if dt == np.float32 else 1e-11)
+    assert counts[0] > 0 and counts[-1] < 200  # outputs leave as their inputs arrive; only the look-ahead waits for finish()
+    assert bs.cap <= 2 * (40000 + max(sizes))  # the resident tail stays bounded
+
+
+def test_block_stream_refuses_to_read_what_is_gone():
+    rng = np.random.default_rng(72)
+    x = rng.standard_normal((200000, 1))
+    # a band-stop this narrow needs a long warm start; 2000 frames of history are not enough for it
+    bs = so.BlockStream(lambda s: s | so.Filt(so.Bandstop, 0.99 * so.kHz, 1.01 * so.kHz), 44.1 * so.kHz, nch=1, history=2000)
+    bs.push(x[:60000])
+    with pytest.raises(so.ErrorException, match="no longer resident"):
+        for k in range(60000, 200000, 20000):
+            bs.push(x[k:k + 20000])
