@@ -671,12 +671,19 @@ static int nextblock(OState* st, int64_t maxlen, int skip) {
             st->started = 1;
             st->k = 0;
         }
+        int k0 = st->k;
         int ok = nextblock(st->kids[st->k], maxlen, skip);
         while (st->k < K - 1 && !ok) {
             st->k++;
             ok = nextblock(st->kids[st->k], maxlen, skip);
         }
-        if (!ok) return 0;
+        if (!ok) {
+            /* advancechild returns nothing and the caller keeps its last AppendBlock, which still names
+               the child that produced it (blocks are immutable, src/appending.jl:82-110): a `lastframe`
+               pad after Append(x, <empty>) takes the last frame of x */
+            st->k = k0;
+            return 0;
+        }
         st->len = st->kids[st->k]->len;
         return 1;
     }

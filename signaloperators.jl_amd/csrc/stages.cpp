@@ -66,7 +66,7 @@ static bool ga_fits(const Stage& S, int stage_dtype) {
     const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
     const size_t pitch4 = (size_t)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
     const size_t tile_bytes = (size_t)rp.ct * pitch4 * 4;
-    const size_t fpitch = (size_t)((rp.tile_len + 16 + 1) & ~1);
+    const size_t fpitch = (size_t)((rp.tile_len + 32 + 1) & ~1);  // (Float32 tiles start up to 31 frames below their first input)
     const bool ok = 3 * fpitch * 8 + kRsTwoDoubles * 8 + 2 * tile_bytes <= avail;
     if (std::getenv("SIGOPS_DEBUG_PLAN"))
         std::fprintf(stderr, "[sigops] GA geometry: kw=%d gper=%d ct=%d tile_len=%d -> %s\n", rp.kw, gper, rp.ct, rp.tile_len, ok ? "fits" : "no");
@@ -737,7 +737,10 @@ void Plan::process_stage(int sid) {
             rp.lds_pitch = (int)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
             const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 4;
             rp.fslots = 1;
-            rp.fpitch = (rp.tile_len + 16 + 1) & ~1;
+            // gains are indexed from the 128-byte aligned frame the tile is staged from: up to 31 frames
+            // below its first input for Float32 tiles (16 were reserved until a long-signal soak found the
+            // gains of one tile running into the array the compute waves were reading)
+            rp.fpitch = (rp.tile_len + 32 + 1) & ~1;
             const DLeaf& L0 = leaves[S.carriers[0].slot_leaf[0]];
             const bool two = !std::getenv("SIGOPS_RS_NOTWO") && rp.tile_len <= 64 * kRsTwoBases &&
                              (S.carriers[0].slot_kind[0] & 0xff) == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1;

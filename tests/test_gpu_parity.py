@@ -465,3 +465,26 @@ def test_after_longer_than_a_child_that_is_never_evaluated():
     assert got.shape == want.shape == (0, 1)
     _both_raise(short)
     _both_raise(so.Append(short, so.Signal(np.ones(5), 6 * so.kHz)))
+
+
+def test_lastframe_pad_after_an_append_whose_last_child_is_empty():
+    x = np.asfortranarray(np.arange(10.0).reshape(5, 2))
+    y = np.asfortranarray(100 + np.arange(20.0).reshape(10, 2))
+    t = so.Pad(so.Append(so.Signal(x, 50 * so.Hz), so.Signal(y, 50 * so.Hz) | so.Until(0 * so.frames)), so.lastframe) | so.Until(8 * so.frames)
+    assert np.array_equal(so.sink(t, so.Array), oracle_sink(t))
+
+
+@pytest.mark.parametrize("nch", [8, 4])
+def test_fused_float32_gain_on_a_signal_of_many_tiles(nch):
+    """Float32 array x Float64 sine gain fused into the periodic resampler (GA instantiation) on a signal
+    long enough for every workgroup to wrap its three gain arrays (> 512 tiles).  The gains of a tile are
+    indexed from the 128-byte aligned frame it is staged from -- up to 31 frames below its first input for
+    Float32 tiles; with 16 reserved they ran into the array the compute waves were reading (found by the
+    BlockStream soak: 1.6e-2 off, run to run different)."""
+    rng = np.random.default_rng(91)
+    n = 454382
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(np.float32))
+    tree = so.Signal(x, 44.1 * so.kHz) | so.Amplify(so.Signal(so.sin, ω=3 * so.Hz)) | so.Until(n * so.frames) | so.ToFramerate(48 * so.kHz)
+    want = oracle_sink(tree)
+    for _ in range(3):
+        assert relerr(so.sink(tree, so.Array), want) <= 1e-9

@@ -175,3 +175,15 @@ def test_reference_quirk_append_never_leaves_a_long_filtered_child():
     assert w.shape == (18000, 1)
     np.testing.assert_array_equal(w[:9000], oracle_sink(rx))
     assert np.abs(w[9100:]).max() < 1e-12  # the resampler's decayed tail, not y
+
+
+def test_lastframe_pad_after_an_append_whose_last_child_is_empty():
+    """`usepad(lastframe)` is `frame(x, block, nframes(block))` on the last block the Pad got
+    (src/padding.jl:158-159); after `Append(x, <empty>)` that is still x's block -- AppendBlocks are
+    immutable and advancechild returned nothing (src/appending.jl:98-110).  Found by the round-2 soak:
+    the oracle's mutable child index had moved on to the empty child."""
+    x = F(np.arange(10.0).reshape(5, 2))
+    y = F(100 + np.arange(20.0).reshape(10, 2))
+    t = so.Pad(so.Append(so.Signal(x, 50 * so.Hz), so.Signal(y, 50 * so.Hz) | so.Until(0 * so.frames)), so.lastframe) | so.Until(8 * so.frames)
+    w = oracle_sink(t)
+    assert np.array_equal(w[:5], x) and np.array_equal(w[5:], np.tile(x[4], (3, 1)))
