@@ -2886,7 +2886,12 @@ __global__ __launch_bounds__(kBlock) void k_sumsq32_blocks(const float* __restri
     float acc = 0.f;
     for (; i < e; ++i) {
         const float v = x[ch * pitch + f];
-        acc = __fadd_rn(acc, __fmul_rn(v, v));
+        // the square is rounded on its own (Julia's x^2, then +): __fmul_rn / __fadd_rn are plain * and + to
+        // the compiler, which fuses them into v_fmac_f32 under its default contraction -- 1 ulp of the rms off
+        // on two of twelve long signals
+        float sq;
+        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(v));
+        acc = acc + sq;
         if (++f == n) {
             f = 0;
             ++ch;
@@ -2909,7 +2914,12 @@ __global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, 
         out = t;
         m = h;
     }
-    if (threadIdx.x == 0) rms[0] = (double)sqrtf(__fdiv_rn(nb ? in[0] : 0.f, count));
+    // (Float32 division and square root through Float64: correctly rounded whatever the device's own
+    //  single-precision sequences do -- v_sqrt_f32 alone is 1 ulp)
+    if (threadIdx.x == 0) {
+        const float mean = (float)((double)(nb ? in[0] : 0.f) / (double)count);
+        rms[0] = (double)(float)sqrt((double)mean);
+    }
 }
 
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,

@@ -423,7 +423,8 @@ def test_float32_normpower_reduction_order():
     assert got.dtype == want.dtype == np.float32
     assert np.array_equal(got, want)
     # ordinary noise, several blocks and channels, an odd number of blocks
-    for shape in ((100_000, 2), (1158, 2), (5000, 3)):
+    # (the last two caught a fused multiply-add in the block sums: 1 ulp of the rms)
+    for shape in ((100_000, 2), (1158, 2), (5000, 3), (1_000_000, 8), (1_105_534, 4)):
         y = np.asfortranarray(rng.standard_normal(shape).astype(np.float32))
         t2 = so.Signal(y, 1 * so.kHz) | so.Normpower
         assert np.array_equal(so.sink(t2)[0], oracle_sink(t2)), shape
