@@ -1,5 +1,5 @@
 """Soak: so.BlockStream with random pipelines, rates, channel counts and ragged block sizes against the one-shot
-sink of the same pipeline over the whole input.  python tools/soak_block_stream.py SEED0 SEED1"""
+sink of the same pipeline over the whole input.  python tools/soak_block_stream.py SEED0 SEED1 [SCALE]"""
 import sys, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import sigops_amd as so
@@ -10,7 +10,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(80000 + seed)
     fs = float(rng.choice(RATES)); fo = float(rng.choice([r for r in RATES if r != fs]))
     nch = int(rng.choice([1, 2, 3, 8])); dt = np.float64 if rng.random() < 0.8 else np.float32
-    N = int(rng.integers(150000, 500000))
+    N = int(rng.integers(150000, 500000)) * int(sys.argv[3] if len(sys.argv) > 3 else 1)
     x = rng.standard_normal((N, nch)).astype(dt)
     k = int(rng.integers(0, 6))
     lo, hi = 0.05 * min(fs, fo), 0.2 * min(fs, fo)
@@ -31,7 +31,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     outs, pos = [], 0
     try:
         while pos < N:
-            m = int(min(N - pos, rng.choice([1, 7, 1000, 4096, 30000, 100000])))
+            m = int(min(N - pos, rng.choice([1, 7, 1000, 4096, 30000, 100000]) * (int(sys.argv[3]) if len(sys.argv) > 3 else 1)))
             outs.append(bs.push(x[pos:pos + m]).cpu().numpy()); pos += m
         outs.append(bs.finish().cpu().numpy())
     except Exception as e:
