@@ -92,26 +92,70 @@ def pmc_traffic(stage_name):
     return None, None
 
 
-def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev):
+def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev, series=None, profile=False):
+    """W untimed executes, then exactly K timed ones between barrier + synchronize pairs.  `series`
+    (a list) receives the device time of every execute, warm-ups first: events recorded on the launch
+    stream between the executes, read after the timed region (no synchronisation inside it)."""
+    nev = min(warmup + steps, 64) + 2 if series is not None else 0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
+    k = 0
+    if profile:
+        # deferred profiling (so_plan_set_profiling(plan, 2)): the library records its per-kernel events
+        # during the executes and never synchronises.  Switched on before the warm-ups (the events are
+        # created by the first execute) and restarted, a counter reset, right before the timed region.
+        plan.set_profiling(2)
+    if nev:
+        ev[0].record()
     for _ in range(warmup):
         plan.execute(optr, stream)
+        if k + 1 < nev:
+            k += 1
+            ev[k].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if profile:
+        plan.set_profiling(2)  # (restart: the means are over the timed executes only)
+    gap = -1
+    if k + 1 < nev:  # (restart the event chain: the host's synchronize + barrier above is device idle time)
+        k += 1
+        ev[k].record()
+        gap = k - 1
+    host = []
     t0 = time.perf_counter()
     for _ in range(steps):
         plan.execute(optr, stream)
+        if k + 1 < nev:
+            k += 1
+            ev[k].record()
+        host.append(time.perf_counter())
+    t_issued = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if series is not None:
+        series.extend(round(ev[i].elapsed_time(ev[i + 1]), 4) for i in range(k) if i != gap)
+        # host side of the same loop: when each execute call returned, and when the last one had
+        series.append({"host_return_ms": [round((h - t0) * 1e3, 3) for h in host[:64]],
+                       "host_issue_total_ms": round((t_issued - t0) * 1e3, 3), "wall_ms": round(elapsed * 1e3, 3)})
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def stage_means(plan):
+    """mean hipEvent time of every step over the executes of the timed region (deferred profiling:
+    events on the launch stream, recorded inside the timed loop, read here after it)"""
+    acc = plan.steps()
+    plan.set_profiling(False)
+    for a in acc:
+        a["GBps"] = a["algorithmic_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
+    return acc
 
 
 def stage_times(plan, optr, stream, reps=5):
@@ -155,9 +199,11 @@ def parity_gate(so, tree_fn, noise_host, tol=1e-6):
     return res
 
 
-def cpu_baseline(so, tree_fn, seconds, nch, ndt):
+def cpu_baseline(so, tree_fn, seconds, nch, ndt, noise_host=None, gpu_result=None):
     """The oracle (kind "port": the Julia reference itself cannot run here) on the same workload,
-    rebuilt -O3 -march=native on THIS host.  Only this leg of bench.py (and the gate) touches oracle/."""
+    rebuilt -O3 -march=native on THIS host.  Only this leg of bench.py (and the gate) touches oracle/.
+    noise_host / gpu_result: the GPU run's own input (host copy) and result -- the oracle then filters the
+    SAME noise and the whole overlap is compared (returned as the second value)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
@@ -179,12 +225,25 @@ def cpu_baseline(so, tree_fn, seconds, nch, ndt):
     else:
         flags = "-O3 -march=x86-64-v3 (native rebuild failed)"
     n_in = int(round(seconds * 44100))
-    rng = np.random.default_rng(1983)
-    noise = np.asfortranarray(rng.standard_normal((n_in, nch)).astype(ndt))
+    if noise_host is not None:
+        n_in = min(n_in, noise_host.shape[0])
+        noise = np.asfortranarray(noise_host[:n_in])
+    else:
+        rng = np.random.default_rng(1983)
+        noise = np.asfortranarray(rng.standard_normal((n_in, nch)).astype(ndt))
     x = tree_fn(so, noise, n_in)
     t0 = time.perf_counter()
     y = ob.oracle_sink(x)
     dt1 = time.perf_counter() - t0
+    full = None
+    if gpu_result is not None:
+        # the oracle saw the first n_in input frames: its last outputs miss inputs the GPU run had
+        # (resampler look-ahead) -- unless it saw everything
+        whole = n_in == noise_host.shape[0]
+        m = y.shape[0] if whole else max(0, y.shape[0] - 4096)
+        err = float(ob.relerr(gpu_result[:m], y[:m]))
+        full = {"relerr": err, "frames_compared": int(m), "channels": int(nch), "whole_workload": bool(whole),
+                "what": "the timed plan's own result (last timed execute) against the CPU oracle on the same noise"}
     # all cores: the channels are independent for this pipeline -> one single-channel sink per thread
     ncpu = os.cpu_count() or 1
     nthr = min(nch, ncpu)
@@ -195,7 +254,7 @@ def cpu_baseline(so, tree_fn, seconds, nch, ndt):
         ys = list(pool.map(ob.oracle_sink, trees))
     dtn = time.perf_counter() - t0
     same = all(np.array_equal(ys[c][:, 0], y[:, c]) for c in range(nch))
-    return {"value": y.shape[0] / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+    return full, {"value": y.shape[0] / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"the whole workload: {seconds:g} s x {nch} ch ({y.shape[0]} output frames), blocksize 4096, 1 thread",
             "seconds": dt1, "flags": flags + " -ffp-contract=off", "cpu_model": cpu_model(), "host_cpus": ncpu,
             "all_cores": {"value": y.shape[0] / dtn, "unit": "frames/s", "cores": nthr, "seconds": dtn,
@@ -283,19 +342,26 @@ def main():
 
     plan, out_t, out, n_out, plan_ms = prepare(headline_fn)
     optr = out.data_ptr()
-    elapsed = timed_loop(plan, optr, stream, args.steps, args.warmup, torch, dist, dev)
-    stages = stage_times(plan, optr, stream)
+    series = []
+    elapsed = timed_loop(plan, optr, stream, args.steps, args.warmup, torch, dist, dev, series=series, profile=True)
+    host_side = series.pop() if series and isinstance(series[-1], dict) else None
+    stages = stage_means(plan)  # per-kernel means over the timed executes themselves
     st = plan.stats()
     checksum = float(out_t[:, :: max(1, n_out // 4096)].double().abs().sum().item())
     plan.close()
+    gpu_result = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        gpu_result = np.asfortranarray(out_t.t().cpu().numpy())  # [n_out x nch], for the full-length comparison
     del out_t, out
 
     secondary = None
     if rank == 0 and world == 1 and args.workload == "ns" and not args.no_secondary:
         p3, o3_t, o3, n3, plan3_ms = prepare(tree_config3)
         steps3 = max(20, args.steps // 2)
-        e3 = timed_loop(p3, o3.data_ptr(), stream, steps3, args.warmup, torch, None, dev)
-        st3 = stage_times(p3, o3.data_ptr(), stream)
+        series3 = []
+        e3 = timed_loop(p3, o3.data_ptr(), stream, steps3, args.warmup, torch, None, dev, series=series3, profile=True)
+        host3 = series3.pop() if series3 and isinstance(series3[-1], dict) else None
+        st3 = stage_means(p3)
         s3 = p3.stats()
         ms3 = e3 / steps3 * 1e3
         dom3 = max(st3, key=lambda s: s["ms"])
@@ -308,7 +374,8 @@ def main():
                                        "frac": s3["algorithmic_bytes"] / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "frac_of_copy_ceiling": s3["algorithmic_bytes"] / (ms3 * 1e-3) / 1e9 / HBM_COPY_GBS,
                                        "from": "timed loop"},
-                     "roofline": roofline_of(dom3, tr3, src3), "stages": st3, "plan_create_ms": plan3_ms}
+                     "roofline": roofline_of(dom3, tr3, src3), "stages": st3, "plan_create_ms": plan3_ms,
+                     "step_ms_series": series3, "host_side": host3}
         p3.close()
         del o3_t, o3
 
@@ -342,13 +409,25 @@ def main():
                               "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
                               "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},
             "stages": stages,
+            "step_ms_series": series,
+            "host_side": host_side,
+            "step_ms_series_note": "device time of every execute, the --warmup ones first (events on the launch stream, no "
+                                   "synchronisation between executes).  After a load step MI355X's power management runs "
+                                   "executes 3-15 up to 40 % slower and settles after ~30 (DESIGN.md, cold-run study): "
+                                   "short runs (20 / 5) sit inside that transient, long ones (200 / 30) mostly outside.",
             "parity_gate": gate,
             "config3": secondary,
         }
         if args.cpu_seconds > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(so, headline_fn, args.cpu_seconds, nch, ndt)
+            noise_host = np.asfortranarray(noise_t.t().cpu().numpy())
+            full, res["cpu_baseline"] = cpu_baseline(so, headline_fn, args.cpu_seconds, nch, ndt, noise_host, gpu_result)
+            res["parity_full"] = full
+            tol = 1e-6 if args.dtype == "f64" else 2e-6
+            if full is not None and not (full["relerr"] <= tol):
+                raise SystemExit(f"bench.py: the timed result differs from the CPU oracle: {full}")
         else:
             res["cpu_baseline"] = None
+            res["parity_full"] = None
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -258,8 +258,22 @@ typedef struct so_step_info {
 } so_step_info_t;
 int32_t so_plan_step_info(const so_plan_t* plan, int32_t index, so_step_info_t* info);
 
+/* How the executes of this plan were issued so far (no reference counterpart; lets tests and
+ * benchmarks tell a captured HIP-graph replay from direct launches).  -1 for an unknown counter. */
+typedef enum so_counter {
+    SO_COUNTER_GRAPH_REPLAYS = 0,   /* executes replayed from the captured launch graph            */
+    SO_COUNTER_GRAPH_CAPTURES = 1,  /* times the launch sequence was captured                      */
+    SO_COUNTER_DIRECT_EXECUTES = 2  /* executes issued launch by launch                            */
+} so_counter_t;
+int64_t so_plan_counter(const so_plan_t* plan, int32_t which);
+
 /* When enabled, so_plan_execute brackets every kernel with hipEvents (on the stream
- * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default. */
+ * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default.
+ *   enable = 1: every execute synchronises the stream and reads its own events;
+ *   enable = 2: deferred -- executes only record (a set of events per execute, the most recent 256
+ *               kept) and never synchronise; after the caller has synchronised the stream,
+ *               so_plan_step_info reports each step's MEAN over the recorded executes.  Lets a
+ *               benchmark time the kernels inside its own timed region. */
 int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable);
 
 void so_plan_destroy(so_plan_t* plan);

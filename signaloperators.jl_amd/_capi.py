@@ -54,7 +54,7 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
-           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos"]
+           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_plan_counter"]
 
 _lib = None
 
@@ -120,6 +120,8 @@ def lib():
     L.so_zpk_to_sos.restype = C.c_int32
     L.so_zpk_to_sos.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_double,
                                 C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.so_plan_counter.restype = C.c_int64
+    L.so_plan_counter.argtypes = [C.c_void_p, C.c_int32]
     L.so_plan_step_info.restype = C.c_int32
     L.so_plan_step_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(so_step_info_t)]
     L.so_resample_positions.restype = C.c_int32

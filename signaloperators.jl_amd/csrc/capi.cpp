@@ -72,8 +72,13 @@ int32_t so_plan_stats(const so_plan_t* plan, so_stats_t* stats) {
 
 int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable) {
     if (!plan) return set_err(SO_ERR_INVALID, "so_plan_set_profiling: null plan");
-    so::plan_set_profiling(plan->p, enable != 0);
+    so::plan_set_profiling(plan->p, enable);
     return SO_OK;
+}
+
+int64_t so_plan_counter(const so_plan_t* plan, int32_t which) {
+    if (!plan) return -1;
+    return so::plan_counter(plan->p, which);
 }
 
 int32_t so_plan_step_info(const so_plan_t* plan, int32_t index, so_step_info_t* info) {

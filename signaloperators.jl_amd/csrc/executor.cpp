@@ -139,6 +139,9 @@ void Plan::finalize() {
                 HIPCHECK(hipMemcpy(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4, hipMemcpyHostToDevice));
             }
         } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
+            for (size_t gi = 0; gi < S.xs_mats_host.size() && S.xs_mats_buf >= 0; ++gi)
+                HIPCHECK(hipMemcpy((char*)bufs[S.xs_mats_buf].d + gi * 2 * 16 * 16 * 8, S.xs_mats_host[gi].data(),
+                                   S.xs_mats_host[gi].size() * 8, hipMemcpyHostToDevice));
             size_t msz = 0;
             for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
             for (size_t gi = 0; gi < S.mpow_host.size(); ++gi)
@@ -154,7 +157,7 @@ void Plan::finalize() {
     for (int sid : order) {
         Stage& S = stages[sid];
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
-        const char* nm = S.kind == ST_SOS ? "k_sos" : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? (S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
@@ -277,6 +280,12 @@ void Plan::release() {
 }
 
 
+// executes a deferred-profiling plan keeps events for (plans of hundreds of steps keep fewer)
+static size_t prof_cap(const Plan* P) {
+    const size_t evset = 2 * std::max<size_t>(1, P->steps.size());
+    return std::max<size_t>(1, std::min<size_t>(kProfExecs, 8192 / evset));
+}
+
 static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& err) {
     try {
         HIPCHECK(hipSetDevice(P->device));
@@ -284,13 +293,20 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
         if (P->out.nframes > 0 && !outp) fail(SO_ERR_INVALID, "so_plan_execute: null output");
         for (auto& h : P->host_leaves)
             if (h.bytes) HIPCHECK(hipMemcpyAsync(P->bufs[h.buf].d, P->array_ptr[h.node], h.bytes, hipMemcpyHostToDevice, st));
-        if (P->profiling && P->events.size() < 2 * P->steps.size()) {
-            while (P->events.size() < 2 * P->steps.size()) {
+        // profiling 1: one set of events, read (after a synchronize) at the end of this execute;
+        // profiling 2 (deferred): a set per execute, up to kProfExecs of them, nothing synchronised here --
+        // so_plan_step_info averages them once the caller has synchronised (bench.py's timed region)
+        const size_t evset = 2 * P->steps.size();
+        const size_t pcap = prof_cap(P);
+        const size_t evneed = P->profiling == 2 ? evset * pcap : evset;
+        if (P->profiling && P->events.size() < evneed) {
+            while (P->events.size() < evneed) {
                 hipEvent_t e;
                 HIPCHECK(hipEventCreate(&e));
                 P->events.push_back(e);
             }
         }
+        const size_t ev0 = P->profiling == 2 ? evset * ((size_t)P->prof_execs % pcap) : 0;
         if (P->out_alias_buf >= 0 && P->out.is_device && P->bufs[P->out_alias_buf].d != outp) {
             // in-place root pieces read the result: point their leaves at this execute's buffer
             P->bufs[P->out_alias_buf].d = outp;
@@ -317,7 +333,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 for (int d : P->step_deps[si])
                     if (P->step_lane[d] != ln) HIPCHECK(hipStreamWaitEvent(st, P->step_done[d], 0));
             }
-            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si], st));
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[ev0 + 2 * si], st));
             if (s.kind == 0) {
                 PwStep& w = P->pw[s.idx];
                 OutView ov{};
@@ -417,13 +433,29 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                                   (double*)P->bufs[S.s0_buf].d, (const double*)P->bufs[S.mpow_buf].d, g,
                                                   S.groups[0], st);
                     }
-                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0; ++gi) {
+                    bool exact_done = false;
+                    if (g.exact && !S.onepass && S.pre_stage < 0 && S.groups.size() <= 2) {
+                        // ill-conditioned cascade: DSP.jl's order of operations, one sequence per channel
+                        SosGeom gg = g;
+                        exact_done = launch_sos_exact(inp, ob.d, gg, S.groups[0], S.groups.size() > 1 ? S.groups[1] : SosCoefs{}, st) == 0;
+                        if (exact_done) nl += 1;
+                    }
+                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0 && !exact_done; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosGeom gg = g;
                         if (gi > 0) gg.in_pitch = ob.pitch;
                         // frames beyond the child's end are zero (Pad(x.signal,zero), reference
                         // src/filters.jl:240): the materialised input covers them; a direct
                         // source always has in_frames == need
+                        if (S.xscan) {  // exact scan between the state pass and the output pass
+                            double* vb = (double*)P->bufs[S.v_buf].d;
+                            double* sb = (double*)P->bufs[S.s0_buf].d;
+                            nl += launch_sos_phase(x, ob.d, vb, nullptr, gg, S.groups[gi], 1, st);
+                            nl += launch_sos_xscan(vb, sb, (const double*)((char*)P->bufs[S.xs_mats_buf].d + gi * 2 * 16 * 16 * 8),
+                                                   (double*)P->bufs[S.sblk_buf].d, gg, S.groups[gi].nsec, st);
+                            nl += launch_sos_phase(x, ob.d, nullptr, sb, gg, S.groups[gi], 3, st);
+                            continue;
+                        }
                         nl += launch_sos(x, ob.d, S.v_buf >= 0 ? (double*)P->bufs[S.v_buf].d : nullptr,
                                          S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr,
                                          S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
@@ -528,7 +560,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     launches += 2;
                 }
             }
-            if (P->profiling) HIPCHECK(hipEventRecord(P->events[2 * si + 1], st));
+            if (P->profiling) HIPCHECK(hipEventRecord(P->events[ev0 + 2 * si + 1], st));
             if (lanes && (P->step_signals[si] || (ln != 0 && si + 1 == P->steps.size())))
                 HIPCHECK(hipEventRecord(P->step_done[si], st));
         }
@@ -561,10 +593,11 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         std::memcpy((char*)outp + (size_t)(f * P->out.frame_stride + c * P->out.chan_stride) * esz,
                                     P->host_tmp.data() + (size_t)(c * P->out.nframes + f) * esz, esz);
             }
-        } else if (!P->host_leaves.empty() || P->profiling) {
+        } else if (!P->host_leaves.empty() || P->profiling == 1) {
             HIPCHECK(hipStreamSynchronize(st));
         }
-        if (P->profiling) {
+        if (P->profiling == 2) P->prof_execs++;
+        if (P->profiling == 1) {
             HIPCHECK(hipStreamSynchronize(st));
             double total = 0, best = -1;
             for (size_t si = 0; si < P->steps.size(); ++si) {
@@ -595,10 +628,23 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
     DeviceGuard guard(P->device);
     const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
                           !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
-    if (!eligible) return plan_execute_direct(P, outp, stream, err);
+    if (!eligible) {
+        P->n_direct++;
+        return plan_execute_direct(P, outp, stream, err);
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch) {
-        if (hipSetDevice(P->device) == hipSuccess && hipGraphLaunch(P->graph_exec, st) == hipSuccess) return SO_OK;
+    // The captured launches read the leaf table on the device as it stood at capture time.  In-place root
+    // pieces read the RESULT through leaves that plan_execute_direct re-points at every new result
+    // pointer: after a direct execute into another buffer the table no longer matches the graph (A, A,
+    // B, A would apply the in-place gains to B's values a second time), so the graph is only replayed
+    // while those leaves still point at its buffer; otherwise this execute goes the direct way, which
+    // points them back.
+    const bool leaves_match = P->out_alias_buf < 0 || P->bufs[P->out_alias_buf].d == outp;
+    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch && leaves_match) {
+        if (hipSetDevice(P->device) == hipSuccess && hipGraphLaunch(P->graph_exec, st) == hipSuccess) {
+            P->n_replays++;
+            return SO_OK;
+        }
         (void)hipGetLastError();
         (void)hipGraphExecDestroy(P->graph_exec);  // fall back to direct launches for good
         P->graph_exec = nullptr;
@@ -609,6 +655,12 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
         // one-time function attribute calls, which must not happen inside a capture)
         P->last_out = outp;
         P->last_epoch = P->array_epoch;
+        P->n_direct++;
+        return plan_execute_direct(P, outp, stream, err);
+    }
+    if (P->graph_exec && P->graph_out == outp && P->graph_epoch == P->array_epoch) {
+        // (the graph is still the right one; only the leaf table had moved)
+        P->n_direct++;
         return plan_execute_direct(P, outp, stream, err);
     }
     if (P->graph_exec) {
@@ -641,6 +693,7 @@ int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
     (void)hipGraphDestroy(graph);
     P->graph_out = outp;
     P->graph_epoch = P->array_epoch;
+    P->n_captures++;
     if (hipGraphLaunch(P->graph_exec, st) != hipSuccess) {
         (void)hipGetLastError();
         P->graph_failed = true;
@@ -697,7 +750,18 @@ int64_t plan_nframes(const Plan* P) {
     return isinf_(R.len) ? SO_LEN_INF : R.len.n;
 }
 void plan_stats(const Plan* P, so_stats_t* st) { *st = P->stats; }
-void plan_set_profiling(Plan* P, bool on) { P->profiling = on; }
+void plan_set_profiling(Plan* P, int mode) {
+    P->profiling = mode < 0 || mode > 2 ? 1 : mode;
+    P->prof_execs = 0;
+}
+int64_t plan_counter(const Plan* P, int which) {
+    switch (which) {
+    case SO_COUNTER_GRAPH_REPLAYS: return P->n_replays;
+    case SO_COUNTER_GRAPH_CAPTURES: return P->n_captures;
+    case SO_COUNTER_DIRECT_EXECUTES: return P->n_direct;
+    default: return -1;
+    }
+}
 int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
     if (info && index >= 0 && index < (int)P->steps.size()) {
         const Step& s = P->steps[index];
@@ -705,6 +769,22 @@ int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
         std::snprintf(info->name, sizeof info->name, "%s", s.name.c_str());
         info->algorithmic_bytes = s.bytes;
         info->ms = s.ms;
+        if (P->profiling == 2 && P->prof_execs > 0) {
+            // deferred mode: mean over the (up to kProfExecs most recent) executes recorded since
+            // so_plan_set_profiling(plan, 2); the caller has synchronised the stream
+            const size_t evset = 2 * P->steps.size();
+            const int64_t n = std::min<int64_t>(P->prof_execs, (int64_t)prof_cap(P));
+            double sum = 0;
+            int64_t got = 0;
+            for (int64_t e = 0; e < n; ++e) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, P->events[evset * e + 2 * index], P->events[evset * e + 2 * index + 1]) == hipSuccess) {
+                    sum += ms;
+                    ++got;
+                } else (void)hipGetLastError();
+            }
+            info->ms = got ? sum / (double)got : 0.0;
+        }
         info->launches = s.launches;
     }
     return (int)P->steps.size();

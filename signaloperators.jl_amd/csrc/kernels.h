@@ -10,6 +10,17 @@ void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, cons
 // returns number of kernel launches
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
                const SosGeom& g, const SosCoefs& cf, hipStream_t st);
+// one pass of the three-pass IIR on its own: phase 1 (chunk end states from zero state -> v) or
+// phase 3 (outputs from the chunk start states s0)
+int launch_sos_phase(const void* x, void* y, double* v, const double* s0, const SosGeom& g, const SosCoefs& cf, int phase,
+                     hipStream_t st);
+// exact scan between them (kernels2.hip): s0[k+1] = M s0[k] + v[k] over ALL earlier chunks, no 2^-70 cut;
+// mats = [M = A^L][MB = M^kXsBlock] (D x D each, row-major), sblk = [nch][nblocks][16] scratch.  3 launches.
+constexpr int kXsBlock = 64;
+int launch_sos_xscan(const double* v, double* s0, const double* mats, double* sblk, const SosGeom& g, int nsec, hipStream_t st);
+// SOS IIR in the reference's order of operations, one sequence per channel (kernels2.hip); a: sections
+// 1..8, b: sections 9..16 (b.nsec == 0: none).  0 when launched, -1: no instantiation
+int launch_sos_exact(const void* x, void* y, const SosGeom& g, const SosCoefs& a, const SosCoefs& b, hipStream_t st);
 // SOS IIR whose state pass was done by the resampler in front (vper: [nch][nper][16])
 int launch_sos_prestate(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
                         double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,

@@ -931,6 +931,40 @@ int launch_sos_prestate(const void* x, void* y, const double* vper, int64_t nper
     return 3;
 }
 
+// One pass of the three-pass form on its own (phase 1: chunk end states v from zero state; phase 3:
+// outputs from the chunk start states s0) -- for callers that put a different scan in between
+// (kernels2.hip launch_sos_xscan).  Returns the number of launches.
+template <int NS, typename T>
+static void launch_sos_phase_t(const void* x, void* y, double* v, const double* s0, const SosGeom& g, const SosCoefs& cf,
+                               int phase, hipStream_t st) {
+    const int64_t nseq = (int64_t)g.nchunks * g.nch;
+    if (phase == 1) {
+        const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
+        hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
+    } else {
+        hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const T*)x, (T*)y, s0, (double*)nullptr, g, cf);
+    }
+}
+int launch_sos_phase(const void* x, void* y, double* v, const double* s0, const SosGeom& g, const SosCoefs& cf, int phase,
+                     hipStream_t st) {
+    if (g.n <= 0 || (phase == 1 && g.nchunks <= 1)) return 0;
+#define SO_PH(NS_)                                                                                     \
+    case NS_:                                                                                          \
+        if (g.in_dtype == SO_F32) launch_sos_phase_t<NS_, float>(x, y, v, s0, g, cf, phase, st);          \
+        else launch_sos_phase_t<NS_, double>(x, y, v, s0, g, cf, phase, st);                              \
+        break;
+    switch (cf.nsec) {
+        SO_PH(1) SO_PH(2) SO_PH(3) SO_PH(4) SO_PH(5) SO_PH(6) SO_PH(7)
+    default:
+        if (g.in_dtype == SO_F32) launch_sos_phase_t<8, float>(x, y, v, s0, g, cf, phase, st);
+        else launch_sos_phase_t<8, double>(x, y, v, s0, g, cf, phase, st);
+    }
+#undef SO_PH
+    return 1;
+}
+
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
                const SosGeom& g, const SosCoefs& cf, hipStream_t st) {
     if (g.n <= 0) return 0;
@@ -2416,6 +2450,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         }
         TilePos pr = tile_first();  // tile being retired
         int sr = 0;                 // ... and its slot
+        const int echo_lag = (g.pad >> 8) & 0xff;  // measurement aid, see below
+        TilePos pe = tile_first();
         for (int it = 0;; ++it) {
             const int allowed = A >= 2 ? cnt0 + cnt1 : (A == 1 ? cnt0 : 0);
             const bool live = pr.tc < ngrp;
@@ -2523,6 +2559,30 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                         const int ppi = (4 * i) % PT, cci = (16 * q + 4 * i) / PT;  // compile-time after unrolling
                         if (kq + ppi < plim) vl[((size_t)cci * (size_t)nper + (size_t)ppi) * 16] = acc[q][i];
                     }
+            }
+            if (echo_lag > 0 && lidx == nactive && it >= echo_lag) {
+                // measurement aid (SIGOPS_RS_DEBUG bits 8..15 = lag in tiles): an idle loader wave reads
+                // the result tile the compute waves stored `lag` tiles ago back through L2 (sc1 loads)
+                // and stores it again -- the memory behaviour of a filter wave working in place
+                if (pe.tc < ngrp) {
+                    TO* __restrict__ yt = y + ((int64_t)((int)pe.tc * CT) * g.out_pitch + pe.tx * g.pt * g.L);
+                    const int64_t left = g.n_out - pe.tx * g.pt * g.L;
+                    const int nfr_t = (int)(left < (int64_t)g.pt * g.L ? left : (int64_t)g.pt * g.L);
+                    constexpr int EV = 16 / (int)sizeof(TO);
+                    typedef TO evec __attribute__((ext_vector_type(EV)));
+                    for (int c = 0; c < CT; ++c) {
+                        TO* row = yt + (int64_t)c * g.out_pitch;
+                        for (int f0 = 0; f0 + 64 * EV * 5 <= nfr_t; f0 += 64 * EV * 5) {
+                            evec v[5];
+#pragma unroll
+                            for (int u = 0; u < 5; ++u)
+                                v[u] = __builtin_nontemporal_load(reinterpret_cast<const evec*>(row + f0 + (u * 64 + lane) * EV));
+#pragma unroll
+                            for (int u = 0; u < 5; ++u) *reinterpret_cast<evec*>(row + f0 + (u * 64 + lane) * EV) = v[u] + (TO)0;  // (x + 0 is not x for -0: the store stays)
+                        }
+                    }
+                }
+                tile_next(pe);
             }
             f_duty(pf, fbw(it), it & 1);  // gains of tile it+2
             rs_stamp(g, wave, it, 4);
@@ -2644,6 +2704,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         tile_next(pf);
         rs_stamp(g, wave, it, 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((g.pad >> 8) & 0xff) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (echo aid: the previous tile's stores have left)
         rs_stamp(g, wave, it, 1);
         __builtin_amdgcn_s_barrier();  // next tile published; all finished reading this one
         rs_stamp(g, wave, it, 2);

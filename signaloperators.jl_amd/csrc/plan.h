@@ -27,7 +27,8 @@ int plan_execute(Plan* p, void* out, void* stream, std::string& err);
 int plan_set_array(Plan* p, int32_t node_index, const void* data, std::string& err);
 int64_t plan_nframes(const Plan* p);
 void plan_stats(const Plan* p, so_stats_t* st);
-void plan_set_profiling(Plan* p, bool on);
+void plan_set_profiling(Plan* p, int mode);
+int64_t plan_counter(const Plan* p, int which);
 int plan_step_info(const Plan* p, int index, so_step_info_t* info);
 void plan_destroy(Plan* p);
 

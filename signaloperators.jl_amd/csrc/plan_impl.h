@@ -107,6 +107,7 @@ struct Stage {
     int64_t base = 0;  // first frame the stage computes (warm start, see process_stage): its buffer holds [base, need)
     int64_t in_base = 0;  // first frame of the child the stage consumes
     bool processed = false;
+    bool under_norm = false;  // a Normpower consumes this stage (directly or through further stages)
     int out_buf = -1, in_buf = -1, aux_buf = -1;
     int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)
     // input source (after processing): either a materialised buffer or a direct view
@@ -122,6 +123,9 @@ struct Stage {
     std::vector<SosCoefs> groups;
     SosGeom sg{};
     int mpow_buf = -1, v_buf = -1, s0_buf = -1;
+    bool xscan = false;  // pass 2 is the exact block scan (launch_sos_xscan): no 2^-70 cut anywhere
+    int xs_mats_buf = -1, sblk_buf = -1;
+    std::vector<std::vector<double>> xs_mats_host;  // per group: [M][M^kXsBlock]
     std::vector<std::vector<double>> mpow_host;  // per group
     // single-pass kernel (k_sos_onepass)
     bool onepass = false;
@@ -187,6 +191,8 @@ struct Step {
     int launches = 0;
 };
 
+constexpr int kProfExecs = 256;  // executes a deferred-profiling plan keeps events for
+
 struct HostLeaf {
     int node;
     const void* src;
@@ -224,7 +230,8 @@ struct Plan {
     int64_t alias_skip = 0;     // ... from its local frame alias_skip on (an IIR's warm-up frames are not stored)
     bool interleaved_host = false;  // host result with frame_stride = nch, chan_stride = 1
     std::vector<char> host_tmp;
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 per-execute (synchronising), 2 deferred (see plan_execute_direct)
+    int64_t prof_execs = 0;
     std::vector<hipEvent_t> events;
     // independent step chains (Append children, Mix operands with their own filters ...) run on
     // separate HIP streams: the small latency-bound kernels of different chains overlap
@@ -243,6 +250,7 @@ struct Plan {
     const void* last_out = nullptr;
     int64_t array_epoch = 0, graph_epoch = -1, last_epoch = -1;
     bool graph_failed = false;
+    int64_t n_replays = 0, n_captures = 0, n_direct = 0;  // so_plan_counter
     so_stats_t stats{};
     int64_t algo_bytes = 0;
     std::map<int, bool> array_counted;
@@ -335,6 +343,7 @@ struct Plan {
                                int force_dtype);
     int stage_for(int ni, int kind);
     void use_stage(Stage& S, const Rect& r, const Map& m);
+    int in_norm = 0;  // > 0: lowering below a Normpower (stages created or used here are marked Stage::under_norm)
     int dry = 0;  // > 0: lower() only looks for the errors evaluating those frames raises (no stages, no buffers)
     void check_frames(int ni, int64_t upto);
     void process_stage(int sid);

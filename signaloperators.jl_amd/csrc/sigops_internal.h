@@ -140,7 +140,7 @@ struct SosGeom {
     int32_t nch;
     int32_t kterms;  // K: terms of the truncated power sum in pass 2
     int32_t in_dtype, out_dtype;
-    int32_t pad;
+    int32_t exact;   // 1: one chunk, DSP.jl's order of operations without fused multiply-adds (ill-conditioned cascades)
     int64_t in_pitch, out_pitch;  // elements between channels
     int64_t store_lo;             // pass 3 stores frames >= store_lo only (warm-up frames of a windowed result)
 };

@@ -107,13 +107,21 @@ class Plan:
             raise S.ErrorException(K.last_error())
 
     def set_profiling(self, on=True):
-        K.lib().so_plan_set_profiling(self.handle, 1 if on else 0)
+        """so_plan_set_profiling: False/0 off, True/1 per execute (synchronising), 2 deferred (events of
+        every execute kept; `steps()` after a synchronize reports the mean)"""
+        K.lib().so_plan_set_profiling(self.handle, int(on))
 
     def stats(self):
         s = K.so_stats_t()
         K.lib().so_plan_stats(self.handle, C.byref(s))
         return {f[0]: (getattr(s, f[0]).decode() if f[0] == "dominant_kernel" else getattr(s, f[0]))
                 for f in K.so_stats_t._fields_}
+
+    def counters(self):
+        """so_plan_counter: how the executes so far were issued (graph replays / captures / direct)"""
+        L = K.lib()
+        return {"graph_replays": L.so_plan_counter(self.handle, 0), "graph_captures": L.so_plan_counter(self.handle, 1),
+                "direct_executes": L.so_plan_counter(self.handle, 2)}
 
     def steps(self):
         """per-step statistics of the last (profiled) execute: so_plan_step_info"""
