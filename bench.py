@@ -22,7 +22,9 @@ One JSON line is printed by rank 0 (driver contract) with these extra objects:
                   algorithmic bytes / its hipEvent time inside the library, on the stream it runs on
   roofline_sink   the whole sink from the TIMED LOOP: algorithmic bytes of the sink / ms_per_step
   stages          every stage of the plan (hipEvent ms, launches, algorithmic bytes)
-  parity_gate     engine vs CPU oracle on a prefix of the same input, checked BEFORE timing
+  parity_gate     engine vs CPU oracle on a prefix of the same input: checked after the timed loops and
+                  before anything is printed (a failure exits without a result line)
+  parity_full     the timed plan's own result against the oracle on the same noise, whole length
   cpu_baseline    the CPU oracle (a port of the reference's block-pull engine) rebuilt here with
                   -O3 -march=native, timed on this host: 1 thread, and all channels in parallel
 """
@@ -131,6 +133,10 @@ def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev, series=None,
             ev[k].record()
         host.append(time.perf_counter())
     t_issued = time.perf_counter()
+    t_lastev = None
+    if nev and k >= 1:
+        ev[k].synchronize()  # the last execute's event: the launch stream has drained
+        t_lastev = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -140,7 +146,9 @@ def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev, series=None,
         series.extend(round(ev[i].elapsed_time(ev[i + 1]), 4) for i in range(k) if i != gap)
         # host side of the same loop: when each execute call returned, and when the last one had
         series.append({"host_return_ms": [round((h - t0) * 1e3, 3) for h in host[:64]],
-                       "host_issue_total_ms": round((t_issued - t0) * 1e3, 3), "wall_ms": round(elapsed * 1e3, 3)})
+                       "host_issue_total_ms": round((t_issued - t0) * 1e3, 3),
+                       "launch_stream_drained_ms": round((t_lastev - t0) * 1e3, 3) if t_lastev else None,
+                       "wall_ms": round(elapsed * 1e3, 3)})
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +191,10 @@ def roofline_of(stage, traffic=None, source=None):
 
 
 def parity_gate(so, tree_fn, noise_host, tol=1e-6):
-    """engine vs oracle on a prefix of the same input (correctness gate before timing)"""
+    """engine vs oracle on a prefix of the same input (BASELINE.md §2's correctness gate).  Runs AFTER the
+    timed loops: freeing this one-shot plan's device buffers right before them stalled the device for
+    40-70 ms somewhere in the next ~100 ms on one run in three (round 3, tools/stall_probe.sh: 0 of 5
+    runs without the gate or with a 1 s pause after it, 5 of 12 with it directly in front)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_bridge import oracle_sink, relerr
 
@@ -195,7 +206,7 @@ def parity_gate(so, tree_fn, noise_host, tol=1e-6):
     res = {"relerr": err, "tolerance": tol, "input_frames": int(n), "output_frames": int(got.shape[0]),
            "oracle": "CPU restatement of the reference (DSP.jl phase-accumulator positions), tests/oracle_bridge.py"}
     if not (got.shape == want.shape and err <= tol):
-        raise SystemExit(f"bench.py: parity gate failed before timing: {res}")
+        raise SystemExit(f"bench.py: parity gate failed (no result is reported): {res}")
     return res
 
 
@@ -333,13 +344,6 @@ def main():
                      "config3: Signal(noise[%d x %d],44.1kHz) |> Amplify(sin 5Hz) |> Until(%gs) |> ToFramerate(48kHz) |> sink") \
         % (n_in, nch, args.seconds) + " (device-resident leaf and result)"
 
-    # ---- correctness gate before timing (rank 0, same device noise, a prefix) ----
-    gate = None
-    if rank == 0:
-        m = min(n_in, 150_000)
-        pre = np.asfortranarray(noise_t[:, :m].t().cpu().numpy())
-        gate = parity_gate(so, headline_fn, pre, 1e-6 if args.dtype == "f64" else 2e-6)
-
     plan, out_t, out, n_out, plan_ms = prepare(headline_fn)
     optr = out.data_ptr()
     series = []
@@ -378,6 +382,13 @@ def main():
                      "step_ms_series": series3, "host_side": host3}
         p3.close()
         del o3_t, o3
+
+    # ---- correctness gate (rank 0, same device noise, a prefix); the whole length: parity_full below ----
+    gate = None
+    if rank == 0:
+        m = min(n_in, 150_000)
+        pre = np.asfortranarray(noise_t[:, :m].t().cpu().numpy())
+        gate = parity_gate(so, headline_fn, pre, 1e-6 if args.dtype == "f64" else 2e-6)
 
     if rank == 0:
         algo = st["algorithmic_bytes"]
