@@ -2103,7 +2103,9 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // compute its chunk states from the staged tiles (see RsPeriodic::nstate).  A separate
 // instantiation: the state waves' 24 tap registers must not raise the register budget (and with
 // it, spills) of the kernels that do not use them.
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false>
+// GADD (with GA): the one fused step is an ADD (`Mix(x32, Signal(sin))`) instead of a multiply: the gain
+// ring then holds zeros outside the fused pieces (the zero extension of the stage's input is 0, not 0 + g).
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -2201,6 +2203,13 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
     const int64_t lo_ok = a0 > 0 ? a0 : 0;
     const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
+    // GADD: frames the fused pieces cover (carriers are sorted and adjacent): the gain is added there only
+    int64_t ga_lo = 0, ga_hi = 0;
+    if constexpr (GADD) {
+        const int64_t bl = rfl64(ctl.car[max(0, min(kCtlCar - 1, __builtin_amdgcn_readfirstlane(ctl.ncar) - 1))].b);
+        ga_lo = lo_ok;
+        ga_hi = bl < g.n_in ? bl : g.n_in;
+    }
     auto is_fast = [&](const TilePos& p, int64_t& xa, int& nfr) __attribute__((always_inline)) {
         const int sh = (int)(p.xb & (kAlign - 1));
         xa = p.xb - sh;
@@ -2316,6 +2325,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     const double2 b = *reinterpret_cast<const double2*>(btab() + bb * 2 * kRsTwoBases + 2 * u);
                     double v = fma(b.x, d.y, b.y * d.x);
                     if (kind0 & 0x100) v = (double)(float)v;
+                    if constexpr (GADD) v = (xa + f >= ga_lo && xa + f < ga_hi) ? v : 0.0;
                     if (f < nfr) Fb[f] = v;
                 }
             }
@@ -2330,8 +2340,11 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 for (int sp = 0; sp < 2; ++sp) {
                     const int shr = sp ? share1 : share0;
                     if (shr < 0) break;
-                    for (int f = (nfr - g.tile_len) + shr * 64 + lane; f < nfr; f += nshares * 64)
-                        Fb[k * g.fpitch + f] = slot_eval(kind, L, xa + f);
+                    for (int f = (nfr - g.tile_len) + shr * 64 + lane; f < nfr; f += nshares * 64) {
+                        double v = slot_eval(kind, L, xa + f);
+                        if constexpr (GADD) v = (xa + f >= ga_lo && xa + f < ga_hi) ? v : 0.0;
+                        Fb[k * g.fpitch + f] = v;
+                    }
                 }
             }
         }
@@ -2450,8 +2463,6 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         }
         TilePos pr = tile_first();  // tile being retired
         int sr = 0;                 // ... and its slot
-        const int echo_lag = (g.pad >> 8) & 0xff;  // measurement aid, see below
-        TilePos pe = tile_first();
         for (int it = 0;; ++it) {
             const int allowed = A >= 2 ? cnt0 + cnt1 : (A == 1 ? cnt0 : 0);
             const bool live = pr.tc < ngrp;
@@ -2560,30 +2571,6 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                         if (kq + ppi < plim) vl[((size_t)cci * (size_t)nper + (size_t)ppi) * 16] = acc[q][i];
                     }
             }
-            if (echo_lag > 0 && lidx == nactive && it >= echo_lag) {
-                // measurement aid (SIGOPS_RS_DEBUG bits 8..15 = lag in tiles): an idle loader wave reads
-                // the result tile the compute waves stored `lag` tiles ago back through L2 (sc1 loads)
-                // and stores it again -- the memory behaviour of a filter wave working in place
-                if (pe.tc < ngrp) {
-                    TO* __restrict__ yt = y + ((int64_t)((int)pe.tc * CT) * g.out_pitch + pe.tx * g.pt * g.L);
-                    const int64_t left = g.n_out - pe.tx * g.pt * g.L;
-                    const int nfr_t = (int)(left < (int64_t)g.pt * g.L ? left : (int64_t)g.pt * g.L);
-                    constexpr int EV = 16 / (int)sizeof(TO);
-                    typedef TO evec __attribute__((ext_vector_type(EV)));
-                    for (int c = 0; c < CT; ++c) {
-                        TO* row = yt + (int64_t)c * g.out_pitch;
-                        for (int f0 = 0; f0 + 64 * EV * 5 <= nfr_t; f0 += 64 * EV * 5) {
-                            evec v[5];
-#pragma unroll
-                            for (int u = 0; u < 5; ++u)
-                                v[u] = __builtin_nontemporal_load(reinterpret_cast<const evec*>(row + f0 + (u * 64 + lane) * EV));
-#pragma unroll
-                            for (int u = 0; u < 5; ++u) *reinterpret_cast<evec*>(row + f0 + (u * 64 + lane) * EV) = v[u] + (TO)0;  // (x + 0 is not x for -0: the store stays)
-                        }
-                    }
-                }
-                tile_next(pe);
-            }
             f_duty(pf, fbw(it), it & 1);  // gains of tile it+2
             rs_stamp(g, wave, it, 4);
             tile_next(pf);
@@ -2660,7 +2647,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
 #pragma unroll
                 for (int q = 0; q < kRsQ; ++q) {
                     abuf[0][q] = (double)ap[q][0];
-                    if constexpr (GA) abuf[0][q] *= gp[q][0];
+                    if constexpr (GA && GADD) abuf[0][q] += gp[q][0];
+                    else if constexpr (GA) abuf[0][q] *= gp[q][0];
                 }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -2668,7 +2656,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
 #pragma unroll
                         for (int q = 0; q < kRsQ; ++q) {
                             abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
-                            if constexpr (GA) abuf[(s + 1) & 1][q] *= gp[q][4 * (s + 1)];
+                            if constexpr (GA && GADD) abuf[(s + 1) & 1][q] += gp[q][4 * (s + 1)];
+                            else if constexpr (GA) abuf[(s + 1) & 1][q] *= gp[q][4 * (s + 1)];
                         }
                     }
 #pragma unroll
@@ -2704,7 +2693,6 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         tile_next(pf);
         rs_stamp(g, wave, it, 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if ((g.pad >> 8) & 0xff) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (echo aid: the previous tile's stores have left)
         rs_stamp(g, wave, it, 1);
         __builtin_amdgcn_s_barrier();  // next tile published; all finished reading this one
         rs_stamp(g, wave, it, 2);
@@ -2712,7 +2700,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
@@ -2721,10 +2709,10 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
                   (ST ? (size_t)4 * g.ksw * 10 : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
 }
 
@@ -2745,6 +2733,16 @@ static int launch_rp_ga(void* y, const double* tab, const int* jend, const RsPer
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
     if (g.kw != 4 * 14 || gper != 1) return -1;
+    if (g.ga == 2) {  // the fused step is an add (`Mix`)
+        if (g.out_f32) {
+            if (g.ftwo) launch_rp_k<float, CT, 14, 1, true, float, true, false, true>(y, tab, jend, g, gsrc, st);
+            else launch_rp_k<float, CT, 14, 1, false, float, true, false, true>(y, tab, jend, g, gsrc, st);
+        } else {
+            if (g.ftwo) launch_rp_k<float, CT, 14, 1, true, double, true, false, true>(y, tab, jend, g, gsrc, st);
+            else launch_rp_k<float, CT, 14, 1, false, double, true, false, true>(y, tab, jend, g, gsrc, st);
+        }
+        return 0;
+    }
     if (g.out_f32) {
         if (g.ftwo) launch_rp_k<float, CT, 14, 1, true, float, true>(y, tab, jend, g, gsrc, st);
         else launch_rp_k<float, CT, 14, 1, false, float, true>(y, tab, jend, g, gsrc, st);
@@ -2858,7 +2856,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_fix(RsFixArgs a) {
                                                           : ((const double*)C.base)[off];
                         }
                         if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
-                        if (C.pad_) val[0][0] *= F[0][0];  // GA carrier: Float32 sample times its Float64 gain
+                        if (C.pad_ >= 3) val[0][0] += F[0][0];     // GA carrier, add: Float32 sample plus its Float64 operand
+                        else if (C.pad_) val[0][0] *= F[0][0];  // GA carrier: Float32 sample times its Float64 gain
                         xv = st32 ? (double)(float)val[0][0] : val[0][0];
                     }
                 } else {

@@ -89,7 +89,8 @@ struct DCarrier {
     int32_t slot_leaf[4];
     int32_t slot_kind[4];
     int32_t pad_;  // 1: GA carrier (k_resample_periodic GA): Float32 array, its single multiply by slot 0
-                   //    is applied by the compute waves (nsteps is 0 for the staging code)
+                   //    is applied by the compute waves (nsteps is 0 for the staging code); 2: a generated
+                   //    piece of such a source (staged as 1.0f); 3 / 4: the same with an ADD (staged as 0.0f)
 };
 
 // Control block of the periodic resampler's fused source.  Every workgroup copies it into LDS
@@ -256,7 +257,7 @@ struct RsPeriodic {
     int32_t nload;      // loader waves that copy / modify (0: all of them)
     int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
     int32_t out_f32;    // fp64 kernel storing into a Float32 result (`sink` of a Float64 signal into Float32)
-    int32_t ga;         // GA instantiation: Float32 tiles, the gain multiplied at the A operand; lds_pitch in floats
+    int32_t ga;         // GA instantiation: Float32 tiles, the gain multiplied (1) or added (2) at the A operand; lds_pitch in floats
     // Fused IIR state pass (the stage's only consumer is an SOS filter): the last nstate (= 2) loader
     // waves multiply every row's staged window [jlo, jlo + 4*ksw) by wtab = (G . Tap), the filter's
     // zero-state end-of-period state as a linear function of the resampler's INPUT, and write

@@ -825,7 +825,7 @@ void Plan::process_stage(int sid) {
             // three gain arrays, no in-place work for the loaders
             RsPeriodic& rp = S.rp;
             const size_t avail = 160 * 1024 - sizeof(RsCtl) - 64;
-            rp.ga = 1;
+            rp.ga = S.carriers[0].pad_ >= 3 ? 2 : 1;
             rp.lds_pitch = (int)((rp.tile_len + 31 + 8 + 3) / 4 * 4);
             const size_t tile_bytes = (size_t)rp.ct * rp.lds_pitch * 4;
             rp.fslots = 1;
@@ -1002,9 +1002,11 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
     // Further carriers may only be generated pieces whose value is that same gain (the tail of an
     // infinite `Amplify`: the array's padding `one` times the gain): staged as 1.0f.
     bool ga = false;
-    if (allow_ga && !cs.empty() && cs[0].dtype == SO_F32 && cs[0].nsteps == 1 && cs[0].op[0] == OP_MUL &&
+    bool ga_add = false;  // ... or PLUS one Float64 per-frame operand (`Mix(x32, Signal(sin))`): added at the A operand
+    if (allow_ga && !cs.empty() && cs[0].dtype == SO_F32 && cs[0].nsteps == 1 && (cs[0].op[0] == OP_MUL || cs[0].op[0] == OP_ADD) &&
         !(cs[0].arg[0] & 0x200) && (cs[0].array_node >= 0 || cs[0].buf >= 0) && monos_all[0].size() == 1) {
         ga = true;
+        ga_add = cs[0].op[0] == OP_ADD;
         for (size_t i = 1; i < cs.size(); ++i)
             if (cs[i].base != nullptr || cs[i].array_node >= 0 || cs[i].buf >= 0 || cs[i].nsteps != 1 ||
                 cs[i].op[0] != OP_LOADF || (cs[i].arg[0] & 0x300) || monos_all[i].size() != 1 || cs[i].dtype != SO_F64)
@@ -1090,7 +1092,7 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         // the staging code copies the raw samples (1.0f for the generated pieces); the multiply
         // happens at the A operand
         for (size_t i = 0; i < cs.size(); ++i) {
-            cs[i].pad_ = i == 0 ? 1 : 2;
+            cs[i].pad_ = (i == 0 ? 1 : 2) + (ga_add ? 2 : 0);  // 1/2: multiply (generated pieces staged as 1.0f), 3/4: add (as 0.0f)
             cs[i].nsteps = 0;
             cs[i].dtype = SO_F32;
         }

@@ -371,6 +371,44 @@ def test_float32_array_times_float64_gain_is_fused(nch, n, res_dt, gen, monkeypa
     assert relerr(res.astype(np.float64), ref.astype(np.float64)) < (1e-10 if res_dt == np.float64 else 1e-7)
 
 
+@pytest.mark.parametrize("nch,n,res_dt,gen,tone_len", [(8, 300_000, np.float64, dict(ω=1 * so.kHz), 0), (4, 120_000, np.float64, dict(ω=440 * so.Hz, ϕ=0.3), 0),
+                                                      (8, 50_000, np.float32, dict(ω=5 * so.Hz), 0), (8, 470_000, np.float64, dict(ω=1 * so.kHz), 0),
+                                                      (8, 60_000, np.float64, dict(ω=100 * so.Hz), 63_000), (4, 30_000, np.float64, dict(ω=100 * so.Hz), 20_000)])
+def test_float32_array_plus_float64_generator_is_fused(nch, n, res_dt, gen, tone_len, monkeypatch):
+    """`Mix(Signal(sin), x::Float32 array)` is a Float64 signal too: the GA instantiation ADDS the
+    generator at the A operand (round 3; the headline pipeline with a Float32 leaf used to materialise
+    the Mix with a K1 pass, 0.67 ms).  The zero extension of the resampler's input stays zero (the gain
+    ring holds zeros outside the fused pieces), a tone longer than the array continues alone (a
+    generated piece, staged as 0.0f), a shorter one ends inside the array (two pieces: K1 path)."""
+    rng = np.random.default_rng(72)
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(np.float32))
+    tone = so.Signal(so.sin, **gen)
+    total = n
+    if tone_len:
+        tone = tone | so.Until(tone_len * so.frames)
+        total = max(n, tone_len)
+    tree = so.Mix(tone, so.Signal(x, 44.1 * so.kHz)) | so.Until(total * so.frames) | so.ToFramerate(48 * so.kHz)
+    want = oracle_sink(tree)
+    assert want.dtype == np.float64
+    res = np.full((so.nframes(tree), nch), np.nan, dtype=res_dt, order="F")
+    so.sink_into(res, tree)
+    if res_dt == np.float64:
+        assert relerr(res, want) < 1e-9
+        assert relerr(res[-2000:], want[-2000:]) < 1e-9  # (the end: where the input's zero extension is read)
+    else:
+        assert relerr(res.astype(np.float64), want.astype(np.float32).astype(np.float64)) < 1e-7
+    if tone_len == 0 or tone_len >= n:
+        from sigops_amd.engine import Plan
+        p = Plan(so.ToChannels(tree, nch), res.shape, res_dt, (1, res.shape[0]), False)
+        names = [s_["name"] for s_ in p.steps()]
+        p.close()
+        assert names == ["k_resample_periodic"], names  # one launch: nothing materialised in front
+    monkeypatch.setenv("SIGOPS_RS_NOGA", "1")
+    ref = np.full_like(res, np.nan)
+    so.sink_into(ref, tree)
+    assert relerr(res.astype(np.float64), ref.astype(np.float64)) < (1e-10 if res_dt == np.float64 else 1e-7)
+
+
 @pytest.mark.parametrize("nch,n,dt", [(8, 70_000, np.float64), (2, 33_333, np.float64), (5, 20_000, np.float32), (12, 9_000, np.float64),
                                      (1, 5_000, np.float64), (8, 600, np.float64)])
 def test_interleaved_leaves_and_results(nch, n, dt):
@@ -489,3 +527,14 @@ def test_fused_float32_gain_on_a_signal_of_many_tiles(nch):
     want = oracle_sink(tree)
     for _ in range(3):
         assert relerr(so.sink(tree, so.Array), want) <= 1e-9
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+def test_filtering_spectral_inequalities_on_the_engine(nch):
+    """runtests.jl:314-350 restated (tests/spectral_checks.py), evaluated by the HIP engine; and the same
+    trees agree with the oracle"""
+    from spectral_checks import filtering_inequalities
+
+    high = filtering_inequalities(lambda t: so.sink(t, so.Array), nch)
+    high_o = filtering_inequalities(oracle_sink, nch)
+    assert relerr(high, high_o) < 1e-9

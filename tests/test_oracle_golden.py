@@ -241,6 +241,13 @@ def test_blocksize_invariance(name, blocksize):
         assert np.array_equal(A(x, blocksize=blocksize), base)
 
 
+@pytest.mark.parametrize("nch", [1, 2])
+def test_filtering_spectral_inequalities(nch):  # runtests.jl:314-350: the reference's only value-level pins of Filt
+    from spectral_checks import filtering_inequalities
+
+    filtering_inequalities(A, nch)
+
+
 def test_filter_state_after():  # runtests.jl:358-362
     full = A(CASES["filt_highpass_cheby"]())
     aft = A(CASES["filt_after"]())
