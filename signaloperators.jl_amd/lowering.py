@@ -194,7 +194,7 @@ def _demand(x, n, out, skip=0):
     if n is None or S.isknowninf(n) or n <= 0:
         return  # (infinite demands are rejected by the planner with the reference's error)
     if isinstance(x, S.FuncSig):
-        if x.fn == S.RANDN:
+        if x.fn in (S.RANDN, S.OPAQUE):
             n0, s0 = out.get(id(x), (0, skip))
             out[id(x)] = (max(n0, n), min(s0, skip))
         return
@@ -230,6 +230,10 @@ def _demand(x, n, out, skip=0):
             if rem <= 0:
                 break
     elif isinstance(x, S.MapSignal):
+        if isinstance(x.fn, S.OpaqueFn):  # host-materialised as a whole: its operands are sunk on their own
+            n0, s0 = out.get(id(x), (0, skip))
+            out[id(x)] = (max(n0, n), min(s0, skip))
+            return
         for c in x.signals:
             _demand(c, capped(c, n), out, skip)
     elif isinstance(x, S.FilteredSignal):
@@ -251,6 +255,49 @@ def _demand(x, n, out, skip=0):
         return
 
 
+def _apply_host(fn, args):
+    """fn over whole arrays if it broadcasts like a ufunc, else element by element"""
+    try:
+        out = np.asarray(fn(*args))
+        if out.shape == np.asarray(args[0]).shape:
+            return out
+    except Exception:  # noqa: BLE001
+        pass
+    return np.frompyfunc(fn, len(args), 1)(*args).astype(np.float64)
+
+
+def _host_function_leaf(s, n):
+    """`Signal(fn)` with a closure the engine has no kernel for: the reference's own arithmetic
+    (src/functions.jl:53-60, every operation separately rounded, first frame t = 1/fs) in NumPy"""
+    if s.fs is None:
+        S.error("Unknown frame rate: function signals need a frame rate before `sink` (use ToFramerate)")
+    t = np.arange(1, n + 1, dtype=np.float64) / float(s.fs)
+    if s.omega is not None:
+        arg = 2 * np.pi * np.fmod(t * float(s.omega) + s.phi, 1.0)
+    else:
+        arg = t + s.phi
+    return np.asfortranarray(np.asarray(_apply_host(s.pyfn, (arg,)), dtype=np.float64).reshape(-1, 1))
+
+
+def _host_map_leaf(s, n, rng):
+    """`OperateOn(fn, xs...)` with an opaque closure (reference src/mapsignal.jl:131-145, frame protocol
+    :249-272): the operands -- extended with the map's padding, `Extend.(signals, padding)` at :26 -- are
+    evaluated by the engine, the closure by NumPy; the result is handed back as an array leaf."""
+    from . import engine
+
+    cols = []
+    for c in s.signals:
+        cl = S.nframes(c)
+        ext = c if (cl is None or S.isknowninf(cl) or cl >= n) else S.Extend(c, s.padding)
+        cols.append(engine.sink(ext | S.Until(n * S.frames), engine.Array, rng=rng))
+    if s.bychannel:
+        out = _apply_host(s.fn.fn, cols)
+    else:  # the closure sees whole frames (tuples of channel values)
+        rows = [s.fn.fn(*[tuple(col[i]) for col in cols]) for i in range(n)]
+        out = np.asarray(rows, dtype=np.float64).reshape(n, -1)
+    return np.asfortranarray(np.asarray(out, dtype=s.dtype if s.dtype != S.I64 else np.float64).reshape(n, -1))
+
+
 def lower(x, nframes_out=None, rng=None):
     x = S._assignal(x)
     lw = Lowered()
@@ -266,6 +313,24 @@ def lower(x, nframes_out=None, rng=None):
     def common(s, kind):
         return dict(kind=kind, dtype=_DT[s.dtype], nch=s.nch, nframes=_len_code(S.nframes(s)),
                     fs=fs_of(s))
+
+    def host_leaf(s, data, infinite, total=None):
+        """a host-materialised sub-tree as an array leaf of the frames the sink reaches; the node keeps
+        the sub-tree's own length (the planner cross-checks the length algebra above it)"""
+        a = S.ArraySig(data, s.fs)
+        lw.keep.append(a)
+        r = common(a, K.NODE_ARRAY)
+        r["nframes"] = K.SO_LEN_UNCHECKED
+        r.update(p0=data.ctypes.data, l0=a.n, i0=0, s0=1, s1=max(a.n, 1))
+        inner = lw.add(**r)
+        r2 = dict(kind=K.NODE_PAD, dtype=_DT[a.dtype], nch=a.nch, nframes=K.SO_LEN_INF, fs=fs_of(s),
+                  i0=K.PAD["zero"], i1=0, children=(inner,))
+        idx = lw.add(**r2)
+        if not infinite:
+            r3 = dict(kind=K.NODE_UNTIL, dtype=_DT[a.dtype], nch=a.nch, nframes=_len_code(total), fs=fs_of(s),
+                      l0=int(total), children=(idx,))
+            idx = lw.add(**r3)
+        return idx
 
     def rec(s):
         key = id(s)
@@ -306,6 +371,9 @@ def lower(x, nframes_out=None, rng=None):
                 r2 = dict(kind=K.NODE_PAD, dtype=K.SO_F64, nch=1, nframes=K.SO_LEN_INF, fs=fs_of(s),
                           i0=K.PAD["zero"], i1=0, children=(inner,))
                 idx = lw.add(**r2)
+            elif s.fn == S.OPAQUE:
+                n, _ = need.get(id(s), (0, 0))
+                idx = host_leaf(s, _host_function_leaf(s, max(n, 0)), infinite=True)
             else:
                 if s.fs is None:
                     S.error("Unknown frame rate: function signals need a frame rate before `sink` "
@@ -344,6 +412,12 @@ def lower(x, nframes_out=None, rng=None):
             r = common(s, K.NODE_RAMP)
             r.update(i0=0 if s.direction == "on" else 1, i1=K.RAMPFN[s.fn], l0=int(R), children=(c,))
             idx = lw.add(**r)
+        elif isinstance(s, S.MapSignal) and isinstance(s.fn, S.OpaqueFn):
+            n, _ = need.get(id(s), (0, 0))
+            total = S.nframes(s)
+            if total is None:
+                S.error("Unknown number of frames in signal.")
+            idx = host_leaf(s, _host_map_leaf(s, max(n, 0), rng), infinite=S.isknowninf(total), total=total)
         elif isinstance(s, S.MapSignal):
             kids = tuple(rec(c) for c in s.signals)
             pk, pv, _ = _pad_fields(s.padding, s.nch)

@@ -231,6 +231,7 @@ class NumberSig(AbstractSignal):
 
 
 SIN, COS, IDENTITY, RANDN = "sin", "cos", "identity", "randn"
+OPAQUE = "opaque"  # any other callable: evaluated on the host at sink time and handed to the engine as an array leaf
 
 
 def _fn_code(fn):
@@ -261,8 +262,9 @@ def randn(*a):
 class FuncSig(AbstractSignal):
     """SignalFunction, reference src/functions.jl:11-60,88-96"""
 
-    def __init__(self, fn, fs=None, omega=None, phi=0.0, rng=None):
+    def __init__(self, fn, fs=None, omega=None, phi=0.0, rng=None, pyfn=None):
         self.fn = fn  # code string
+        self.pyfn = pyfn  # OPAQUE: the host callable itself
         self.fs = fs
         self.omega = omega
         self.phi = float(phi)
@@ -478,16 +480,34 @@ def _map_code(fn):
         return fn
     if isinstance(fn, str) and fn in (ADD, MUL, SUB, DIV, TUPLECAT, AS1CHANNEL, REVERSECH):
         return fn
+    if isinstance(fn, OpaqueFn):
+        return fn
     try:
         if fn in table:
             return table[fn]
     except TypeError:
         pass
-    error(f"OperateOn: function {fn!r} is an opaque closure for the HIP engine; "
-          "only +,*,-,/ and the channel operators are lowerable")
+    if callable(fn):
+        # an arbitrary closure (reference src/mapsignal.jl:131-145): the map is evaluated on the host at
+        # sink time -- its operands by the engine, the closure by NumPy -- and enters the tree as an
+        # array leaf (lowering.py)
+        return OpaqueFn(fn)
+    error(f"OperateOn: {fn!r} is not a function")
+
+
+class OpaqueFn:
+    """a host callable used as a map function"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __repr__(self):
+        return f"OpaqueFn({self.fn!r})"
 
 
 def default_pad(fn):  # src/mapsignal.jl:274-276
+    if isinstance(fn, OpaqueFn):
+        return zero
     return one if fn in (MUL, DIV) else zero
 
 
@@ -508,6 +528,22 @@ class MapSignal(AbstractSignal):
         t = dts[0]
         for d in dts[1:]:
             t = promote_type(t, d)
+        if isinstance(fn, OpaqueFn):
+            # test-value type inference (src/mapsignal.jl:139-143): the closure applied to ones
+            try:
+                if bychannel:
+                    v = fn.fn(*[np.ones((), dtype=c.dtype)[()] for c in self.signals])
+                else:
+                    v = fn.fn(*[tuple(np.ones(c.nch, dtype=c.dtype)) for c in self.signals])
+                    v = np.asarray(v).reshape(-1)
+                    self._opaque_nch = int(v.size)
+                t = np.asarray(v).dtype
+                t = F32 if t == F32 else (I64 if np.issubdtype(t, np.integer) else F64)
+            except Exception as e:  # noqa: BLE001
+                error(f"OperateOn: could not apply {fn.fn!r} to test values: {e}")
+            self.dtype = t
+            self.nch = self.signals[0].nch if bychannel else self._opaque_nch
+            return
         if fn == DIV and t == I64:
             t = F64
         if fn == TOELTYPE:
@@ -636,9 +672,11 @@ def Signal(x=None, fs=None, *, ω=None, frequency=None, ϕ=0, phase=None, omega=
         return ArraySig(x, fs)
     if callable(x) or (isinstance(x, str) and x in (SIN, COS, IDENTITY, RANDN)):
         code = _fn_code(x)
+        pyfn = None
         if code is None:
-            error(f"Signal({x!r}): opaque closures cannot be lowered to the HIP engine; "
-                  "whitelisted functions are sin, cos, identity and randn")
+            # what the engine cannot lower is materialised on the host and passed
+            # as an array leaf (here: the closure is evaluated with NumPy at sink time, lowering.py)
+            code, pyfn = OPAQUE, x
         if code == RANDN:  # src/functions.jl:109-110
             return FuncSig(RANDN, fs, None, 0.0, rng=rng)
         if frequency is not None and ω is None:
@@ -651,7 +689,7 @@ def Signal(x=None, fs=None, *, ω=None, frequency=None, ϕ=0, phase=None, omega=
             p = U.inseconds(ph) if isinstance(ph, Quantity) else float(ph)
         else:
             p = U.inradians(ph, w) / (2 * math.pi)
-        return FuncSig(code, fs, w, p)
+        return FuncSig(code, fs, w, p, pyfn=pyfn)
     error(f"Don't know how create a signal from {x!r}.")
 
 
@@ -749,7 +787,7 @@ def ToFramerate(x, fs=None, blocksize=default_blocksize):
     if isinstance(x, ArraySig):  # src/arrays.jl:47-50
         return _resample(x, fs, bs) if known else ArraySig(x.data, fs)
     if isinstance(x, FuncSig):  # src/functions.jl:62-63
-        return FuncSig(x.fn, fs, x.omega, x.phi, rng=x.rng)
+        return FuncSig(x.fn, fs, x.omega, x.phi, rng=x.rng, pyfn=x.pyfn)
     if isinstance(x, NumberSig):  # src/numbers.jl:56-57
         return NumberSig(x.val, fs, dB=x.dB, dtype=x.dtype)
     if isinstance(x, MapSignal):  # src/mapsignal.jl:46-64

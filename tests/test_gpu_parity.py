@@ -538,3 +538,37 @@ def test_filtering_spectral_inequalities_on_the_engine(nch):
     high = filtering_inequalities(lambda t: so.sink(t, so.Array), nch)
     high_o = filtering_inequalities(oracle_sink, nch)
     assert relerr(high, high_o) < 1e-9
+
+
+def test_opaque_closures_are_materialised_on_the_host():
+    """what the engine cannot lower is materialised on the host and passed as an
+    array leaf -- `Signal(fn)` with an arbitrary closure (reference src/functions.jl:53-60) and
+    `OperateOn(fn, xs...)` (src/mapsignal.jl:131-145) -- instead of sending the whole tree to the CPU.
+    The closure runs in NumPy; its operands and everything above it run on the GPU."""
+    rng = np.random.default_rng(81)
+    x = np.asfortranarray(rng.standard_normal((30_000, 2)))
+    cube = lambda t: np.sin(t) ** 3  # noqa: E731
+    tone = so.Signal(cube, 44.1 * so.kHz, ω=440 * so.Hz)
+    tree = so.Mix(tone, so.Signal(x, 44.1 * so.kHz)) | so.Until(30_000 * so.frames) | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz)
+    got = so.sink(tree, so.Array)
+    # the same tree with the closure's values supplied as data (what the host evaluation must equal)
+    t = np.arange(1, 30_001) / 44100.0
+    vals = cube(2 * np.pi * np.fmod(t * 440.0 + 0.0, 1.0)).reshape(-1, 1)
+    ref_tree = (so.Mix(so.Signal(np.asfortranarray(vals), 44.1 * so.kHz), so.Signal(x, 44.1 * so.kHz)) | so.Until(30_000 * so.frames)
+                | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz))
+    want = oracle_sink(ref_tree)
+    assert got.shape == want.shape and relerr(got, want) < 1e-9
+    # a closure without a frequency sees t + phase; first frame t = 1/fs (runtests.jl:564-566 semantics)
+    ramp = so.sink(so.Signal(lambda t: 2 * t, 10 * so.Hz) | so.Until(5 * so.frames), so.Array)
+    assert np.allclose(ramp[:, 0], 2 * np.arange(1, 6) / 10.0, rtol=0, atol=1e-15)
+    # OperateOn with a closure: operands on the GPU (one of them filtered), padded with the map's padding
+    a = so.Signal(x, 10 * so.kHz) | so.Filt(so.Highpass, 1 * so.kHz)
+    b = so.Signal(np.asfortranarray(rng.standard_normal((20_000, 2))), 10 * so.kHz)
+    m = so.OperateOn(lambda u, v: np.maximum(u, v), a, b) | so.Amplify(0.5)
+    got_m = so.sink(m, so.Array)
+    fa = oracle_sink(a)
+    fb = np.vstack([oracle_sink(b), np.zeros((10_000, 2))])  # default padding of an opaque map: zero
+    assert got_m.shape == (30_000, 2) and relerr(got_m, 0.5 * np.maximum(fa, fb)) < 1e-9
+    # bychannel=false: the closure sees whole frames
+    sw = so.sink(so.OperateOn(lambda fr: (fr[1], fr[0] + fr[1]), so.Signal(x, 10 * so.kHz), bychannel=False), so.Array)
+    assert np.array_equal(sw, np.column_stack([x[:, 1], x[:, 0] + x[:, 1]]))
