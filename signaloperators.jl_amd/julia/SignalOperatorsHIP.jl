@@ -89,8 +89,21 @@ function demand!(need, x::CutApply{<:Any,<:Any,K}, n, skip=0) where K
     K <: Val{:Until} ? demand!(need, child(x), finite_min(child(x), min(n, L)), skip) :
                        demand!(need, child(x), finite_min(child(x), n + L), skip + L)
 end
-demand!(need, x::Union{PaddedSignal,RampSignal}, n, skip=0) = demand!(need, child(x), finite_min(child(x), n), skip)
-demand!(need, x::MapSignal, n, skip=0) = foreach(s -> demand!(need, s, finite_min(s, n), skip), x.signals)
+# sub-trees the engine cannot lower are sunk by the stock CPU sink (stock_leaf! below): record how many
+# of their frames the GPU sink reaches and stop there
+record!(need, x, n, skip) = (need[x] = (max(n, get(need, x, (0, skip))[1]), min(skip, get(need, x, (0, skip))[2])); nothing)
+demand!(need, x::SignalFunction, n, skip=0) = lowerable_fn(x.fn) ? nothing : record!(need, x, n, skip)
+function demand!(need, x::Union{PaddedSignal,RampSignal}, n, skip=0)
+    opaque = x isa RampSignal ? !(x.fn === sinramp || x.fn === identity) :
+        !(x.Pad === zero || x.Pad === one || x.Pad === lastframe || x.Pad === cycle || x.Pad === mirror ||
+          x.Pad isa Number || x.Pad isa Union{Tuple,AbstractVector})
+    opaque ? record!(need, x, n, skip) : demand!(need, child(x), finite_min(child(x), n), skip)
+end
+function demand!(need, x::MapSignal, n, skip=0)
+    fn = x.fn isa FnBr ? x.fn.fn : x.fn
+    (lowerable_map(fn) && (x.padding === one || x.padding === zero)) || return record!(need, x, n, skip)
+    foreach(s -> demand!(need, s, finite_min(s, n), skip), x.signals)
+end
 function demand!(need, x::AppendSignals, n, skip=0)
     rem, sk = n, skip
     for s in x.signals
@@ -152,9 +165,41 @@ function lower_node!(lw, x::SignalFunction{<:SignalOperators.RandFn})
                            2 #= zero =#, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL, C_NULL, 0, 0))
     Int32(length(lw.nodes) - 1)
 end
+# SURVEY.md section 8(b): a sub-tree the engine cannot lower (opaque closures) is materialised by the
+# STOCK CPU sink -- `sink(sub, Array)`, reference src/sink.jl:64-92 -- for the frames the GPU sink
+# reaches, and enters the node table as an ARRAY leaf under an (unreachable) zero Pad and, for a
+# finite sub-tree, an Until of its own length, so that the length algebra above it is unchanged.
+function stock_leaf!(lw, x)
+    n, _ = get(lw.need, x, (isinf(nframes(x)) ? 0 : Int(nframes(x)), 0))
+    data = n > 0 ? SignalOperators.sink(x |> Until(n * frames), Array) : zeros(sampletype(x), 0, nchannels(x))
+    data = convert(Matrix{float(sampletype(x))}, reshape(data, size(data, 1), :))
+    push!(lw.keep, data)
+    dt = sodtype(eltype(data))
+    push!(lw.nodes, SoNode(Int32(ARRAY), dt, Int32(size(data, 2)), Int32(0), C_NULL, Int64(-3) #= SO_LEN_UNCHECKED =#,
+                           sofs(framerate(x)), 0, 0, 0, 0, size(data, 1), 0, 0.0, 0.0, 0.0, 0.0, pointer(data), C_NULL,
+                           1, max(size(data, 1), 1)))
+    kids = Int32[Int32(length(lw.nodes) - 1)]
+    push!(lw.keep, kids)
+    push!(lw.nodes, SoNode(Int32(PAD), dt, Int32(size(data, 2)), Int32(1), pointer(kids), LEN_INF, sofs(framerate(x)),
+                           2 #= zero =#, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL, C_NULL, 0, 0))
+    idx = Int32(length(lw.nodes) - 1)
+    if !isinf(nframes(x))
+        kids2 = Int32[idx]
+        push!(lw.keep, kids2)
+        push!(lw.nodes, SoNode(Int32(UNTIL), dt, Int32(size(data, 2)), Int32(1), pointer(kids2), Int64(nframes(x)),
+                               sofs(framerate(x)), 0, 0, 0, 0, Int64(nframes(x)), 0, 0.0, 0.0, 0.0, 0.0, C_NULL, C_NULL, 0, 0))
+        idx = Int32(length(lw.nodes) - 1)
+    end
+    idx
+end
+# (demand analysis stops at such a sub-tree: it is sunk on its own)
+lowerable_fn(fn) = fn === sin || fn === cos || fn === identity
+lowerable_map(fn) = fn === (+) || fn === (*) || fn === (-) || fn === (/) || fn === tuplecat || fn isa GetChanFn ||
+    fn isa As1Channel || fn isa AsNChannels || fn isa ToEltypeFn || fn === reverse
+
 function lower_node!(lw, x::SignalFunction)
-    code = x.fn === sin ? 0 : x.fn === cos ? 1 : x.fn === identity ? 2 :
-        error("Signal($(x.fn)) is an opaque closure: materialise it with the stock sink first")
+    lowerable_fn(x.fn) || return stock_leaf!(lw, x)
+    code = x.fn === sin ? 0 : x.fn === cos ? 1 : 2
     push_node!(lw, x, FUNC; i0=code, i1=ismissing(x.ω) ? 0 : 1,
                d0=ismissing(x.ω) ? 0.0 : Float64(x.ω), d1=x.ϕ, nch=1, dtype=SO_F64)
 end
@@ -169,23 +214,25 @@ function lower_node!(lw, x::PaddedSignal{<:Any,<:Any,E}) where E
         p === lastframe ? (4, 0.0, C_NULL) : p === cycle ? (5, 0.0, C_NULL) :
         p === mirror ? (6, 0.0, C_NULL) : p isa Number ? (0, Float64(p), C_NULL) :
         p isa Union{Tuple,AbstractVector} ? (1, 0.0, pointer(push!(lw.keep, Float64.(collect(p)))[end])) :
-        error("opaque padding closure")
+        return stock_leaf!(lw, x)   # an opaque padding closure (src/padding.jl:150-192): the padded signal as a whole
     push_node!(lw, x, PAD; kids=Int32[c], i0=kind, i1=E ? 1 : 0, d0=val, p0=vec)
 end
 lower_node!(lw, x::AppendSignals) =
     push_node!(lw, x, APPEND; kids=Int32[lower!(lw, s) for s in x.signals])
 function lower_node!(lw, x::RampSignal{D}) where D
-    fn = x.fn === sinramp ? 0 : x.fn === identity ? 1 : error("opaque ramp closure")
+    (x.fn === sinramp || x.fn === identity) || return stock_leaf!(lw, x)   # a custom ramp function (src/ramps.jl:26)
+    fn = x.fn === sinramp ? 0 : 1
     push_node!(lw, x, RAMP; kids=Int32[lower!(lw, child(x))], i0=D === :on ? 0 : 1, i1=fn,
                l0=resolvelen(x))
 end
 function lower_node!(lw, x::MapSignal)
     fn = x.fn isa FnBr ? x.fn.fn : x.fn
+    (lowerable_map(fn) && (x.padding === one || x.padding === zero)) || return stock_leaf!(lw, x)   # src/mapsignal.jl:131-145
     code, extra = fn === (+) ? (0, 0) : fn === (*) ? (1, 0) : fn === (-) ? (2, 0) : fn === (/) ? (3, 0) :
         fn === tuplecat ? (4, 0) : fn isa GetChanFn ? (5, fn.n) : fn isa As1Channel ? (6, 0) :
         fn isa AsNChannels ? (7, fn.ch) : fn isa ToEltypeFn ? (8, sodtype(typeof(fn).parameters[1])) :
-        fn === reverse ? (9, 0) : error("OperateOn($fn): opaque closure, not lowerable")
-    pad = x.padding === one ? 3 : x.padding === zero ? 2 : error("opaque map padding")
+        (9, 0)
+    pad = x.padding === one ? 3 : 2
     push_node!(lw, x, MAP; kids=Int32[lower!(lw, s) for s in x.signals], i0=code,
                i1=x.bychannel ? 1 : 0, i2=pad, i3=extra)
 end
