@@ -278,6 +278,28 @@ int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable);
 
 void so_plan_destroy(so_plan_t* plan);
 
+/* ---- the exchange step of a sharded sink (no reference counterpart: the
+ *      reference is single-process).  One process per GPU; every rank evaluates its share of the
+ *      result with so_plan_execute -- the frames of its Append children (reference
+ *      src/appending.jl:59-76: children are independent) or its slab of channels -- and the shares are
+ *      gathered into the full planar buffer of every rank by grouped RCCL send / recv (xGMI inside a
+ *      node).  RCCL is bound at run time; without it these return SO_ERR_UNSUPPORTED. ------------- */
+typedef struct so_comm so_comm_t; /* opaque */
+typedef struct so_slab {   /* what ONE rank contributes: `rows` runs of `row_elems` elements ...          */
+    int64_t rows, row_elems;
+    int64_t dst_offset;     /* ... and where they go in every rank's full buffer: first element,       */
+    int64_t dst_row_stride; /*     elements between runs (planar result: rows = channels, stride =      */
+} so_slab_t;                /*     chan_stride; a time range: dst_offset = its first frame)             */
+/* rank 0 fills 128 bytes that the host passes to every rank (MPI, a file, a socket ...) */
+int32_t so_comm_unique_id(void* id128);
+int32_t so_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, so_comm_t** comm);
+/* mine: this rank's share (device pointer; runs src_row_stride elements apart; may already sit at its place in
+ * `full`: then nothing is copied locally); slabs[world]: every rank's share; full: device buffer */
+int32_t so_comm_allgather(so_comm_t* comm, const void* mine, int64_t src_row_stride, void* full,
+                          const so_slab_t* slabs, int32_t dtype, void* stream);
+const char* so_comm_last_error(void);
+void so_comm_destroy(so_comm_t* comm);
+
 /* ---- filter design (replaces the DSP.jl calls the reference makes at sink time:
  *      src/filters.jl:10-11,94 and src/reformatting.jl:93-96).  Host-side fp64; a
  *      Julia host would normally pass DSP.jl's own coefficients instead. ---------- */

@@ -45,6 +45,10 @@ class so_stats_t(C.Structure):
                 ("dominant_kernel_bytes", C.c_int64), ("dominant_kernel", C.c_char * 64)]
 
 
+class so_slab_t(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("row_elems", C.c_int64), ("dst_offset", C.c_int64), ("dst_row_stride", C.c_int64)]
+
+
 class so_step_info_t(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("algorithmic_bytes", C.c_int64), ("ms", C.c_double),
                 ("launches", C.c_int32), ("pad", C.c_int32)]
@@ -54,7 +58,8 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
-           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_plan_counter"]
+           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_plan_counter",
+           "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_last_error", "so_comm_destroy"]
 
 _lib = None
 
@@ -120,6 +125,15 @@ def lib():
     L.so_zpk_to_sos.restype = C.c_int32
     L.so_zpk_to_sos.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_double,
                                 C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.so_comm_unique_id.restype = C.c_int32
+    L.so_comm_unique_id.argtypes = [C.c_void_p]
+    L.so_comm_create.restype = C.c_int32
+    L.so_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.so_comm_allgather.restype = C.c_int32
+    L.so_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(so_slab_t), C.c_int32, C.c_void_p]
+    L.so_comm_last_error.restype = C.c_char_p
+    L.so_comm_destroy.restype = None
+    L.so_comm_destroy.argtypes = [C.c_void_p]
     L.so_plan_counter.restype = C.c_int64
     L.so_plan_counter.argtypes = [C.c_void_p, C.c_int32]
     L.so_plan_step_info.restype = C.c_int32

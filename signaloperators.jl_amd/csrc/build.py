@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["kernels.hip", "kernels2.hip", "planner.cpp", "stages.cpp", "accumulator.cpp", "executor.cpp", "design.cpp", "capi.cpp"]
+SRCS = ["kernels.hip", "kernels2.hip", "planner.cpp", "stages.cpp", "accumulator.cpp", "executor.cpp", "design.cpp", "capi.cpp", "comm.cpp"]
 HDRS = ["kernels.h", "plan.h", "plan_impl.h", "sigops_internal.h", "../../include/sigops.h"]  # (flag changes in this file: --force)
 OUT = os.path.join(HERE, "libsigops.so")
 
@@ -60,7 +60,7 @@ def build(force=False, verbose=True):
     # the translation units are independent: compile them side by side (kernels.hip dominates)
     with ThreadPoolExecutor(max_workers=len(SRCS)) as pool:
         objs = list(pool.map(compile_one, SRCS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -86,7 +86,97 @@ def _dist_info(rank, world):
     return rank, world
 
 
-def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0):
+def assemble_ranges(outs, counts, nch, total):
+    """device reassembly of all-gathered, padded time slabs: outs [world][nch][width] -> [nch][total]"""
+    import torch
+
+    full = torch.empty((nch, total), dtype=outs.dtype, device=outs.device)
+    pos = 0
+    for r, cnt in enumerate(counts):
+        full[:, pos:pos + cnt] = outs[r, :, :cnt]
+        pos += cnt
+    return full
+
+
+def assemble_channels(outs, bounds, n):
+    """device reassembly of all-gathered, padded channel slabs: outs [world][wmax][n] -> [nch][n]"""
+    import torch
+
+    nch = bounds[-1][1]
+    full = torch.empty((nch, n), dtype=outs.dtype, device=outs.device)
+    for r, (lo, hi) in enumerate(bounds):
+        full[lo:hi] = outs[r, :hi - lo]
+    return full
+
+
+class NativeComm:
+    """The library's own exchange (include/sigops.h so_comm_*: grouped RCCL send / recv behind the C-ABI,
+    what a Julia host would call).  `NativeComm.from_torch()` bootstraps the 128-byte id over an
+    initialised torch.distributed group; `NativeComm.single()` is the one-rank communicator."""
+
+    def __init__(self, id128, world, rank, device=0):
+        import ctypes as C
+
+        from . import _capi as K
+
+        self.world, self.rank, self.device = world, rank, device
+        self.handle = C.c_void_p()
+        st = K.lib().so_comm_create(id128, world, rank, device, C.byref(self.handle))
+        if st != 0:
+            raise S.ErrorException(K.lib().so_comm_last_error().decode())
+
+    @staticmethod
+    def new_id():
+        import ctypes as C
+
+        from . import _capi as K
+
+        buf = C.create_string_buffer(128)
+        if K.lib().so_comm_unique_id(buf) != 0:
+            raise S.ErrorException(K.lib().so_comm_last_error().decode())
+        return buf.raw
+
+    @classmethod
+    def single(cls, device=0):
+        return cls(cls.new_id(), 1, 0, device)
+
+    @classmethod
+    def from_torch(cls, device=0):
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.new_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], world, rank, device)
+
+    def allgather(self, mine, src_row_stride, full, slabs, stream=None):
+        """slabs: [(rows, row_elems, dst_offset, dst_row_stride)] per rank, in elements of `full`"""
+        import ctypes as C
+
+        from . import _capi as K
+
+        arr = (K.so_slab_t * len(slabs))(*[K.so_slab_t(*map(int, t)) for t in slabs])
+        dt = K.SO_F32 if full.element_size() == 4 else K.SO_F64
+        st = K.lib().so_comm_allgather(self.handle, C.c_void_p(mine.data_ptr() if mine is not None else 0), int(src_row_stride),
+                                       C.c_void_p(full.data_ptr()), arr, dt, C.c_void_p(stream or 0))
+        if st != 0:
+            raise S.ErrorException(K.lib().so_comm_last_error().decode())
+
+    def close(self):
+        from . import _capi as K
+
+        if self.handle:
+            K.lib().so_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, comm=None, force_gather=False):
     """Evaluate Append(children...) with children sharded over ranks.
 
     Default compute = the HIP engine with a DEVICE-RESIDENT result: the rank's slab is written by
@@ -94,18 +184,22 @@ def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, 
     device (RCCL over xGMI; uneven shares -> slabs padded to the widest) and the planar
     [nframes x nch] result is assembled on the device -- no host hop anywhere.  Returns a
     column-major torch tensor on every rank when gather=True, else (local_slab, start).
-    `compute` (tests: the CPU oracle under gloo) switches to the NumPy path."""
-    return _sink_ranges(x, shard_append, rank, world, gather, compute, device)
+    `compute` (tests: the CPU oracle under gloo) switches to the NumPy path.
+    `comm` (a NativeComm): the exchange goes through the library's own so_comm_allgather instead -- the
+    engine writes this rank's share straight into its place of the full buffer and the other shares
+    arrive there too: no padded slabs, no reassembly.  `force_gather`: run the collective even with one
+    rank (exercises the device branch on a single GPU)."""
+    return _sink_ranges(x, shard_append, rank, world, gather, compute, device, comm, force_gather)
 
 
-def sink_time_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, align=1):
+def sink_time_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, align=1, comm=None, force_gather=False):
     """Evaluate ONE signal with its time axis cut into contiguous ranges, one per rank (see the module
     docstring); same result layout and gather as `sink_append_sharded`."""
     x = S._assignal(x)
-    return _sink_ranges(x, lambda y, r, w: shard_time(y, r, w, align), rank, world, gather, compute, device)
+    return _sink_ranges(x, lambda y, r, w: shard_time(y, r, w, align), rank, world, gather, compute, device, comm, force_gather)
 
 
-def _sink_ranges(x, shard, rank, world, gather, compute, device):
+def _sink_ranges(x, shard, rank, world, gather, compute, device, comm=None, force_gather=False):
     rank, world = _dist_info(rank, world)
     sub, start, count = shard(x, rank, world)
     nch = x.nch
@@ -119,26 +213,34 @@ def _sink_ranges(x, shard, rank, world, gather, compute, device):
     from .engine import sink_into
 
     tdt = torch.float32 if dt == S.F32 else torch.float64
-    width = max(counts) if gather and world > 1 else count
+    total = int(S.nframes(x))
+    if comm is not None and gather:
+        # the library's exchange: every share lands at its place in `full`, the own one is written there
+        # by the engine itself
+        full = torch.empty((nch, max(total, 1)), dtype=tdt, device=f"cuda:{device}")
+        if sub is not None and count > 0:
+            sink_into(full.t()[start:start + count], sub, device=device)
+        starts = [sum(counts[:r]) for r in range(world)]
+        slabs = [(nch, counts[r], starts[r], full.stride(0)) for r in range(world)]
+        torch.cuda.synchronize(device)
+        comm.allgather(full[:, start:] if count > 0 else None, full.stride(0), full, slabs,
+                       torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+        return full.t()[:total]
+    width = max(counts) if gather and (world > 1 or force_gather) else count
     slab = torch.zeros((nch, max(width, 1)), dtype=tdt, device=f"cuda:{device}")
     if sub is not None and count > 0:
         sink_into(slab.t()[:count], sub, device=device)  # result strides (1, width): written in place
     if not gather:
         return slab.t()[:count], start
-    if world == 1:
+    if world == 1 and not force_gather:
         return slab.t()[:count]
     outs = torch.empty((world, nch, width), dtype=tdt, device=slab.device)
     dist.all_gather_into_tensor(outs, slab)
-    total = int(S.nframes(x))
-    full = torch.empty((nch, total), dtype=tdt, device=slab.device)
-    pos = 0
-    for r in range(world):
-        full[:, pos:pos + counts[r]] = outs[r, :, :counts[r]]
-        pos += counts[r]
-    return full.t()
+    return assemble_ranges(outs, counts, nch, total).t()
 
 
-def sink_channels_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0):
+def sink_channels_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, comm=None, force_gather=False):
     """Channel-striped sink of a signal whose channels are independent: each rank evaluates its
     contiguous slab of channels with a device-resident result.  Planar layout makes a slab one
     contiguous block of the full result, so with equal slabs the optional all-gather writes the
@@ -163,7 +265,16 @@ def sink_channels_sharded(x, *, rank=None, world=None, gather=True, compute=None
     bounds = [block_range(x.nch, r, world) for r in range(world)]
     wmax = max(hi - lo for lo, hi in bounds)
     even = all(hi - lo == wmax for lo, hi in bounds)
-    if gather and world > 1 and even:
+    if comm is not None and gather:  # the library's exchange: a channel slab is one contiguous run of the planar result
+        full = torch.empty((x.nch, n), dtype=tdt, device=f"cuda:{device}")
+        if sub is not None:
+            sink_into(full[c0:c1].t(), sub, device=device)
+        slabs = [(1, (hi - lo) * n, lo * n, 0) for lo, hi in bounds]
+        torch.cuda.synchronize(device)
+        comm.allgather(full[c0:] if c1 > c0 else None, 0, full, slabs, torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+        return full.t()
+    if gather and (world > 1 or force_gather) and even:
         full = torch.empty((x.nch, n), dtype=tdt, device=f"cuda:{device}")
         mine = full[c0:c1]  # this rank's slab of the final buffer
         sink_into(mine.t(), sub, device=device)
@@ -174,14 +285,11 @@ def sink_channels_sharded(x, *, rank=None, world=None, gather=True, compute=None
         sink_into(slab[:c1 - c0].t(), sub, device=device)
     if not gather:
         return slab[:c1 - c0].t(), c0, c1
-    if world == 1:
+    if world == 1 and not force_gather:
         return slab[:c1 - c0].t()
     outs = torch.empty((world, wmax, n), dtype=tdt, device=slab.device)
     dist.all_gather_into_tensor(outs, slab)
-    full = torch.empty((x.nch, n), dtype=tdt, device=slab.device)
-    for r, (lo, hi) in enumerate(bounds):
-        full[lo:hi] = outs[r, :hi - lo]
-    return full.t()
+    return assemble_channels(outs, bounds, n).t()
 
 
 def _gather_channels_host(local, nch, n, dt, world, device):
