@@ -5,8 +5,8 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["kernels.hip", "kernels2.hip", "planner.cpp", "stages.cpp", "accumulator.cpp", "executor.cpp", "design.cpp", "capi.cpp", "comm.cpp"]
-HDRS = ["kernels.h", "plan.h", "plan_impl.h", "sigops_internal.h", "../../include/sigops.h"]  # (flag changes in this file: --force)
+SRCS = ["k_pointwise.hip", "k_sos.hip", "k_resample.hip", "kernels2.hip", "planner.cpp", "stages.cpp", "accumulator.cpp", "executor.cpp", "design.cpp", "capi.cpp", "comm.cpp"]
+HDRS = ["kernels.h", "kcommon.h", "plan.h", "plan_impl.h", "sigops_internal.h", "../../include/sigops.h"]  # (flag changes in this file: --force)
 OUT = os.path.join(HERE, "libsigops.so")
 
 
@@ -19,7 +19,7 @@ def _obj(src):
 
 
 def _stale(src):
-    """an object is rebuilt when its source or a header it includes is newer (kernels.hip takes
+    """an object is rebuilt when its source or a header it includes is newer (k_resample.hip takes
     minutes: it must not be recompiled for a change to the planner's headers)"""
     o = _obj(src)
     if not os.path.exists(o):
@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
         return o
 
-    # the translation units are independent: compile them side by side (kernels.hip dominates)
+    # the translation units are independent: compile them side by side (k_resample.hip dominates)
     with ThreadPoolExecutor(max_workers=len(SRCS)) as pool:
         objs = list(pool.map(compile_one, SRCS))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]

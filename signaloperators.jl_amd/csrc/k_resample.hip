@@ -1,1269 +1,8 @@
-// Hand-written HIP kernels for gfx950 (MI355X, CDNA4; wave64).  No CUDA shims, no
-// dual paths.  Every kernel here is HBM-bound integer/fp64 streaming work: the
-// levers are coalesced loads/stores, LDS staging and enough workgroups for 256 CUs.
-//
-//   k_pointwise   K1  fused generator / map / ramp / index kernel
-//                     (replaces frame() recursion + sink_helper!, reference
-//                      src/sink.jl:256-260, src/mapsignal.jl:249-272)
-//   k_sos_*       K2  second-order-sections IIR, time-parallel by exact chunked
-//                     state propagation (reference src/filters.jl:252-255 + DSP.jl DF2T)
-//   k_resample    K3  polyphase FIR resampler (reference src/reformatting.jl:92-98)
-//   k_sumsq_*     K4  Normpower reduction (reference src/filters.jl:296-309)
-#include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#include <algorithm>
-
-#include "../../include/sigops.h"
-#include "kernels.h"
-#include "sigops_internal.h"
+// Hand-written HIP kernels for gfx950 (MI355X, CDNA4; wave64).  No CUDA shims, no dual paths.
+// K3 k_resample*: polyphase FIR resampler (reference src/reformatting.jl:92-98, src/filters.jl:248-255)
+#include "kcommon.h"
 
 namespace so {
-
-// ---------------------------------------------------------------------------
-// leaf evaluators
-// All leaf parameters are wave-uniform (scalar registers); only the frame index n (and,
-// in channel-vectorised evaluation, nothing else) lives per lane.  sf is -1/0/+1, so the
-// per-lane address math is one 64-bit add in the common planar case (no 64-bit multiplies,
-// which are quarter-rate on CDNA).
-__device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
-    int64_t f = L.df;
-    if (L.sf > 0) f += n;
-    else if (L.sf < 0) f -= n;
-    // (cycle / mirror padding, reference src/padding.jl:132-148, is resolved on the host
-    //  into one piece per wrap with sf = +1 / -1: no integer division on the device)
-    const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;  // uniform
-    const int64_t off = (L.fstride == 1 ? f : f * L.fstride) + choff;
-    if (L.dtype == SO_F32) return (double)((const float*)L.base)[off];
-    return ((const double*)L.base)[off];
-}
-
-// Compact fp64 sin/cos kernels (Taylor on |t| <= 1/4 after exact octant reduction).  The
-// device library's sinpi/cos carry large-argument paths that cost ~40 VGPRs of pressure in
-// every kernel that inlines the interpreter; these need ~12 and are accurate to ~1 ulp.
-// fma with a CONSTANT operand held in a scalar register pair.  hipcc otherwise materialises
-// every fp64 polynomial coefficient with two v_mov_b32 into the accumulator of a v_fmac (35 of
-// the ~110 instructions of one sinpi evaluation, all on the vector ALU that the fp64 MFMAs of
-// the resampler also need); s_mov_b32 is free by comparison.  Same operands, same rounding.
-__device__ __forceinline__ double fma_addc(double a, double b, double c_const) {  // a*b + C
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
-    return r;
-}
-__device__ __forceinline__ double fma_mulc(double a, double b_const, double c) {  // a*C + c
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_const), "v"(c));
-    return r;
-}
-__device__ __forceinline__ void sincospi_quarter(double t, double& s, double& c) {
-    const double t2 = t * t;
-    double ps = 7.952054001475513e-07;
-    ps = fma_addc(ps, t2, -2.1915353447830217e-05);
-    ps = fma_addc(ps, t2, 0.00046630280576761255);
-    ps = fma_addc(ps, t2, -0.0073704309457143504);
-    ps = fma_addc(ps, t2, 0.08214588661112823);
-    ps = fma_addc(ps, t2, -0.5992645293207921);
-    ps = fma_addc(ps, t2, 2.5501640398773455);
-    ps = fma_addc(ps, t2, -5.16771278004997);
-    const double t3 = t2 * t;
-    s = fma_mulc(t, 3.141592653589793, fma_mulc(t, 1.2246467991473532e-16, t3 * ps));
-    double pc = -1.3878952462213771e-07;
-    pc = fma_addc(pc, t2, 4.303069587032947e-06);
-    pc = fma_addc(pc, t2, -0.0001046381049248457);
-    pc = fma_addc(pc, t2, 0.0019295743094039231);
-    pc = fma_addc(pc, t2, -0.02580689139001406);
-    pc = fma_addc(pc, t2, 0.2353306303588932);
-    pc = fma_addc(pc, t2, -1.3352627688545895);
-    pc = fma_addc(pc, t2, 4.0587121264167685);
-    pc = fma_addc(pc, t2, -4.934802200544679);
-    c = fma(pc, t2, 1.0);
-}
-// sinpi(x) with Julia's semantics: exact at integers and half-integers (src/functions.jl:57-60)
-__device__ __forceinline__ double sinpi_c(double x) {
-    const double k = rint(2.0 * x);
-    const double t = fma(-0.5, k, x);  // exact, |t| <= 1/4
-    double s, c;
-    sincospi_quarter(t, s, c);
-    const int q = (int)((long long)k & 3);
-    const double r = (q & 1) ? c : s;
-    return (q & 2) ? -r : r;
-}
-// sin(pi x) and cos(pi x) together (same reduction and kernels as sinpi_c)
-__device__ __forceinline__ void sincospi_c(double x, double& so, double& co) {
-    const double k = rint(2.0 * x);
-    const double t = fma(-0.5, k, x);
-    double s, c;
-    sincospi_quarter(t, s, c);
-    const int q = (int)((long long)k & 3);
-    const double rs = (q & 1) ? c : s, rc = (q & 1) ? s : c;
-    so = (q & 2) ? -rs : rs;
-    co = (q == 1 || q == 2) ? -rc : rc;
-}
-// (sin, cos)(2 pi phase) of frames i0 + stride*lane, lane < count, of a sine generator (phase as
-// in func_eval, i0 already 1-based); out of line so that its ~40 live registers do not add to
-// the resampler's main loops
-__device__ __attribute__((noinline)) void sine_table(int64_t i0, int stride, int count, double omega, double phi,
-                                                     double fs, int has_omega, double* dst) {
-    const int lane = threadIdx.x & 63;
-    if (lane < count) {
-        const double t = __ddiv_rn((double)(i0 + (int64_t)stride * lane), fs);
-        const double ph = has_omega ? __dadd_rn(__dmul_rn(t, omega), phi) : __dadd_rn(t, phi);
-        double sb, cb;
-        sincospi_c(2.0 * ph, sb, cb);
-        dst[2 * lane] = sb;
-        dst[2 * lane + 1] = cb;
-    }
-}
-// cos(x), x in radians, |x| < 2^20: two-term Cody-Waite reduction to x = k*pi/2 + r
-__device__ __forceinline__ double cos_c(double x) {
-    const double k = rint(x * 0.6366197723675814);
-    double r = fma(-k, 1.5707963267948966, x);
-    r = fma(-k, 6.123233995736766e-17, r);
-    double s, c;
-    sincospi_quarter(r * 0.3183098861837907, s, c);  // r/pi in [-1/4, 1/4]
-    const int q = (int)((long long)k & 3);
-    const double v = (q & 1) ? s : c;  // cos(r + k pi/2): c, -s, -c, s
-    return (q == 1 || q == 2) ? -v : v;
-}
-
-// reference src/functions.jl:53-60 — every operation separately rounded (Julia does
-// not contract), frame index is 1-based so the first sample is t = 1/fs
-__device__ __forceinline__ double func_eval(const DLeaf& L, int64_t n) {
-    double i1 = (double)((L.sf ? n : 0) + L.df + 1);
-    double t = __ddiv_rn(i1, L.v2);
-    if (L.flag) {
-        double ph = __dadd_rn(__dmul_rn(t, L.v0), L.v1);
-        if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * ph);
-        double a = __dmul_rn(6.283185307179586, ph - trunc(ph));  // 2π*(ph % 1.0)
-        return L.mode == SO_FN_COS ? cos_c(a) : a;
-    }
-    double tt = __dadd_rn(t, L.v1);
-    if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * tt);
-    return L.mode == SO_FN_COS ? cos_c(tt) : tt;
-}
-
-// reference src/ramps.jl:60-72
-__device__ __forceinline__ double ramp_eval(const DLeaf& L, int64_t n) {
-    int64_t n0 = (L.sf ? n : 0) + L.df;
-    double x;
-    if (L.flag == 0)
-        x = __ddiv_rn((double)n0, L.v0);
-    else
-        x = __dsub_rn(1.0, __ddiv_rn((double)(n0 + 1 - L.modn), L.v0));
-    return L.mode == SO_RAMP_SINRAMP ? sinpi_c(0.5 * x) : x;
-}
-
-// One per-frame slot in closed form (DCarrier::slot_kind): the same arithmetic as the
-// interpreter's OP_CONST / OP_SCALAR / OP_FUNC / OP_RAMP, without the stack machine.
-__device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n) {
-    double v;
-    switch (kind & 0xff) {
-    case OP_CONST: v = L.v0; break;
-    case OP_SCALAR: v = *(const double*)L.base; break;
-    case OP_FUNC: v = func_eval(L, n); break;
-    default: v = ramp_eval(L, n); break;
-    }
-    return (kind & 0x100) ? (double)(float)v : v;
-}
-
-// A leaf read from LDS sits in vector registers; its mode/flag fields then look lane-varying
-// to the compiler and every `if (L.flag)` / `L.mode == ...` becomes compute-both-and-select
-// (all three trig kernels per frame).  Passing the fields through readfirstlane makes the
-// branches scalar again.
-__device__ __forceinline__ int64_t rfl64(int64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ double rfl_f64(double v) {
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ DLeaf leaf_uniform(const DLeaf& L) {
-    DLeaf U = L;
-    const uint64_t b = (uint64_t)(uintptr_t)L.base;
-    U.base = (const void*)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                                      __builtin_amdgcn_readfirstlane((uint32_t)b));
-    U.v0 = rfl_f64(L.v0);
-    U.v1 = rfl_f64(L.v1);
-    U.v2 = rfl_f64(L.v2);
-    U.df = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.df)));
-    U.modn = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.modn)));
-    U.sf = __builtin_amdgcn_readfirstlane(L.sf);
-    U.mode = __builtin_amdgcn_readfirstlane(L.mode);
-    U.flag = __builtin_amdgcn_readfirstlane(L.flag);
-    return U;
-}
-
-// frames n and n+1 at once
-__device__ __forceinline__ void slot_eval2(int kind, const DLeaf& L, int64_t n, double& o0, double& o1) {
-    double v0, v1;
-    switch (kind & 0xff) {
-    case OP_CONST: v0 = v1 = L.v0; break;
-    case OP_SCALAR: v0 = v1 = *(const double*)L.base; break;
-    case OP_FUNC:
-        v0 = func_eval(L, n);
-        v1 = func_eval(L, n + 1);
-        break;
-    default:
-        v0 = ramp_eval(L, n);
-        v1 = ramp_eval(L, n + 1);
-        break;
-    }
-    if (kind & 0x100) {
-        v0 = (double)(float)v0;
-        v1 = (double)(float)v1;
-    }
-    o0 = v0;
-    o1 = v1;
-}
-
-// ---------------------------------------------------------------------------
-// D-deep register stack machine over E elements per thread.  Program words are
-// wave-uniform (scalar loads); the stack lives in VGPRs (static indexing only).
-// D is 2 for left-fold chains (almost every tree) and kStackDepth otherwise, which keeps
-// the register footprint of the common case small enough for high occupancy.
-//   CV == false: element e is frame n[e] of channel c (K1: E frames per thread).
-//   CV == true : element e is channel c+e of the single frame n[0] (stage-kernel tile
-//                staging: all channels of a frame at once -> E independent loads in flight).
-#define SO_PUSH(expr)                                   \
-    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
-        _Pragma("unroll") for (int d = D - 1; d > 0; --d) st[d][e] = st[d - 1][e]; \
-        st[0][e] = (expr);                              \
-    }
-#define SO_POP1()                                       \
-    _Pragma("unroll") for (int d = 1; d < D - 1; ++d) st[d][e] = st[d + 1][e];
-#define SO_BIN(opr)                                     \
-    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
-        st[0][e] = st[1][e] opr st[0][e];               \
-        SO_POP1()                                       \
-    }
-
-// HEAVY == false drops the generator/ramp opcodes (the planner always hoists them into the
-// per-frame program), so the per-sample interpreter carries no transcendental code.
-// PAIR (E == 2, n[1] == n[0] + 1 for every lane, same parity of n[0] across the wave): array
-// leaves with unit frame stride are read with one 16-byte (fp64) / 8-byte (fp32) load per lane
-// when the pair is naturally aligned -- the widest, best-coalesced form of a streaming read.
-template <int E, bool CV, int D, bool HEAVY, bool PAIR = false>
-__device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc, int len,
-                                            const DLeaf* __restrict__ leaves,
-                                            const int64_t (&n)[CV ? 1 : E], int c,
-                                            double (&F)[kMaxFrameSlots][CV ? 1 : E],
-                                            double (&out)[E], bool pair_rt = true) {
-    double st[D][E];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int e = 0; e < E; ++e) st[d][e] = 0.0;
-    for (int i = 0; i < len; ++i) {
-        const DOp op = ops[pc + i];
-        switch (op.code) {
-        case OP_CONST: {
-            const double v = leaves[op.arg].v0;
-            SO_PUSH(v);
-            break;
-        }
-        case OP_LOAD: {
-            const DLeaf& L = leaves[op.arg];
-            if constexpr (PAIR && E == 2 && !CV) {
-                if (pair_rt && L.sf > 0 && L.fstride == 1) {  // wave-uniform
-                    const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;
-                    const int64_t off = n[0] + L.df + choff;  // element index of the pair's first frame
-                    const int par = __builtin_amdgcn_readfirstlane((int)off) & 1;
-                    double v0, v1;
-                    bool done = false;
-                    if (L.dtype == SO_F64) {
-                        if (((((uintptr_t)L.base) >> 3) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 7) == 0) {
-                            const double2 v = *reinterpret_cast<const double2*>((const double*)L.base + off);
-                            v0 = v.x;
-                            v1 = v.y;
-                            done = true;
-                        }
-                    } else if (((((uintptr_t)L.base) >> 2) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 3) == 0) {
-                        const float2 v = *reinterpret_cast<const float2*>((const float*)L.base + off);
-                        v0 = (double)v.x;
-                        v1 = (double)v.y;
-                        done = true;
-                    }
-                    if (done) {
-#pragma unroll
-                        for (int d = D - 1; d > 0; --d) {
-                            st[d][0] = st[d - 1][0];
-                            st[d][1] = st[d - 1][1];
-                        }
-                        st[0][0] = v0;
-                        st[0][1] = v1;
-                        break;
-                    }
-                }
-            }
-            SO_PUSH(leaf_load(L, n[CV ? 0 : e], CV ? c + e : c));
-            break;
-        }
-        case OP_SCALAR: {
-            const double v = *(const double*)leaves[op.arg].base;
-            SO_PUSH(v);
-            break;
-        }
-        case OP_FUNC:
-            if constexpr (HEAVY) {
-                const DLeaf& L = leaves[op.arg];
-                SO_PUSH(func_eval(L, n[CV ? 0 : e]));
-            }
-            break;
-        case OP_RAMP:
-            if constexpr (HEAVY) {
-                const DLeaf& L = leaves[op.arg];
-                SO_PUSH(ramp_eval(L, n[CV ? 0 : e]));
-            }
-            break;
-        case OP_ADD: SO_BIN(+); break;
-        case OP_SUB: SO_BIN(-); break;
-        case OP_MUL: SO_BIN(*); break;
-        case OP_DIV: SO_BIN(/); break;
-        case OP_NEG:
-#pragma unroll
-            for (int e = 0; e < E; ++e) st[0][e] = -st[0][e];
-            break;
-        case OP_ROUND32:
-#pragma unroll
-            for (int e = 0; e < E; ++e) st[0][e] = (double)(float)st[0][e];
-            break;
-        case OP_STOREF:
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                switch (op.arg) {
-                case 0: F[0][CV ? 0 : e] = st[0][e]; break;
-                case 1: F[1][CV ? 0 : e] = st[0][e]; break;
-                case 2: F[2][CV ? 0 : e] = st[0][e]; break;
-                default: F[3][CV ? 0 : e] = st[0][e]; break;
-                }
-                st[0][e] = st[1][e];
-                SO_POP1()
-            }
-            break;
-        case OP_LOADF:
-            switch (op.arg) {
-            case 0: SO_PUSH(F[0][CV ? 0 : e]); break;
-            case 1: SO_PUSH(F[1][CV ? 0 : e]); break;
-            case 2: SO_PUSH(F[2][CV ? 0 : e]); break;
-            default: SO_PUSH(F[3][CV ? 0 : e]); break;
-            }
-            break;
-        default: break;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = st[0][e];
-}
-
-// K1: one workgroup = kBlock*E consecutive frames x a channel chunk of one piece.
-// Lane l handles frames base + l + e*kBlock, so every load/store instruction is a
-// fully coalesced run of 64 consecutive elements per wave.
-// DEEP == false: every piece of the launch needs a stack depth <= 2 (left-fold chains: almost
-// every tree), so the 4-deep interpreters are not even compiled in -- half the registers, twice
-// the waves per SIMD, and this kernel is bound by bytes in flight.
-// CHAIN: pieces whose per-sample program is `array (op) F_s (op) F_t ...` (Amplify / Mix / Ramp chains
-// over one array: the commonest maps) skip the interpreter in the channel loop: the program is
-// decoded once into scalar registers and eight channels' 16-byte loads are issued back to back,
-// so a lane has 128 bytes in flight instead of 16 (the interpreter issues one load per channel
-// pass and then waits for it: K1 was bound by bytes in flight).
-// IL (with CHAIN): interleaved frames -- a result or a leaf with frame_stride = nch, chan_stride = 1
-// (WAV buffers, `PermutedDimsArray` inputs; reference src/WAV.jl:3-6, src/AxisArrays.jl:38-39) -- go
-// through an LDS tile of 512 frames x 8 channels: global accesses are runs of consecutive
-// elements across the workgroup (whole frames when the piece has <= 8 channels), the lanes pick
-// their (frame pair, channel) values out of LDS.  Without it a lane's accesses are nch elements
-// apart and every 16-byte access moves a 64-byte sector.
-template <int E, bool DEEP, bool CHAIN = false, bool IL = false>
-__global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__ pieces,
-                                                      int npieces, const DOp* __restrict__ ops,
-                                                      const DLeaf* __restrict__ leaves,
-                                                      OutView out) {
-    const int64_t bid = blockIdx.x;
-    int lo = 0, hi = npieces - 1;
-    while (lo < hi) {  // wave-uniform binary search: piece owning this workgroup
-        int mid = (lo + hi + 1) >> 1;
-        if (pieces[mid].block0 <= bid) lo = mid;
-        else hi = mid - 1;
-    }
-    const DPiece P = pieces[lo];
-    const int64_t rel = bid - P.block0;
-    const int64_t bf = rel % P.nblk_f;
-    const int bc = (int)(rel / P.nblk_f);
-    const int cbeg = P.c0 + bc * P.chc;
-    const int cend = min(P.c1, cbeg + P.chc);
-    // A workgroup walks P.sub consecutive blocks of kBlock*E frames: the piece lookup above and the
-    // program fetches are chains of dependent scalar loads (~a microsecond while the chip streams),
-    // paid once per workgroup instead of once per 64 KB.
-    for (int sb = 0; sb < P.sub; ++sb) {
-    int64_t n[E], ns[E];
-    bool valid[E];
-    // light variant, block entirely inside the piece: lane l owns the PAIR of frames
-    // (base + 2l, base + 2l + 1) and reads / writes it as one 16-byte access where alignment allows
-    const int64_t blk0 = P.a + (bf * P.sub + sb) * (int64_t)(kBlock * E);
-    if (blk0 >= P.b) break;
-    const bool pair = !DEEP && E == 2 && blk0 + kBlock * E <= P.b;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        ns[e] = pair ? blk0 + (int64_t)E * threadIdx.x + e : blk0 + threadIdx.x + (int64_t)e * kBlock;
-        valid[e] = ns[e] < P.b;
-        n[e] = valid[e] ? ns[e] : P.b - 1;  // clamp: loads stay in range, store is skipped
-    }
-    double F[kMaxFrameSlots][E];
-#pragma unroll
-    for (int k = 0; k < kMaxFrameSlots; ++k)
-#pragma unroll
-        for (int e = 0; e < E; ++e) F[k][e] = 0.0;
-    double v[E];
-    const bool deep = DEEP && P.depth > 2;  // wave-uniform
-    if (P.frame_len > 0) {
-        if constexpr (DEEP) {
-            if (deep) run_program<E, false, kStackDepth, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
-            else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
-        } else run_program<E, false, 2, true>(ops, P.frame_pc, P.frame_len, leaves, n, cbeg, F, v);
-    }
-    if constexpr (CHAIN && !DEEP && E == 2) {
-        constexpr int kIlPitch = 9;  // doubles per frame row of the LDS tile (8 channels + 1: bank spread)
-        __shared__ double il_tile[IL ? kBlock * E * kIlPitch : 1];
-        const bool out_il = IL && out.fstride > 1 && out.cstride == 1;
-        if (P.chain && pair && (out.fstride == 1 || out_il)) {  // (wave-uniform)
-            const DLeaf& L = leaves[ops[P.samp_pc].arg];
-            const bool in_il = IL && L.fstride > 1 && L.cstride == 1;
-            const int nst = (P.samp_len - 1) >> 1;
-            int sop[4], sslot[4];  // operand: frame slot 0..3, or 4 = the constant cval[i]
-            double cval[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const DOp o = ops[P.samp_pc + 1 + 2 * (i < nst ? i : 0)];
-                sslot[i] = i < nst ? (o.code == OP_LOADF ? o.arg : 4) : 0;
-                cval[i] = i < nst && o.code == OP_CONST ? leaves[o.arg].v0 : 0.0;
-                sop[i] = i < nst ? ops[P.samp_pc + 2 + 2 * i].code : -1;
-            }
-            const bool in64 = L.dtype == SO_F64, out64 = out.dtype == SO_F64;
-            const int isz = in64 ? 8 : 4, osz = out64 ? 8 : 4;
-            constexpr int CB = 8;
-            for (int cb = cbeg; cb < cend; cb += CB) {
-                double val[CB][2];
-                // ---- loads of up to eight channels, all in flight together ----
-                const int nb = cend - cb < CB ? cend - cb : CB;  // channels of this batch
-                if (in_il) {
-                    // the batch's 512 x nb block of the interleaved leaf, element runs of nb per frame
-                    // (every wave moves and reads only ITS 128 frames of the tile: wave barriers suffice,
-                    //  the four waves of the workgroup stay independent)
-                    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, f0w = wv * 64 * E;
-                    const int64_t off0 = (blk0 + f0w + L.df) * L.fstride + ((int64_t)L.sc * cb + L.dc);
-                    if (in64 && nb == L.fstride && !(nb & 1) && ((((uintptr_t)L.base) + off0 * 8) & 15) == 0) {
-                        // whole frames: the block is one contiguous run -> 16-byte loads, all in flight
-                        const double2* src = reinterpret_cast<const double2*>((const double*)L.base + off0);
-                        const int nv = 64 * E * nb / 2;
-                        for (int v0 = ln; v0 < nv; v0 += 8 * 64) {
-                            double2 w[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (v0 + j * 64 < nv) w[j] = src[v0 + j * 64];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (v0 + j * 64 < nv) {
-                                    const int e0 = 2 * (v0 + j * 64), f = f0w + e0 / nb, cc = e0 % nb;
-                                    il_tile[f * kIlPitch + cc] = w[j].x;
-                                    il_tile[f * kIlPitch + cc + 1] = w[j].y;
-                                }
-                        }
-                    } else {
-                        for (int idx = ln; idx < 64 * E * nb; idx += 64) {
-                            const int f = idx / nb, cc = idx - f * nb;
-                            const int64_t off = off0 + (int64_t)f * L.fstride + (int64_t)L.sc * cc;
-                            il_tile[(f0w + f) * kIlPitch + cc] = in64 ? ((const double*)L.base)[off] : (double)((const float*)L.base)[off];
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int u = 0; u < CB; ++u) {
-                        val[u][0] = u < nb ? il_tile[(2 * threadIdx.x) * kIlPitch + u] : 0.0;
-                        val[u][1] = u < nb ? il_tile[(2 * threadIdx.x + 1) * kIlPitch + u] : 0.0;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-#pragma unroll
-                for (int u = 0; u < CB; ++u) {
-                    if (in_il) break;
-                    val[u][0] = val[u][1] = 0.0;
-                    if (cb + u < cend) {
-                        const int64_t off = ((int64_t)L.sc * (cb + u) + L.dc) * L.cstride + ns[0] + L.df;
-                        const char* pa = (const char*)L.base + off * isz;
-                        const uintptr_t a0 = (uintptr_t)rfl64((int64_t)(uintptr_t)pa);  // lane 0's address
-                        if (in64) {
-                            if ((a0 & 15) == 0) {
-                                const double2 w = *reinterpret_cast<const double2*>(pa);
-                                val[u][0] = w.x;
-                                val[u][1] = w.y;
-                            } else {
-                                val[u][0] = ((const double*)pa)[0];
-                                val[u][1] = ((const double*)pa)[1];
-                            }
-                        } else if ((a0 & 7) == 0) {
-                            const float2 w = *reinterpret_cast<const float2*>(pa);
-                            val[u][0] = (double)w.x;
-                            val[u][1] = (double)w.y;
-                        } else {
-                            val[u][0] = (double)((const float*)pa)[0];
-                            val[u][1] = (double)((const float*)pa)[1];
-                        }
-                    }
-                }
-                // ---- the chain: the opcode switch outside the element loops ----
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i >= nst) break;
-                    double m[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        m[e] = sslot[i] == 0 ? F[0][e] : sslot[i] == 1 ? F[1][e] : sslot[i] == 2 ? F[2][e] : sslot[i] == 3 ? F[3][e] : cval[i];
-#define SO_CH(EXPR)                                          \
-    _Pragma("unroll") for (int u = 0; u < CB; ++u) _Pragma("unroll") for (int e = 0; e < 2; ++e) { \
-        const double x = val[u][e];                          \
-        val[u][e] = (EXPR);                                  \
-    }
-                    switch (sop[i]) {
-                    case OP_ADD: SO_CH(x + m[e]) break;
-                    case OP_SUB: SO_CH(x - m[e]) break;
-                    case OP_MUL: SO_CH(x * m[e]) break;
-                    default: SO_CH(x / m[e]) break;
-                    }
-#undef SO_CH
-                }
-                // ---- stores ----
-                if (out_il) {
-#pragma unroll
-                    for (int u = 0; u < CB; ++u)
-                        if (u < nb) {
-                            il_tile[(2 * threadIdx.x) * kIlPitch + u] = val[u][0];
-                            il_tile[(2 * threadIdx.x + 1) * kIlPitch + u] = val[u][1];
-                        }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, f0w = wv * 64 * E;
-                    const int64_t ooff0 = (blk0 + f0w) * out.fstride + cb;
-                    if (!(out.pad & 1) && out64 && nb == out.fstride && !(nb & 1) && ((((uintptr_t)out.base) + ooff0 * 8) & 15) == 0) {
-                        double2* dst = reinterpret_cast<double2*>((double*)out.base + ooff0);
-                        const int nv = 64 * E * nb / 2;
-                        for (int v0 = ln; v0 < nv; v0 += 64) {
-                            const int e0 = 2 * v0, f = f0w + e0 / nb, cc = e0 % nb;
-                            double2 w;
-                            w.x = il_tile[f * kIlPitch + cc];
-                            w.y = il_tile[f * kIlPitch + cc + 1];
-                            dst[v0] = w;
-                        }
-                    } else {
-                        for (int idx = ln; idx < 64 * E * nb; idx += 64) {
-                            const int f = idx / nb, cc = idx - f * nb;
-                            const int64_t off = ooff0 + (int64_t)f * out.fstride + cc;
-                            const double w = il_tile[(f0w + f) * kIlPitch + cc];
-                            if (out64) ((double*)out.base)[off] = w;
-                            else ((float*)out.base)[off] = (float)w;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    continue;
-                }
-#pragma unroll
-                for (int u = 0; u < CB; ++u) {
-                    if (cb + u < cend) {
-                        const int64_t off = (int64_t)(cb + u) * out.cstride + ns[0];
-                        char* pa = (char*)out.base + off * osz;
-                        const uintptr_t a0 = (uintptr_t)rfl64((int64_t)(uintptr_t)pa);
-                        if (out64) {
-                            if ((a0 & 15) == 0) {
-                                double2 w;
-                                w.x = val[u][0];
-                                w.y = val[u][1];
-                                *reinterpret_cast<double2*>(pa) = w;
-                            } else {
-                                ((double*)pa)[0] = val[u][0];
-                                ((double*)pa)[1] = val[u][1];
-                            }
-                        } else if ((a0 & 7) == 0) {
-                            float2 w;
-                            w.x = (float)val[u][0];
-                            w.y = (float)val[u][1];
-                            *reinterpret_cast<float2*>(pa) = w;
-                        } else {
-                            ((float*)pa)[0] = (float)val[u][0];
-                            ((float*)pa)[1] = (float)val[u][1];
-                        }
-                    }
-                }
-            }
-            continue;
-        }
-    }
-    for (int c = cbeg; c < cend; ++c) {
-        if constexpr (DEEP) {
-            if (deep) run_program<E, false, kStackDepth, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
-            else run_program<E, false, 2, false>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v);
-        } else run_program<E, false, 2, false, true>(ops, P.samp_pc, P.samp_len, leaves, n, c, F, v, pair);
-        if constexpr (!DEEP && E == 2) {
-            if (pair && out.fstride == 1) {  // aligned pair store (wave-uniform alignment)
-                const int64_t off = (int64_t)c * out.cstride + ns[0];
-                const int par = __builtin_amdgcn_readfirstlane((int)off) & 1;
-                if (out.dtype == SO_F64 && ((uintptr_t)out.base & 7) == 0 && ((((uintptr_t)out.base) >> 3) & 1) == (uintptr_t)par) {
-                    double2 w;
-                    w.x = v[0];
-                    w.y = v[1];
-                    *reinterpret_cast<double2*>((double*)out.base + off) = w;
-                    continue;
-                }
-                if (out.dtype == SO_F32 && ((uintptr_t)out.base & 3) == 0 && ((((uintptr_t)out.base) >> 2) & 1) == (uintptr_t)par) {
-                    float2 w;
-                    w.x = (float)v[0];
-                    w.y = (float)v[1];
-                    *reinterpret_cast<float2*>((float*)out.base + off) = w;
-                    continue;
-                }
-            }
-        }
-        if (out.dtype == SO_F32) {
-            float* o = (float*)out.base + (int64_t)c * out.cstride;
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (valid[e]) o[ns[e] * out.fstride] = (float)v[e];
-        } else {
-            double* o = (double*)out.base + (int64_t)c * out.cstride;
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (valid[e]) o[ns[e] * out.fstride] = v[e];
-        }
-    }
-    }  // sub-blocks
-}
-
-void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, const DOp* d_ops,
-                      const DLeaf* d_leaves, OutView out, bool deep, hipStream_t st, bool chain, bool il) {
-    if (nblocks <= 0) return;
-    if (chain && !deep && il)
-        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false, true, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
-                           npieces, d_ops, d_leaves, out);
-    else if (chain && !deep)
-        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
-                           npieces, d_ops, d_leaves, out);
-    else if (deep)
-        hipLaunchKernelGGL((k_pointwise<kPointwiseE, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
-                           npieces, d_ops, d_leaves, out);
-    else
-        hipLaunchKernelGGL((k_pointwise<kPointwiseE, false>), dim3((unsigned)nblocks), dim3(kBlock), 0, st, d_pieces,
-                           npieces, d_ops, d_leaves, out);
-}
-
-// ---------------------------------------------------------------------------
-// K2: SOS IIR.  The recurrence is linear, so a chunk's output is the zero-state
-// response to its own samples plus the zero-input response to the state at its start.
-//   pass 1  k_sos_tiled<.,.,false> : v_k = state at the END of chunk k from zero state (only the
-//           last min(L,W) frames matter: older frames have decayed below 2^-70)
-//   pass 2  k_sos_scan  : s0_k = sum_{j=1..K} M^(j-1) v_{k-j},  M = A^L (host-computed
-//           powers of the cascade's state matrix); K terms until ||M^K|| < 2^-70
-//   pass 3  k_sos_tiled<.,.,true>  : run DF2T on chunk k from s0_k and write the output
-// DF2T per section (DSP.jl filt!):
-//   y = s1 + b0 x ; s1 = s2 + b1 x - a1 y ; s2 = b2 x - a2 y ; out = y*g after the cascade
-template <int NS>
-__device__ __forceinline__ double sos_step(double x, double (&s)[2 * NS], const SosCoefs& cf) {
-    double y = x;
-#pragma unroll
-    for (int f = 0; f < NS; ++f) {
-        const double xi = y;
-        y = s[2 * f] + cf.b0[f] * xi;
-        s[2 * f] = s[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * y;
-        s[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
-    }
-    return y;
-}
-
-// Tiled streaming of 64 sequences per wave (sequence = one chunk of one channel).  A tile is
-// 64 rows x kTT frames: the wave loads it with coalesced 128-byte row segments (4 rows per
-// load instruction), parks it in LDS with an odd row pitch, then every lane walks ITS row
-// (conflict-free, stride kTT+1) through the DF2T cascade with the section states in registers
-// and, for the apply pass, writes the outputs back through LDS the same coalesced way.
-// APPLY == false: pass 1 (final state of the last min(L,W) frames from zero state)
-// APPLY == true : pass 3 (outputs from the propagated initial state)
-constexpr int kTT = 16;
-
-template <int NS, typename T, bool APPLY>
-__global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T* __restrict__ y,
-                                                      const double* __restrict__ s0,
-                                                      double* __restrict__ v, SosGeom g,
-                                                      SosCoefs cf) {
-    __shared__ double tile[kBlock / 64][64 * (kTT + 1)];
-    __shared__ int64_t rowbase[kBlock / 64][64];  // element offset of each row's first frame
-    __shared__ int rowlen[kBlock / 64][64];       // frames this row has to process
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nck = APPLY ? g.nchunks : g.nchunks - 1;  // pass 1 skips every channel's last chunk
-    const int64_t nseq = (int64_t)nck * g.nch;
-    const int64_t seq = ((int64_t)blockIdx.x * (kBlock / 64) + w) * 64 + lane;
-    const bool live = seq < nseq;
-    const int k = live ? (int)(seq % nck) : 0;
-    const int ch = live ? (int)(seq / nck) : 0;
-    int64_t beg = (int64_t)k * g.chunk;
-    int64_t end = beg + g.chunk < g.n ? beg + g.chunk : g.n;
-    if (!APPLY) beg = end - (g.warm < g.chunk ? g.warm : g.chunk);  // full chunks only: end = beg+L
-    const int len = live ? (int)(end - beg) : 0;
-    rowbase[w][lane] = beg;  // frame offset (the row's channel is kept in rowch)
-    rowlen[w][lane] = len;
-    double s[2 * NS];
-#pragma unroll
-    for (int d = 0; d < 2 * NS; ++d) s[d] = 0.0;
-    if (APPLY && live && k > 0 && s0 != nullptr) {
-        const double* sp = s0 + ((int64_t)ch * g.nchunks + k) * (2 * NS);
-#pragma unroll
-        for (int d = 0; d < 2 * NS; ++d) s[d] = sp[d];
-    }
-    // every row of this wave belongs to a (chunk, channel); rows are consecutive chunks of one
-    // channel except where the wave straddles a channel boundary, so the per-row channel is
-    // kept alongside the frame offset
-    __shared__ int rowch[kBlock / 64][64];
-    rowch[w][lane] = ch;
-    __builtin_amdgcn_wave_barrier();
-    int maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-    double* tl = tile[w];
-    const int rsub = lane >> 4, col = lane & 15;  // load/store role: 4 rows x 16 columns
-    // The passes are latency-bound (a few waves per CU, each a chain of tile round trips): all 16
-    // loads of a tile are issued together and the NEXT tile's loads are issued before this tile's
-    // arithmetic, so a wave always has one tile (8 KB) in flight.
-    const T* xrow[16];  // this lane's 16 load rows: element address of (row, column col)
-    int xlen[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = j * 4 + rsub;
-        xlen[j] = rowlen[w][r];
-        xrow[j] = x + ((int64_t)rowch[w][r] * g.in_pitch + rowbase[w][r] + col);
-    }
-    double xv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xv[j] = col < xlen[j] ? (double)xrow[j][0] : 0.0;
-    for (int t0 = 0; t0 < maxlen; t0 += kTT) {
-        // ---- tile t0 (loaded one iteration ago: 16 instructions x (4 rows x 128 B)) -> LDS ----
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tl[(j * 4 + rsub) * (kTT + 1) + col] = xv[j];
-        __builtin_amdgcn_wave_barrier();
-        if (t0 + kTT < maxlen) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xv[j] = t0 + kTT + col < xlen[j] ? (double)xrow[j][t0 + kTT] : 0.0;
-        }
-        // ---- every lane: its own row through the cascade ----
-        double* row = tl + lane * (kTT + 1);
-#pragma unroll
-        for (int t = 0; t < kTT; ++t) {
-            const double yv = sos_step<NS>(row[t], s, cf);
-            if (APPLY) row[t] = yv * cf.gain;
-            // (frames past a short row's end are zeros and never stored; their effect on
-            //  the state is irrelevant: only full chunks feed pass 1)
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (APPLY) {
-            // ---- coalesced store ----
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int r = j * 4 + rsub;
-                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= g.store_lo) {
-                    const int64_t o = (int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col;
-                    // (a Float64 filter writing a Float32 result itself: `convert` on store, src/sink.jl:262-266)
-                    if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)tl[r * (kTT + 1) + col];
-                    else y[o] = (T)tl[r * (kTT + 1) + col];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (!APPLY && live) {
-        double* vp = v + ((int64_t)ch * g.nchunks + k) * (2 * NS);
-#pragma unroll
-        for (int d = 0; d < 2 * NS; ++d) vp[d] = s[d];
-    }
-}
-
-// mpow: [kterms][D][D] row-major powers of M = A^L built on the host (mpow[0] = I, mpow[1] = M);
-// the host uses them to choose the truncation K, the kernel only needs M itself.
-template <int NS>
-__global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ v,
-                                                     const double* __restrict__ mpow, SosGeom g,
-                                                     double* __restrict__ s0) {
-    constexpr int D = 2 * NS;
-    // Horner form of  s0_k = sum_{j=1..K} M^(j-1) v_(k-j):  s <- M s + v_(k-j), oldest term first.
-    // One matrix (M = A^L, second entry of the host's power table) in LDS, read as broadcasts; no
-    // barrier and no matrix fetch per term -- the per-term global round trips of the previous
-    // power-table form made this the longest of the three passes.
-    __shared__ double m1[D * D];
-    if ((int)threadIdx.x < D * D) m1[threadIdx.x] = g.kterms >= 2 ? mpow[(int64_t)D * D + threadIdx.x] : 0.0;
-    __syncthreads();
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    const bool live = tid < nseq;
-    const int k = live ? (int)(tid % g.nchunks) : 0;
-    const int ch = live ? (int)(tid / g.nchunks) : 0;
-    double acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    const int jmax = live ? (k < g.kterms ? k : g.kterms) : 0;
-    const double* vp = v + ((int64_t)ch * g.nchunks + (k - jmax)) * D;  // oldest term, then forward
-    for (int j = jmax; j >= 1; --j, vp += D) {
-        double vv[D], t[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) vv[d] = vp[d];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-            double a = vv[r];
-#pragma unroll
-            for (int d = 0; d < D; ++d) a = fma(m1[r * D + d], acc[d], a);
-            t[r] = a;
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = t[d];
-    }
-    if (live) {
-        double* sp = s0 + ((int64_t)ch * g.nchunks + k) * D;
-#pragma unroll
-        for (int d = 0; d < D; ++d) sp[d] = acc[d];
-    }
-}
-
-template <int NS, typename T>
-static void launch_sos_t(const void* x, void* y, double* v, double* s0, const double* mpow,
-                         const SosGeom& g, const SosCoefs& cf, hipStream_t st) {
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    if (g.nchunks > 1) {
-        const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
-        hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, st, (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
-        hipLaunchKernelGGL((k_sos_scan<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, st, v, mpow, g, s0);
-    }
-    hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, (const T*)x, (T*)y, g.nchunks > 1 ? (const double*)s0 : nullptr,
-                       (double*)nullptr, g, cf);
-}
-
-template <typename T>
-static void launch_sos_ns(const void* x, void* y, double* v, double* s0, const double* mpow,
-                          const SosGeom& g, const SosCoefs& cf, hipStream_t st) {
-    switch (cf.nsec) {
-    case 1: launch_sos_t<1, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 2: launch_sos_t<2, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 3: launch_sos_t<3, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 4: launch_sos_t<4, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 5: launch_sos_t<5, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 6: launch_sos_t<6, T>(x, y, v, s0, mpow, g, cf, st); break;
-    case 7: launch_sos_t<7, T>(x, y, v, s0, mpow, g, cf, st); break;
-    default: launch_sos_t<8, T>(x, y, v, s0, mpow, g, cf, st); break;
-    }
-}
-
-// The state pass already done by the resampler in front (k_resample_periodic's state waves):
-// vper[ch][period][16] holds the zero-state end-of-period states; a chunk is pt periods:
-//   v_chunk = sum_{p<pt} Q^(pt-1-p) v_p,  Q = A^Ls   (Horner, Q in LDS)
-template <int NS>
-__global__ __launch_bounds__(kBlock) void k_sos_combine(const double* __restrict__ vper, int64_t nper,
-                                                        const double* __restrict__ qmat, int pt, SosGeom g,
-                                                        double* __restrict__ v) {
-    constexpr int D = 2 * NS;
-    __shared__ double q[D * D];
-    if ((int)threadIdx.x < D * D) q[threadIdx.x] = qmat[threadIdx.x];
-    __syncthreads();
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    if (tid >= nseq) return;
-    const int k = (int)(tid % g.nchunks), ch = (int)(tid / g.nchunks);
-    if ((int64_t)(k + 1) * pt > nper) return;  // (an incomplete last chunk: its end state is never used)
-    double acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    const double* vp = vper + ((int64_t)ch * nper + (int64_t)k * pt) * 16;
-    const int64_t half = (int64_t)g.nch * nper * 16;  // the second state wave's partial sums
-    for (int p = 0; p < pt; ++p, vp += 16) {
-        double t[D];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-            double a = vp[r] + vp[half + r];
-#pragma unroll
-            for (int d = 0; d < D; ++d) a = fma(q[r * D + d], acc[d], a);
-            t[r] = a;
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = t[d];
-    }
-    double* o = v + ((int64_t)ch * g.nchunks + k) * D;
-#pragma unroll
-    for (int d = 0; d < D; ++d) o[d] = acc[d];
-}
-
-template <int NS, typename T>
-static void launch_sos_pre_t(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
-                             double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,
-                             hipStream_t st) {
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    hipLaunchKernelGGL((k_sos_combine<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, vper, nper,
-                       qmat, pt, g, v);
-    hipLaunchKernelGGL((k_sos_scan<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v, mpow, g, s0);
-    hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       (const T*)x, (T*)y, (const double*)s0, (double*)nullptr, g, cf);
-}
-
-// IIR with the state pass precomputed (returns the number of launches)
-int launch_sos_prestate(const void* x, void* y, const double* vper, int64_t nper, const double* qmat, int pt,
-                        double* v, double* s0, const double* mpow, const SosGeom& g, const SosCoefs& cf,
-                        hipStream_t st) {
-    if (g.n <= 0) return 0;
-#define SO_PRE(NS_)                                                                                             \
-    case NS_:                                                                                                   \
-        if (g.in_dtype == SO_F32) launch_sos_pre_t<NS_, float>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st); \
-        else launch_sos_pre_t<NS_, double>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);                    \
-        break;
-    switch (cf.nsec) {
-        SO_PRE(1) SO_PRE(2) SO_PRE(3) SO_PRE(4) SO_PRE(5) SO_PRE(6) SO_PRE(7)
-    default:
-        if (g.in_dtype == SO_F32) launch_sos_pre_t<8, float>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);
-        else launch_sos_pre_t<8, double>(x, y, vper, nper, qmat, pt, v, s0, mpow, g, cf, st);
-    }
-#undef SO_PRE
-    return 3;
-}
-
-// One pass of the three-pass form on its own (phase 1: chunk end states v from zero state; phase 3:
-// outputs from the chunk start states s0) -- for callers that put a different scan in between
-// (kernels2.hip launch_sos_xscan).  Returns the number of launches.
-template <int NS, typename T>
-static void launch_sos_phase_t(const void* x, void* y, double* v, const double* s0, const SosGeom& g, const SosCoefs& cf,
-                               int phase, hipStream_t st) {
-    const int64_t nseq = (int64_t)g.nchunks * g.nch;
-    if (phase == 1) {
-        const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
-        hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
-    } else {
-        hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const T*)x, (T*)y, s0, (double*)nullptr, g, cf);
-    }
-}
-int launch_sos_phase(const void* x, void* y, double* v, const double* s0, const SosGeom& g, const SosCoefs& cf, int phase,
-                     hipStream_t st) {
-    if (g.n <= 0 || (phase == 1 && g.nchunks <= 1)) return 0;
-#define SO_PH(NS_)                                                                                     \
-    case NS_:                                                                                          \
-        if (g.in_dtype == SO_F32) launch_sos_phase_t<NS_, float>(x, y, v, s0, g, cf, phase, st);          \
-        else launch_sos_phase_t<NS_, double>(x, y, v, s0, g, cf, phase, st);                              \
-        break;
-    switch (cf.nsec) {
-        SO_PH(1) SO_PH(2) SO_PH(3) SO_PH(4) SO_PH(5) SO_PH(6) SO_PH(7)
-    default:
-        if (g.in_dtype == SO_F32) launch_sos_phase_t<8, float>(x, y, v, s0, g, cf, phase, st);
-        else launch_sos_phase_t<8, double>(x, y, v, s0, g, cf, phase, st);
-    }
-#undef SO_PH
-    return 1;
-}
-
-int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,
-               const SosGeom& g, const SosCoefs& cf, hipStream_t st) {
-    if (g.n <= 0) return 0;
-    if (g.in_dtype == SO_F32) launch_sos_ns<float>(x, y, v, s0, mpow, g, cf, st);
-    else launch_sos_ns<double>(x, y, v, s0, mpow, g, cf, st);
-    return g.nchunks > 1 ? 3 : 1;
-}
-
-// ---------------------------------------------------------------------------
-// K2 single pass: one read and one write of the signal (the three-pass form above reads it twice).
-//
-// Every WAVE works on its own: it takes the next tile in TIME ORDER (atomic ticket; a tile is
-// 2048 frames of one channel), loads it with coalesced 16-byte accesses and transposes it
-// through a small LDS buffer so that lane k holds sub-chunk k (kSosLc consecutive frames) in
-// REGISTERS:
-//   1. zero-state DF2T over the lane's sub-chunk                    -> v_k  (state at its end)
-//   2. inclusive scan over the 64 lanes with powers of M = A^lc (Kogge-Stone, ds_bpermute):
-//                                                    P_k = sum_{i<=k} M^(k-i) v_i ; V = P_63
-//   3. V (the tile's zero-state end state, a function of the tile's own samples only) is
-//      published; the state entering the tile is
-//          sigma = sum_{j>=0} (A^tf)^j V_(t-1-j),  truncated after kt terms (||(A^tf)^kt|| < 2^-70)
-//      -- a look-back over kt earlier tiles of the same channel that are all in flight or done
-//      (lower tickets) and whose V never waits for anything: no serial chain through the tiles.
-//      V slots are pre-set to an all-ones bit pattern (a NaN no arithmetic produces) and written
-//      with agent-scope atomic stores, so "is it there yet" and the value are ONE memory round
-//      trip, with no flag, no fence and no cache-wide writeback/invalidate.
-//   4. s0_k = P_(k-1) + M^k sigma (M^k by the binary expansion of k), DF2T from s0_k on the
-//      registers, transpose back, coalesced store.
-// No workgroup barrier after the matrices are staged: loads, arithmetic, look-back latency and
-// stores of the ~12 waves of a CU overlap on their own.  State matrices are lower
-// block-triangular (cascade), so only those entries are multiplied.  The arithmetic that
-// produces the outputs is the same DF2T recurrence as DSP.jl's filt! from a start state that
-// differs from the sequential one by rounding (~1e-16 relative).
-template <int D>
-__device__ __forceinline__ void matvec_tri(const double* __restrict__ m, const double (&v)[D], double (&out)[D]) {
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-        double a = 0.0;
-#pragma unroll
-        for (int c = 0; c <= (r | 1); ++c) a = fma(m[r * D + c], v[c], a);
-        out[r] = a;
-    }
-}
-__device__ __forceinline__ double bperm_f64(int byte_addr, double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_bpermute(byte_addr, lo);
-    hi = __builtin_amdgcn_ds_bpermute(byte_addr, hi);
-    return __hiloint2double(hi, lo);
-}
-constexpr int kSosTf = 64 * kSosLc;            // frames per wave tile
-constexpr unsigned long long kSosEmpty = ~0ull;  // "not published yet"
-
-template <int NS, typename T>
-__global__ __launch_bounds__(kBlock, 2) void k_sos_onepass(const T* __restrict__ x, T* __restrict__ y, SosOne g,
-                                                        SosCoefs cf, const double* __restrict__ tabs,
-                                                        int* __restrict__ sync, double* __restrict__ vpub) {
-    constexpr int D = 2 * NS;
-    constexpr int LC = kSosLc, LP = kSosLc + 1;  // odd pitch: the 16 rows of a round fall on different banks
-    constexpr int V = 16 / (int)sizeof(T);       // elements per 16-byte vector
-    constexpr int RV = 512 / V / 64;             // vectors per lane and round (a round = 512 frames = 16 rows)
-    typedef T vecT __attribute__((ext_vector_type(V)));
-    extern __shared__ double lds_raw[];
-    double* const ksm = lds_raw;  // [nlev][D*D]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    T* const buf = reinterpret_cast<T*>(lds_raw + g.nlev * D * D) + wave * (16 * LP);  // this wave's transposer
-    for (int i = tid; i < g.nlev * D * D; i += blockDim.x) ksm[i] = tabs[i];
-    __syncthreads();  // (the only workgroup barrier)
-    // One ticket per workgroup and up to kSosBatch tiles per wave: same-address atomics run at
-    // ~10-30 ns each on this chip, so a ticket per tile would by itself cost more than the whole
-    // kernel (measured: 112 500 tickets = 1.36 ms with all arithmetic removed).  A wave's tiles are
-    // the SAME time tile of g.bt different channels: tile (t, c_i) waits for (t-1, c_i), which is
-    // iteration i of a wave with a lower slot number -- the chain of "publish after the previous
-    // iteration's wait" steps down one iteration per link, so it is at most g.bt long.  (Time-
-    // consecutive tiles in one wave would chain through ALL running workgroups: measured 267 ms.)
-    __shared__ int s_ticket;
-    if (tid == 0) s_ticket = atomicAdd(&sync[0], 1);
-    __syncthreads();
-    const int ncs = (g.nch + g.bt - 1) / g.bt;             // channel slots per time tile
-    const int64_t slot = (int64_t)s_ticket * (kBlock / 64) + wave;  // time-major: (t-1, cs) is a lower slot
-    if (slot >= (int64_t)g.ntiles * ncs) return;
-    const int tt = (int)(slot / ncs), cs = (int)(slot - (int64_t)tt * ncs);
-    const int64_t f0 = (int64_t)tt * kSosTf;
-    const int64_t left = g.n - f0;  // frames of this time tile inside the signal (>= 1)
-    const int ch0 = cs * g.bt;
-    const int nit = g.nch - ch0 < g.bt ? g.nch - ch0 : g.bt;
-    const int grp = lane >> 4, rrow = (lane & 15) * LP;
-    const int k = lane;
-    auto issue_loads = [&](int ch, vecT (&ld)[4][RV]) {
-        const T* __restrict__ xin = x + (int64_t)ch * g.in_pitch + f0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < RV; ++j) {
-                const int f = (r * (512 / V) + j * 64 + lane) * V;
-#pragma unroll
-                for (int e = 0; e < V; ++e) ld[r][j][e] = (T)0;
-                if (g.vec_in && f + V <= left) ld[r][j] = *reinterpret_cast<const vecT*>(xin + f);
-                else {
-#pragma unroll
-                    for (int e = 0; e < V; ++e)
-                        if (f + e < left) ld[r][j][e] = xin[f + e];
-                }
-            }
-    };
-    vecT ld[4][RV];
-    issue_loads(ch0, ld);
-#pragma unroll 1
-    for (int it = 0; it < nit; ++it) {
-        const int ch = ch0 + it;
-        T* __restrict__ yout = y + (int64_t)ch * g.out_pitch + f0;
-        // ---- four transposition rounds: lane k gets sub-chunk k in registers ----
-        T xr[LC];
-#pragma unroll
-        for (int n = 0; n < LC; ++n) xr[n] = (T)0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < RV; ++j) {
-                const int fl = (j * 64 + lane) * V;  // frame inside the round
-                T* dst = buf + (fl / LC) * LP + (fl % LC);
-#pragma unroll
-                for (int e = 0; e < V; ++e) dst[e] = ld[r][j][e];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (grp == r) {
-#pragma unroll
-                for (int n = 0; n < LC; ++n) xr[n] = buf[rrow + n];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // the next tile's loads fly during this tile's arithmetic
-        if (it + 1 < nit) issue_loads(ch + 1, ld);
-        // ---- 1: zero-state pass over the lane's sub-chunk ----
-        double s[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) s[d] = 0.0;
-        if (!(g.debug & 1)) {
-#pragma unroll
-            for (int n = 0; n < LC; ++n) (void)sos_step<NS>((double)xr[n], s, cf);
-        }
-        // ---- 2: inclusive scan over the lanes ----
-#pragma unroll 1
-        for (int lev = 0; lev < 6 && !(g.debug & 2); ++lev) {
-            const int d = 1 << lev;
-            const int addr = (lane - d) << 2;
-            double p[D], q[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) p[i] = bperm_f64(addr, s[i]);
-            matvec_tri<D>(ksm + lev * D * D, p, q);
-            if (k >= d) {
-#pragma unroll
-                for (int i = 0; i < D; ++i) s[i] += q[i];
-            }
-        }
-        // ---- 3: publish V, look back ----
-        if (k == 63) {
-            double* vp = vpub + ((int64_t)tt * g.nch + ch) * D;
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                double pv = s[i];
-                if ((unsigned long long)__double_as_longlong(pv) == kSosEmpty) pv = __longlong_as_double(0x7ff8000000000000ll);
-                __hip_atomic_store(vp + i, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        double e0[D];  // P_(k-1)
-        {
-            const int addr = (lane - 1) << 2;
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const double up = bperm_f64(addr, s[i]);
-                e0[i] = k > 0 ? up : 0.0;
-            }
-        }
-        // ---- 4a: the outputs from P_(k-1) alone, on the registers.  The part that needs sigma is
-        //      added afterwards (superposition): the look-back's memory round trip -- the earlier
-        //      tile publishes its V at about the time this one asks for it -- hides behind this pass
-        //      instead of stalling every wave of the CU at the same point (measured: 0.5 ms).
-        // (Float64: the outputs replace the samples in their registers; Float32 samples keep the
-        //  sum in Float64 until the final rounding)
-        typedef typename std::conditional<sizeof(T) == 8, T, double>::type YT;
-        YT yloc[sizeof(T) == 8 ? 1 : LC];
-        YT* const yv = sizeof(T) == 8 ? reinterpret_cast<YT*>(xr) : yloc;
-        if (!(g.debug & 16)) {
-#pragma unroll
-            for (int n = 0; n < LC; ++n) yv[n] = sos_step<NS>((double)xr[n], e0, cf);
-        }
-        const int nb = tt < g.kt ? tt : g.kt;  // earlier tiles that still matter
-        if (nb > 0 && !(g.debug & 4)) {        // (wave-uniform)
-            double w[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) w[i] = 0.0;
-            if (k < nb) {
-                const double* vp = vpub + ((int64_t)(tt - 1 - k) * g.nch + ch) * D;
-                double vv[D];
-                for (;;) {
-                    if (g.debug & 64) {
-#pragma unroll
-                        for (int i = 0; i < D; ++i) vv[i] = 0.0;
-                        break;
-                    }
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        vv[i] = __hip_atomic_load(vp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (unsigned long long)__double_as_longlong(vv[i]) != kSosEmpty;
-                    }
-                    if (ok) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                matvec_tri<D>(tabs + (size_t)(g.nlev + k) * D * D, vv, w);  // (A^tf)^k V_(t-1-k)
-            }
-            // sum of the first nb lanes into lane 0 (the others hold zeros), then to every lane
-            for (int off = 1; off < nb; off <<= 1) {
-                const int addr = (lane ^ off) << 2;
-#pragma unroll
-                for (int i = 0; i < D; ++i) w[i] += bperm_f64(addr, w[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i) w[i] = rfl_f64(w[i]);
-            // M^k sigma by the binary expansion of k
-#pragma unroll 1
-            for (int lev = 0; lev < 6 && !(g.debug & 8); ++lev) {
-                double q[D];
-                matvec_tri<D>(ksm + lev * D * D, w, q);
-                if ((k >> lev) & 1) {
-#pragma unroll
-                    for (int i = 0; i < D; ++i) w[i] = q[i];
-                }
-            }
-            // ---- 4b: zero-input response of the sub-chunk to M^k sigma ----
-            if (!(g.debug & (16 | 32))) {
-#pragma unroll
-                for (int n = 0; n < LC; ++n) yv[n] += sos_step<NS>(0.0, w, cf);
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < LC; ++n) xr[n] = (T)(yv[n] * cf.gain);
-        // ---- transpose back and store ----
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (grp == r) {
-#pragma unroll
-                for (int n = 0; n < LC; ++n) buf[rrow + n] = xr[n];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < RV; ++j) {
-                const int fl = (j * 64 + lane) * V;
-                const T* src = buf + (fl / LC) * LP + (fl % LC);
-                const int f = r * 512 + fl;
-                if (g.vec_out && f + V <= left) {
-                    vecT o;
-#pragma unroll
-                    for (int e = 0; e < V; ++e) o[e] = src[e];
-                    *reinterpret_cast<vecT*>(yout + f) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < V; ++e)
-                        if (f + e < left) yout[f + e] = src[e];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-static bool first_use_on_device(bool (&seen)[64]);
-
-template <int NS, typename T>
-static void launch_sos_one_t(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
-                             int* sync, double* vpub, hipStream_t st) {
-    const size_t ldsb = (size_t)g.nlev * 4 * NS * NS * 8 + (size_t)(kBlock / 64) * 16 * (kSosLc + 1) * sizeof(T);
-    const int64_t nslots = (int64_t)g.ntiles * ((g.nch + g.bt - 1) / g.bt);  // one per wave
-    const int64_t per = kBlock / 64;
-    hipLaunchKernelGGL((k_sos_onepass<NS, T>), dim3((unsigned)((nslots + per - 1) / per)), dim3(kBlock), ldsb, st,
-                       (const T*)x, (T*)y, g, cf, tabs, sync, vpub);
-}
-
-template <typename T>
-static void launch_sos_one_ns(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
-                              int* sync, double* vpub, hipStream_t st) {
-    switch (cf.nsec) {
-    case 1: launch_sos_one_t<1, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 2: launch_sos_one_t<2, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 3: launch_sos_one_t<3, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 4: launch_sos_one_t<4, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 5: launch_sos_one_t<5, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 6: launch_sos_one_t<6, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    case 7: launch_sos_one_t<7, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    default: launch_sos_one_t<8, T>(x, y, g, cf, tabs, sync, vpub, st); break;
-    }
-}
-
-void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs& cf, const double* tabs,
-                        int* sync, double* vpub, int dtype, hipStream_t st) {
-    if (g.n <= 0) return;
-    if (dtype == SO_F32) launch_sos_one_ns<float>(x, y, g, cf, tabs, sync, vpub, st);
-    else launch_sos_one_ns<double>(x, y, g, cf, tabs, sync, vpub, st);
-}
 
 // ---------------------------------------------------------------------------
 // K3: polyphase resampler.  Output m sits at fine-grid position q_m (SURVEY.md
@@ -1422,7 +161,6 @@ __global__ __launch_bounds__(kBlock) void k_resample_tiled(const T* __restrict__
     }
 }
 
-static bool first_use_on_device(bool (&seen)[64]);
 
 template <typename T>
 static void launch_resample_tiled_t(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
@@ -1577,16 +315,6 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
     }
 }
 
-// hipFuncSetAttribute is per device: remember it per (kernel, device) -- a process that drives
-// several GPUs must raise the dynamic-LDS limit on each of them.
-static bool first_use_on_device(bool (&seen)[64]) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = dev < 0 ? 0 : (dev > 63 ? 63 : dev);
-    const bool first = !seen[dev];
-    seen[dev] = true;
-    return first;
-}
 
 int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
                          const int* jend, const RsRows& g, int dtype, hipStream_t st) {
@@ -2887,119 +1615,6 @@ void launch_resample_fix(const RsFixArgs& a, hipStream_t st) {
     if (a.nfix <= 0) return;
     const int per = kBlock / 64;
     hipLaunchKernelGGL(k_resample_fix, dim3((unsigned)((a.nfix + per - 1) / per)), dim3(kBlock), 0, st, a);
-}
-
-// ---------------------------------------------------------------------------
-// K4: sum of squares over a planar [nch][pitch] buffer with n valid frames per
-// channel; deterministic two-stage tree (no atomics), fp64 accumulation.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_sumsq_partial(const T* __restrict__ x, int64_t n,
-                                                          int nch, int64_t pitch,
-                                                          double* __restrict__ partial) {
-    __shared__ double red[kBlock / 64];
-    const int64_t total = n * nch;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * kBlock) {
-        const int64_t ch = i / n, f = i - ch * n;
-        const double v = (double)x[ch * pitch + f];
-        acc += v * v;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < kBlock / 64; ++w) s += red[w];
-        partial[blockIdx.x] = s;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sumsq_final(const double* __restrict__ partial,
-                                                        int nparts, double count,
-                                                        double* __restrict__ rms) {
-    __shared__ double red[kBlock];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partial[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) rms[0] = sqrt(red[0] / count);
-}
-
-// Float32 signals: Julia reduces `mean(x -> float(x)^2, vals)` in Float32 -- pairwise over blocks of
-// 1024 values (Base.mapreduce_impl).  The same order as the oracle's restatement
-// (oracle/sigops_oracle.c, NORMPOWER): every block summed front to back in Float32 (separate
-// multiply and add), then neighbours folded level by level; rms = sqrt(sum / count) in Float32.
-__global__ __launch_bounds__(kBlock) void k_sumsq32_blocks(const float* __restrict__ x, int64_t n, int nch,
-                                                           int64_t pitch, float* __restrict__ part, int64_t nb) {
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= nb) return;
-    const int64_t total = n * nch;
-    const int64_t e = (b + 1) * 1024 < total ? (b + 1) * 1024 : total;
-    int64_t i = b * 1024;
-    int64_t ch = i / n, f = i - ch * n;
-    float acc = 0.f;
-    for (; i < e; ++i) {
-        const float v = x[ch * pitch + f];
-        // the square is rounded on its own (Julia's x^2, then +): __fmul_rn / __fadd_rn are plain * and + to
-        // the compiler, which fuses them into v_fmac_f32 under its default contraction -- 1 ulp of the rms off
-        // on two of twelve long signals
-        float sq;
-        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(v));
-        acc = acc + sq;
-        if (++f == n) {
-            f = 0;
-            ++ch;
-        }
-    }
-    part[b] = acc;
-}
-__global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, float* __restrict__ b, int64_t nb,
-                                                         float count, double* __restrict__ rms) {
-    float* in = a;
-    float* out = b;
-    int64_t m = nb;
-    while (m > 1) {
-        const int64_t h = (m + 1) / 2;
-        for (int64_t i = threadIdx.x; i < m / 2; i += kBlock) out[i] = __fadd_rn(in[2 * i], in[2 * i + 1]);
-        if ((m & 1) && threadIdx.x == 0) out[m / 2] = in[m - 1];
-        __syncthreads();
-        float* t = in;
-        in = out;
-        out = t;
-        m = h;
-    }
-    // (Float32 division and square root through Float64: correctly rounded whatever the device's own
-    //  single-precision sequences do -- v_sqrt_f32 alone is 1 ulp)
-    if (threadIdx.x == 0) {
-        const float mean = (float)((double)(nb ? in[0] : 0.f) / (double)count);
-        rms[0] = (double)(float)sqrt((double)mean);
-    }
-}
-
-void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
-                int nparts, double* rms, hipStream_t st) {
-    if (dtype == SO_F32) {
-        const int64_t nb = (n * nch + 1023) / 1024;
-        float* pa = (float*)partial;
-        hipLaunchKernelGGL(k_sumsq32_blocks, dim3((unsigned)((nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const float*)x, n, nch, pitch, pa, nb);
-        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nb, nb, (float)((double)n * (double)nch), rms);
-        return;
-    }
-    if (dtype == SO_F32)
-        hipLaunchKernelGGL((k_sumsq_partial<float>), dim3(nparts), dim3(kBlock), 0, st,
-                           (const float*)x, n, nch, pitch, partial);
-    else
-        hipLaunchKernelGGL((k_sumsq_partial<double>), dim3(nparts), dim3(kBlock), 0, st,
-                           (const double*)x, n, nch, pitch, partial);
-    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(kBlock), 0, st, partial, nparts,
-                       (double)n * (double)nch, rms);
 }
 
 }  // namespace so

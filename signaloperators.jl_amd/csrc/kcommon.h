@@ -1,0 +1,368 @@
+// Device helpers shared by the kernel translation units (k_pointwise.hip, k_sos.hip, k_resample.hip):
+// leaf evaluators, the compact sin/cos kernels, the register stack machine of the fused pointwise
+// programs.  Split out of kernels.hip in round 3: one 3 000-line translation unit took 2.5 minutes to
+// compile and its 6 MB code object was loaded whole by a process's first launch (8 ms before a
+// one-shot sink of a 5 s sine could start); three units compile side by side and load on demand.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "../../include/sigops.h"
+#include "kernels.h"
+#include "sigops_internal.h"
+
+namespace so {
+
+// ---------------------------------------------------------------------------
+// leaf evaluators
+// All leaf parameters are wave-uniform (scalar registers); only the frame index n (and,
+// in channel-vectorised evaluation, nothing else) lives per lane.  sf is -1/0/+1, so the
+// per-lane address math is one 64-bit add in the common planar case (no 64-bit multiplies,
+// which are quarter-rate on CDNA).
+__device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
+    int64_t f = L.df;
+    if (L.sf > 0) f += n;
+    else if (L.sf < 0) f -= n;
+    // (cycle / mirror padding, reference src/padding.jl:132-148, is resolved on the host
+    //  into one piece per wrap with sf = +1 / -1: no integer division on the device)
+    const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;  // uniform
+    const int64_t off = (L.fstride == 1 ? f : f * L.fstride) + choff;
+    if (L.dtype == SO_F32) return (double)((const float*)L.base)[off];
+    return ((const double*)L.base)[off];
+}
+
+// Compact fp64 sin/cos kernels (Taylor on |t| <= 1/4 after exact octant reduction).  The
+// device library's sinpi/cos carry large-argument paths that cost ~40 VGPRs of pressure in
+// every kernel that inlines the interpreter; these need ~12 and are accurate to ~1 ulp.
+// fma with a CONSTANT operand held in a scalar register pair.  hipcc otherwise materialises
+// every fp64 polynomial coefficient with two v_mov_b32 into the accumulator of a v_fmac (35 of
+// the ~110 instructions of one sinpi evaluation, all on the vector ALU that the fp64 MFMAs of
+// the resampler also need); s_mov_b32 is free by comparison.  Same operands, same rounding.
+__device__ __forceinline__ double fma_addc(double a, double b, double c_const) {  // a*b + C
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
+    return r;
+}
+__device__ __forceinline__ double fma_mulc(double a, double b_const, double c) {  // a*C + c
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_const), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void sincospi_quarter(double t, double& s, double& c) {
+    const double t2 = t * t;
+    double ps = 7.952054001475513e-07;
+    ps = fma_addc(ps, t2, -2.1915353447830217e-05);
+    ps = fma_addc(ps, t2, 0.00046630280576761255);
+    ps = fma_addc(ps, t2, -0.0073704309457143504);
+    ps = fma_addc(ps, t2, 0.08214588661112823);
+    ps = fma_addc(ps, t2, -0.5992645293207921);
+    ps = fma_addc(ps, t2, 2.5501640398773455);
+    ps = fma_addc(ps, t2, -5.16771278004997);
+    const double t3 = t2 * t;
+    s = fma_mulc(t, 3.141592653589793, fma_mulc(t, 1.2246467991473532e-16, t3 * ps));
+    double pc = -1.3878952462213771e-07;
+    pc = fma_addc(pc, t2, 4.303069587032947e-06);
+    pc = fma_addc(pc, t2, -0.0001046381049248457);
+    pc = fma_addc(pc, t2, 0.0019295743094039231);
+    pc = fma_addc(pc, t2, -0.02580689139001406);
+    pc = fma_addc(pc, t2, 0.2353306303588932);
+    pc = fma_addc(pc, t2, -1.3352627688545895);
+    pc = fma_addc(pc, t2, 4.0587121264167685);
+    pc = fma_addc(pc, t2, -4.934802200544679);
+    c = fma(pc, t2, 1.0);
+}
+// sinpi(x) with Julia's semantics: exact at integers and half-integers (src/functions.jl:57-60)
+__device__ __forceinline__ double sinpi_c(double x) {
+    const double k = rint(2.0 * x);
+    const double t = fma(-0.5, k, x);  // exact, |t| <= 1/4
+    double s, c;
+    sincospi_quarter(t, s, c);
+    const int q = (int)((long long)k & 3);
+    const double r = (q & 1) ? c : s;
+    return (q & 2) ? -r : r;
+}
+// sin(pi x) and cos(pi x) together (same reduction and kernels as sinpi_c)
+__device__ __forceinline__ void sincospi_c(double x, double& so, double& co) {
+    const double k = rint(2.0 * x);
+    const double t = fma(-0.5, k, x);
+    double s, c;
+    sincospi_quarter(t, s, c);
+    const int q = (int)((long long)k & 3);
+    const double rs = (q & 1) ? c : s, rc = (q & 1) ? s : c;
+    so = (q & 2) ? -rs : rs;
+    co = (q == 1 || q == 2) ? -rc : rc;
+}
+// (sin, cos)(2 pi phase) of frames i0 + stride*lane, lane < count, of a sine generator (phase as
+// in func_eval, i0 already 1-based); out of line so that its ~40 live registers do not add to
+// the resampler's main loops
+__device__ __attribute__((noinline)) void sine_table(int64_t i0, int stride, int count, double omega, double phi,
+                                                     double fs, int has_omega, double* dst) {
+    const int lane = threadIdx.x & 63;
+    if (lane < count) {
+        const double t = __ddiv_rn((double)(i0 + (int64_t)stride * lane), fs);
+        const double ph = has_omega ? __dadd_rn(__dmul_rn(t, omega), phi) : __dadd_rn(t, phi);
+        double sb, cb;
+        sincospi_c(2.0 * ph, sb, cb);
+        dst[2 * lane] = sb;
+        dst[2 * lane + 1] = cb;
+    }
+}
+// cos(x), x in radians, |x| < 2^20: two-term Cody-Waite reduction to x = k*pi/2 + r
+__device__ __forceinline__ double cos_c(double x) {
+    const double k = rint(x * 0.6366197723675814);
+    double r = fma(-k, 1.5707963267948966, x);
+    r = fma(-k, 6.123233995736766e-17, r);
+    double s, c;
+    sincospi_quarter(r * 0.3183098861837907, s, c);  // r/pi in [-1/4, 1/4]
+    const int q = (int)((long long)k & 3);
+    const double v = (q & 1) ? s : c;  // cos(r + k pi/2): c, -s, -c, s
+    return (q == 1 || q == 2) ? -v : v;
+}
+
+// reference src/functions.jl:53-60 — every operation separately rounded (Julia does
+// not contract), frame index is 1-based so the first sample is t = 1/fs
+__device__ __forceinline__ double func_eval(const DLeaf& L, int64_t n) {
+    double i1 = (double)((L.sf ? n : 0) + L.df + 1);
+    double t = __ddiv_rn(i1, L.v2);
+    if (L.flag) {
+        double ph = __dadd_rn(__dmul_rn(t, L.v0), L.v1);
+        if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * ph);
+        double a = __dmul_rn(6.283185307179586, ph - trunc(ph));  // 2π*(ph % 1.0)
+        return L.mode == SO_FN_COS ? cos_c(a) : a;
+    }
+    double tt = __dadd_rn(t, L.v1);
+    if (L.mode == SO_FN_SIN) return sinpi_c(2.0 * tt);
+    return L.mode == SO_FN_COS ? cos_c(tt) : tt;
+}
+
+// reference src/ramps.jl:60-72
+__device__ __forceinline__ double ramp_eval(const DLeaf& L, int64_t n) {
+    int64_t n0 = (L.sf ? n : 0) + L.df;
+    double x;
+    if (L.flag == 0)
+        x = __ddiv_rn((double)n0, L.v0);
+    else
+        x = __dsub_rn(1.0, __ddiv_rn((double)(n0 + 1 - L.modn), L.v0));
+    return L.mode == SO_RAMP_SINRAMP ? sinpi_c(0.5 * x) : x;
+}
+
+// One per-frame slot in closed form (DCarrier::slot_kind): the same arithmetic as the
+// interpreter's OP_CONST / OP_SCALAR / OP_FUNC / OP_RAMP, without the stack machine.
+__device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n) {
+    double v;
+    switch (kind & 0xff) {
+    case OP_CONST: v = L.v0; break;
+    case OP_SCALAR: v = *(const double*)L.base; break;
+    case OP_FUNC: v = func_eval(L, n); break;
+    default: v = ramp_eval(L, n); break;
+    }
+    return (kind & 0x100) ? (double)(float)v : v;
+}
+
+// A leaf read from LDS sits in vector registers; its mode/flag fields then look lane-varying
+// to the compiler and every `if (L.flag)` / `L.mode == ...` becomes compute-both-and-select
+// (all three trig kernels per frame).  Passing the fields through readfirstlane makes the
+// branches scalar again.
+__device__ __forceinline__ int64_t rfl64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double rfl_f64(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ DLeaf leaf_uniform(const DLeaf& L) {
+    DLeaf U = L;
+    const uint64_t b = (uint64_t)(uintptr_t)L.base;
+    U.base = (const void*)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                      __builtin_amdgcn_readfirstlane((uint32_t)b));
+    U.v0 = rfl_f64(L.v0);
+    U.v1 = rfl_f64(L.v1);
+    U.v2 = rfl_f64(L.v2);
+    U.df = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.df)));
+    U.modn = (int64_t)__builtin_bit_cast(uint64_t, rfl_f64(__builtin_bit_cast(double, (uint64_t)L.modn)));
+    U.sf = __builtin_amdgcn_readfirstlane(L.sf);
+    U.mode = __builtin_amdgcn_readfirstlane(L.mode);
+    U.flag = __builtin_amdgcn_readfirstlane(L.flag);
+    return U;
+}
+
+// frames n and n+1 at once
+__device__ __forceinline__ void slot_eval2(int kind, const DLeaf& L, int64_t n, double& o0, double& o1) {
+    double v0, v1;
+    switch (kind & 0xff) {
+    case OP_CONST: v0 = v1 = L.v0; break;
+    case OP_SCALAR: v0 = v1 = *(const double*)L.base; break;
+    case OP_FUNC:
+        v0 = func_eval(L, n);
+        v1 = func_eval(L, n + 1);
+        break;
+    default:
+        v0 = ramp_eval(L, n);
+        v1 = ramp_eval(L, n + 1);
+        break;
+    }
+    if (kind & 0x100) {
+        v0 = (double)(float)v0;
+        v1 = (double)(float)v1;
+    }
+    o0 = v0;
+    o1 = v1;
+}
+
+// ---------------------------------------------------------------------------
+// D-deep register stack machine over E elements per thread.  Program words are
+// wave-uniform (scalar loads); the stack lives in VGPRs (static indexing only).
+// D is 2 for left-fold chains (almost every tree) and kStackDepth otherwise, which keeps
+// the register footprint of the common case small enough for high occupancy.
+//   CV == false: element e is frame n[e] of channel c (K1: E frames per thread).
+//   CV == true : element e is channel c+e of the single frame n[0] (stage-kernel tile
+//                staging: all channels of a frame at once -> E independent loads in flight).
+#define SO_PUSH(expr)                                   \
+    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
+        _Pragma("unroll") for (int d = D - 1; d > 0; --d) st[d][e] = st[d - 1][e]; \
+        st[0][e] = (expr);                              \
+    }
+#define SO_POP1()                                       \
+    _Pragma("unroll") for (int d = 1; d < D - 1; ++d) st[d][e] = st[d + 1][e];
+#define SO_BIN(opr)                                     \
+    _Pragma("unroll") for (int e = 0; e < E; ++e) {     \
+        st[0][e] = st[1][e] opr st[0][e];               \
+        SO_POP1()                                       \
+    }
+
+// HEAVY == false drops the generator/ramp opcodes (the planner always hoists them into the
+// per-frame program), so the per-sample interpreter carries no transcendental code.
+// PAIR (E == 2, n[1] == n[0] + 1 for every lane, same parity of n[0] across the wave): array
+// leaves with unit frame stride are read with one 16-byte (fp64) / 8-byte (fp32) load per lane
+// when the pair is naturally aligned -- the widest, best-coalesced form of a streaming read.
+template <int E, bool CV, int D, bool HEAVY, bool PAIR = false>
+__device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc, int len,
+                                            const DLeaf* __restrict__ leaves,
+                                            const int64_t (&n)[CV ? 1 : E], int c,
+                                            double (&F)[kMaxFrameSlots][CV ? 1 : E],
+                                            double (&out)[E], bool pair_rt = true) {
+    double st[D][E];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[d][e] = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const DOp op = ops[pc + i];
+        switch (op.code) {
+        case OP_CONST: {
+            const double v = leaves[op.arg].v0;
+            SO_PUSH(v);
+            break;
+        }
+        case OP_LOAD: {
+            const DLeaf& L = leaves[op.arg];
+            if constexpr (PAIR && E == 2 && !CV) {
+                if (pair_rt && L.sf > 0 && L.fstride == 1) {  // wave-uniform
+                    const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;
+                    const int64_t off = n[0] + L.df + choff;  // element index of the pair's first frame
+                    const int par = __builtin_amdgcn_readfirstlane((int)off) & 1;
+                    double v0, v1;
+                    bool done = false;
+                    if (L.dtype == SO_F64) {
+                        if (((((uintptr_t)L.base) >> 3) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 7) == 0) {
+                            const double2 v = *reinterpret_cast<const double2*>((const double*)L.base + off);
+                            v0 = v.x;
+                            v1 = v.y;
+                            done = true;
+                        }
+                    } else if (((((uintptr_t)L.base) >> 2) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 3) == 0) {
+                        const float2 v = *reinterpret_cast<const float2*>((const float*)L.base + off);
+                        v0 = (double)v.x;
+                        v1 = (double)v.y;
+                        done = true;
+                    }
+                    if (done) {
+#pragma unroll
+                        for (int d = D - 1; d > 0; --d) {
+                            st[d][0] = st[d - 1][0];
+                            st[d][1] = st[d - 1][1];
+                        }
+                        st[0][0] = v0;
+                        st[0][1] = v1;
+                        break;
+                    }
+                }
+            }
+            SO_PUSH(leaf_load(L, n[CV ? 0 : e], CV ? c + e : c));
+            break;
+        }
+        case OP_SCALAR: {
+            const double v = *(const double*)leaves[op.arg].base;
+            SO_PUSH(v);
+            break;
+        }
+        case OP_FUNC:
+            if constexpr (HEAVY) {
+                const DLeaf& L = leaves[op.arg];
+                SO_PUSH(func_eval(L, n[CV ? 0 : e]));
+            }
+            break;
+        case OP_RAMP:
+            if constexpr (HEAVY) {
+                const DLeaf& L = leaves[op.arg];
+                SO_PUSH(ramp_eval(L, n[CV ? 0 : e]));
+            }
+            break;
+        case OP_ADD: SO_BIN(+); break;
+        case OP_SUB: SO_BIN(-); break;
+        case OP_MUL: SO_BIN(*); break;
+        case OP_DIV: SO_BIN(/); break;
+        case OP_NEG:
+#pragma unroll
+            for (int e = 0; e < E; ++e) st[0][e] = -st[0][e];
+            break;
+        case OP_ROUND32:
+#pragma unroll
+            for (int e = 0; e < E; ++e) st[0][e] = (double)(float)st[0][e];
+            break;
+        case OP_STOREF:
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                switch (op.arg) {
+                case 0: F[0][CV ? 0 : e] = st[0][e]; break;
+                case 1: F[1][CV ? 0 : e] = st[0][e]; break;
+                case 2: F[2][CV ? 0 : e] = st[0][e]; break;
+                default: F[3][CV ? 0 : e] = st[0][e]; break;
+                }
+                st[0][e] = st[1][e];
+                SO_POP1()
+            }
+            break;
+        case OP_LOADF:
+            switch (op.arg) {
+            case 0: SO_PUSH(F[0][CV ? 0 : e]); break;
+            case 1: SO_PUSH(F[1][CV ? 0 : e]); break;
+            case 2: SO_PUSH(F[2][CV ? 0 : e]); break;
+            default: SO_PUSH(F[3][CV ? 0 : e]); break;
+            }
+            break;
+        default: break;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = st[0][e];
+}
+
+// hipFuncSetAttribute is per device: remember it per (kernel, device) -- a process that drives
+// several GPUs must raise the dynamic-LDS limit on each of them.
+static inline bool first_use_on_device(bool (&seen)[64]) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : (dev > 63 ? 63 : dev);
+    const bool first = !seen[dev];
+    seen[dev] = true;
+    return first;
+}
+
+}  // namespace so

@@ -1,4 +1,4 @@
-// Host-callable launchers of the HIP kernels in kernels.hip.
+// Host-callable launchers of the HIP kernels in k_pointwise.hip, k_sos.hip, k_resample.hip and kernels2.hip.
 #pragma once
 #include <hip/hip_runtime_api.h>
 

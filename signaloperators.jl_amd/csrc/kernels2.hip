@@ -1,4 +1,4 @@
-// Round-3 kernels (a translation unit of their own: kernels.hip takes minutes to compile).
+// Round-3 kernels (a translation unit of their own).
 //
 //   k_sos_exact   K2x  SOS IIR in DSP.jl's own order of operations -- one sequence per channel from the
 //                      first frame to the last, every product and sum rounded on its own (Julia does

@@ -234,7 +234,7 @@ void Plan::process_stage(int sid) {
                 int c = std::atoi(ev);
                 if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
             }
-            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in kernels.hip)
+            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in k_resample.hip)
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
             // (b) a tile (pt super-periods) covers ~1100 input frames per channel
             int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
@@ -1170,7 +1170,7 @@ void Plan::fuse_state_passes() {
         if (!S3.periodic || S2.sg.exact || S2.xscan || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
             rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
             (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
-            continue;  // (the instantiations with state waves: kernels.hip launch_rp_st)
+            continue;  // (the instantiations with state waves: k_resample.hip launch_rp_st)
         // nothing else may read the intermediate
         bool other = false;
         for (auto& L : leaves)
@@ -1209,7 +1209,7 @@ void Plan::fuse_state_passes() {
         const double* h = (const double*)nd3.p0;
         const int hlen = nd3.i2, nphi = S3.rg.nphi, taps = S3.rg.taps;
         const int jlo = rp0.jlo;
-        const int ksw = 2 * 24;  // two state waves x kSwK k-steps (kernels.hip)
+        const int ksw = 2 * 24;  // two state waves x kSwK k-steps (k_resample.hip)
         if ((S3.jend_last - jlo + 1 + 3) / 4 > ksw) continue;  // the staged span of a row must fit
         // (window slots beyond the span have zero taps; there a row's window runs into the next
         //  row's staged frames or the slot's slack -- finite values: the kernel zeroes its LDS ring

@@ -284,12 +284,13 @@ def _host_map_leaf(s, n, rng):
     :249-272): the operands -- extended with the map's padding, `Extend.(signals, padding)` at :26 -- are
     evaluated by the engine, the closure by NumPy; the result is handed back as an array leaf."""
     from . import engine
+    from .units import frames
 
     cols = []
     for c in s.signals:
         cl = S.nframes(c)
         ext = c if (cl is None or S.isknowninf(cl) or cl >= n) else S.Extend(c, s.padding)
-        cols.append(engine.sink(ext | S.Until(n * S.frames), engine.Array, rng=rng))
+        cols.append(engine.sink(ext | S.Until(n * frames), engine.Array, rng=rng))
     if s.bychannel:
         out = _apply_host(s.fn.fn, cols)
     else:  # the closure sees whole frames (tuples of channel values)

@@ -552,7 +552,8 @@ def test_opaque_closures_are_materialised_on_the_host():
     tree = so.Mix(tone, so.Signal(x, 44.1 * so.kHz)) | so.Until(30_000 * so.frames) | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz)
     got = so.sink(tree, so.Array)
     # the same tree with the closure's values supplied as data (what the host evaluation must equal)
-    t = np.arange(1, 30_001) / 44100.0
+    # (the tone is infinite: the resampler under the filter reads it a little beyond frame 30 000)
+    t = np.arange(1, 30_201) / 44100.0
     vals = cube(2 * np.pi * np.fmod(t * 440.0 + 0.0, 1.0)).reshape(-1, 1)
     ref_tree = (so.Mix(so.Signal(np.asfortranarray(vals), 44.1 * so.kHz), so.Signal(x, 44.1 * so.kHz)) | so.Until(30_000 * so.frames)
                 | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz))
