@@ -267,6 +267,14 @@ typedef enum so_counter {
 } so_counter_t;
 int64_t so_plan_counter(const so_plan_t* plan, int32_t which);
 
+/* Diagnostic: compile `body` (HIP source of a pointwise step as the planner generates it: per-piece device
+ * functions + `extern "C" __global__ void k_rtc(...)`) with hipRTC for gfx950 against the library's own
+ * embedded definitions.  Needs no device.  SO_OK, or SO_ERR_UNSUPPORTED with the compiler's log (also
+ * copied to `log`).  Pointwise steps the ahead-of-time interpreter kernel could only run after
+ * materialising sub-expressions are specialised this way at plan time (SIGOPS_RTC=0 disables, =1 forces
+ * it for every pointwise step); reference shape: one loop per map nest, src/mapsignal.jl:249-272. */
+int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity);
+
 /* When enabled, so_plan_execute brackets every kernel with hipEvents (on the stream
  * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default.
  *   enable = 1: every execute synchronises the stream and reads its own events;

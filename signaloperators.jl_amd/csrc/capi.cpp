@@ -76,6 +76,14 @@ int32_t so_plan_set_profiling(so_plan_t* plan, int32_t enable) {
     return SO_OK;
 }
 
+int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity) {
+    if (!body) return set_err(SO_ERR_INVALID, "so_rtc_compile_check: null source");
+    std::string err;
+    const int st = so::rtc_compile_check(body, err);
+    if (log && log_capacity > 0) std::snprintf(log, (size_t)log_capacity, "%s", err.c_str());
+    return st == 0 ? SO_OK : set_err(SO_ERR_UNSUPPORTED, err);
+}
+
 int64_t so_plan_counter(const so_plan_t* plan, int32_t which) {
     if (!plan) return -1;
     return so::plan_counter(plan->p, which);

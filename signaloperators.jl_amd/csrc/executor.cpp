@@ -186,6 +186,8 @@ void Plan::plan_lanes() {
     const int kFinal = -2;
     std::vector<std::set<int>> rd(n), wr(n);
     auto piece_reads = [&](const PwStep& w, std::set<int>& out) {
+        for (int li : w.rtc_leaves)  // (a hipRTC step has no programs: its source names these leaves)
+            if (li >= 0 && li < (int)leaves.size() && leaves[li].buf >= 0) out.insert(leaves[li].buf);
         for (int pi = w.piece0; pi < w.piece0 + w.npieces; ++pi) {
             const DPiece& P = pieces[pi];
             for (int k = 0; k < P.frame_len + P.samp_len; ++k) {
@@ -360,8 +362,12 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 if (w.nblocks > 0) {
                     static const int il_scalar = std::getenv("SIGOPS_K1_ILSCALAR") ? 1 : 0;  // ablation knob
                     ov.pad = il_scalar;
-                    launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st, w.chain,
-                                     w.il || (ov.fstride > 1 && ov.cstride == 1));
+                    if (w.rtc) {
+                        if (rtc_launch(w.rtc, w.nblocks, P->d_pieces + w.piece0, w.npieces, P->d_leaves, ov, st) != 0)
+                            fail(SO_ERR_RUNTIME, "hipRTC kernel launch failed");
+                    } else
+                        launch_pointwise(P->d_pieces + w.piece0, w.npieces, w.nblocks, P->d_ops, P->d_leaves, ov, w.deep, st, w.chain,
+                                         w.il || (ov.fstride > 1 && ov.cstride == 1));
                     s.launches = 1;
                     launches++;
                 }

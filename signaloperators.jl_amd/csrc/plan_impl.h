@@ -180,6 +180,8 @@ struct PwStep {
     bool chain = false;  // some piece takes k_pointwise's chain path
     bool il = false;     // ... with an interleaved leaf (the LDS-transposing instantiation)
     std::vector<int> pre;  // pointwise steps that materialise sub-expressions this one reads (run first)
+    const void* rtc = nullptr;  // hipRTC-specialised kernel of this step (rtc.cpp), or null: the interpreter (k_pointwise)
+    std::vector<int> rtc_leaves;  // ... and the leaves its source refers to (dependencies, plan_lanes)
 };
 
 struct Step {
@@ -348,6 +350,8 @@ struct Plan {
     void check_frames(int ni, int64_t upto);
     void process_stage(int sid);
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
+    std::string rtc_expr(int e, std::vector<int>& monos, bool in_mono);
+    std::string rtc_source(const std::vector<Piece>& ps);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
     bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false);
     RsCtl make_ctl(const Stage& S) const;
@@ -386,6 +390,12 @@ double maxabs(const Mat& a);
 Mat ident(int D);
 Mat sos_state_matrix(const SosCoefs& cf);
 Mat matpow(Mat A, int64_t e, int D);
+
+// ---- rtc.cpp ----
+const void* rtc_kernel(const std::string& body, int device, std::string& err);
+int rtc_compile_check(const std::string& body, std::string& err);
+int rtc_launch(const void* fn, int64_t nblocks, const DPiece* d_pieces, int npieces, const DLeaf* d_leaves, OutView out,
+               hipStream_t st);
 
 // ---- accumulator.cpp ----
 void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,

@@ -817,30 +817,89 @@ int Plan::legalise(int ei, const Rect& r, std::vector<int>& pre) {
 
 void Plan::push_pw_step(int idx) {
     for (int q : pw[idx].pre) push_pw_step(q);
-    steps.push_back(Step{0, idx, "k_pointwise", pw[idx].bytes});
+    steps.push_back(Step{0, idx, pw[idx].rtc ? "k_pointwise_rtc" : "k_pointwise", pw[idx].bytes});
 }
 
 // compile pieces into one pointwise launch writing `out_buf` (or the final output)
 int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_dtype) {
     std::vector<Piece> ps = ps_in;
+    // ---- hipRTC (rtc.cpp): the step as straight-line source instead of interpreter programs.
+    //      SIGOPS_RTC=1: every pointwise step of up to 32 pieces; 0: never; default: steps the interpreter
+    //      could only run after materialising sub-expressions (too deep / too many per-frame values), when
+    //      they are big enough to pay for a compile ----
+    const void* rtc_fn = nullptr;
+    std::vector<int> rtc_leaves;
+    {
+        const char* ev = std::getenv("SIGOPS_RTC");
+        const int mode = ev ? std::atoi(ev) : 2;
+        bool over = false;
+        int64_t elems = 0;
+        int np = 0;
+        for (auto& p : ps) {
+            if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
+            ++np;
+            elems += (p.r.b - p.r.a) * (int64_t)(p.r.c1 - p.r.c0);
+            over = over || depth(p.e) > kStackDepth || frame_slots(p.e) > kMaxFrameSlots;
+        }
+        const bool want = np > 0 && np <= 32 && (mode == 1 || (mode == 2 && over && elems >= (1 << 20)));
+        if (want && !dry) {
+            const size_t leaves_before = leaves.size();
+            std::string err;
+            try {
+                const std::string src = rtc_source(ps);
+                rtc_fn = rtc_kernel(src, device, err);
+            } catch (const PlanError& e) {
+                err = e.msg;
+            }
+            if (rtc_fn)
+                for (size_t i = leaves_before; i < leaves.size(); ++i) rtc_leaves.push_back((int)i);
+            else if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                std::fprintf(stderr, "[sigops] hipRTC not used: %s\n", err.c_str());
+        }
+    }
     std::vector<int> pre;
     for (auto& p : ps) {
+        if (rtc_fn) break;
         if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
         if (depth(p.e) > kStackDepth || frame_slots(p.e) > kMaxFrameSlots) p.e = legalise(p.e, p.r, pre);
     }
     PwStep st;
     st.pre = pre;
+    st.rtc = rtc_fn;
+    st.rtc_leaves = rtc_leaves;
     st.piece0 = (int)pieces.size();
     st.out_buf = out_buf;
     int64_t blk = 0;
     constexpr int E = kPointwiseE;
     for (auto& p : ps) {
         if (p.r.a >= p.r.b || p.r.c0 >= p.r.c1) continue;
-        if (depth(p.e) > kStackDepth)
+        if (!rtc_fn && depth(p.e) > kStackDepth)
             fail(SO_ERR_UNSUPPORTED, "expression too deep for the fused pointwise kernel (stack depth > 4)");
         std::vector<DOp> code, fcode;
         std::map<int, int> hoisted;
         int nchp = p.r.c1 - p.r.c0;
+        if (rtc_fn) {  // geometry only: the programs are in the compiled kernel
+            DPiece d{};
+            d.depth = 2;
+            d.a = p.r.a;
+            d.b = p.r.b;
+            d.c0 = p.r.c0;
+            d.c1 = p.r.c1;
+            d.nblk_f = (d.b - d.a + kBlock * E - 1) / (kBlock * E);
+            d.sub = (int)std::max<int64_t>(1, std::min<int64_t>(2, d.nblk_f / 16384));
+            d.nblk_f = (d.nblk_f + d.sub - 1) / d.sub;
+            int chc = nchp;
+            if (d.nblk_f < 2048 && nchp > 1) {
+                int64_t want = (2048 + d.nblk_f - 1) / d.nblk_f;
+                chc = (int)std::max<int64_t>(1, nchp / std::min<int64_t>(want, nchp));
+            }
+            d.chc = chc;
+            d.block0 = blk;
+            blk += d.nblk_f * ((nchp + chc - 1) / chc);
+            pieces.push_back(d);
+            st.bytes += (d.b - d.a) * (int64_t)nchp * (int64_t)dsize(out_dtype);
+            continue;
+        }
         // generators / ramps always go to the per-frame program: the per-sample interpreter
         // has no transcendental opcodes
         gen(p.e, code, hoisted, fcode, true);
