@@ -450,6 +450,18 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosGeom gg = g;
                         if (gi > 0) gg.in_pitch = ob.pitch;
+                        if (gi == 0 && S.src_op) {  // fused sine source of the cascade's input
+                            const DLeaf& F = S.src_fn;
+                            gg.src_op = S.src_op;
+                            gg.src_has_omega = F.flag;
+                            gg.src_df = F.df;
+                            gg.src_omega = F.v0;
+                            gg.src_phi = F.v1;
+                            gg.src_fs = F.v2;
+                            const double step = 6.283185307179586476925 * (F.flag ? F.v0 / F.v2 : 1.0 / F.v2);
+                            gg.src_cd = std::cos(step);
+                            gg.src_sd = std::sin(step);
+                        }
                         // frames beyond the child's end are zero (Pad(x.signal,zero), reference
                         // src/filters.jl:240): the materialised input covers them; a direct
                         // source always has in_frames == need

@@ -91,6 +91,14 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
     double xv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) xv[j] = col < xlen[j] ? (double)xrow[j][0] : 0.0;
+    // fused sine source: (sin, cos) of the generator's phase at this lane's first frame, evaluated like
+    // func_eval (every operation rounded on its own, first frame t = 1/fs)
+    double gs = 0.0, gc = 1.0;
+    if (g.src_op != 0) {
+        const double tt = __ddiv_rn((double)(beg + g.src_df + 1), g.src_fs);
+        const double ph = g.src_has_omega ? __dadd_rn(__dmul_rn(tt, g.src_omega), g.src_phi) : __dadd_rn(tt, g.src_phi);
+        sincospi_c(2.0 * ph, gs, gc);
+    }
     for (int t0 = 0; t0 < maxlen; t0 += kTT) {
         // ---- tile t0 (loaded one iteration ago: 16 instructions x (4 rows x 128 B)) -> LDS ----
 #pragma unroll
@@ -102,12 +110,29 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
         }
         // ---- every lane: its own row through the cascade ----
         double* row = tl + lane * (kTT + 1);
+        if (g.src_op == 0) {
 #pragma unroll
-        for (int t = 0; t < kTT; ++t) {
-            const double yv = sos_step<NS>(row[t], s, cf);
-            if (APPLY) row[t] = yv * cf.gain;
-            // (frames past a short row's end are zeros and never stored; their effect on
-            //  the state is irrelevant: only full chunks feed pass 1)
+            for (int t = 0; t < kTT; ++t) {
+                const double yv = sos_step<NS>(row[t], s, cf);
+                if (APPLY) row[t] = yv * cf.gain;
+                // (frames past a short row's end are zeros and never stored; their effect on
+                //  the state is irrelevant: only full chunks feed pass 1)
+            }
+        } else {
+            // fused source (SosGeom::src_op): the array sample plus / times a sine generator, the value
+            // of `Mix(Signal(sin), x)` / `Amplify(x, Signal(sin))` (reference src/mapsignal.jl:249-272,
+            // src/functions.jl:57-60) formed here instead of by a K1 pass through HBM.  The lane walks
+            // its row in time, so the sine advances by one rotation per frame from the exact value at
+            // the row's first frame (gs, gc below).
+#pragma unroll
+            for (int t = 0; t < kTT; ++t) {
+                const double xin = g.src_op == 1 ? row[t] + gs : row[t] * gs;
+                const double ns_ = fma(gs, g.src_cd, gc * g.src_sd), nc_ = fma(gc, g.src_cd, -(gs * g.src_sd));
+                gs = ns_;
+                gc = nc_;
+                const double yv = sos_step<NS>(xin, s, cf);
+                if (APPLY) row[t] = yv * cf.gain;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (APPLY) {

@@ -123,6 +123,8 @@ struct Stage {
     std::vector<SosCoefs> groups;
     SosGeom sg{};
     int mpow_buf = -1, v_buf = -1, s0_buf = -1;
+    int src_op = 0;      // fused sine source of the first group's input (SosGeom::src_op): 1 add, 2 multiply
+    DLeaf src_fn{};      // ... the generator (E_FUNC leaf: v0 omega, v1 phi, v2 fs, flag has_omega, df)
     bool xscan = false;  // pass 2 is the exact block scan (launch_sos_xscan): no 2^-70 cut anywhere
     int xs_mats_buf = -1, sblk_buf = -1;
     std::vector<std::vector<double>> xs_mats_host;  // per group: [M][M^kXsBlock]

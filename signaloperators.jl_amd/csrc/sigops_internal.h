@@ -144,6 +144,13 @@ struct SosGeom {
     int32_t exact;   // 1: one chunk, DSP.jl's order of operations without fused multiply-adds (ill-conditioned cascades)
     int64_t in_pitch, out_pitch;  // elements between channels
     int64_t store_lo;             // pass 3 stores frames >= store_lo only (warm-up frames of a windowed result)
+    // fused sine source (k_sos_tiled): the input is x[n] (+|*) sinpi(2((n + src_df + 1)/fs * omega + phi)) --
+    // `Mix` / `Amplify` of an array with `Signal(sin)` formed in the filter's own loads
+    int32_t src_op;               // 0 none, 1 add, 2 multiply
+    int32_t src_has_omega;
+    int64_t src_df;
+    double src_omega, src_phi, src_fs;
+    double src_cd, src_sd;        // cos / sin of the phase step per frame (2 pi omega / fs)
 };
 
 // Single-pass variant (k_sos_onepass): one read and one write of the signal.  A WAVE owns a tile of

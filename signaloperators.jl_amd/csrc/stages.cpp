@@ -809,6 +809,39 @@ void Plan::process_stage(int sid) {
                 if (e.leaf.dc != 0) direct = false;
             }
         }
+        // ... or that load plus / times ONE sine generator (`Mix(Signal(sin), x)`, `Amplify(x, Signal(sin))`
+        // in Float64): the IIR forms the sum / product in its own loads (k_sos_tiled, SosGeom::src_op) --
+        // no K1 pass, no intermediate in HBM (config 4: every scene is Mix |> Filt)
+        if (!direct && S.kind == ST_SOS && (e.op == E_ADD || e.op == E_MUL) && e.dtype == SO_F64 && N.dtype == SO_F64 &&
+            !S.sg.exact && !S.onepass && in_frames == need && !std::getenv("SIGOPS_SOS_NOSRC")) {
+            auto strip = [&](int x) {
+                while (exprs[x].op == E_RETYPE) x = exprs[x].a;
+                return x;
+            };
+            const int ea = strip(e.a), eb = strip(e.b);
+            const int li = exprs[ea].op == E_LOAD ? ea : (exprs[eb].op == E_LOAD ? eb : -1);
+            const int fi = li == ea ? eb : ea;
+            if (li >= 0) {
+                const Expr& l = exprs[li];
+                const Expr& f = exprs[fi];
+                const bool load_ok = l.leaf.mode == LM_PLAIN && l.leaf.sf == 1 && l.leaf.sc == 1 && l.leaf.fstride == 1 &&
+                                     l.leaf.dtype == SO_F64 && l.leaf.df >= 0 && l.leaf.dc >= 0 &&
+                                     (l.leaf.cstride > 0 || l.leaf.cstride == -1 || N.nch == 1) &&
+                                     (l.array_node >= 0 || l.leaf.dc == 0);
+                const bool fn_ok = f.op == E_FUNC && f.leaf.mode == SO_FN_SIN && f.leaf.sf == 1 && f.dtype == SO_F64;
+                if (load_ok && fn_ok) {
+                    direct = true;
+                    S.in_array_node = l.array_node;
+                    S.in_buf = l.leaf.buf;
+                    S.in_offset = l.leaf.df;
+                    S.in_pitch = l.leaf.cstride;
+                    if (l.array_node >= 0) S.in_offset = l.leaf.df + l.leaf.dc * std::max<int64_t>(l.leaf.cstride, 0);
+                    S.src_op = e.op == E_ADD ? 1 : 2;
+                    S.src_fn = f.leaf;
+                    if (l.array_node >= 0) count_array(l.array_node);
+                }
+            }
+        }
     }
     if (S.kind == ST_NORM) {
         // materialise the child straight into `vals` (the stage's own output buffer)
@@ -1167,7 +1200,7 @@ void Plan::fuse_state_passes() {
         if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
         Stage& S3 = stages[i3];
         const RsPeriodic& rp0 = S3.rp;
-        if (!S3.periodic || S2.sg.exact || S2.xscan || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
+        if (!S3.periodic || S2.sg.exact || S2.xscan || S2.src_op || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
             rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
             (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
             continue;  // (the instantiations with state waves: k_resample.hip launch_rp_st)

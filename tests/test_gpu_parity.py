@@ -573,3 +573,35 @@ def test_opaque_closures_are_materialised_on_the_host():
     # bychannel=false: the closure sees whole frames
     sw = so.sink(so.OperateOn(lambda fr: (fr[1], fr[0] + fr[1]), so.Signal(x, 10 * so.kHz), bychannel=False), so.Array)
     assert np.array_equal(sw, np.column_stack([x[:, 1], x[:, 0] + x[:, 1]]))
+
+
+@pytest.mark.parametrize("nch,n,build", [
+    (2, 300_000, lambda x, n: so.Mix(so.Signal(so.sin, ω=1 * so.kHz) | so.Until(n * so.frames), x)),
+    (2, 300_000, lambda x, n: so.Mix(x, so.Signal(so.sin, ω=1 * so.kHz, ϕ=0.25)) | so.Until(n * so.frames)),
+    (8, 120_000, lambda x, n: so.Amplify(x, so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(n * so.frames)),
+    (1, 70_001, lambda x, n: so.Mix(so.Signal(so.sin), x) | so.Until(n * so.frames)),  # sin without a frequency: a 1 Hz tone
+])
+def test_filter_forms_mix_with_a_sine_in_its_own_loads(nch, n, build, monkeypatch):
+    """`Mix(Signal(sin), x) |> Filt` (BASELINE configs 2 and 4): the IIR adds / multiplies the generator
+    while it loads its input (SosGeom::src_op) -- one rotation per frame from the exact value at the start
+    of every chunk -- instead of reading a K1-materialised copy.  Same values as the materialising path."""
+    from sigops_amd.engine import Plan
+
+    rng = np.random.default_rng(95)
+    x = so.Signal(np.asfortranarray(rng.standard_normal((n, nch))), 44.1 * so.kHz)
+    tree = build(x, n) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    want = oracle_sink(tree)
+    res = np.empty((n, nch), order="F")
+    p = Plan(so.ToChannels(tree, nch), res.shape, res.dtype, (1, n), False)
+    p.execute(res.ctypes.data)
+    names = [s_["name"] for s_ in p.steps()]
+    p.close()
+    assert names == ["k_sos"], names
+    assert relerr(res, want) < 1e-11
+    # a window far into the signal (warm start: the generator's phase follows the stage's first frame)
+    a, m = n - 50_000, 20_000
+    w = so.sink(tree | so.After(a * so.frames) | so.Until(m * so.frames), so.Array)
+    assert relerr(w, want[a:a + m]) < 1e-10
+    monkeypatch.setenv("SIGOPS_SOS_NOSRC", "1")
+    ref = so.sink(tree, so.Array)
+    assert relerr(res, ref) < 1e-12
