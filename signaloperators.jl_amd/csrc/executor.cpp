@@ -530,9 +530,13 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsRows rr = S.rr;
                         rr.in_pitch = in_pitch;
                         rr.out_pitch = ob.pitch;
-                        launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                             (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
-                                             (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
+                        static const bool rr_v1 = std::getenv("SIGOPS_RR_V1") != nullptr;  // measurement aid: the round-2 kernel
+                        if (rr_v1 || rr.debug ||
+                            launch_resample_rows2(inp, ob.d, (const double*)P->bufs[S.mtab_buf].d, (const int*)P->bufs[S.mjend_buf].d, rr,
+                                                  N.dtype, st) != 0)
+                            launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                                 (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
+                                                 (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
                     } else if (S.tiled) {
                         RsTiled rt = S.rt;
                         rt.g.in_pitch = in_pitch;
