@@ -530,13 +530,12 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsRows rr = S.rr;
                         rr.in_pitch = in_pitch;
                         rr.out_pitch = ob.pitch;
-                        static const bool rr_v1 = std::getenv("SIGOPS_RR_V1") != nullptr;  // measurement aid: the round-2 kernel
-                        if (rr_v1 || rr.debug ||
-                            launch_resample_rows2(inp, ob.d, (const double*)P->bufs[S.mtab_buf].d, (const int*)P->bufs[S.mjend_buf].d, rr,
-                                                  N.dtype, st) != 0)
-                            launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
-                                                 (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
-                                                 (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
+                        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                            std::fprintf(stderr, "[sigops] k_resample_rows: ct=%d pb=%d tile_len=%d pitch=%d kw=%d ngroups=%d L=%lld M=%lld taps=%d\n", rr.ct, rr.pb,
+                                         rr.tile_len, rr.pitch, rr.kw, rr.ngroups, (long long)rr.L, (long long)rr.M, rr.taps);
+                        launch_resample_rows(inp, ob.d, (const double*)P->bufs[S.tab_buf].d,
+                                             (const int*)P->bufs[S.jend_buf].d, (const double*)P->bufs[S.mtab_buf].d,
+                                             (const int*)P->bufs[S.mjend_buf].d, rr, N.dtype, st);
                     } else if (S.tiled) {
                         RsTiled rt = S.rt;
                         rt.g.in_pitch = in_pitch;

@@ -36,8 +36,6 @@ void launch_resample_tiled(const void* x, void* y, const double* pfbt, const dou
 // returns 0 when launched, -1 when no instantiation fits the geometry
 int launch_resample_rows(const void* x, void* y, const double* ctab, const int* jr, const double* mtab,
                          const int* jend, const RsRows& g, int dtype, hipStream_t st);
-// v2 of its MFMA path (kernels2.hip: persistent, loader / compute waves); -1: geometry not covered
-int launch_resample_rows2(const void* x, void* y, const double* mtab, const int* jend, const RsRows& g, int dtype, hipStream_t st);
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st);
 void launch_resample_fix(const RsFixArgs& a, hipStream_t st);

@@ -8,8 +8,6 @@
 //                      and a fused multiply-add's different rounding is amplified to 1e-7 ... 1e-3.
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
-
 #include "../../include/sigops.h"
 #include "kernels.h"
 #include "sigops_internal.h"
@@ -224,175 +222,6 @@ int launch_sos_xscan(const double* v, double* s0, const double* mats, double* sb
     default: launch_xs_t<8>(v, s0, mats, sblk, g, st); break;
     }
     return 3;
-}
-
-// ---------------------------------------------------------------------------
-// K3r v2: the MFMA path of the row-tiled resampler (k_resample_rows, k_resample.hip) as a persistent,
-// wave-specialised kernel (round 3).  Measured on BASELINE config 5's slab (10 000 000 x 128 -> 16 kHz):
-// v1 staged a tile with all waves, then computed it -- 2.4 ms of staging plus 4.2 ms of MFMAs and tap
-// loads, 6.4 ms together, no overlap (two workgroups per CU ran in phase) -- and only 10 of its 16 waves
-// had a unit to compute (160 outputs = 10 groups of 16).  Here one workgroup per CU loops over tiles:
-//   * waves [0, NC) compute: wave w owns output group(s) w, w + NC, ... of every tile -- for each k-step
-//     ONE tap load from the L2-resident tap block feeds the MFMAs of all NQ 16-row tiles;
-//   * waves [NC, 16) load: the NEXT tile travels global -> registers while this one is computed (plain
-//     coalesced loads, zero fill outside the signal) and registers -> LDS between two barriers.  The
-//     roles are separate waves because vmcnt retires in order: a compute wave waiting for a tap would
-//     also wait for its own staging loads.
-// Same arithmetic as v1: one accumulation chain per output over the zero-padded [kw x 16] tap block.
-typedef double v4d2 __attribute__((ext_vector_type(4)));
-constexpr int kR2Load = 6, kR2Threads = 1024, kR2Regs = 48;  // loader waves, workgroup, staged elements per loader lane
-
-template <typename T, int NQ, int CT>
-__global__ __launch_bounds__(kR2Threads) void k_resample_rows2(const T* __restrict__ x, T* __restrict__ y,
-                                                               const double* __restrict__ mtab, const int* __restrict__ jend,
-                                                               RsRows g) {
-    extern __shared__ double lds_raw2[];
-    T* const lds = reinterpret_cast<T*>(lds_raw2);
-    constexpr int NC = kR2Threads / 64 - kR2Load;       // compute waves
-    constexpr int KMAX = kR2Regs / CT;                  // staged elements per loader lane and channel row
-    constexpr int NLT = kR2Load * 64;                   // loader lanes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t ntx = (g.nperiods + g.pb - 1) / g.pb;
-    const int64_t ntiles = ntx * (g.nch / CT);
-    const bool loader = wave >= NC;
-    const int lidx = (wave - NC) * 64 + lane;
-    T stg[CT][KMAX];
-    auto fetch = [&](int64_t t) {  // tile t -> registers (loader lanes)
-        const int64_t tx = t % ntx, tc = t / ntx;
-        const int64_t xbase = tx * g.pb * g.M + g.jlo;
-        // valid LDS positions [lo, hi): inside the tile and inside the signal (zero fill elsewhere).  The
-        // row base is wave-uniform and the per-lane part a 32-bit index: scalar-base addressing, one
-        // address register per lane for all 48 loads
-        const int64_t lo64 = -xbase > 0 ? -xbase : 0, hi64 = g.n_in - xbase < g.tile_len ? g.n_in - xbase : g.tile_len;
-        const int lo = (int)(lo64 < g.tile_len ? lo64 : g.tile_len), hi = (int)(hi64 > 0 ? hi64 : 0);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const T* __restrict__ rowp = x + ((int64_t)((int)tc * CT + c) * g.in_pitch + xbase);
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int i = lidx + k * NLT;
-                stg[c][k] = (i >= lo && i < hi) ? rowp[i] : (T)0;
-            }
-        }
-    };
-    // The two roles run separate loops with the same number of workgroup barriers (whole waves take one
-    // branch): the loaders' 48 staging registers and the compute waves' operand buffers never share a
-    // live range (one merged loop spilled 250-580 registers per lane).
-    if (loader) {
-        int64_t t = blockIdx.x;
-        if (t < ntiles) fetch(t);
-        for (; t < ntiles; t += gridDim.x) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const int i = lidx + k * NLT;
-                    if (i < g.tile_len) lds[c * g.pitch + i] = stg[c][k];
-                }
-            __syncthreads();  // tile t is in LDS
-            if (t + gridDim.x < ntiles) fetch(t + gridDim.x);  // in flight during the MFMAs of tile t
-            __syncthreads();  // every compute wave has read tile t
-        }
-        return;
-    }
-    const int kq = lane >> 4, n16 = lane & 15;
-    const int ksteps = g.kw >> 2, pbmask = g.pb - 1;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        __syncthreads();  // tile t is in LDS
-        const int64_t tx = t % ntx, tc = t / ntx;
-        const int c0 = (int)tc * CT;
-        const int64_t P0 = tx * g.pb;
-        for (int gi = wave; gi < g.ngroups; gi += NC) {
-            const T* __restrict__ ap[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int rho_a = 16 * q + n16;  // A operand row of this lane
-                ap[q] = lds + (rho_a >> g.pbshift) * g.pitch + (rho_a & pbmask) * (int)g.M - g.jlo + (jend[gi] - (g.kw - 1)) + kq;
-            }
-            const double* __restrict__ bp = mtab + ((size_t)gi * g.kw + kq) * 16 + n16;
-            v4d2 acc[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = v4d2{0.0, 0.0, 0.0, 0.0};
-            // taps and samples four k-steps ahead (L2 / LDS latency under the MFMAs of the previous four)
-            double b0[4], a0[NQ][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sn = j < ksteps ? j : ksteps - 1;  // (never read past the tap block)
-                b0[j] = bp[(size_t)(4 * sn) * 16];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) a0[q][j] = (double)ap[q][4 * sn];
-            }
-            for (int s4 = 0; s4 < ksteps; s4 += 4) {
-                double b1[4], a1[NQ][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int sn = s4 + 4 + j;
-                    sn = sn < ksteps ? sn : ksteps - 1;
-                    b1[j] = bp[(size_t)(4 * sn) * 16];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) a1[q][j] = (double)ap[q][4 * sn];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (s4 + j < ksteps) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q][j], b0[j], acc[q], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    b0[j] = b1[j];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) a0[q][j] = a1[q][j];
-                }
-            }
-            const int r = gi * 16 + n16;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
-                    const int64_t period = P0 + (rho & pbmask);
-                    const int64_t m = period * g.L + r;
-                    if (period < g.nperiods && r < (int)g.L && m < g.n_out)
-                        y[(int64_t)(c0 + (rho >> g.pbshift)) * g.out_pitch + m] = (T)acc[q][i];
-                }
-        }
-        __syncthreads();  // every wave has read tile t: LDS may take the next one
-    }
-}
-
-template <typename T, int NQ, int CT>
-static void launch_rows2_t(const void* x, void* y, const double* mtab, const int* jend, const RsRows& g, size_t ldsb, hipStream_t st) {
-    static bool seen[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = dev < 0 ? 0 : (dev > 63 ? 63 : dev);
-    if (!seen[dev]) {
-        seen[dev] = true;
-        (void)hipFuncSetAttribute((const void*)k_resample_rows2<T, NQ, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    const int64_t ntiles = ((g.nperiods + g.pb - 1) / g.pb) * (g.nch / g.ct);
-    hipLaunchKernelGGL((k_resample_rows2<T, NQ, CT>), dim3((unsigned)std::min<int64_t>(ntiles, 256)), dim3(kR2Threads), ldsb, st,
-                       (const T*)x, (T*)y, mtab, jend, g);
-}
-
-// 0 when launched; -1: the geometry is not one of v2's (the caller uses k_resample_rows)
-int launch_resample_rows2(const void* x, void* y, const double* mtab, const int* jend, const RsRows& g, int dtype, hipStream_t st) {
-    if (g.n_out <= 0) return 0;
-    const int rows = g.ct * g.pb, nq = rows / 16;
-    if (g.kw <= 0 || rows % 16 || nq > 4 || (g.ct != 8 && g.ct != 4) || g.tile_len > kR2Load * 64 * (kR2Regs / g.ct)) return -1;
-    const size_t esz = dtype == SO_F32 ? 4 : 8;
-    const size_t ldsb = ((size_t)g.ct * g.pitch * esz + 7) / 8 * 8;
-#define SO_R2(NQ_, CT_)                                                                            \
-    if (nq == NQ_ && g.ct == CT_) {                                                                \
-        if (dtype == SO_F32) launch_rows2_t<float, NQ_, CT_>(x, y, mtab, jend, g, ldsb, st);         \
-        else launch_rows2_t<double, NQ_, CT_>(x, y, mtab, jend, g, ldsb, st);                        \
-        return 0;                                                                                  \
-    }
-    SO_R2(1, 8) SO_R2(2, 8) SO_R2(4, 8) SO_R2(1, 4) SO_R2(2, 4) SO_R2(4, 4)
-#undef SO_R2
-    return -1;
 }
 
 }  // namespace so

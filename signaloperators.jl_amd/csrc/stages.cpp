@@ -398,9 +398,7 @@ void Plan::process_stage(int sid) {
             // tile choice: the largest row count whose tile fits; two workgroups per CU (tiles of at
             // most 75 KB) overlap one's staging with the other's MFMAs (config 5: 0.77 -> 0.66 ms),
             // so that budget is tried first as long as it still gives an MFMA-able tile (>= 16 rows)
-            // (v2 of the MFMA path, kernels2.hip, is one persistent workgroup per CU that overlaps the next tile's
-            //  loads with this one's MFMAs itself: it takes the biggest tile, more rows per tap load)
-            const bool lds_forced = std::getenv("SIGOPS_RR_MAXLDS") != nullptr || !std::getenv("SIGOPS_RR_V1");
+            const bool lds_forced = std::getenv("SIGOPS_RR_MAXLDS") != nullptr;
             for (int pass = 0; pass < 2 && !best_ct; ++pass) {
                 const size_t budget = lds_forced ? rr_max_lds : (pass == 0 ? (size_t)75 * 1024 : rr_max_lds);
                 for (int rows : {64, 32, 16, 8, 4, 2, 1}) {
