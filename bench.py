@@ -81,16 +81,16 @@ def cpu_model():
 
 def pmc_traffic(stage_name):
     """HBM bytes per execute of a stage from the committed rocprofv3 PMC passes of this command
-    (profiles/r02/bench_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
+    (profiles/r03/bench_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
     MI355X_MICROARCH.md prescribes).  A file read, NOT a measurement of this run."""
-    path = os.path.join(ROOT, "profiles", "r02", "bench_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r03", "bench_pmc_hbm.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
     for key, val in d.get("stages", {}).items():
         if stage_name.startswith(key):
-            return val.get("corrected_bytes_per_execute"), "profiles/r02/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command; not this run)"
+            return val.get("corrected_bytes_per_execute"), "profiles/r03/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command; not this run)"
     return None, None
 
 

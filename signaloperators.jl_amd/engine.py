@@ -269,8 +269,9 @@ class BlockStream:
     ("raise the stream's history").  An output frame is final when every input frame it depends on
     has arrived (the lowering's demand analysis: the newest input of the last output of every
     resampler, `Filt` one to one).  Concatenated, the outputs are the sink of the pipeline over the
-    whole input.  Not streamable: `Normpower`, pads that index the end of the input, anything whose
-    early outputs depend on the input's total length."""
+    whole input.  Not streamable, and refused with an error at the first push (`_streamable`): `Normpower`,
+    ramps at the end of the signal (`RampOff`, `Ramp`, `FadeTo`), pads that index the end of the input --
+    anything whose early outputs depend on the input's total length."""
 
     def __init__(self, pipeline, fs, nch=1, dtype=np.float64, history=1 << 16, device=0):
         import torch
@@ -353,6 +354,7 @@ class BlockStream:
         total = S.nframes(tree)
         if total is None or S.isknowninf(total):
             S.error("BlockStream: the pipeline must have as many frames as its input decides")
+        _streamable(tree)
         upto = total if self.closed else self._final_frames(leaf, tree, int(total))
         m = upto - self.emitted
         nch_out = tree.nch
@@ -378,6 +380,23 @@ class BlockStream:
 
             return torch.empty((0, self.nch), dtype=self.tdt, device=self.dev)
         return self._emit()
+
+
+def _streamable(x):
+    """Refuse what `BlockStream` cannot stream: nodes whose early outputs depend on the input's TOTAL
+    length, which a stream does not know -- each push would silently apply them to the input received
+    so far (ADVICE r2).  `Normpower` divides by the rms of everything (reference src/filters.jl:296-309);
+    a ramp off / `FadeTo` is anchored at the end (src/ramps.jl:65-72); `lastframe`, `cycle` and `mirror`
+    pads index from the end of the signal (src/padding.jl:132-148)."""
+    if isinstance(x, S.NormedSignal):
+        S.error("BlockStream: Normpower needs the whole signal (its rms); not streamable")
+    if isinstance(x, S.RampSignal) and x.direction == "off":
+        S.error("BlockStream: a ramp at the END of the signal (RampOff, Ramp, FadeTo) is anchored at a length the "
+                "stream does not know yet; not streamable")
+    if isinstance(x, S.PaddedSignal) and x.pad in (S.lastframe, S.cycle, S.mirror):
+        S.error("BlockStream: lastframe / cycle / mirror padding indexes the end of the input; not streamable")
+    for c in getattr(x, "children", ()) or ():
+        _streamable(c)
 
 
 def filt(b, a, x, si=None, *, device=0):

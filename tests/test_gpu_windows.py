@@ -247,3 +247,17 @@ def test_block_stream_refuses_to_read_what_is_gone():
     with pytest.raises(so.ErrorException, match="no longer resident"):
         for k in range(60000, 200000, 20000):
             bs.push(x[k:k + 20000])
+
+
+@pytest.mark.parametrize("name,pipeline", [
+    ("Normpower", lambda x: x | so.Filt(so.Lowpass, 3 * so.kHz) | so.Normpower),
+    ("Ramp", lambda x: x | so.Ramp(10 * so.ms)),
+    ("RampOff", lambda x: so.Mix(x | so.RampOff(10 * so.ms), x)),
+    ("lastframe", lambda x: x | so.Pad(so.lastframe) | so.Until(10 * so.s)),
+])
+def test_block_stream_refuses_pipelines_that_need_the_total_length(name, pipeline):
+    """a ramp at the end, `Normpower` or an end-indexing pad used to be applied to the input
+    received so far at every push -- wrong frames, marked final.  Now an error at the first push."""
+    bs = so.BlockStream(pipeline, fs=44.1 * so.kHz, nch=2)
+    with pytest.raises(so.ErrorException, match="not streamable"):
+        bs.push(np.zeros((5000, 2)))
