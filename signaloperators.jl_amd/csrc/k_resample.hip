@@ -833,7 +833,11 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // it, spills) of the kernels that do not use them.
 // GADD (with GA): the one fused step is an ADD (`Mix(x32, Signal(sin))`) instead of a multiply: the gain
 // ring then holds zeros outside the fused pieces (the zero extension of the stage's input is 0, not 0 + g).
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false>
+// Q: 16-row MFMA tiles per workgroup tile (rows = 16 Q = periods x channels).  Q = 1 (round 3) halves the tile for
+// rates whose period is long (44.1 -> 16 kHz: 441 inputs per period, 36 k-steps): two 32-row slots of it do not fit
+// LDS, two 16-row slots do, and the ring, the edge handling and the fused sources of this kernel then serve
+// what used to go to the row-tiled kernel without any overlap of loads and MFMAs (config 5).
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -1144,12 +1148,12 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const uint32_t lane16 = (uint32_t)llane * 16u;                            // per-lane byte offset in a chunk
         // state waves: row offsets of the A operands, first slot of this wave's half of the window
         constexpr int kSwK = 24;  // k-steps per state wave (planner: 2 * kSwK * 4 >= staged span of a row)
-        int srow[kRsQ];
+        int srow[Q];
         int swk0 = 0;
         if constexpr (ST) {
             swk0 = swave ? (wave - nldr) * kSwK * 4 : 0;
 #pragma unroll
-            for (int q = 0; q < kRsQ; ++q) {
+            for (int q = 0; q < Q; ++q) {
                 const int rho = 16 * q + (lane & 15);
                 srow[q] = (rho >> g.ptshift) * g.lds_pitch + (rho & (g.pt - 1)) * (int)g.M + (lane >> 4);
             }
@@ -1259,22 +1263,22 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 const T* __restrict__ cur = lds + sr * bufsz + sh + swk0;
                 const double* __restrict__ wl = fbase + (size_t)kFDepth * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0) +
                                                 (size_t)(swk0 + (lane >> 4)) * 10 + ((lane & 15) < 10 ? (lane & 15) : 0);
-                v4d acc[kRsQ];
+                v4d acc[Q];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-                double abuf[2][kRsQ], bbuf[2];
+                for (int q = 0; q < Q; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                double abuf[2][Q], bbuf[2];
                 bbuf[0] = wl[0];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) abuf[0][q] = (double)cur[srow[q]];
+                for (int q = 0; q < Q; ++q) abuf[0][q] = (double)cur[srow[q]];
 #pragma unroll
                 for (int s = 0; s < kSwK; ++s) {
                     if (s + 1 < kSwK) {
 #pragma unroll
-                        for (int q = 0; q < kRsQ; ++q) abuf[(s + 1) & 1][q] = (double)cur[srow[q] + 4 * (s + 1)];
+                        for (int q = 0; q < Q; ++q) abuf[(s + 1) & 1][q] = (double)cur[srow[q] + 4 * (s + 1)];
                         bbuf[(s + 1) & 1] = wl[40 * (s + 1)];
                     }
 #pragma unroll
-                    for (int q = 0; q < kRsQ; ++q)
+                    for (int q = 0; q < Q; ++q)
                         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], bbuf[s & 1], acc[q], 0, 0, 0);
                 }
                 // Eight stores, no waits between them: every address is ONE per-lane base plus a
@@ -1283,14 +1287,14 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 // per tile, measured).  Rows (lane>>4)+4i+16q are (period (lane>>4)&(pt-1)..., channel ...).
                 // Row (lane>>4) + 4i + 16q of the result is (period kq + (4i mod pt), channel (16q + 4i) / pt),
                 // kq = lane >> 4 (no carry: kq < 4 <= pt): the per-lane part of the address is ONE pointer.
-                constexpr int PT = kRsRows / CT;
+                constexpr int PT = (16 * Q) / CT;
                 const int kq = lane >> 4;
                 const int64_t nper = g.nperiods;
                 double* vl = g.vper + ((size_t)(wave - nldr) * (size_t)g.nch + (size_t)((int)pr.tc * CT)) * (size_t)nper * 16 +
                              (size_t)(pr.tx * PT + kq) * 16 + (lane & 15);
                 const int plim = (int)(nper - pr.tx * PT < PT ? nper - pr.tx * PT : PT);  // periods of this tile inside the signal
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q)
+                for (int q = 0; q < Q; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         constexpr int kDummy = 0;
@@ -1315,15 +1319,15 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const int ptmask = g.pt - 1, ptshift = g.ptshift;  // pt is a power of two
     const int gbeg = wave * G;
     double breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
-    int rowoff[kRsQ];
-    int goff[kRsQ];  // GA: the same offset without the channel row (gains depend on the frame only)
+    int rowoff[Q];
+    int goff[Q];  // GA: the same offset without the channel row (gains depend on the frame only)
 #pragma unroll
     for (int gg = 0; gg < G; ++gg)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             breg[gg][s] = gbeg + gg < g.ngroups ? tab[((size_t)(gbeg + gg) * KS + s) * 64 + lane] : 0.0;
 #pragma unroll
-    for (int q = 0; q < kRsQ; ++q) {
+    for (int q = 0; q < Q; ++q) {
         const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
         rowoff[q] = (rho >> ptshift) * g.lds_pitch + (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
         goff[q] = (rho & ptmask) * (int)g.M - g.jlo - (KS * 4 - 1) + kq;
@@ -1333,9 +1337,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     for (int gg = 0; gg < G; ++gg) jeg[gg] = gbeg + gg < g.ngroups ? jend[gbeg + gg] : 0;
     // output offsets of this lane's 4 accumulator rows per row-tile, relative to the tile's
     // (channel c0, period P0) origin
-    int64_t yoff[kRsQ][4];
+    int64_t yoff[Q][4];
 #pragma unroll
-    for (int q = 0; q < kRsQ; ++q)
+    for (int q = 0; q < Q; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
@@ -1358,22 +1362,22 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             const int gi = gbeg + gg;
             if (gi < g.ngroups && !(g.pad & 1)) {
                 const int je = jeg[gg];
-                v4d acc[kRsQ];
+                v4d acc[Q];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < Q; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
                 // A operands are software-pipelined one k-step ahead (double-buffered
                 // registers) so the LDS latency hides under the previous step's MFMAs; the
                 // per-step address is an immediate offset from fixed row pointers.
-                const T* __restrict__ ap[kRsQ];
-                const double* __restrict__ gp[kRsQ];  // GA: this tile's gains at the A operand's frames
+                const T* __restrict__ ap[Q];
+                const double* __restrict__ gp[Q];  // GA: this tile's gains at the A operand's frames
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) {
+                for (int q = 0; q < Q; ++q) {
                     ap[q] = cur + (rowoff[q] + je);
                     gp[q] = fbase + (size_t)fbr(it) * g.fslots * g.fpitch + (sh + goff[q] + je);
                 }
-                double abuf[2][kRsQ];
+                double abuf[2][Q];
 #pragma unroll
-                for (int q = 0; q < kRsQ; ++q) {
+                for (int q = 0; q < Q; ++q) {
                     abuf[0][q] = (double)ap[q][0];
                     if constexpr (GA && GADD) abuf[0][q] += gp[q][0];
                     else if constexpr (GA) abuf[0][q] *= gp[q][0];
@@ -1382,26 +1386,26 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                 for (int s = 0; s < KS; ++s) {
                     if (s + 1 < KS) {
 #pragma unroll
-                        for (int q = 0; q < kRsQ; ++q) {
+                        for (int q = 0; q < Q; ++q) {
                             abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
                             if constexpr (GA && GADD) abuf[(s + 1) & 1][q] += gp[q][4 * (s + 1)];
                             else if constexpr (GA) abuf[(s + 1) & 1][q] *= gp[q][4 * (s + 1)];
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < kRsQ; ++q)
+                    for (int q = 0; q < Q; ++q)
                         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
                 }
                 const int r = gi * 16 + n16;  // output index inside the period
                 if (g.pad & 4) continue;
                 if (interior && gi * 16 + 16 <= g.L) {
 #pragma unroll
-                    for (int q = 0; q < kRsQ; ++q)
+                    for (int q = 0; q < Q; ++q)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ytile[yoff[q][i] + gi * 16] = (TO)acc[q][i];
                 } else {
 #pragma unroll
-                    for (int q = 0; q < kRsQ; ++q)
+                    for (int q = 0; q < Q; ++q)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int rho = 16 * q + kq + 4 * i;
@@ -1428,7 +1432,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
@@ -1437,10 +1441,10 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
                   (ST ? (size_t)4 * g.ksw * 10 : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
 }
 
@@ -1509,10 +1513,35 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
     return -1;
 }
 
+// 16-row tiles (RsPeriodic::rows == 16): Float64, one group per compute wave, long windows
+template <int CT>
+static int launch_rp_q1(void* y, const double* tab, const int* jend, const RsPeriodic& g, const RsGlobalTables& gsrc,
+                        hipStream_t st) {
+    const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+    if (gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
+#define SO_RQ(KS_)                                                                                                  \
+    if (g.kw == 4 * KS_) {                                                                                          \
+        if (g.ftwo) launch_rp_k<double, CT, KS_, 1, true, double, false, false, false, 1>(y, tab, jend, g, gsrc, st);  \
+        else launch_rp_k<double, CT, KS_, 1, false, double, false, false, false, 1>(y, tab, jend, g, gsrc, st);        \
+        return 0;                                                                                                   \
+    }
+    SO_RQ(28) SO_RQ(36)
+#undef SO_RQ
+    return -1;
+}
+
 // returns 0 when launched, -1 if no instantiation fits (caller falls back to k_resample)
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
+    if (g.rows == 16) {
+        if (dtype != SO_F64) return -1;
+        switch (g.ct) {
+        case 8: return launch_rp_q1<8>(y, tab, jend, g, gsrc, st);
+        case 4: return launch_rp_q1<4>(y, tab, jend, g, gsrc, st);
+        default: return -1;
+        }
+    }
     if (g.nstate > 0) {
         switch (g.ct) {
         case 8: return launch_rp_st<8>(y, tab, jend, g, gsrc, st);

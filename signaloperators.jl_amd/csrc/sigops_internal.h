@@ -245,7 +245,9 @@ struct RsPeriodic {
     int64_t n_in, n_out;
     int64_t L, M;       // outputs / inputs per (super-)period
     int64_t nperiods;
-    int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == 32
+    int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == rows
+    int32_t rows;       // 32 (two 16-row MFMA tiles) or 16 (one: long periods, see k_resample_periodic's Q)
+    int32_t pad0;
     int32_t ngroups;    // groups of 16 consecutive outputs per period
     int32_t kw;         // inputs in a group's window (multiple of 4)
     int32_t tile_len;   // inputs per channel staged in LDS

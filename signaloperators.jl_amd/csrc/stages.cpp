@@ -115,7 +115,7 @@ static double sos_rounding_sensitivity(const double* sos, int nsec, double gain)
 // Can this periodic resampler stage run the GA instantiation (Float32 tiles, Float64 gain at the A
 // operand)?  Geometry the instantiations cover, and the LDS budget with three gain arrays.
 static bool ga_fits(const Stage& S, int stage_dtype) {
-    if (!S.periodic || stage_dtype != SO_F64 || std::getenv("SIGOPS_RS_NOGA")) return false;
+    if (!S.periodic || S.rp.rows != 32 || stage_dtype != SO_F64 || std::getenv("SIGOPS_RS_NOGA")) return false;
     const RsPeriodic& rp = S.rp;
     const int gper = (rp.ngroups + rp.ncompute - 1) / std::max(1, rp.ncompute);
     if (rp.kw != 56 || gper != 1 || !(rp.ct == 8 || rp.ct == 4)) return false;
@@ -219,6 +219,10 @@ void Plan::process_stage(int sid) {
         // accumulator's wrap-around tie (previous input, last phase, alpha = 1) where it is the rule
         auto wrap_at = [&](int64_t r) { return !wrap.empty() && wrap[r % g.L]; };
         // ---- periodic (SGPR-tap) variant for rational rates ---------------------------
+        // (32-row tiles first; 16-row tiles -- k_resample_periodic's Q = 1 -- where two 32-row slots do not fit LDS or the
+        //  window needs more k-steps than a 32-row instantiation has: long periods, e.g. 44.1 -> 16 kHz)
+        for (int rows_try : {32, 16}) {
+        if (stages[sid].periodic || std::getenv(rows_try == 16 ? "SIGOPS_RS_NOQ1" : "SIGOPS_RS_NOPERIODIC_")) continue;
         if ((!g.arbitrary || g.exact) && need >= 2048) {
             constexpr int RM = 16;  // outputs per group = N of the 16x16x4 MFMA tile
             const int64_t Lb = g.L, Mb = g.M;
@@ -234,7 +238,8 @@ void Plan::process_stage(int sid) {
                 int c = std::atoi(ev);
                 if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
             }
-            const int pt = 32 / ct;  // tile = 32 rows (kRsRows in k_resample.hip)
+            if (rows_try == 16 && (N.dtype != SO_F64 || (ct != 8 && ct != 4))) continue;  // (the Q = 1 instantiations)
+            const int pt = rows_try / ct;  // tile = 32 or 16 rows (k_resample_periodic's Q)
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
             // (b) a tile (pt super-periods) covers ~1100 input frames per channel
             int64_t tmin = 16 / std::__gcd<int64_t>(Lb, 16);
@@ -278,8 +283,12 @@ void Plan::process_stage(int sid) {
                 const int ksneed = (g.taps + (int)maxspan + 3) / 4;
                 gper = ngroups <= 12 ? 1 : (ngroups <= 24 ? 2 : 0);
                 if (const char* ev = std::getenv("SIGOPS_RS_GPER")) gper = std::atoi(ev);  // tuning knob
-                const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14};
-                if (gper == 1) {
+                const int ks1[] = {12, 14, 16, 20, 28}, ks2[] = {14}, ks16[] = {28, 36};
+                if (rows_try == 16) {
+                    if (gper == 1)
+                        for (int k : ks16)
+                            if (!kw && k >= ksneed) kw = 4 * k;
+                } else if (gper == 1) {
                     for (int k : ks1)
                         if (!kw && k >= ksneed) kw = 4 * k;
                 } else if (gper == 2 || gper == 3) {
@@ -329,13 +338,15 @@ void Plan::process_stage(int sid) {
                 rp.nperiods = (need + Ls - 1) / Ls;
                 rp.pt = pt;
                 rp.ct = ct;
+                rp.rows = rows_try;
                 rp.ngroups = ngroups;
                 rp.kw = kw;
                 rp.tile_len = (int)tile_len;
                 rp.lds_pitch = (int)pitch;
                 rp.jlo = jlo;
                 rp.nch = N.nch;
-                rp.ptshift = pt == 32 ? 5 : pt == 16 ? 4 : pt == 8 ? 3 : 2;
+                rp.ptshift = 0;
+                while ((1 << rp.ptshift) < pt) ++rp.ptshift;  // pt is a power of two
                 rp.nslots = nslots;
                 // persistent kernel: 16 waves per workgroup (8 when a wave owns three groups and
                 // needs the registers), one workgroup per CU; the waves that do not compute load
@@ -357,6 +368,7 @@ void Plan::process_stage(int sid) {
                 stages[sid].tab_buf = raw_buf(tab.size() * 8);
                 stages[sid].jend_buf = raw_buf(jend.size() * 4);
             }
+        }
         }
         // ---- row-tiled variant: rational rates the MFMA kernel's geometry does not cover -------
         if (!stages[sid].periodic && (!g.arbitrary || g.exact) && need >= 2048 && g.m0 == 0 &&
@@ -1201,7 +1213,7 @@ void Plan::fuse_state_passes() {
         Stage& S3 = stages[i3];
         const RsPeriodic& rp0 = S3.rp;
         if (!S3.periodic || S2.sg.exact || S2.xscan || S2.src_op || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
-            rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
+            rp0.rows != 32 || rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
             (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
             continue;  // (the instantiations with state waves: k_resample.hip launch_rp_st)
         // nothing else may read the intermediate
