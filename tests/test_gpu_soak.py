@@ -7,10 +7,11 @@
 * 60 windows `After(a) |> Until(m)` of long stateful trees (warm starts),
 * 40 filter designs across the IIR geometry choices (orders 1-12, Butterworth / Chebyshev I, cut-offs
   0.0005-0.49 fs, FIR, cascades; includes ill-conditioned ones that take the exact-order kernel),
-* 16 long (> 512 tiles per workgroup ring wrap) fused-source resamplers in Float32 and Float64.
+* 16 long (> 512 tiles per workgroup ring wrap) fused-source resamplers in Float32 and Float64,
+* 84 checks over channel counts 1 ... 65 and 540 at sizes around the planner's switch points.
 
-These replace tools/tree_soak.py, tree_soak_multiblock.py, tree_soak_windows.py, soak_filters.py and
-soak_long_fused.py (reference behaviour under test: the whole of SURVEY.md section 8(a))."""
+These replace tools/tree_soak.py, tree_soak_multiblock.py, tree_soak_windows.py, soak_filters.py,
+soak_long_fused.py, soak_channels.py and soak_thresholds.py (reference behaviour under test: the whole of SURVEY.md section 8(a))."""
 import os
 
 import numpy as np
@@ -206,3 +207,52 @@ def test_soak_long_fused_resamplers(seed):
     tol = 2e-6 if want.dtype == np.float32 else 1e-8
     for _ in range(2):  # (twice: the ring protocols are timing dependent)
         assert relerr(so.sink(t, so.Array), want) <= tol, (fi, fo, nch, dt.__name__, N, k)
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 5, 6, 7, 9, 12, 16, 24, 33, 65])
+def test_soak_channel_counts(nch):
+    """every stateful path at channel counts on both sides of the tile widths (the resampler picks 8-, 4-, 2- or
+    1-channel tiles, the IIR packs chunks x channels into waves); replaces tools/soak_channels.py"""
+    rng = np.random.default_rng(700 + nch)
+    N = 30_000
+    dt = np.float32 if nch % 3 == 0 else np.float64
+    x = so.Signal(np.asfortranarray(rng.standard_normal((N, nch)).astype(dt)), 44.1 * so.kHz)
+    trees = {
+        "resample": x | so.ToFramerate(48 * so.kHz),
+        "down": x | so.ToFramerate(16 * so.kHz),
+        "filt": x | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz),
+        "fused": x | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(N * so.frames) | so.ToFramerate(48 * so.kHz),
+        "pipeline": so.Mix(so.Signal(so.sin, ω=1 * so.kHz), x) | so.Until(N * so.frames) | so.Filt(so.Lowpass, 4 * so.kHz) | so.ToFramerate(48 * so.kHz),
+        "window": x | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz) | so.After(25_001 * so.frames),
+        "normpower": x | so.Normpower | so.Ramp(5 * so.ms),
+    }
+    for name, t in trees.items():
+        want = oracle_sink(t)
+        got = so.sink(t, so.Array)
+        assert got.shape == want.shape, (nch, name)
+        assert relerr(got, want) <= (2e-6 if dt == np.float32 else 1e-9), (nch, dt.__name__, name)
+
+
+@pytest.mark.parametrize("nch", [1, 2, 8])
+@pytest.mark.parametrize("base", [2048, 4096, 8192, 16384, 640 * 16, 147 * 64])
+def test_soak_sizes_around_the_planner_switch_points(nch, base):
+    """sizes and window offsets around the planner's switch points (2048: periodic resampler; 4096: the reference's
+    block; 8192: warm starts; chunk and tile multiples), +-2 frames; replaces tools/soak_thresholds.py"""
+    rng = np.random.default_rng(99 + nch + base)
+    for d in (-2, -1, 0, 1, 2):
+        N = base + d
+        dt = np.float32 if (d == 1) else np.float64
+        x = so.Signal(np.asfortranarray(rng.standard_normal((N + 9000, nch)).astype(dt)), 44.1 * so.kHz)
+        trees = {
+            "resample out=N": x | so.ToFramerate(48 * so.kHz) | so.Until(N * so.frames),
+            "resample in=N": x | so.Until(N * so.frames) | so.ToFramerate(48 * so.kHz),
+            "filt N": x | so.Until(N * so.frames) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz),
+            "fused N": x | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(N * so.frames) | so.ToFramerate(48 * so.kHz),
+            "window at N": x | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz) | so.After(N * so.frames) | so.Until(700 * so.frames),
+            "filt window at N": x | so.Filt(so.Lowpass, 3 * so.kHz) | so.After(N * so.frames),
+        }
+        for name, t in trees.items():
+            want = oracle_sink(t)
+            got = so.sink(t, so.Array)
+            assert got.shape == want.shape, (nch, N, name)
+            assert relerr(got, want) <= (2e-6 if dt == np.float32 else 1e-9), (nch, N, dt.__name__, name)
