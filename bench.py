@@ -150,7 +150,7 @@ def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev, series=None,
                        "launch_stream_drained_ms": round((t_lastev - t0) * 1e3, 3) if t_lastev else None,
                        "wall_ms": round(elapsed * 1e3, 3)})
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -304,7 +304,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if torch.cuda.device_count() >= world:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            # fewer GPUs than ranks (a one-GPU box): the ranks share devices and synchronise over gloo -- a way to
+            # run the N > 1 code path of the default workload where RCCL refuses two ranks on one device; the
+            # numbers of such a run mean nothing and say so ("oversubscribed")
+            dist.init_process_group("gloo")
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         dist.barrier()
     import sigops_amd as so
 
@@ -410,7 +417,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": headline_name, "in_frames": n_in, "out_frames": n_out, "channels": nch,
-                       "parallelism": f"{world} independent signals, one per GPU, no collective",
+                       "parallelism": f"{world} independent signals, one per GPU, no collective"
+                                      + (" (OVERSUBSCRIBED: more ranks than GPUs, gloo barriers; not a measurement)"
+                                         if dist is not None and dist.get_backend() != "nccl" else ""),
                        "plan_create_ms": plan_ms, "launches_per_step": st["n_launches"], "stages": st["n_stages"],
                        "scratch_bytes": st["scratch_bytes"], "checksum": checksum,
                        "note": "warm-up is exactly --warmup steps; the first ~15 launches after an idle gap run up to 20% slower"},
