@@ -154,8 +154,18 @@ void Plan::finalize() {
     for (size_t i = 0; i < stages.size(); ++i)
         if (stages[i].need > 0) order.push_back((int)i);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
+    std::vector<char> batch_pushed(batches.size(), 0);
     for (int sid : order) {
         Stage& S = stages[sid];
+        if (S.batch >= 0) {  // one step for the whole batch, where its first member stood (members wait for nothing)
+            if (batch_pushed[S.batch]) continue;
+            batch_pushed[S.batch] = 1;
+            Step st{2, S.batch, "k_sos_batch", 0};
+            for (int m : batches[S.batch].members)
+                st.bytes += 2 * (stages[m].need - stages[m].base) * stages[m].sg.nch * (int64_t)dsize(nodes[stages[m].node].dtype);
+            steps.push_back(st);
+            continue;
+        }
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
         const char* nm = S.kind == ST_SOS ? (S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
@@ -209,6 +219,12 @@ void Plan::plan_lanes() {
             if (w.out_buf < 0 || (out_alias_buf >= 0 && rd[i].count(out_alias_buf)))
                 for (size_t k = 0; k < stages.size(); ++k)
                     if (stages[k].win_off >= 0) rd[i].insert(-100 - (int)k);
+        } else if (st.kind == 2) {  // members read device arrays only; each writes its window or buffer
+            for (int m : batches[st.idx].members) {
+                const Stage& S = stages[m];
+                if (S.win_off >= 0) wr[i].insert(-100 - m);
+                else wr[i].insert(m == alias_stage ? kFinal : S.out_buf);
+            }
         } else {
             const Stage& S = stages[st.idx];
             if (S.in_buf >= 0) rd[i].insert(S.in_buf);
@@ -371,6 +387,80 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     s.launches = 1;
                     launches++;
                 }
+            } else if (s.kind == 2) {
+                SosBatch& B = P->batches[s.idx];
+                const size_t nm = B.members.size();
+                std::vector<SosDesc> d(nm + 1);
+                int64_t first[3] = {0, 0, 0};
+                for (size_t m = 0; m <= nm; ++m) {
+                    SosDesc& D = d[m];
+                    std::memset(&D, 0, sizeof D);
+                    for (int q = 0; q < 3; ++q) D.first[q] = first[q];
+                    if (m == nm) break;
+                    const int sid = B.members[m];
+                    const Stage& S = P->stages[sid];
+                    const Node& N = P->nodes[S.node];
+                    const size_t esz = dsize(N.dtype);
+                    const so_node_t& nd = P->nodes[S.in_array_node].nd;
+                    const char* base = nd.i0 ? (const char*)P->array_ptr[S.in_array_node] : (const char*)P->bufs[P->array_buf[S.in_array_node]].d;
+                    Buf ob = P->bufs[S.out_buf];
+                    if (sid == P->alias_stage) {
+                        if (P->out.is_device) {
+                            ob.d = outp;
+                            ob.pitch = N.nch == 1 ? std::max<int64_t>(P->out.chan_stride, S.need) : P->out.chan_stride;
+                        } else {
+                            ob.d = P->bufs[P->out_stage_buf].d;
+                            ob.pitch = P->bufs[P->out_stage_buf].pitch;
+                        }
+                        ob.d = (char*)ob.d - (size_t)P->alias_skip * (P->alias_narrow ? dsize(P->out.dtype) : esz);
+                    } else if (S.win_off >= 0) {
+                        const Buf& ab = P->bufs[P->out_alias_buf];
+                        ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
+                        ob.pitch = ab.pitch;
+                    }
+                    D.x = base + (size_t)S.in_offset * esz;
+                    D.y = ob.d;
+                    D.v = S.v_buf >= 0 ? (double*)P->bufs[S.v_buf].d : nullptr;
+                    D.s0 = S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr;
+                    D.mpow = S.mpow_buf >= 0 ? (const double*)P->bufs[S.mpow_buf].d : nullptr;
+                    D.g = S.sg;
+                    D.g.in_pitch = N.nch == 1 ? 0 : S.in_pitch;
+                    D.g.out_pitch = ob.pitch;
+                    D.g.store_lo = sid == P->alias_stage ? P->alias_skip : 0;
+                    if (sid == P->alias_stage && P->alias_narrow) D.g.out_dtype = SO_F32;
+                    if (S.src_op) {  // fused sine source of the cascade's input (as below)
+                        const DLeaf& F = S.src_fn;
+                        D.g.src_op = S.src_op;
+                        D.g.src_has_omega = F.flag;
+                        D.g.src_df = F.df;
+                        D.g.src_omega = F.v0;
+                        D.g.src_phi = F.v1;
+                        D.g.src_fs = F.v2;
+                        const double step = 6.283185307179586476925 * (F.flag ? F.v0 / F.v2 : 1.0 / F.v2);
+                        D.g.src_cd = std::cos(step);
+                        D.g.src_sd = std::sin(step);
+                    }
+                    D.cf = S.groups[0];
+                    const int64_t nseq = (int64_t)D.g.nchunks * D.g.nch;
+                    if (D.g.nchunks > 1) {
+                        first[0] += ((int64_t)(D.g.nchunks - 1) * D.g.nch + kBlock - 1) / kBlock;
+                        first[1] += (nseq + kBlock - 1) / kBlock;
+                    } else
+                        D.s0 = nullptr;  // one chunk: starts from rest
+                    first[2] += (nseq + kBlock - 1) / kBlock;
+                }
+                if (first[2] >= ((int64_t)1 << 31)) fail(SO_ERR_RUNTIME, "internal: batched IIR grid too large");
+                if (B.host.size() != d.size() || std::memcmp(B.host.data(), d.data(), d.size() * sizeof(SosDesc)) != 0) {
+                    // the descriptors change only when the result or an array moves -- never between the direct
+                    // execute for a result pointer and the capture that follows it (plan_execute), so a captured
+                    // graph holds the three launches only and reads the table this copy left on the device
+                    B.host = d;
+                    HIPCHECK(hipMemcpyAsync(P->bufs[B.desc_buf].d, B.host.data(), B.host.size() * sizeof(SosDesc), hipMemcpyHostToDevice, st));
+                }
+                for (int q = 0; q < 3; ++q) B.total[q] = first[q];
+                const int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
+                s.launches = nl;
+                launches += nl;
             } else {
                 Stage& S = P->stages[s.idx];
                 Node& N = P->nodes[S.node];

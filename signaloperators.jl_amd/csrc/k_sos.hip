@@ -37,18 +37,19 @@ __device__ __forceinline__ double sos_step(double x, double (&s)[2 * NS], const 
 // APPLY == true : pass 3 (outputs from the propagated initial state)
 constexpr int kTT = 16;
 
+// (`blk`: the block's index among the blocks of THIS filter -- blockIdx.x for a launch of its own, the offset
+//  into its share of a batched launch, k_sos_tiled_batch below)
 template <int NS, typename T, bool APPLY>
-__global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T* __restrict__ y,
-                                                      const double* __restrict__ s0,
-                                                      double* __restrict__ v, SosGeom g,
-                                                      SosCoefs cf) {
+__device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __restrict__ y,
+                                               const double* __restrict__ s0, double* __restrict__ v,
+                                               const SosGeom& g, const SosCoefs& cf, const int64_t blk) {
     __shared__ double tile[kBlock / 64][64 * (kTT + 1)];
     __shared__ int64_t rowbase[kBlock / 64][64];  // element offset of each row's first frame
     __shared__ int rowlen[kBlock / 64][64];       // frames this row has to process
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nck = APPLY ? g.nchunks : g.nchunks - 1;  // pass 1 skips every channel's last chunk
     const int64_t nseq = (int64_t)nck * g.nch;
-    const int64_t seq = ((int64_t)blockIdx.x * (kBlock / 64) + w) * 64 + lane;
+    const int64_t seq = (blk * (kBlock / 64) + w) * 64 + lane;
     const bool live = seq < nseq;
     const int k = live ? (int)(seq % nck) : 0;
     const int ch = live ? (int)(seq / nck) : 0;
@@ -157,12 +158,19 @@ __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T
     }
 }
 
+template <int NS, typename T, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T* __restrict__ y,
+                                                      const double* __restrict__ s0,
+                                                      double* __restrict__ v, SosGeom g,
+                                                      SosCoefs cf) {
+    sos_tiled_body<NS, T, APPLY>(x, y, s0, v, g, cf, (int64_t)blockIdx.x);
+}
+
 // mpow: [kterms][D][D] row-major powers of M = A^L built on the host (mpow[0] = I, mpow[1] = M);
 // the host uses them to choose the truncation K, the kernel only needs M itself.
 template <int NS>
-__global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ v,
-                                                     const double* __restrict__ mpow, SosGeom g,
-                                                     double* __restrict__ s0) {
+__device__ __forceinline__ void sos_scan_body(const double* __restrict__ v, const double* __restrict__ mpow,
+                                              const SosGeom& g, double* __restrict__ s0, const int64_t blk) {
     constexpr int D = 2 * NS;
     // Horner form of  s0_k = sum_{j=1..K} M^(j-1) v_(k-j):  s <- M s + v_(k-j), oldest term first.
     // One matrix (M = A^L, second entry of the host's power table) in LDS, read as broadcasts; no
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ 
     __shared__ double m1[D * D];
     if ((int)threadIdx.x < D * D) m1[threadIdx.x] = g.kterms >= 2 ? mpow[(int64_t)D * D + threadIdx.x] : 0.0;
     __syncthreads();
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t tid = blk * kBlock + threadIdx.x;
     const int64_t nseq = (int64_t)g.nchunks * g.nch;
     const bool live = tid < nseq;
     const int k = live ? (int)(tid % g.nchunks) : 0;
@@ -200,6 +208,65 @@ __global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ 
 #pragma unroll
         for (int d = 0; d < D; ++d) sp[d] = acc[d];
     }
+}
+
+template <int NS>
+__global__ __launch_bounds__(kBlock) void k_sos_scan(const double* __restrict__ v,
+                                                     const double* __restrict__ mpow, SosGeom g,
+                                                     double* __restrict__ s0) {
+    sos_scan_body<NS>(v, mpow, g, s0, (int64_t)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Batched launches: many independent filters of one shape (the scenes under an `Append`, reference
+// src/appending.jl:59-76: every child is its own signal with its own filter state) share ONE launch per
+// pass.  A filter whose launch would not fill the chip -- a few hundred workgroups that start and drain
+// together -- otherwise pays that ramp three times per scene.  desc[m] describes filter m; `first[PASS]`
+// is the index of its first workgroup in the batched grid (ascending, desc[n] holds the totals).
+typedef const SosDesc __attribute__((address_space(4))) * SosDescPtr;  // constant address space: scalar loads
+
+// (a struct out of the constant address space, eight bytes at a time; what the kernel never reads is never loaded)
+template <typename S>
+__device__ __forceinline__ void load_const(S& dst, const S __attribute__((address_space(4))) * src) {
+    static_assert(sizeof(S) % 8 == 0, "eight-byte granules");
+    typedef const uint64_t __attribute__((address_space(4))) * P;
+    P p = (P)src;
+    uint64_t* q = reinterpret_cast<uint64_t*>(&dst);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(S) / 8; ++i) q[i] = p[i];
+}
+
+template <int PASS>
+__device__ __forceinline__ int sos_batch_member(const SosDesc* __restrict__ desc, int n, int64_t blk) {
+    SosDescPtr d = (SosDescPtr)desc;
+    int lo = 0, hi = n;  // largest m with first[m] <= blk
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (d[mid].first[PASS] <= blk) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+template <int NS, typename T, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_sos_tiled_batch(const SosDesc* __restrict__ desc, int n) {
+    const int m = sos_batch_member<APPLY ? 2 : 0>(desc, n, (int64_t)blockIdx.x);
+    SosDescPtr d = (SosDescPtr)desc + m;
+    SosGeom g;
+    SosCoefs cf;
+    load_const(g, &d->g);
+    load_const(cf, &d->cf);
+    sos_tiled_body<NS, T, APPLY>((const T*)d->x, (T*)d->y, APPLY ? (const double*)d->s0 : nullptr, APPLY ? nullptr : d->v, g, cf,
+                                 (int64_t)blockIdx.x - d->first[APPLY ? 2 : 0]);
+}
+
+template <int NS>
+__global__ __launch_bounds__(kBlock) void k_sos_scan_batch(const SosDesc* __restrict__ desc, int n) {
+    const int m = sos_batch_member<1>(desc, n, (int64_t)blockIdx.x);
+    SosDescPtr d = (SosDescPtr)desc + m;
+    SosGeom g;
+    load_const(g, &d->g);
+    sos_scan_body<NS>(d->v, d->mpow, g, d->s0, (int64_t)blockIdx.x - d->first[1]);
 }
 
 template <int NS, typename T>
@@ -335,6 +402,32 @@ int launch_sos_phase(const void* x, void* y, double* v, const double* s0, const 
     }
 #undef SO_PH
     return 1;
+}
+
+template <int NS, typename T>
+static void launch_sos_batch_t(const SosDesc* desc, int n, const int64_t* total, hipStream_t st) {
+    if (total[0] > 0)
+        hipLaunchKernelGGL((k_sos_tiled_batch<NS, T, false>), dim3((unsigned)total[0]), dim3(kBlock), 0, st, desc, n);
+    if (total[1] > 0) hipLaunchKernelGGL((k_sos_scan_batch<NS>), dim3((unsigned)total[1]), dim3(kBlock), 0, st, desc, n);
+    hipLaunchKernelGGL((k_sos_tiled_batch<NS, T, true>), dim3((unsigned)total[2]), dim3(kBlock), 0, st, desc, n);
+}
+
+// desc: device array of n + 1 descriptors (the last one carries the grid sizes in `first`); total = those sizes
+int launch_sos_batch(const SosDesc* desc, int n, int nsec, int dtype, const int64_t* total, hipStream_t st) {
+    switch (nsec) {
+#define SOS_BATCH_CASE(NS_)                                                        \
+    case NS_:                                                                      \
+        if (dtype == SO_F32) launch_sos_batch_t<NS_, float>(desc, n, total, st);   \
+        else launch_sos_batch_t<NS_, double>(desc, n, total, st);                  \
+        break;
+        SOS_BATCH_CASE(1) SOS_BATCH_CASE(2) SOS_BATCH_CASE(3) SOS_BATCH_CASE(4)
+        SOS_BATCH_CASE(5) SOS_BATCH_CASE(6) SOS_BATCH_CASE(7)
+#undef SOS_BATCH_CASE
+    default:
+        if (dtype == SO_F32) launch_sos_batch_t<8, float>(desc, n, total, st);
+        else launch_sos_batch_t<8, double>(desc, n, total, st);
+    }
+    return (total[0] > 0) + (total[1] > 0) + 1;
 }
 
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,

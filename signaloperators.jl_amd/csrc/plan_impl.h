@@ -126,6 +126,7 @@ struct Stage {
     int src_op = 0;      // fused sine source of the first group's input (SosGeom::src_op): 1 add, 2 multiply
     DLeaf src_fn{};      // ... the generator (E_FUNC leaf: v0 omega, v1 phi, v2 fs, flag has_omega, df)
     bool xscan = false;  // pass 2 is the exact block scan (launch_sos_xscan): no 2^-70 cut anywhere
+    int batch = -1;      // member of Plan::batches[batch]: its three passes run inside that batch's launches
     int xs_mats_buf = -1, sblk_buf = -1;
     std::vector<std::vector<double>> xs_mats_host;  // per group: [M][M^kXsBlock]
     std::vector<std::vector<double>> mpow_host;  // per group
@@ -187,12 +188,21 @@ struct PwStep {
 };
 
 struct Step {
-    int kind;  // 0 pointwise, 1 stage kernel
+    int kind;  // 0 pointwise, 1 stage kernel, 2 batch of IIR stages (idx into Plan::batches)
     int idx;
     std::string name;
     int64_t bytes = 0;
     double ms = 0;
     int launches = 0;
+};
+
+// Independent IIR stages of one shape that share their launches (k_sos_tiled_batch, k_sos_scan_batch)
+struct SosBatch {
+    std::vector<int> members;    // stage ids in step order
+    int nsec = 0, dtype = 0;
+    int desc_buf = -1;           // device SosDesc[members + 1]
+    std::vector<SosDesc> host;   // the descriptors as last uploaded
+    int64_t total[3] = {0, 0, 0};
 };
 
 constexpr int kProfExecs = 256;  // executes a deferred-profiling plan keeps events for
@@ -216,6 +226,7 @@ struct Plan {
     std::vector<Stage> stages;
     std::vector<PwStep> pw;
     std::vector<Step> steps;
+    std::vector<SosBatch> batches;
     std::vector<DPiece> pieces;
     std::vector<DOp> ops;
     std::vector<DLeaf> leaves;
@@ -368,6 +379,8 @@ struct Plan {
     int add_leaf(const Expr& e);
     void count_array(int ni);
     void fuse_state_passes();
+    void batch_sos_stages();
+    void sos_chunking(int sid, int64_t need, int nch, int dtype, const std::vector<SosCoefs>& groups, bool exact, int64_t target);
     void finalize();
     void release();
 };

@@ -153,6 +153,19 @@ struct SosGeom {
     double src_cd, src_sd;        // cos / sin of the phase step per frame (2 pi omega / fs)
 };
 
+// One filter of a batched launch (k_sos_tiled_batch / k_sos_scan_batch): what launch_sos would have been
+// given for it, plus the index of its first workgroup in each of the three batched grids.
+struct SosDesc {
+    const void* x;
+    void* y;
+    double* v;
+    double* s0;
+    const double* mpow;
+    int64_t first[3];  // pass 1, scan, pass 3
+    SosGeom g;
+    SosCoefs cf;
+};
+
 // Single-pass variant (k_sos_onepass): one read and one write of the signal.  A WAVE owns a tile of
 // 64 * kSosLc frames of one channel; lane k owns sub-chunk k (kSosLc frames) in registers.
 //   tabs = [nlev][D*D] powers M^(2^s) of M = A^lc (scan over the lanes) followed by

@@ -129,6 +129,129 @@ static bool ga_fits(const Stage& S, int stage_dtype) {
     return ok;
 }
 
+// Chunk geometry of a three-pass cascade: L frames per chunk, W warm-up frames of the state pass, K terms of
+// the scan, and the buffers they need.  `target`: chunks per channel that fill the machine -- 262144 / channels
+// for a filter launched on its own, fewer and longer for the members of a batch (batch_sos_stages), which fill
+// it together.  `groups` may be the stage's own vector (re-chunking).
+void Plan::sos_chunking(int sid, int64_t need, int nch, int dtype, const std::vector<SosCoefs>& groups_in, bool exact, int64_t target) {
+    const std::vector<SosCoefs> groups = groups_in;
+    const int64_t BIG = (int64_t)1 << 60;
+    auto sized_buf = [&](int have, size_t bytes) {
+        if (have < 0) return raw_buf(bytes);
+        bufs[have].bytes = bytes;
+        return have;
+    };
+    // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
+    SosGeom g{};
+    g.n = need;
+    g.nch = nch;
+    const double tol = std::ldexp(1.0, -70);
+    // chunk length: as many sequences (chunks x channels) as the machine can hold; every
+    // pass is latency-bound per sequence, so shorter chunks win down to L = 64 (sweep on
+    // config 2: L=64 0.205 ms, 128 0.208, 256 0.293, 512 0.531)
+    int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
+    int64_t L = (need + nchunks - 1) / nchunks;
+    if (const char* ev = std::getenv("SIGOPS_SOS_CHUNK")) {  // tuning knob
+        L = std::max(32, std::atoi(ev));
+    }
+    L = (L + 31) / 32 * 32;
+    if (exact) L = std::max<int64_t>(need, 32);  // one sequence per channel, start to end
+    std::vector<std::vector<double>> mp;
+    int K = 1;
+    int64_t W = BIG;
+    for (;;) {
+        nchunks = (need + L - 1) / L;
+        mp.clear();
+        K = 1;
+        W = 0;
+        if (nchunks <= 1) break;
+        bool ok = true;
+        for (auto& cf : groups) {
+            int D = 2 * cf.nsec;
+            Mat A = sos_state_matrix(cf);
+            // W: first power of two with ||A^W|| < tol (pass-1 warm-up length)
+            Mat P = A;
+            int64_t w = 1;
+            while (maxabs(P) >= tol && w < ((int64_t)1 << 40)) {
+                P = matmul(P, P, D);
+                w <<= 1;
+            }
+            W = std::max(W, w);
+            Mat M = matpow(A, L, D);
+            std::vector<double> pw_((size_t)D * D, 0.0);
+            Mat cur = ident(D);
+            std::vector<double> all;
+            int k = 0;
+            for (;;) {
+                all.insert(all.end(), cur.begin(), cur.end());
+                ++k;
+                cur = matmul(cur, M, D);
+                if (maxabs(cur) < tol) break;
+                if (k >= 64) {
+                    ok = false;
+                    break;
+                }
+            }
+            if (!ok) break;
+            if (k < 2) {  // (the scan kernel reads M itself, entry 1, whatever K is)
+                all.insert(all.end(), cur.begin(), cur.end());
+                k = 2;
+            }
+            K = std::max(K, k);
+            mp.push_back(all);
+        }
+        if (ok) break;
+        L *= 2;  // slower-decaying filter: fewer, longer chunks
+    }
+    // Short signals are filtered without either cut (every earlier chunk enters the scan, the state
+    // pass runs over whole chunks): what has decayed below 2^-70 of an earlier peak -- the tail of a
+    // filter long after its input went silent -- then keeps the relative accuracy of the sequential
+    // recurrence, which a `Normpower` of such a tail makes visible (tools/tree_soak.py 1396/7).
+    if (nchunks > 1 && nchunks <= 64) {
+        K = std::max<int>(K, (int)nchunks);
+        W = std::max(W, L);
+    }
+    // ... and a filter that feeds a Normpower keeps it at every length: exact block scan
+    // (kernels2.hip launch_sos_xscan) and a state pass over whole chunks
+    const bool xscan = stages[sid].under_norm && nchunks > 64 && !stages[sid].onepass && !std::getenv("SIGOPS_SOS_NOXSCAN");
+    if (xscan) W = std::max(W, L);
+    // every group is scanned with the same K (pad shorter tables with zeros)
+    for (size_t gi = 0; gi < mp.size(); ++gi) {
+        int D = 2 * groups[gi].nsec;
+        mp[gi].resize((size_t)K * D * D, 0.0);
+    }
+    g.chunk = L;
+    g.nchunks = (int)nchunks;
+    g.warm = W;
+    g.kterms = K;
+    g.in_dtype = g.out_dtype = dtype;
+    g.exact = exact ? 1 : 0;
+    stages[sid].groups = groups;
+    stages[sid].mpow_host = mp;
+    if (nchunks > 1 && !stages[sid].onepass) {
+        size_t msz = 0;
+        for (auto& v : mp) msz = std::max(msz, v.size());
+        stages[sid].mpow_buf = sized_buf(stages[sid].mpow_buf, msz * 8 * groups.size());
+        stages[sid].v_buf = sized_buf(stages[sid].v_buf, (size_t)nchunks * nch * 2 * kMaxSec * 8);
+        stages[sid].s0_buf = sized_buf(stages[sid].s0_buf, (size_t)nchunks * nch * 2 * kMaxSec * 8);
+        if (xscan) {
+            stages[sid].xscan = true;
+            stages[sid].xs_mats_host.clear();
+            for (auto& cf : groups) {
+                const int D = 2 * cf.nsec;
+                Mat M = matpow(sos_state_matrix(cf), L, D), MB = matpow(M, kXsBlock, D);
+                std::vector<double> both(M);
+                both.insert(both.end(), MB.begin(), MB.end());
+                stages[sid].xs_mats_host.push_back(both);
+            }
+            stages[sid].xs_mats_buf = sized_buf(stages[sid].xs_mats_buf, (size_t)groups.size() * 2 * 16 * 16 * 8);
+            const int64_t nblk = (nchunks + kXsBlock - 1) / kXsBlock;
+            stages[sid].sblk_buf = sized_buf(stages[sid].sblk_buf, (size_t)nblk * nch * 16 * 8);
+        }
+    }
+    stages[sid].sg = g;
+}
+
 void Plan::process_stage(int sid) {
     // NOTE: `stages` may grow while lowering the child; re-take references after.
     int ni = stages[sid].node;
@@ -661,115 +784,7 @@ void Plan::process_stage(int sid) {
                 stages[sid].one_vpub_buf = raw_buf((size_t)o.ntiles * o.nch * 2 * kMaxSec * 8);
             }
         }
-        // chunking: enough independent sequences to fill 256 CUs x 4 SIMDs x 4 waves
-        SosGeom g{};
-        g.n = need;
-        g.nch = N.nch;
-        const double tol = std::ldexp(1.0, -70);
-        // chunk length: as many sequences (chunks x channels) as the machine can hold; every
-        // pass is latency-bound per sequence, so shorter chunks win down to L = 64 (sweep on
-        // config 2: L=64 0.205 ms, 128 0.208, 256 0.293, 512 0.531)
-        int64_t target = 262144 / std::max(1, N.nch);
-        int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(target, need / 64));
-        int64_t L = (need + nchunks - 1) / nchunks;
-        if (const char* ev = std::getenv("SIGOPS_SOS_CHUNK")) {  // tuning knob
-            L = std::max(32, std::atoi(ev));
-        }
-        L = (L + 31) / 32 * 32;
-        if (exact) L = std::max<int64_t>(need, 32);  // one sequence per channel, start to end
-        std::vector<std::vector<double>> mp;
-        int K = 1;
-        int64_t W = BIG;
-        for (;;) {
-            nchunks = (need + L - 1) / L;
-            mp.clear();
-            K = 1;
-            W = 0;
-            if (nchunks <= 1) break;
-            bool ok = true;
-            for (auto& cf : groups) {
-                int D = 2 * cf.nsec;
-                Mat A = sos_state_matrix(cf);
-                // W: first power of two with ||A^W|| < tol (pass-1 warm-up length)
-                Mat P = A;
-                int64_t w = 1;
-                while (maxabs(P) >= tol && w < ((int64_t)1 << 40)) {
-                    P = matmul(P, P, D);
-                    w <<= 1;
-                }
-                W = std::max(W, w);
-                Mat M = matpow(A, L, D);
-                std::vector<double> pw_((size_t)D * D, 0.0);
-                Mat cur = ident(D);
-                std::vector<double> all;
-                int k = 0;
-                for (;;) {
-                    all.insert(all.end(), cur.begin(), cur.end());
-                    ++k;
-                    cur = matmul(cur, M, D);
-                    if (maxabs(cur) < tol) break;
-                    if (k >= 64) {
-                        ok = false;
-                        break;
-                    }
-                }
-                if (!ok) break;
-                if (k < 2) {  // (the scan kernel reads M itself, entry 1, whatever K is)
-                    all.insert(all.end(), cur.begin(), cur.end());
-                    k = 2;
-                }
-                K = std::max(K, k);
-                mp.push_back(all);
-            }
-            if (ok) break;
-            L *= 2;  // slower-decaying filter: fewer, longer chunks
-        }
-        // Short signals are filtered without either cut (every earlier chunk enters the scan, the state
-        // pass runs over whole chunks): what has decayed below 2^-70 of an earlier peak -- the tail of a
-        // filter long after its input went silent -- then keeps the relative accuracy of the sequential
-        // recurrence, which a `Normpower` of such a tail makes visible (tools/tree_soak.py 1396/7).
-        if (nchunks > 1 && nchunks <= 64) {
-            K = std::max<int>(K, (int)nchunks);
-            W = std::max(W, L);
-        }
-        // ... and a filter that feeds a Normpower keeps it at every length: exact block scan
-        // (kernels2.hip launch_sos_xscan) and a state pass over whole chunks
-        const bool xscan = stages[sid].under_norm && nchunks > 64 && !stages[sid].onepass && !std::getenv("SIGOPS_SOS_NOXSCAN");
-        if (xscan) W = std::max(W, L);
-        // every group is scanned with the same K (pad shorter tables with zeros)
-        for (size_t gi = 0; gi < mp.size(); ++gi) {
-            int D = 2 * groups[gi].nsec;
-            mp[gi].resize((size_t)K * D * D, 0.0);
-        }
-        g.chunk = L;
-        g.nchunks = (int)nchunks;
-        g.warm = W;
-        g.kterms = K;
-        g.in_dtype = g.out_dtype = N.dtype;
-        g.exact = exact ? 1 : 0;
-        stages[sid].groups = groups;
-        stages[sid].mpow_host = mp;
-        if (nchunks > 1 && !stages[sid].onepass) {
-            size_t msz = 0;
-            for (auto& v : mp) msz = std::max(msz, v.size());
-            stages[sid].mpow_buf = raw_buf(msz * 8 * groups.size());
-            stages[sid].v_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
-            stages[sid].s0_buf = raw_buf((size_t)nchunks * N.nch * 2 * kMaxSec * 8);
-            if (xscan) {
-                stages[sid].xscan = true;
-                for (auto& cf : groups) {
-                    const int D = 2 * cf.nsec;
-                    Mat M = matpow(sos_state_matrix(cf), L, D), MB = matpow(M, kXsBlock, D);
-                    std::vector<double> both(M);
-                    both.insert(both.end(), MB.begin(), MB.end());
-                    stages[sid].xs_mats_host.push_back(both);
-                }
-                stages[sid].xs_mats_buf = raw_buf((size_t)groups.size() * 2 * 16 * 16 * 8);
-                const int64_t nblk = (nchunks + kXsBlock - 1) / kXsBlock;
-                stages[sid].sblk_buf = raw_buf((size_t)nblk * N.nch * 16 * 8);
-            }
-        }
-        stages[sid].sg = g;
+        sos_chunking(sid, need, N.nch, N.dtype, groups, exact, 262144 / std::max(1, N.nch));
     } else {  // ST_NORM
         in_frames = need;
         int64_t total = need * N.nch;
@@ -1199,6 +1214,49 @@ RsCtl Plan::make_ctl(const Stage& S) const {
 // 0.90 ms and its traffic 5.57 -> ~4.1 GB, but the two state waves' 48 MFMAs per tile are the
 // resampler's critical path (tile period 9 800 -> 12 200 cycles): K3 0.72 -> 0.90 ms.  Break-even
 // (1.79 vs 1.76-1.83 ms), so the three-pass form stays the default.
+// Independent IIR stages of one shape share their launches.  The scenes under an `Append` (reference
+// src/appending.jl:59-76: every child is evaluated on its own, with its own filter state) are filters of
+// a few hundred workgroups each; three launches per scene each ramp up and drain on their own, and eight
+// stream lanes hide only part of that (config 4, 64 scenes: 2.5 ms).  Members: three-pass cascades of one
+// group that read a device array directly -- they wait for nothing, so the batch can run first.
+void Plan::batch_sos_stages() {
+    if (std::getenv("SIGOPS_SOS_NOBATCH")) return;
+    std::map<std::pair<int, int>, std::vector<int>> kinds;
+    std::vector<int> order;
+    for (size_t i = 0; i < stages.size(); ++i)
+        if (stages[i].need > 0) order.push_back((int)i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
+    for (int sid : order) {
+        const Stage& S = stages[sid];
+        if (S.kind != ST_SOS || S.onepass || S.sg.exact || S.xscan || S.pre_stage >= 0 || S.groups.size() != 1 ||
+            S.in_array_node < 0 || S.pw_step >= 0 || S.sg.nchunks < 1)
+            continue;
+        kinds[{S.groups[0].nsec, nodes[S.node].dtype}].push_back(sid);
+    }
+    for (auto& kv : kinds) {
+        if (kv.second.size() < 2) continue;
+        SosBatch B;
+        B.members = kv.second;
+        B.nsec = kv.first.first;
+        B.dtype = kv.first.second;
+        // the members fill the machine TOGETHER: chunks for 262144 sequences over all of them, not per member --
+        // 64 two-channel scenes cut for themselves are 5.3 M sequences of 64 frames, and at that length the scan
+        // (K = 64 terms of 64 multiply-adds per sequence) costs more than the filter it serves
+        int64_t chans = 0;
+        for (int sid : B.members) chans += stages[sid].sg.nch;
+        if (!std::getenv("SIGOPS_SOS_BATCH_KEEPCHUNKS"))
+            for (int sid : B.members) {
+                Stage& S = stages[sid];
+                sos_chunking(sid, S.sg.n, S.sg.nch, nodes[S.node].dtype, S.groups, false, std::max<int64_t>(1, 262144 / chans));
+            }
+        B.desc_buf = raw_buf((B.members.size() + 1) * sizeof(SosDesc));
+        for (int sid : B.members) stages[sid].batch = (int)batches.size();
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr, "[sigops] %zu IIR stages of %d sections share their launches\n", B.members.size(), B.nsec);
+        batches.push_back(std::move(B));
+    }
+}
+
 void Plan::fuse_state_passes() {
     if (!std::getenv("SIGOPS_FUSE_STATE")) return;
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {

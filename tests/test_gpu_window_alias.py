@@ -107,7 +107,8 @@ def test_device_result_repointed_between_executes():
     plan.close()
 
 
-def test_graph_replay_after_the_result_moved_away_and_back():
+@pytest.mark.parametrize("orders", [(2, 4, 6), (5, 5, 5)])
+def test_graph_replay_after_the_result_moved_away_and_back(orders):
     """in-place root pieces (ramp edges of window-aliased stages) read the RESULT
     through leaves that are re-pointed at every new result pointer.  With device leaves the plan is
     graph-eligible: A, A (captured for A), B (direct, leaves now point at B), A -- replaying A's graph
@@ -117,8 +118,8 @@ def test_graph_replay_after_the_result_moved_away_and_back():
     host = [_noise(rng, n, 2) for n in (9999, 12001, 8000)]
     dev = [torch.from_numpy(np.ascontiguousarray(h.T)).cuda() for h in host]  # [nch][n]: planar, time fastest
     def tree_of(arrs):
-        return so.Append(*[so.Signal(a if isinstance(a, np.ndarray) else a.t(), 44.1 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) | so.Ramp(5 * so.ms)
-                           for a in arrs])
+        return so.Append(*[so.Signal(a if isinstance(a, np.ndarray) else a.t(), 44.1 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz, order=o) | so.Ramp(5 * so.ms)
+                           for a, o in zip(arrs, orders)])
     with oracle_semantics("intended"):
         want = oracle_sink(tree_of(host))
     n = want.shape[0]
@@ -132,7 +133,10 @@ def test_graph_replay_after_the_result_moved_away_and_back():
         torch.cuda.synchronize()
         assert relerr(buf[:, :n].t().cpu().numpy(), want) <= 1e-9, (i, "A" if buf is A else "B")
     c = plan.counters()
-    assert c["graph_replays"] >= 2 and c["graph_captures"] >= 1, c  # (the graph path really ran)
+    # filters of three different orders keep their own launches: four steps, replayed as a graph; filters of one
+    # order share their launches (test_gpu_sos_batch.py): two steps, launched directly -- same sequence either way
+    if len(set(orders)) == 3:
+        assert c["graph_replays"] >= 2 and c["graph_captures"] >= 1, c  # (the graph path really ran)
     assert c["graph_replays"] + c["direct_executes"] + c["graph_captures"] == len(order), c
     plan.close()
 
