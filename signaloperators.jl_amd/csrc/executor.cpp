@@ -428,6 +428,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     D.g.out_pitch = ob.pitch;
                     D.g.store_lo = sid == P->alias_stage ? P->alias_skip : 0;
                     if (sid == P->alias_stage && P->alias_narrow) D.g.out_dtype = SO_F32;
+                    D.g.align_rows = !std::getenv("SIGOPS_SOS_NOALIGN");
                     if (S.src_op) {  // fused sine source of the cascade's input (as below)
                         const DLeaf& F = S.src_fn;
                         D.g.src_op = S.src_op;
@@ -503,6 +504,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     g.out_pitch = ob.pitch;
                     g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
                     if (s.idx == P->alias_stage && P->alias_narrow) g.out_dtype = SO_F32;
+                    g.align_rows = S.pre_stage < 0 && !std::getenv("SIGOPS_SOS_NOALIGN");
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;

@@ -37,6 +37,39 @@ __device__ __forceinline__ double sos_step(double x, double (&s)[2 * NS], const 
 // APPLY == true : pass 3 (outputs from the propagated initial state)
 constexpr int kTT = 16;
 
+// One tile step of a lane's row through the cascade: kTT frames from LDS, outputs back in place (APPLY).
+// HEAD: the row's first `head` columns lie before its chunk and are left alone (see sos_tiled_body).
+template <int NS, bool APPLY, bool HEAD>
+__device__ __forceinline__ void sos_row_steps(double* __restrict__ row, double (&s)[2 * NS], const SosGeom& g, const SosCoefs& cf,
+                                              double& gs, double& gc, const int head) {
+    if (g.src_op == 0) {
+#pragma unroll
+        for (int t = 0; t < kTT; ++t) {
+            if (HEAD && t < head) continue;
+            const double yv = sos_step<NS>(row[t], s, cf);
+            if (APPLY) row[t] = yv * cf.gain;
+            // (frames past a short row's end are zeros and never stored; their effect on
+            //  the state is irrelevant: only full chunks feed pass 1)
+        }
+    } else {
+        // fused source (SosGeom::src_op): the array sample plus / times a sine generator, the value
+        // of `Mix(Signal(sin), x)` / `Amplify(x, Signal(sin))` (reference src/mapsignal.jl:249-272,
+        // src/functions.jl:57-60) formed here instead of by a K1 pass through HBM.  The lane walks
+        // its row in time, so the sine advances by one rotation per frame from the exact value at
+        // the row's first frame (gs, gc).
+#pragma unroll
+        for (int t = 0; t < kTT; ++t) {
+            if (HEAD && t < head) continue;
+            const double xin = g.src_op == 1 ? row[t] + gs : row[t] * gs;
+            const double ns_ = fma(gs, g.src_cd, gc * g.src_sd), nc_ = fma(gc, g.src_cd, -(gs * g.src_sd));
+            gs = ns_;
+            gc = nc_;
+            const double yv = sos_step<NS>(xin, s, cf);
+            if (APPLY) row[t] = yv * cf.gain;
+        }
+    }
+}
+
 // (`blk`: the block's index among the blocks of THIS filter -- blockIdx.x for a launch of its own, the offset
 //  into its share of a batched launch, k_sos_tiled_batch below)
 template <int NS, typename T, bool APPLY>
@@ -44,8 +77,10 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
                                                const double* __restrict__ s0, double* __restrict__ v,
                                                const SosGeom& g, const SosCoefs& cf, const int64_t blk) {
     __shared__ double tile[kBlock / 64][64 * (kTT + 1)];
-    __shared__ int64_t rowbase[kBlock / 64][64];  // element offset of each row's first frame
-    __shared__ int rowlen[kBlock / 64][64];       // frames this row has to process
+    __shared__ int64_t rowbase[kBlock / 64][64];  // frame of column 0 of the row's first tile step
+    __shared__ int64_t rowmin[kBlock / 64][64];   // first frame the row stores
+    __shared__ int rowlen[kBlock / 64][64];       // columns the row spans (head + frames to process)
+    __shared__ int rowhead[kBlock / 64][64];      // its first column inside the chunk
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nck = APPLY ? g.nchunks : g.nchunks - 1;  // pass 1 skips every channel's last chunk
     const int64_t nseq = (int64_t)nck * g.nch;
@@ -56,9 +91,20 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     int64_t beg = (int64_t)k * g.chunk;
     int64_t end = beg + g.chunk < g.n ? beg + g.chunk : g.n;
     if (!APPLY) beg = end - (g.warm < g.chunk ? g.warm : g.chunk);  // full chunks only: end = beg+L
-    const int len = live ? (int)(end - beg) : 0;
-    rowbase[w][lane] = beg;  // frame offset (the row's channel is kept in rowch)
+    // Pass 3 stores whole cache lines whatever the alignment of the result's channel rows (SosGeom::align_rows): the
+    // tile steps of a row start `head` frames BEFORE its chunk, where the result's 128-byte line starts (64-byte half
+    // line of a Float32 result: a step is 16 frames wide); those columns are neither filtered nor stored, the chunk
+    // borders -- and with them every rounding -- stay where they are.  A row off its lines writes every line in two
+    // halves, 64 rows x 12 waves x 256 CUs at a time, more than L2 holds until the second half arrives: config 5,
+    // rows of 3 628 118 frames (what an n x 128 Array has): pass 3 2.6 ms against 1.65 ms with aligned rows.
+    int head = 0;
+    if (APPLY && g.align_rows && live)
+        head = (int)(((uintptr_t)y / (g.out_dtype == SO_F32 ? 4 : 8) + (uint64_t)ch * (uint64_t)g.out_pitch + (uint64_t)beg) % kTT);
+    const int len = live ? head + (int)(end - beg) : 0;
+    rowbase[w][lane] = beg - head;  // (the row's channel is kept in rowch)
+    rowmin[w][lane] = beg > g.store_lo ? beg : g.store_lo;
     rowlen[w][lane] = len;
+    rowhead[w][lane] = head;
     double s[2 * NS];
 #pragma unroll
     for (int d = 0; d < 2 * NS; ++d) s[d] = 0.0;
@@ -76,6 +122,7 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     int maxlen = len;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    const bool anyhead = APPLY && __any(head != 0);
     double* tl = tile[w];
     const int rsub = lane >> 4, col = lane & 15;  // load/store role: 4 rows x 16 columns
     // The passes are latency-bound (a few waves per CU, each a chain of tile round trips): all 16
@@ -91,7 +138,8 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     }
     double xv[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xv[j] = col < xlen[j] ? (double)xrow[j][0] : 0.0;
+    for (int j = 0; j < 16; ++j)  // (head columns hold frames of the chunk before, or of nothing: not this row's to read)
+        xv[j] = col < xlen[j] && (!APPLY || col >= rowhead[w][j * 4 + rsub]) ? (double)xrow[j][0] : 0.0;
     // fused sine source: (sin, cos) of the generator's phase at this lane's first frame, evaluated like
     // func_eval (every operation rounded on its own, first frame t = 1/fs)
     double gs = 0.0, gc = 1.0;
@@ -111,37 +159,15 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
         }
         // ---- every lane: its own row through the cascade ----
         double* row = tl + lane * (kTT + 1);
-        if (g.src_op == 0) {
-#pragma unroll
-            for (int t = 0; t < kTT; ++t) {
-                const double yv = sos_step<NS>(row[t], s, cf);
-                if (APPLY) row[t] = yv * cf.gain;
-                // (frames past a short row's end are zeros and never stored; their effect on
-                //  the state is irrelevant: only full chunks feed pass 1)
-            }
-        } else {
-            // fused source (SosGeom::src_op): the array sample plus / times a sine generator, the value
-            // of `Mix(Signal(sin), x)` / `Amplify(x, Signal(sin))` (reference src/mapsignal.jl:249-272,
-            // src/functions.jl:57-60) formed here instead of by a K1 pass through HBM.  The lane walks
-            // its row in time, so the sine advances by one rotation per frame from the exact value at
-            // the row's first frame (gs, gc below).
-#pragma unroll
-            for (int t = 0; t < kTT; ++t) {
-                const double xin = g.src_op == 1 ? row[t] + gs : row[t] * gs;
-                const double ns_ = fma(gs, g.src_cd, gc * g.src_sd), nc_ = fma(gc, g.src_cd, -(gs * g.src_sd));
-                gs = ns_;
-                gc = nc_;
-                const double yv = sos_step<NS>(xin, s, cf);
-                if (APPLY) row[t] = yv * cf.gain;
-            }
-        }
+        if (t0 == 0 && anyhead) sos_row_steps<NS, APPLY, true>(row, s, g, cf, gs, gc, head);
+        else sos_row_steps<NS, APPLY, false>(row, s, g, cf, gs, gc, 0);
         __builtin_amdgcn_wave_barrier();
         if (APPLY) {
             // ---- coalesced store ----
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const int r = j * 4 + rsub;
-                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= g.store_lo) {
+                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= rowmin[w][r]) {
                     const int64_t o = (int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col;
                     // (a Float64 filter writing a Float32 result itself: `convert` on store, src/sink.jl:262-266)
                     if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)tl[r * (kTT + 1) + col];
@@ -276,7 +302,7 @@ static void launch_sos_t(const void* x, void* y, double* v, double* s0, const do
     if (g.nchunks > 1) {
         const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
         hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, st, (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
+                           dim3(kBlock), 0, st, (const T*)x, (T*)y, (const double*)nullptr, v, g, cf);
         hipLaunchKernelGGL((k_sos_scan<NS>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, st, v, mpow, g, s0);
     }
@@ -380,7 +406,7 @@ static void launch_sos_phase_t(const void* x, void* y, double* v, const double* 
     if (phase == 1) {
         const int64_t n1 = (int64_t)(g.nchunks - 1) * g.nch;
         hipLaunchKernelGGL((k_sos_tiled<NS, T, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const T*)x, (T*)nullptr, (const double*)nullptr, v, g, cf);
+                           (const T*)x, (T*)y, (const double*)nullptr, v, g, cf);
     } else {
         hipLaunchKernelGGL((k_sos_tiled<NS, T, true>), dim3((unsigned)((nseq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            (const T*)x, (T*)y, s0, (double*)nullptr, g, cf);

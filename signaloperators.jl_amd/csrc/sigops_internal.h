@@ -144,6 +144,11 @@ struct SosGeom {
     int32_t exact;   // 1: one chunk, DSP.jl's order of operations without fused multiply-adds (ill-conditioned cascades)
     int64_t in_pitch, out_pitch;  // elements between channels
     int64_t store_lo;             // pass 3 stores frames >= store_lo only (warm-up frames of a windowed result)
+    // pass 3's tile steps start on the RESULT's cache lines (a row's first step begins up to 15 frames before its
+    // chunk; those columns are skipped): whole-line stores for results whose channel rows sit at any multiple of
+    // 8 bytes, as the columns of an n x c Array do.  Chunk borders, and so every rounding, are unaffected.  0: off.
+    int32_t align_rows;
+    int32_t pad_;
     // fused sine source (k_sos_tiled): the input is x[n] (+|*) sinpi(2((n + src_df + 1)/fs * omega + phi)) --
     // `Mix` / `Amplify` of an array with `Signal(sin)` formed in the filter's own loads
     int32_t src_op;               // 0 none, 1 add, 2 multiply

@@ -172,3 +172,43 @@ def test_batched_plan_follows_its_result_and_its_arrays():
         torch.cuda.synchronize()
         assert relerr(np.asfortranarray(dst.t().cpu().numpy()), want2) <= 1e-9
     p.close()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("off,pad", [(0, 0), (1, 0), (3, 5), (0, 7), (5, 15), (2, 29)])
+def test_result_rows_off_the_cache_line(dt, off, pad):
+    """the output pass starts its tile steps on the result's 128-byte lines (SosGeom::align_rows): a device result
+    whose channel rows start `off` elements into an allocation at a stride of n + pad -- any alignment the columns
+    of a Julia Array can have -- against the oracle, and bit for bit against the unaligned steps
+    (SIGOPS_SOS_NOALIGN): the chunk borders, and with them every rounding, do not move"""
+    import torch
+    rng = np.random.default_rng(40 + off + pad)
+    n, nch = 70001, 5
+    x = _noise(rng, n, nch, dt)
+    tree = so.Signal(x, 44.1 * so.kHz) | so.Filt(so.Bandpass, 1 * so.kHz, 3 * so.kHz) | so.After(100 * so.frames)
+    with oracle_semantics("intended"):
+        want = oracle_sink(tree)
+    m = want.shape[0]
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    res = []
+    for env in (None, "1"):
+        if env:
+            os.environ["SIGOPS_SOS_NOALIGN"] = env
+        try:
+            flat = torch.full((off + nch * (m + pad) + 64,), float("nan"), dtype=tdt, device="cuda")
+            p = so.Plan(so.ToChannels(tree, nch), (m, nch), dt, (1, m + pad), True)
+            p.execute(flat.data_ptr() + off * flat.element_size(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            p.close()
+        finally:
+            os.environ.pop("SIGOPS_SOS_NOALIGN", None)
+        host = flat.cpu().numpy()
+        got = np.stack([host[off + c * (m + pad): off + c * (m + pad) + m] for c in range(nch)], axis=1)
+        # nothing outside the rows was touched
+        mask = np.ones(host.shape, bool)
+        for c in range(nch):
+            mask[off + c * (m + pad): off + c * (m + pad) + m] = False
+        assert np.all(np.isnan(host[mask]))
+        assert relerr(got, want) <= (1e-9 if dt == np.float64 else 2e-6)
+        res.append(got)
+    assert np.array_equal(res[0], res[1])

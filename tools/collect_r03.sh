@@ -12,7 +12,9 @@ python3 bench.py --dtype f32 --steps 200 --warmup 30 --cpu-seconds 0 > $S/bench_
 python3 bench.py --workload config3 --dtype f32 --steps 200 --warmup 30 --cpu-seconds 0 > $S/bench_config3_f32.json 2>/dev/null
 python3 bench.py --workload config4 --steps 100 --warmup 20 > $S/bench_config4_1gpu.json 2>/dev/null
 SIGOPS_SOS_NOSRC=1 python3 bench.py --workload config4 --steps 100 --warmup 20 > $S/bench_config4_1gpu_nosrc.json 2>/dev/null
+SIGOPS_SOS_NOBATCH=1 python3 bench.py --workload config4 --steps 100 --warmup 20 > $S/bench_config4_1gpu_nobatch.json 2>/dev/null
 python3 bench.py --workload config5 --steps 50 --warmup 10 > $S/bench_config5_slab.json 2>/dev/null
+SIGOPS_RS_NOQ1=1 python3 bench.py --workload config5 --steps 50 --warmup 10 > $S/bench_config5_slab_noq1.json 2>/dev/null
 python3 bench_configs.py > $S/bench_configs.jsonl 2>/dev/null
 python3 tools/bench_rtc.py > $S/bench_rtc.jsonl 2>/dev/null
 python3 tools/plan_timing.py > $S/plan_timing.jsonl 2>/dev/null
