@@ -167,7 +167,7 @@ void Plan::finalize() {
             continue;
         }
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
-        const char* nm = S.kind == ST_SOS ? (S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? "k_resample_tiled" : "k_resample") : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? (S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
@@ -632,8 +632,12 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsTiled rt = S.rt;
                         rt.g.in_pitch = in_pitch;
                         rt.g.out_pitch = ob.pitch;
-                        launch_resample_tiled(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
-                                              (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
+                        if (rt.pair)
+                            launch_resample_tiled2(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
+                                                  (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
+                        else
+                            launch_resample_tiled(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
+                                                  (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
                     } else
                         launch_resample(inp, ob.d, (const double*)P->bufs[S.pfb_buf].d,
                                         (const double*)P->bufs[S.dpfb_buf].d, g, st);

@@ -1,39 +1,9 @@
 // Hand-written HIP kernels for gfx950 (MI355X, CDNA4; wave64).  No CUDA shims, no dual paths.
 // K3 k_resample*: polyphase FIR resampler (reference src/reformatting.jl:92-98, src/filters.jl:248-255)
 #include "kcommon.h"
+#include "krespos.h"
 
 namespace so {
-
-// ---------------------------------------------------------------------------
-// K3: polyphase resampler.  Output m sits at fine-grid position q_m (SURVEY.md
-// Appendix A): j = newest input, p = phase, alpha = fractional phase;
-//   y[m] = sum_k pfb[p][k] x[j-k]  +  alpha * sum_k dpfb[p][k] x[j-k]
-// (DSP.jl FIRArbitrary: yLower + yUpper*alpha; rational kernels have alpha == 0).
-// Position arithmetic is bit-exact with the oracle: two separately rounded fp64
-// operations (no FMA contraction) or pure int64.
-__device__ __forceinline__ void rs_pos(const RsGeom& g, int64_t m, int64_t& j, int& p,
-                                       double& alpha) {
-    if (g.arbitrary && g.exact) {
-        const int64_t N = m * ((int64_t)g.nphi * g.M);
-        const int64_t qi = g.c0i + N / g.L;
-        alpha = __ddiv_rn((double)(N % g.L), (double)g.L);
-        j = qi / g.nphi;
-        p = (int)(qi % g.nphi);
-    } else if (g.arbitrary) {
-        const double t = __dmul_rn((double)m, g.delta);
-        const double q = __dadd_rn(g.c0, t);
-        const double fl = floor(q);
-        const int64_t qi = (int64_t)fl;
-        alpha = q - fl;
-        j = qi / g.nphi;
-        p = (int)(qi % g.nphi);
-    } else {
-        const int64_t qi = g.c0i + m * g.M;
-        alpha = 0.0;
-        j = qi / g.L;
-        p = (int)(qi % g.L);
-    }
-}
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_resample(const T* __restrict__ x,

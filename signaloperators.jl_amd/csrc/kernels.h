@@ -32,6 +32,7 @@ void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs&
 void launch_resample(const void* x, void* y, const double* pfb, const double* dpfb,
                      const RsGeom& g, hipStream_t st);
 // pfbt / dpfbt: polyphase tables transposed to [taps][nphi]
+void launch_resample_tiled2(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g, hipStream_t st);
 void launch_resample_tiled(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
                            hipStream_t st);
 // returns 0 when launched, -1 when no instantiation fits the geometry

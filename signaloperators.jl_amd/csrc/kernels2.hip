@@ -10,6 +10,7 @@
 
 #include "../../include/sigops.h"
 #include "kernels.h"
+#include "krespos.h"
 #include "sigops_internal.h"
 
 namespace so {
@@ -222,6 +223,184 @@ int launch_sos_xscan(const double* v, double* s0, const double* mats, double* sb
     default: launch_xs_t<8>(v, s0, mats, sblk, g, st); break;
     }
     return 3;
+}
+
+
+// ---------------------------------------------------------------------------
+// K3t2: the tiled resampler for rates without a usable period (k_resample_tiled, k_resample.hip), two outputs per
+// lane.  The one-output form reads two table values and ct inputs from LDS per tap for 2 ct multiply-adds and is
+// bound by those reads (38 taps x 10 reads per output of 8 channels: 0.27 ms of LDS time in its 0.57 ms on a quarter
+// of config 3 at x pi/3).  A lane that owns outputs m and m + 1 walks the union of their input windows once: an input
+// (ct LDS reads) serves both outputs, each with the tap it has in THAT output's filter (four table reads), 12 reads
+// for 4 ct multiply-adds.  Taps outside an output's window are read from a row of zeros on either side of the table
+// (index clamped, not selected), so every output still adds its own taps oldest first: the same sums as the
+// one-output form, bit for bit, on finite inputs (a NaN or Inf next to a window meets a zero weight: it reaches the
+// one or two outputs beside those the reference puts it in).
+// Measured (26 460 000 / 4 x 8 frames at x pi/3): 0.569 -> 0.487 ms, of which staging 0.14 ms, the result's stores
+// 0.10 ms and the tap loop 0.26 ms (its multiply-adds alone: 0.11) -- the phases of the two workgroups of a CU do
+// not overlap (they start together and stay in step).
+// (The matrix cores are no help here: v_mfma_f64_16x16x4 runs at the vector rate on this chip, 64 cycles, and a
+//  banded weight matrix over 8 of 16 rows wastes four fifths of it -- built and measured: 0.65 ms.)
+constexpr int kT2Threads = 512;  // eight waves share a staged tile (two workgroups per CU: four waves per SIMD)
+
+// The staged inputs are kept as doubles, frame by frame: the CT channels of a frame side by side (16-byte reads with
+// immediate offsets, no address arithmetic per channel) in rows of CT + 2 doubles -- with 16 bytes per lane a
+// quarter wave reads at a time, and 80-byte (48-byte) rows put its 16 lanes on 16 different bank groups.
+template <int CT>
+struct T2Row {
+    static constexpr int pitch = CT >= 2 ? CT + 2 : 1;
+};
+
+template <typename T, int CT>
+__global__ __launch_bounds__(kT2Threads) void k_resample_tiled2(const T* __restrict__ x, T* __restrict__ y,
+                                                                const double* __restrict__ pfbt,
+                                                                const double* __restrict__ dpfbt, RsTiled g) {
+    constexpr int FP = T2Row<CT>::pitch;
+    extern __shared__ double lds_raw[];
+    const int taps = g.g.taps, nphi = g.g.nphi;
+    // tables as [tap + 1][phase], a row of zeros before tap 0 and one after the last
+    double* const tp = lds_raw;
+    double* const td = tp + (size_t)(taps + 2) * nphi;
+    double* const xs = td + (size_t)(taps + 2) * nphi;
+    const int tid = threadIdx.x;
+    const bool arb = g.g.arbitrary != 0;
+    for (int i0 = tid; i0 < (taps + 2) * nphi; i0 += 4 * kT2Threads) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kT2Threads - nphi;  // row -1 and row taps: zeros
+            const bool real = i >= 0 && i < taps * nphi;
+            a[u] = real ? pfbt[i] : 0.0;
+            b[u] = (real && arb) ? dpfbt[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kT2Threads;
+            if (i < (taps + 2) * nphi) {
+                tp[i] = a[u];
+                td[i] = b[u];
+            }
+        }
+    }
+    const int64_t tx = (int64_t)blockIdx.x % g.ntiles, tc = (int64_t)blockIdx.x / g.ntiles;
+    const int c0 = (int)tc * CT;
+    const int64_t m0 = tx * g.tile_out;
+    const int64_t m1 = m0 + g.tile_out < g.g.n_out ? m0 + g.tile_out : g.g.n_out;
+    int64_t j0, j1;
+    int p;
+    double alpha;
+    rs_pos(g.g, g.g.m0 + m0, j0, p, alpha);
+    rs_pos(g.g, g.g.m0 + m1 - 1, j1, p, alpha);
+    constexpr int kLeft = 8;  // frames staged before the first window: the union window of a pair starts up to
+                              // (wave maximum of j_B - j_A) - (its own) frames before its first output's
+    const int64_t xlo = j0 - (taps - 1) - kLeft;  // global input frame of LDS frame 0
+    const int nfr = (int)(j1 - xlo + 1);          // <= tile_in by the planner's choice of tile_out
+    // staging: eight loads in flight per thread (consecutive lanes read consecutive frames of a channel)
+    {
+        const int total = CT * nfr;
+        for (int e0 = tid; e0 < total; e0 += 8 * kT2Threads) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kT2Threads;
+                const int c = e / nfr, i = e - c * nfr;
+                const int64_t n = xlo + i;
+                v[u] = (e < total && n >= 0 && n < g.g.n_in) ? (double)x[(int64_t)(c0 + c) * g.g.in_pitch + n] : 0.0;  // Pad(x.signal, zero), src/filters.jl:240
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kT2Threads;
+                const int c = e / nfr, i = e - c * nfr;
+                if (e < total) xs[i * FP + c] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int tdo = (taps + 2) * nphi;
+    for (int64_t ma = m0 + 2 * tid; ma < m1; ma += 2 * kT2Threads) {
+        const bool two = ma + 1 < m1;
+        int64_t jA, jB;
+        int pA, pB;
+        double alA, alB;
+        rs_pos(g.g, g.g.m0 + ma, jA, pA, alA);
+        rs_pos(g.g, g.g.m0 + (two ? ma + 1 : ma), jB, pB, alB);
+        const int d = (int)(jB - jA);  // 0, 1, 2 ... : how much later output B's window ends
+        int dmax = d;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+        const double* const tA = tp + nphi + pA;  // tA[k * nphi]: tap k of output A's phase, k = -1 .. taps
+        const double* const tB = tp + nphi + pB;
+        double loA[CT], hiA[CT], loB[CT], hiB[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) loA[c] = hiA[c] = loB[c] = hiB[c] = 0.0;
+        // q = distance from the pair's newest input, oldest first; tap of that input: q in B's filter, q - d in A's
+        const int q0 = taps - 1 + dmax;
+        const double* __restrict__ xf = xs + ((int)(jB - xlo) - q0) * FP;  // the oldest frame of the union window
+        for (int q = q0; q >= 0; --q, xf += FP) {
+            const int kA = min(max(q - d, -1), taps) * nphi, kB = min(q, taps) * nphi;
+            const double fA = tA[kA], fB = tB[kB];
+            const double gA = arb ? tA[kA + tdo] : 0.0, gB = arb ? tB[kB + tdo] : 0.0;
+            double xv[CT];
+            if constexpr (CT >= 2) {
+#pragma unroll
+                for (int c = 0; c < CT; c += 2) {
+                    const double2 w2 = *reinterpret_cast<const double2*>(xf + c);
+                    xv[c] = w2.x;
+                    xv[c + 1] = w2.y;
+                }
+            } else
+                xv[0] = xf[0];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                loA[c] += fA * xv[c];
+                hiA[c] += gA * xv[c];
+                loB[c] += fB * xv[c];
+                hiB[c] += gB * xv[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const double rA = arb ? loA[c] + hiA[c] * alA : loA[c];
+            const double rB = arb ? loB[c] + hiB[c] * alB : loB[c];
+            T* o = y + (int64_t)(c0 + c) * g.g.out_pitch + ma;
+            o[0] = (T)rA;
+            if (two) o[1] = (T)rB;
+        }
+    }
+}
+
+template <typename T>
+static void launch_resample_tiled2_t(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,
+                                     hipStream_t st) {
+    const size_t ldsb = ((size_t)2 * (g.g.taps + 2) * g.g.nphi * 8 + (size_t)(g.ct >= 2 ? g.ct + 2 : 1) * g.tile_in * 8 + 15) / 16 * 16;
+    const unsigned grid = (unsigned)(g.ntiles * (g.g.nch / g.ct));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : (dev > 63 ? 63 : dev);
+#define SO_RT2(CTV)                                                                                                       \
+    {                                                                                                                     \
+        static bool seen[64];                                                                                             \
+        if (!seen[dev]) { /* (per device: a process may drive several GPUs) */                                            \
+            (void)hipFuncSetAttribute((const void*)k_resample_tiled2<T, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                        \
+            seen[dev] = true;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_resample_tiled2<T, CTV>), dim3(grid), dim3(kT2Threads), ldsb, st, (const T*)x, (T*)y, pfbt, \
+                           dpfbt, g);                                                                                     \
+    }
+    switch (g.ct) {
+    case 8: SO_RT2(8) break;
+    case 4: SO_RT2(4) break;
+    case 2: SO_RT2(2) break;
+    default: SO_RT2(1) break;
+    }
+#undef SO_RT2
+}
+
+void launch_resample_tiled2(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g, hipStream_t st) {
+    if (g.g.n_out <= 0) return;
+    if (g.g.in_dtype == SO_F32) launch_resample_tiled2_t<float>(x, y, pfbt, dpfbt, g, st);
+    else launch_resample_tiled2_t<double>(x, y, pfbt, dpfbt, g, st);
 }
 
 }  // namespace so

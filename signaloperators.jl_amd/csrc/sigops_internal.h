@@ -218,6 +218,8 @@ struct RsTiled {
     int32_t tile_in;   // input frames per channel the LDS tile can hold
     int32_t pitch;     // LDS elements between channel rows
     int64_t ntiles;    // tiles along time
+    int32_t pair;      // 1: k_resample_tiled2 (two outputs per lane)
+    int32_t pad_;
 };
 
 // DSP.jl's FIRArbitrary positions its outputs with a floating-point phase accumulator

@@ -639,9 +639,12 @@ void Plan::process_stage(int sid) {
             for (; ct >= 1; ct >>= 1) {
                 if (N.nch % ct) continue;
                 // two workgroups per CU when the tables allow it (their staging and arithmetic overlap)
-                size_t budget = tabs <= (size_t)24 * 1024 ? (size_t)78 * 1024 - tabs : (size_t)150 * 1024 - std::min<size_t>(tabs, 150 * 1024);
-                int64_t tile_in = (int64_t)(budget / ((size_t)ct * esz_t));
-                int64_t tile_out = (int64_t)std::floor((double)(tile_in - g.taps - 4) / step);
+                size_t budget = tabs <= (size_t)24 * 1024 ? (size_t)77 * 1024 - tabs - (size_t)2 * (g.taps + 2 * g.nphi + 2) * 8 : (size_t)150 * 1024 - std::min<size_t>(tabs, 150 * 1024);
+                // (the two-outputs-per-lane form keeps the tile as doubles, frame by frame, in rows of ct + 2)
+                const bool pair = step <= 6.0 && !std::getenv("SIGOPS_RS_NOPAIR");  // (the windows of a pair within 8 frames)
+                const size_t frame_bytes = pair ? (size_t)(ct >= 2 ? ct + 2 : 1) * 8 : (size_t)ct * esz_t;
+                int64_t tile_in = (int64_t)(budget / frame_bytes);
+                int64_t tile_out = (int64_t)std::floor((double)(tile_in - g.taps - 24) / step);  // (k_resample_tiled2 stages 8 frames before the first window)
                 tile_out = std::min<int64_t>(tile_out, 4096);
                 if (tabs <= (size_t)100 * 1024 && tile_out >= 128) {
                     RsTiled rt{};
@@ -651,6 +654,7 @@ void Plan::process_stage(int sid) {
                     rt.tile_in = (int32_t)tile_in;
                     rt.pitch = (int32_t)(tile_in | 1);
                     rt.ntiles = (need + tile_out - 1) / tile_out;
+                    rt.pair = pair;
                     stages[sid].tiled = true;
                     stages[sid].rt = rt;
                     stages[sid].pfbt_host.assign((size_t)g.taps * g.nphi, 0.0);
@@ -1228,7 +1232,9 @@ void Plan::batch_sos_stages() {
     std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
     for (int sid : order) {
         const Stage& S = stages[sid];
-        if (S.kind != ST_SOS || S.onepass || S.sg.exact || S.xscan || S.pre_stage >= 0 || S.groups.size() != 1 ||
+        // (not below a Normpower: such a filter keeps every chunk in its scan, or the exact block scan, by its OWN
+        //  chunk count -- sos_chunking -- which the batch would change)
+        if (S.kind != ST_SOS || S.onepass || S.sg.exact || S.xscan || S.under_norm || S.pre_stage >= 0 || S.groups.size() != 1 ||
             S.in_array_node < 0 || S.pw_step >= 0 || S.sg.nchunks < 1)
             continue;
         kinds[{S.groups[0].nsec, nodes[S.node].dtype}].push_back(sid);

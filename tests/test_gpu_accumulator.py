@@ -117,3 +117,44 @@ def test_tiled_resampler_equals_the_thread_per_output_kernel(monkeypatch):
     monkeypatch.setenv("SIGOPS_RS_NOTILED", "1")
     b = so.sink(tree)[0]
     assert relerr(a, b) < 1e-13
+
+
+@pytest.mark.parametrize("fs_in,fs_out,nch,n,dt", [
+    (1000.0, 1000.0 * np.pi, 8, 70000, np.float64),       # benchmarks.jl "resampling-irrational", eight channels
+    (1000.0, 1000.0 * np.pi / 3, 16, 50000, np.float64),  # two channel groups
+    (1000.0, 1000.0 * np.pi, 2, 40000, np.float64),
+    (44100.5, 48000.0, 3, 60000, np.float64),              # non-integer frame rate, one channel per workgroup
+    (1000.0, 1000.0 / np.e, 8, 90000, np.float32),         # down, Float32 samples
+    (48000.0, 44100.5, 24, 30000, np.float32),
+    (48000.0, 9000.5, 4, 90000, np.float64),               # x 0.19: the windows of a pair five or six frames apart
+    (999.0, 16000.0, 8, 9000, np.float64),                 # x 16: many outputs per input
+    (22050.0, 22050.0 * np.sqrt(2), 8, 2101, np.float64)])  # barely more than one tile, odd length
+def test_two_outputs_per_lane_form_of_the_tiled_resampler(fs_in, fs_out, nch, n, dt, monkeypatch):
+    """k_resample_tiled2 (kernels2.hip): a lane walks the union of the input windows of two neighbouring outputs --
+    against the oracle (DSP.jl FIRArbitrary: yLower + alpha * yUpper per output), and bit for bit against the
+    one-output form of the same tiles (SIGOPS_RS_NOPAIR): every output adds its own taps in the same order"""
+    rng = np.random.default_rng(206)
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(dt))
+    tree = so.Signal(x, fs_in * so.Hz) | so.ToFramerate(fs_out * so.Hz) | so.After(37 * so.frames)
+    got = so.sink(tree)[0]
+    want = oracle_sink(tree)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
+    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 2e-6) * np.abs(want).max()
+    monkeypatch.setenv("SIGOPS_RS_NOPAIR", "1")
+    one = so.sink(tree)[0]
+    assert np.array_equal(got, one)
+
+
+def test_two_outputs_per_lane_form_is_the_one_that_runs():
+    import torch
+    x = torch.randn((8, 100000), dtype=torch.float64, device="cuda")
+    tree = so.Signal(x.t(), 1000 * so.Hz) | so.ToFramerate(1000 * np.pi * so.Hz)
+    n = so.nframes(tree)
+    out = torch.empty((8, n), dtype=torch.float64, device="cuda")
+    p = so.Plan(so.ToChannels(tree, 8), (n, 8), np.float64, (1, n), True)
+    p.set_profiling(True)
+    p.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert [s["name"] for s in p.steps()] == ["k_resample_tiled2"]
+    p.close()

@@ -26,4 +26,8 @@ for env in ("", "1"):
     algo = 8 * nch * (n + n_out)
     print(json.dumps({"kernel": "k_resample" if env else "k_resample_tiled", "in_frames": n, "out_frames": n_out, "channels": nch,
                       "ms": ms, "algorithmic_GBps": algo / ms / 1e6, "frac_of_8TBps": algo / ms / 1e6 / 8000}))
+    plan.set_profiling(True)
+    for _ in range(3):
+        plan.execute(out.data_ptr(), st); torch.cuda.synchronize()
+    print("   steps:", [(s_["name"], round(s_["ms"], 4), s_["launches"]) for s_ in plan.steps()])
     plan.close()
