@@ -275,6 +275,14 @@ int64_t so_plan_counter(const so_plan_t* plan, int32_t which);
  * it for every pointwise step); reference shape: one loop per map nest, src/mapsignal.jl:249-272. */
 int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity);
 
+/* Large pointwise steps the interpreter CAN run are specialised too, but never at the caller's expense: the plan
+ * uses the specialised kernel if this process or the on-disk cache of code objects ($SIGOPS_CACHE_DIR, default
+ * $XDG_CACHE_HOME/sigops-hip or ~/.cache/sigops-hip; an empty SIGOPS_CACHE_DIR disables it) has it, otherwise it
+ * keeps the interpreter -- same values, operation for operation -- while a background thread compiles the kernel
+ * for the plans to come.  so_rtc_wait_idle returns when every compile queued so far has finished (a service
+ * warming up; tests).  SIGOPS_RTC_NOASYNC=1 switches the background path off. */
+int32_t so_rtc_wait_idle(void);
+
 /* When enabled, so_plan_execute brackets every kernel with hipEvents (on the stream
  * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default.
  *   enable = 1: every execute synchronises the stream and reads its own events;

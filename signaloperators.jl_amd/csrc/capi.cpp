@@ -84,6 +84,11 @@ int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity) 
     return st == 0 ? SO_OK : set_err(SO_ERR_UNSUPPORTED, err);
 }
 
+int32_t so_rtc_wait_idle(void) {
+    so::rtc_wait_idle();
+    return SO_OK;
+}
+
 int64_t so_plan_counter(const so_plan_t* plan, int32_t which) {
     if (!plan) return -1;
     return so::plan_counter(plan->p, which);

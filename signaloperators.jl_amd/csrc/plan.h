@@ -21,6 +21,7 @@ int resample_positions(double fs_in, double fs_out, double rate, int nphi, const
                        int64_t n_out, int64_t* j, int32_t* p, double* alpha, int64_t* nfix, int64_t* nbaked);
 
 int rtc_compile_check(const std::string& body, std::string& err);  // rtc.cpp
+void rtc_wait_idle();                                                // rtc.cpp
 
 struct Plan;
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,

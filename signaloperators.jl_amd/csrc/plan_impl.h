@@ -408,6 +408,8 @@ Mat matpow(Mat A, int64_t e, int D);
 
 // ---- rtc.cpp ----
 const void* rtc_kernel(const std::string& body, int device, std::string& err);
+const void* rtc_kernel_if_ready(const std::string& body, int device);
+void rtc_wait_idle();
 int rtc_compile_check(const std::string& body, std::string& err);
 int rtc_launch(const void* fn, int64_t nblocks, const DPiece* d_pieces, int npieces, const DLeaf* d_leaves, OutView out,
                hipStream_t st);

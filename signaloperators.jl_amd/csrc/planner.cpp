@@ -842,12 +842,17 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
             over = over || depth(p.e) > kStackDepth || frame_slots(p.e) > kMaxFrameSlots;
         }
         const bool want = np > 0 && np <= 32 && (mode == 1 || (mode == 2 && over && elems >= (1 << 20)));
-        if (want && !dry) {
+        // ... and big steps the interpreter can run as they are: the specialised kernel if it is already there (this
+        // process, or the code objects on disk), else the interpreter now and a background compile for later plans
+        // (the straight-line form runs 12-20 % faster on Float64 maps, 20-45 % on Float32 ones: tools/k1_probe.py)
+        const bool later = !want && mode == 2 && np > 0 && np <= 32 && elems >= (1 << 22) && !std::getenv("SIGOPS_RTC_NOASYNC");
+        if ((want || later) && !dry) {
             const size_t leaves_before = leaves.size();
             std::string err;
             try {
                 const std::string src = rtc_source(ps);
-                rtc_fn = rtc_kernel(src, device, err);
+                rtc_fn = want ? rtc_kernel(src, device, err) : rtc_kernel_if_ready(src, device);
+                if (!rtc_fn && later) err = "not compiled yet (queued)";
             } catch (const PlanError& e) {
                 err = e.msg;
             }
