@@ -266,6 +266,11 @@ lower_node!(lw, x::NormedSignal) = push_node!(lw, x, NORMPOWER; kids=Int32[lower
 
 check(st) = st == 0 || error(unsafe_string(ccall((:so_last_error, libsigops), Cstring, ())))
 
+# Large map nests are specialised by hipRTC off the caller's path (first sink of a shape: interpreter kernel; later
+# sinks, and later sessions through ~/.cache/sigops-hip: the compiled one, same values).  A long-running service
+# can wait for the queue once it has seen its workload:
+warmup_done() = check(ccall((:so_rtc_wait_idle, libsigops), Int32, ()))
+
 # The method the engine plugs into: reference src/sink.jl:225-226 dispatch point.
 function SignalOperators.sink!(result::HIPSink{T}, x, ::IsSignal) where T
     lw = Lowering()
