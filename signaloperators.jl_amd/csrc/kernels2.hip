@@ -317,8 +317,12 @@ __global__ __launch_bounds__(kT2Threads) void k_resample_tiled2(const T* __restr
     }
     __syncthreads();
     const int tdo = (taps + 2) * nphi;
-    for (int64_t ma = m0 + 2 * tid; ma < m1; ma += 2 * kT2Threads) {
-        const bool two = ma + 1 < m1;
+    // (whole waves stay in the loop -- the wave maximum below reads every lane --; lanes past the tile's end work on
+    //  its last output and store nothing)
+    for (int64_t mw = m0 + 2 * (tid & ~63); mw < m1; mw += 2 * kT2Threads) {
+        const int64_t ma_ = mw + 2 * (tid & 63);
+        const bool one = ma_ < m1, two = ma_ + 1 < m1;
+        const int64_t ma = one ? ma_ : m1 - 1;
         int64_t jA, jB;
         int pA, pB;
         double alA, alB;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(kT2Threads) void k_resample_tiled2(const T* __restr
             const double rA = arb ? loA[c] + hiA[c] * alA : loA[c];
             const double rB = arb ? loB[c] + hiB[c] * alB : loB[c];
             T* o = y + (int64_t)(c0 + c) * g.g.out_pitch + ma;
-            o[0] = (T)rA;
+            if (one) o[0] = (T)rA;
             if (two) o[1] = (T)rB;
         }
     }
