@@ -238,7 +238,9 @@ int launch_sos_xscan(const double* v, double* s0, const double* mats, double* sb
 // one or two outputs beside those the reference puts it in).
 // Measured (26 460 000 / 4 x 8 frames at x pi/3): 0.569 -> 0.487 ms, of which staging 0.14 ms, the result's stores
 // 0.10 ms and the tap loop 0.26 ms (its multiply-adds alone: 0.11) -- the phases of the two workgroups of a CU do
-// not overlap (they start together and stay in step).
+// not overlap (they start together and stay in step).  A persistent form that prefetches the next tile into registers
+// was built and is slower: 12 more doubles per thread push the 8-channel kernel from 108 to 155 VGPRs -- one
+// workgroup per CU instead of two (0.59 ms) -- or, capped at 128, spill the prefetch itself (0.68 ms).
 // (The matrix cores are no help here: v_mfma_f64_16x16x4 runs at the vector rate on this chip, 64 cycles, and a
 //  banded weight matrix over 8 of 16 rows wastes four fifths of it -- built and measured: 0.65 ms.)
 constexpr int kT2Threads = 512;  // eight waves share a staged tile (two workgroups per CU: four waves per SIMD)
