@@ -607,3 +607,31 @@ def test_filter_forms_mix_with_a_sine_in_its_own_loads(nch, n, build, monkeypatc
     monkeypatch.setenv("SIGOPS_SOS_NOSRC", "1")
     ref = so.sink(tree, so.Array)
     assert relerr(res, ref) < 1e-10
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", ["mix2", "mix3", "amp_of_mix", "mixed_types", "gain_and_arrays", "four_arrays"])
+def test_maps_over_several_arrays(dt, shape, monkeypatch):
+    """`Mix(a, b)`, `Amplify(Mix(a, b), c)` ...: maps over two to four arrays, Float32 arithmetic rounded per operation
+    (reference src/mapsignal.jl:249-272 evaluates every child per frame) -- against the oracle, and the specialised
+    (hipRTC) form of the same step bit for bit against the interpreter.  (A chain-path form of K1 with array operands
+    -- all of a batch's loads in flight together -- was built in round 3 and measured SLOWER than the interpreter:
+    Mix(a, b) 3.6-4.0 against 4.65 TB/s at 156-204 VGPRs; removed.)"""
+    rng = np.random.default_rng(77)
+    n, nch = 70001, 3
+    mk = lambda d=dt: so.Signal(np.asfortranarray(rng.standard_normal((n, nch)).astype(d)), 44.1 * so.kHz)
+    a, b, c, d = mk(), mk(), mk(), mk()
+    tone = so.Signal(so.sin, 44.1 * so.kHz, ω=440 * so.Hz) | so.Until(n * so.frames)
+    tree = {"mix2": lambda: so.Mix(a, b),
+            "mix3": lambda: so.Mix(a, b, c),
+            "amp_of_mix": lambda: so.Amplify(so.Mix(a, b), c),
+            "mixed_types": lambda: so.Mix(a, mk(np.float32 if dt == np.float64 else np.float64)),
+            "gain_and_arrays": lambda: so.Amplify(so.Mix(a, tone), b) | so.Ramp(20 * so.ms),
+            "four_arrays": lambda: so.Mix(a, b, c, d)}[shape]() | so.After(13 * so.frames) | so.Until(60001 * so.frames)
+    got = so.sink(tree)[0]
+    want = oracle_sink(tree)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert relerr(got, want) <= (1e-12 if got.dtype == np.float64 else 1e-6)
+    monkeypatch.setenv("SIGOPS_RTC", "1")
+    special = so.sink(tree)[0]
+    assert np.array_equal(got, special)
