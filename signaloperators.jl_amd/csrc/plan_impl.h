@@ -364,6 +364,7 @@ struct Plan {
     void process_stage(int sid);
     int emit_pointwise(const std::vector<Piece>& ps, int out_buf, int out_dtype);
     std::string rtc_expr(int e, std::vector<int>& monos, bool in_mono);
+    std::vector<int>* rtc_loads = nullptr;  // rtc_source: the array leaves of the piece being written, read as frame pairs
     std::string rtc_source(const std::vector<Piece>& ps);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
     bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false);

@@ -844,7 +844,7 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
         const bool want = np > 0 && np <= 32 && (mode == 1 || (mode == 2 && over && elems >= (1 << 20)));
         // ... and big steps the interpreter can run as they are: the specialised kernel if it is already there (this
         // process, or the code objects on disk), else the interpreter now and a background compile for later plans
-        // (the straight-line form runs 12-20 % faster on Float64 maps, 20-45 % on Float32 ones: tools/k1_probe.py)
+        // (the straight-line form runs 15-20 % faster on Float64 maps, 1.6-2.1x on Float32 ones: tools/k1_probe.py)
         const bool later = !want && mode == 2 && np > 0 && np <= 32 && elems >= (1 << 22) && !std::getenv("SIGOPS_RTC_NOASYNC");
         if ((want || later) && !dry) {
             const size_t leaves_before = leaves.size();
