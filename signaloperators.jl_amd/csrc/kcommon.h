@@ -137,30 +137,37 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
                     const int64_t off = n[0] + L.df + choff;  // element index of the pair's first frame
                     const int par = __builtin_amdgcn_readfirstlane((int)off) & 1;
                     double v0, v1;
-                    bool done = false;
+                    // (global_load_*, and no flag between the load and its push: the samples are waited for where the
+                    //  next operation needs them, not here)
                     if (L.dtype == SO_F64) {
+                        const double __attribute__((address_space(1)))* pa = SO_GLOBAL_PTR(double, L.base) + off;
                         if (((((uintptr_t)L.base) >> 3) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 7) == 0) {
-                            const double2 v = *reinterpret_cast<const double2*>((const double*)L.base + off);
+                            const so_v2d v = *(const so_v2d __attribute__((address_space(1)))*)pa;
                             v0 = v.x;
                             v1 = v.y;
-                            done = true;
+                        } else {
+                            v0 = pa[0];
+                            v1 = pa[1];
                         }
-                    } else if (((((uintptr_t)L.base) >> 2) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 3) == 0) {
-                        const float2 v = *reinterpret_cast<const float2*>((const float*)L.base + off);
-                        v0 = (double)v.x;
-                        v1 = (double)v.y;
-                        done = true;
+                    } else {
+                        const float __attribute__((address_space(1)))* pa = SO_GLOBAL_PTR(float, L.base) + off;
+                        if (((((uintptr_t)L.base) >> 2) & 1) == (uintptr_t)par && ((uintptr_t)L.base & 3) == 0) {
+                            const so_v2f v = *(const so_v2f __attribute__((address_space(1)))*)pa;
+                            v0 = (double)v.x;
+                            v1 = (double)v.y;
+                        } else {
+                            v0 = (double)pa[0];
+                            v1 = (double)pa[1];
+                        }
                     }
-                    if (done) {
 #pragma unroll
-                        for (int d = D - 1; d > 0; --d) {
-                            st[d][0] = st[d - 1][0];
-                            st[d][1] = st[d - 1][1];
-                        }
-                        st[0][0] = v0;
-                        st[0][1] = v1;
-                        break;
+                    for (int d = D - 1; d > 0; --d) {
+                        st[d][0] = st[d - 1][0];
+                        st[d][1] = st[d - 1][1];
                     }
+                    st[0][0] = v0;
+                    st[0][1] = v1;
+                    break;
                 }
             }
             SO_PUSH(leaf_load(L, n[CV ? 0 : e], CV ? c + e : c));

@@ -12,6 +12,14 @@ namespace so {
 // in channel-vectorised evaluation, nothing else) lives per lane.  sf is -1/0/+1, so the
 // per-lane address math is one 64-bit add in the common planar case (no 64-bit multiplies,
 // which are quarter-rate on CDNA).
+// Array leaves live in global memory: reading them through address-space-1 pointers gives global_load_* instead of
+// flat_load_* (DLeaf::base is a `const void*`).  A FLAT load counts on lgkmcnt as well as vmcnt, so every wait for a
+// scalar load -- the interpreter's next program word, the next leaf's descriptor -- also waited for the samples just
+// requested: one memory round trip per operand, one after the other.
+#define SO_GLOBAL_PTR(T, p) ((const T __attribute__((address_space(1)))*)(p))
+typedef double so_v2d __attribute__((ext_vector_type(2)));
+typedef float so_v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
     int64_t f = L.df;
     if (L.sf > 0) f += n;
@@ -20,8 +28,8 @@ __device__ __forceinline__ double leaf_load(const DLeaf& L, int64_t n, int c) {
     //  into one piece per wrap with sf = +1 / -1: no integer division on the device)
     const int64_t choff = ((int64_t)L.sc * c + L.dc) * L.cstride;  // uniform
     const int64_t off = (L.fstride == 1 ? f : f * L.fstride) + choff;
-    if (L.dtype == SO_F32) return (double)((const float*)L.base)[off];
-    return ((const double*)L.base)[off];
+    if (L.dtype == SO_F32) return (double)SO_GLOBAL_PTR(float, L.base)[off];
+    return SO_GLOBAL_PTR(double, L.base)[off];
 }
 
 // Compact fp64 sin/cos kernels (Taylor on |t| <= 1/4 after exact octant reduction).  The
