@@ -635,10 +635,12 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
 #pragma unroll
                 for (int e = 0; e < V; ++e) val[c][e] = ok ? fill : 0.0;
         } else if (vec) {
-            const T* xp = (const T*)C.base + (int64_t)c0 * C.cstride + g0 + C.df;
+            // (global_load, not flat_load: a FLAT load also counts on lgkmcnt, which the LDS stores below and the LDS-DMA
+            //  ring wait on -- kleaf.h SO_GLOBAL_PTR)
+            const T __attribute__((address_space(1)))* xp = SO_GLOBAL_PTR(T, C.base) + (int64_t)c0 * C.cstride + g0 + C.df;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const vecT v = *reinterpret_cast<const vecT*>(xp + (int64_t)c * C.cstride);
+                const vecT v = *(const vecT __attribute__((address_space(1)))*)(xp + (int64_t)c * C.cstride);
 #pragma unroll
                 for (int e = 0; e < V; ++e) val[c][e] = (double)v[e];
             }
@@ -648,8 +650,8 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
                 double xv = 0.0;
                 if (ok) {
                     const int64_t off = (int64_t)(c0 + c) * C.cstride + g0 + C.df;
-                    xv = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
-                                           : ((const double*)C.base)[off];
+                    xv = C.dtype == SO_F32 ? (double)SO_GLOBAL_PTR(float, C.base)[off]
+                                           : SO_GLOBAL_PTR(double, C.base)[off];
                 }
 #pragma unroll
                 for (int e = 0; e < V; ++e) val[c][e] = xv;
@@ -1579,8 +1581,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_fix(RsFixArgs a) {
                         double val[1][1] = {{C.pad_ == 2 ? 1.0 : 0.0}};
                         if (C.base != nullptr) {
                             const int64_t off = (int64_t)c * C.cstride + n + C.df;
-                            val[0][0] = C.dtype == SO_F32 ? (double)((const float*)C.base)[off]
-                                                          : ((const double*)C.base)[off];
+                            val[0][0] = C.dtype == SO_F32 ? (double)SO_GLOBAL_PTR(float, C.base)[off]
+                                                          : SO_GLOBAL_PTR(double, C.base)[off];
                         }
                         if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
                         if (C.pad_ >= 3) val[0][0] += F[0][0];     // GA carrier, add: Float32 sample plus its Float64 operand
