@@ -339,7 +339,6 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
 //   jend [ngroups]           newest input of the group's window, relative to the period base
 // Operand maps (cdna_hip_programming.md §3): A[l&15][k=l>>4], B[k=l>>4][l&15],
 // D: col = l&15, row = (l>>4) + 4*reg.
-constexpr int kRsRows = 32;  // rows per tile = 2 MFMA row-tiles
 
 // v = v (op) F_k  chain of a carrier on a CT x V register block (wave-uniform control flow)
 // (CarT: DCarrier in memory, or StepTab in registers -- hence the fully unrolled, guarded loop:
