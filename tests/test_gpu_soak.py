@@ -256,3 +256,17 @@ def test_soak_sizes_around_the_planner_switch_points(nch, base):
             got = so.sink(t, so.Array)
             assert got.shape == want.shape, (nch, N, name)
             assert relerr(got, want) <= (2e-6 if dt == np.float32 else 1e-9), (nch, N, dt.__name__, name)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_soak_round3_paths(block):
+    """tools/soak_round3.py, ten seeds per block: batches of independent filters into device results at random row
+    offsets and strides, rates without a period at every channel-group width through windows, big maps over several
+    arrays before and after their background specialisation (3 700 checks of it ran clean on the final round-3 code)"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_round3.py")
+    spec = importlib.util.spec_from_file_location("soak_round3", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    checks, bad = mod.run(2000 + 10 * block, 2010 + 10 * block)
+    assert checks >= 20 and bad == 0
