@@ -129,8 +129,15 @@ static bool ga_fits(const Stage& S, int stage_dtype) {
     return ok;
 }
 
+// Sequences (chunks x channels) a three-pass cascade is cut into when the signal is long enough: two thirds of what
+// the chip runs at once (256 CUs x 12 waves x 64 rows = 196 608).  With 262 144 -- a round and a third -- the last third
+// ran on a mostly idle machine: the headline's K2 1.10 -> 1.01-1.02 ms (L 896 -> 1760), config 5's 1.94 -> 1.72, config
+// 4's batch 1.76 -> 1.70 (sweeps with SIGOPS_SOS_CHUNK; beyond that, fewer sequences lose again: 85 000 -> 1.32 ms, and
+// individual lengths swing by +-15 % with the row stride's place in the memory channels: 1024, 1376, 1600, 1664 are bad)
+constexpr int64_t kSosSequences = 131072;
+
 // Chunk geometry of a three-pass cascade: L frames per chunk, W warm-up frames of the state pass, K terms of
-// the scan, and the buffers they need.  `target`: chunks per channel that fill the machine -- 262144 / channels
+// the scan, and the buffers they need.  `target`: chunks per channel that fill the machine -- kSosSequences / channels
 // for a filter launched on its own, fewer and longer for the members of a batch (batch_sos_stages), which fill
 // it together.  `groups` may be the stage's own vector (re-chunking).
 void Plan::sos_chunking(int sid, int64_t need, int nch, int dtype, const std::vector<SosCoefs>& groups_in, bool exact, int64_t target) {
@@ -788,7 +795,7 @@ void Plan::process_stage(int sid) {
                 stages[sid].one_vpub_buf = raw_buf((size_t)o.ntiles * o.nch * 2 * kMaxSec * 8);
             }
         }
-        sos_chunking(sid, need, N.nch, N.dtype, groups, exact, 262144 / std::max(1, N.nch));
+        sos_chunking(sid, need, N.nch, N.dtype, groups, exact, kSosSequences / std::max(1, N.nch));
     } else {  // ST_NORM
         in_frames = need;
         int64_t total = need * N.nch;
@@ -1245,7 +1252,7 @@ void Plan::batch_sos_stages() {
         B.members = kv.second;
         B.nsec = kv.first.first;
         B.dtype = kv.first.second;
-        // the members fill the machine TOGETHER: chunks for 262144 sequences over all of them, not per member --
+        // the members fill the machine TOGETHER: chunks for kSosSequences sequences over all of them, not per member --
         // 64 two-channel scenes cut for themselves are 5.3 M sequences of 64 frames, and at that length the scan
         // (K = 64 terms of 64 multiply-adds per sequence) costs more than the filter it serves
         int64_t chans = 0;
@@ -1253,7 +1260,7 @@ void Plan::batch_sos_stages() {
         if (!std::getenv("SIGOPS_SOS_BATCH_KEEPCHUNKS"))
             for (int sid : B.members) {
                 Stage& S = stages[sid];
-                sos_chunking(sid, S.sg.n, S.sg.nch, nodes[S.node].dtype, S.groups, false, std::max<int64_t>(1, 262144 / chans));
+                sos_chunking(sid, S.sg.n, S.sg.nch, nodes[S.node].dtype, S.groups, false, std::max<int64_t>(1, kSosSequences / chans));
             }
         B.desc_buf = raw_buf((B.members.size() + 1) * sizeof(SosDesc));
         for (int sid : B.members) stages[sid].batch = (int)batches.size();
