@@ -129,11 +129,12 @@ static bool ga_fits(const Stage& S, int stage_dtype) {
     return ok;
 }
 
-// Sequences (chunks x channels) a three-pass cascade is cut into when the signal is long enough: two thirds of what
-// the chip runs at once (256 CUs x 12 waves x 64 rows = 196 608).  With 262 144 -- a round and a third -- the last third
-// ran on a mostly idle machine: the headline's K2 1.10 -> 1.01-1.02 ms (L 896 -> 1760), config 5's 1.94 -> 1.72, config
-// 4's batch 1.76 -> 1.70 (sweeps with SIGOPS_SOS_CHUNK; beyond that, fewer sequences lose again: 85 000 -> 1.32 ms, and
-// individual lengths swing by +-15 % with the row stride's place in the memory channels: 1024, 1376, 1600, 1664 are bad)
+// Sequences (chunks x channels) a three-pass cascade is cut into when the signal is long enough: 512 workgroups of 256
+// rows, two per CU, all resident at once (three fit) and finishing together.  The former 262 144 were 1 004 workgroups,
+// 3.9 per CU: a CU runs three at a time, so a quarter of them waited for a slot and ran on a draining machine.  Sweeps
+// with SIGOPS_SOS_CHUNK: the headline's K2 1.10 -> 1.01 ms (L 896 -> 1760), config 5's 1.94 -> 1.67, config 4's batch
+// 1.76 -> 1.70; a length that gives 8.1 waves per CU instead of 8.0 (L 1728) costs 20 %, 768 workgroups (three per CU,
+// L 1184) do as well as 512, fewer than 2 per CU lose again (L 2688: 1.32 ms).
 constexpr int64_t kSosSequences = 131072;
 
 // Chunk geometry of a three-pass cascade: L frames per chunk, W warm-up frames of the state pass, K terms of
