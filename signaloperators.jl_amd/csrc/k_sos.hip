@@ -90,7 +90,14 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     const int ch = live ? (int)(seq / nck) : 0;
     int64_t beg = (int64_t)k * g.chunk;
     int64_t end = beg + g.chunk < g.n ? beg + g.chunk : g.n;
-    if (!APPLY) beg = end - (g.warm < g.chunk ? g.warm : g.chunk);  // full chunks only: end = beg+L
+    // pass 1: the last min(L, W) frames of the chunk (full chunks only: end = beg + L), W rounded up to whole tile
+    // steps -- a row shorter than a step would be followed by zeros INSIDE the step, and the state keeps turning over
+    // them: a filter that forgets within 8 frames (W = 1 ... 8; a first-order Butterworth at fs/4 has its pole at 0)
+    // handed on the state of 16 - W frames later, i.e. nothing (tools/soak_kernels.py seed 10102: 7 % off)
+    if (!APPLY) {
+        const int64_t w16 = (g.warm + (kTT - 1)) / kTT * kTT;
+        beg = end - (w16 < g.chunk ? w16 : g.chunk);
+    }
     // Pass 3 stores whole cache lines whatever the alignment of the result's channel rows (SosGeom::align_rows): the
     // tile steps of a row start `head` frames BEFORE its chunk, where the result's 128-byte line starts (64-byte half
     // line of a Float32 result: a step is 16 frames wide); those columns are neither filtered nor stored, the chunk
