@@ -112,6 +112,90 @@ static double sos_rounding_sensitivity(const double* sos, int nsec, double gain)
     return r;
 }
 
+// ... and how far apart are the CHUNKED evaluation and the sequential one?  The probe above sees what a different
+// rounding of the same recurrence does; it does not see the state hand-over of the time-parallel form, s0[k+1] =
+// M s0[k] + v[k] with M = A^L by repeated squaring: for cascades with clustered poles (a band-stop whose upper edge is
+// at Nyquist: ten poles next to -1) the powers of the nearly defective A lose digits that the recurrence itself does
+// not -- 4e-5 between engine and oracle with a rounding sensitivity of 1e-8 (tools/soak_degenerate_filters.py).
+// Measured the same way: the cascade over a pseudo-random probe sequentially and in chunks of the planned length
+// (zero-state end states, Horner scan with the same M, outputs from the scanned states), both in Float64 with every
+// operation rounded on its own; norm-wise relative difference.  Cached per coefficient set and length.
+static double sos_chunk_sensitivity(const std::vector<SosCoefs>& groups, int64_t L, int64_t need) {
+    static std::mutex mu;
+    static std::map<std::vector<double>, double> cache;
+    std::vector<double> key;
+    for (auto& cf : groups) {
+        for (int f = 0; f < cf.nsec; ++f) {
+            key.push_back(cf.b0[f]); key.push_back(cf.b1[f]); key.push_back(cf.b2[f]);
+            key.push_back(cf.a1[f]); key.push_back(cf.a2[f]);
+        }
+        key.push_back(cf.gain);
+    }
+    key.push_back((double)L);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    const int64_t nchunks = std::min<int64_t>(48, (need + L - 1) / L);
+    const int64_t n = std::min<int64_t>(need, nchunks * L);
+    double worst = 0.0;
+    if (nchunks >= 2) {
+        std::vector<double> x((size_t)n), yseq((size_t)n), ychk((size_t)n);
+        uint64_t st = 2463534242ULL;
+        for (auto& v : x) {
+            st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+            v = (double)((st >> 11) & 0xFFFFFFFFFFFFFULL) / 4503599627370496.0 - 0.5;
+        }
+        for (auto& cf : groups) {  // (groups of a long cascade filter one after the other, each chunked on its own)
+            const int ns = cf.nsec, D = 2 * ns;
+            auto step = [&](double xin, std::vector<double>& sv) {
+                volatile double y = xin;
+                for (int f = 0; f < ns; ++f) {
+                    const double xi = y;
+                    volatile double t0 = cf.b0[f] * xi;
+                    y = sv[2 * f] + t0;
+                    volatile double t1 = cf.b1[f] * xi, t2 = cf.a1[f] * y, t3 = sv[2 * f + 1] + t1;
+                    sv[2 * f] = t3 - t2;
+                    volatile double t4 = cf.b2[f] * xi, t5 = cf.a2[f] * y;
+                    sv[2 * f + 1] = t4 - t5;
+                }
+                return (double)y;
+            };
+            std::vector<double> sv((size_t)D, 0.0);
+            for (int64_t i = 0; i < n; ++i) yseq[(size_t)i] = step(x[(size_t)i], sv) * cf.gain;
+            const Mat M = matpow(sos_state_matrix(cf), L, D);
+            std::vector<double> s0((size_t)D, 0.0), v((size_t)D), t((size_t)D);
+            for (int64_t k = 0; k * L < n; ++k) {
+                const int64_t a = k * L, b = std::min<int64_t>(n, a + L);
+                std::vector<double> run = s0;  // outputs from the scanned state
+                for (int64_t i = a; i < b; ++i) ychk[(size_t)i] = step(x[(size_t)i], run) * cf.gain;
+                std::fill(v.begin(), v.end(), 0.0);  // end state from rest
+                for (int64_t i = a; i < b; ++i) (void)step(x[(size_t)i], v);
+                for (int r = 0; r < D; ++r) {  // s0 <- M s0 + v (the device's Horner step)
+                    double acc = v[(size_t)r];
+                    for (int d = 0; d < D; ++d) acc = std::fma(M[(size_t)r * D + d], s0[(size_t)d], acc);
+                    t[(size_t)r] = acc;
+                }
+                s0 = t;
+            }
+            long double num = 0, den = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                const long double d = (long double)ychk[(size_t)i] - yseq[(size_t)i];
+                num += d * d;
+                den += (long double)yseq[(size_t)i] * yseq[(size_t)i];
+            }
+            double r = den > 0 ? (double)std::sqrt((double)(num / den)) : 0.0;
+            if (!std::isfinite(r)) r = 0.0;  // (an unstable design: nothing to protect)
+            worst = std::max(worst, r);
+            x = yseq;  // the next group filters this group's output
+        }
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = worst;
+    return worst;
+}
+
 // Can this periodic resampler stage run the GA instantiation (Float32 tiles, Float64 gain at the A
 // operand)?  Geometry the instantiations cover, and the LDS budget with three gain arrays.
 static bool ga_fits(const Stage& S, int stage_dtype) {
@@ -707,7 +791,19 @@ void Plan::process_stage(int sid) {
         {
             const char* ev = std::getenv("SIGOPS_SOS_EXACT");  // 1: always, 0: never (measurement aid)
             if (ev) exact = std::atoi(ev) != 0;
-            else exact = nsec >= 3 && sos_rounding_sensitivity(sos, nsec, nd.d0) > kSosExactTol;
+            else {
+                exact = nsec >= 3 && sos_rounding_sensitivity(sos, nsec, nd.d0) > kSosExactTol;
+                if (!exact && nsec >= 2) {  // ... or the chunked form itself, at the chunk length this signal would get
+                    const int64_t tgt = kSosSequences / std::max(1, N.nch);
+                    const int64_t nck = std::max<int64_t>(1, std::min<int64_t>(tgt, need / 64));
+                    const int64_t Lp = ((need + nck - 1) / nck + 31) / 32 * 32;
+                    const double cs = nck > 1 ? sos_chunk_sensitivity(groups, Lp, need) : 0.0;
+                    exact = cs > kSosExactTol;
+                    if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                        std::fprintf(stderr, "[sigops] IIR of %d sections: rounding sensitivity %.3g, chunked (L = %lld) %.3g -> %s\n", nsec,
+                                     nsec >= 3 ? sos_rounding_sensitivity(sos, nsec, nd.d0) : 0.0, (long long)Lp, cs, exact ? "sequential" : "time-parallel");
+                }
+            }
         }
         // ---- warm start: frames before the first one anybody reads (After, a later window of a
         //      stream) matter only through the filter state, and what a state contributes has decayed

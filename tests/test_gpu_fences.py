@@ -128,3 +128,23 @@ def test_filters_that_forget_within_a_tile_step(dt, kind, frac):
     want = oracle_sink(tree)
     assert got.shape == want.shape
     assert relerr(got, want) <= (1e-12 if dt == np.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_band_stop_up_to_nyquist_runs_in_the_reference_order(dt):
+    """ten poles next to -1 (Butterworth band-stop from 0.375 fs to 0.4999 fs): the rounding-sensitivity probe of the
+    recurrence says 5e-10, but the chunked form's state hand-over -- powers of a nearly defective matrix -- was 4e-5
+    away from the reference (tools/soak_degenerate_filters.py).  The planner now measures the chunked form too
+    (sos_chunk_sensitivity) and runs such a cascade sequentially: the oracle's values bit for bit in Float64."""
+    rng = np.random.default_rng(4242)
+    fs = 48000.0
+    x = so.Signal(np.asfortranarray(rng.standard_normal((70000, 3)).astype(dt)), fs * so.Hz)
+    t = so.Filt(x, so.Bandstop, 0.375 * fs * so.Hz, 0.4999 * fs * so.Hz, method=so.Butterworth(5))
+    got, want = so.sink(t)[0], oracle_sink(t)
+    if dt == np.float64:
+        assert np.array_equal(got, want)
+    else:
+        assert relerr(got, want) <= 1e-6
+    # its neighbour with the edge at 0.49 fs stays on the time-parallel kernels, and is as close as ever
+    t2 = so.Filt(x, so.Bandstop, 0.375 * fs * so.Hz, 0.49 * fs * so.Hz, method=so.Butterworth(5))
+    assert relerr(so.sink(t2)[0], oracle_sink(t2)) <= (1e-11 if dt == np.float64 else 1e-6)
