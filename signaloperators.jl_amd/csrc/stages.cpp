@@ -137,7 +137,7 @@ static double sos_chunk_sensitivity(const std::vector<SosCoefs>& groups, int64_t
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
     }
-    const int64_t nchunks = std::min<int64_t>(48, (need + L - 1) / L);
+    const int64_t nchunks = std::min<int64_t>(std::max<int64_t>(8, std::min<int64_t>(48, 65536 / L)), (need + L - 1) / L);
     const int64_t n = std::min<int64_t>(need, nchunks * L);
     double worst = 0.0;
     if (nchunks >= 2) {
@@ -149,18 +149,17 @@ static double sos_chunk_sensitivity(const std::vector<SosCoefs>& groups, int64_t
         }
         for (auto& cf : groups) {  // (groups of a long cascade filter one after the other, each chunked on its own)
             const int ns = cf.nsec, D = 2 * ns;
+            // (host code is built for baseline x86-64: no fused multiply-add to contract into, every operation rounds)
             auto step = [&](double xin, std::vector<double>& sv) {
-                volatile double y = xin;
+                double y = xin;
+                double* sp = sv.data();
                 for (int f = 0; f < ns; ++f) {
                     const double xi = y;
-                    volatile double t0 = cf.b0[f] * xi;
-                    y = sv[2 * f] + t0;
-                    volatile double t1 = cf.b1[f] * xi, t2 = cf.a1[f] * y, t3 = sv[2 * f + 1] + t1;
-                    sv[2 * f] = t3 - t2;
-                    volatile double t4 = cf.b2[f] * xi, t5 = cf.a2[f] * y;
-                    sv[2 * f + 1] = t4 - t5;
+                    y = sp[2 * f] + cf.b0[f] * xi;
+                    sp[2 * f] = (sp[2 * f + 1] + cf.b1[f] * xi) - cf.a1[f] * y;
+                    sp[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * y;
                 }
-                return (double)y;
+                return y;
             };
             std::vector<double> sv((size_t)D, 0.0);
             for (int64_t i = 0; i < n; ++i) yseq[(size_t)i] = step(x[(size_t)i], sv) * cf.gain;
