@@ -429,6 +429,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     D.g.store_lo = sid == P->alias_stage ? P->alias_skip : 0;
                     if (sid == P->alias_stage && P->alias_narrow) D.g.out_dtype = SO_F32;
                     D.g.align_rows = !std::getenv("SIGOPS_SOS_NOALIGN");
+                    D.g.bad = B.bad_buf >= 0 && S.sg.nchunks > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")
+                                  ? (int32_t*)P->bufs[B.bad_buf].d + B.bad_off[m] : nullptr;
                     if (S.src_op) {  // fused sine source of the cascade's input (as below)
                         const DLeaf& F = S.src_fn;
                         D.g.src_op = S.src_op;
@@ -459,7 +461,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     HIPCHECK(hipMemcpyAsync(P->bufs[B.desc_buf].d, B.host.data(), B.host.size() * sizeof(SosDesc), hipMemcpyHostToDevice, st));
                 }
                 for (int q = 0; q < 3; ++q) B.total[q] = first[q];
-                const int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
+                const bool poison = B.bad_buf >= 0 && !std::getenv("SIGOPS_SOS_NOPOISON");
+                if (poison) HIPCHECK(hipMemsetAsync(P->bufs[B.bad_buf].d, 0x7f, P->bufs[B.bad_buf].bytes, st));  // "no non-finite chunk yet"
+                int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
+                if (poison) nl += launch_sos_poison_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.dtype, st);
                 s.launches = nl;
                 launches += nl;
             } else {
@@ -505,6 +510,11 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     g.store_lo = s.idx == P->alias_stage ? P->alias_skip : 0;
                     if (s.idx == P->alias_stage && P->alias_narrow) g.out_dtype = SO_F32;
                     g.align_rows = S.pre_stage < 0 && !std::getenv("SIGOPS_SOS_NOALIGN");
+                    g.bad = nullptr;
+                    if (S.bad_buf >= 0 && S.pre_stage < 0 && !S.onepass && !S.xscan && !g.exact && !std::getenv("SIGOPS_SOS_NOPOISON")) {
+                        g.bad = (int32_t*)P->bufs[S.bad_buf].d;
+                        HIPCHECK(hipMemsetAsync(g.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite chunk yet"
+                    }
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;
@@ -570,6 +580,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                          S.s0_buf >= 0 ? (double*)P->bufs[S.s0_buf].d : nullptr,
                                          S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
                                          gg, S.groups[gi], st);
+                        nl += launch_sos_poison(ob.d, gg, st);  // (behind a NaN the reference stays NaN: SosGeom::bad)
+                        if (gg.bad && gi + 1 < S.groups.size()) HIPCHECK(hipMemsetAsync(gg.bad, 0x7f, (size_t)N.nch * 4, st));
                     }
                     s.launches = nl;
                     launches += nl;

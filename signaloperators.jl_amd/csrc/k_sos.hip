@@ -189,7 +189,40 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
 #pragma unroll
         for (int d = 0; d < 2 * NS; ++d) vp[d] = s[d];
     }
+    if (APPLY && live && g.bad != nullptr) {  // a non-finite state at the end of the row: everything behind it is NaN
+        bool nf = false;
+#pragma unroll
+        for (int d = 0; d < 2 * NS; ++d) nf = nf || !(fabs(s[d]) <= 1.7976931348623157e308);
+        if (nf) atomicMin(g.bad + ch, k);
+    }
 }
+
+// NaN over the frames behind a channel's first non-finite chunk (SosGeom::bad): the reference's sequential recurrence
+// never recovers from a NaN or Inf (reference src/filters.jl:252-255 -> DSP.jl filt!: the state carries it on), the
+// chunked form does after K chunks.  A few workgroups per channel; channels without a bad chunk return at once.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sos_poison(T* __restrict__ y, SosGeom g) {
+    const int ch = blockIdx.y;
+    const int kb = g.bad[ch];
+    if (kb >= g.nchunks - 1) return;  // (nothing behind the last chunk; the usual case: kb is the large initial value)
+    int64_t f0 = (int64_t)(kb + 1) * g.chunk;
+    if (f0 < g.store_lo) f0 = g.store_lo;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int64_t f = f0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; f < g.n; f += (int64_t)gridDim.x * kBlock) {
+        const int64_t o = (int64_t)ch * g.out_pitch + f;
+        if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)nan;
+        else y[o] = (T)nan;
+    }
+}
+
+int launch_sos_poison(void* y, const SosGeom& g, hipStream_t st) {
+    if (g.bad == nullptr || g.nchunks <= 1) return 0;
+    const dim3 grid(32, (unsigned)g.nch);
+    if (g.in_dtype == SO_F32) hipLaunchKernelGGL((k_sos_poison<float>), grid, dim3(kBlock), 0, st, (float*)y, g);
+    else hipLaunchKernelGGL((k_sos_poison<double>), grid, dim3(kBlock), 0, st, (double*)y, g);
+    return 1;
+}
+
 
 template <int NS, typename T, bool APPLY>
 __global__ __launch_bounds__(kBlock) void k_sos_tiled(const T* __restrict__ x, T* __restrict__ y,
@@ -434,6 +467,35 @@ int launch_sos_phase(const void* x, void* y, double* v, const double* s0, const 
         else launch_sos_phase_t<8, double>(x, y, v, s0, g, cf, phase, st);
     }
 #undef SO_PH
+    return 1;
+}
+
+// ... and for the members of a batch (one launch: blockIdx.y = member, its channels in turn)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sos_poison_batch(const SosDesc* __restrict__ desc) {
+    SosDescPtr d = (SosDescPtr)desc + blockIdx.y;
+    SosGeom g;
+    load_const(g, &d->g);
+    if (g.bad == nullptr || g.nchunks <= 1) return;
+    T* y = (T*)d->y;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int ch = 0; ch < g.nch; ++ch) {
+        const int kb = g.bad[ch];
+        if (kb >= g.nchunks - 1) continue;
+        int64_t f0 = (int64_t)(kb + 1) * g.chunk;
+        if (f0 < g.store_lo) f0 = g.store_lo;
+        for (int64_t f = f0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; f < g.n; f += (int64_t)gridDim.x * kBlock) {
+            const int64_t o = (int64_t)ch * g.out_pitch + f;
+            if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)nan;
+            else y[o] = (T)nan;
+        }
+    }
+}
+
+int launch_sos_poison_batch(const SosDesc* desc, int n, int dtype, hipStream_t st) {
+    const dim3 grid(8, (unsigned)n);
+    if (dtype == SO_F32) hipLaunchKernelGGL((k_sos_poison_batch<float>), grid, dim3(kBlock), 0, st, desc);
+    else hipLaunchKernelGGL((k_sos_poison_batch<double>), grid, dim3(kBlock), 0, st, desc);
     return 1;
 }
 

@@ -128,6 +128,7 @@ struct Stage {
     bool xscan = false;  // pass 2 is the exact block scan (launch_sos_xscan): no 2^-70 cut anywhere
     int batch = -1;      // member of Plan::batches[batch]: its three passes run inside that batch's launches
     int xs_mats_buf = -1, sblk_buf = -1;
+    int bad_buf = -1;    // first non-finite chunk per channel (SosGeom::bad)
     std::vector<std::vector<double>> xs_mats_host;  // per group: [M][M^kXsBlock]
     std::vector<std::vector<double>> mpow_host;  // per group
     // single-pass kernel (k_sos_onepass)
@@ -201,6 +202,8 @@ struct SosBatch {
     std::vector<int> members;    // stage ids in step order
     int nsec = 0, dtype = 0;
     int desc_buf = -1;           // device SosDesc[members + 1]
+    int bad_buf = -1;            // the members' SosGeom::bad arrays, back to back (one memset per execute)
+    std::vector<int> bad_off;    // member m's first channel in it
     std::vector<SosDesc> host;   // the descriptors as last uploaded
     int64_t total[3] = {0, 0, 0};
 };

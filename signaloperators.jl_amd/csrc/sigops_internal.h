@@ -149,6 +149,10 @@ struct SosGeom {
     // 8 bytes, as the columns of an n x c Array do.  Chunk borders, and so every rounding, are unaffected.  0: off.
     int32_t align_rows;
     int32_t pad_;
+    // bad[channel]: the first chunk whose output pass ended in a non-finite state (set to a large value before the
+    // passes).  The reference's recurrence stays NaN from the first non-finite sample of a channel to its end; the
+    // scan only looks back K chunks, so k_sos_poison writes NaN over everything behind that chunk.  nullptr: off.
+    int32_t* bad;
     // fused sine source (k_sos_tiled): the input is x[n] (+|*) sinpi(2((n + src_df + 1)/fs * omega + phi)) --
     // `Mix` / `Amplify` of an array with `Signal(sin)` formed in the filter's own loads
     int32_t src_op;               // 0 none, 1 add, 2 multiply

@@ -340,6 +340,7 @@ void Plan::sos_chunking(int sid, int64_t need, int nch, int dtype, const std::ve
             stages[sid].sblk_buf = sized_buf(stages[sid].sblk_buf, (size_t)nblk * nch * 16 * 8);
         }
     }
+    if (nchunks > 1 && !stages[sid].onepass && !exact) stages[sid].bad_buf = sized_buf(stages[sid].bad_buf, (size_t)nch * 4);
     stages[sid].sg = g;
 }
 
@@ -1359,6 +1360,14 @@ void Plan::batch_sos_stages() {
                 sos_chunking(sid, S.sg.n, S.sg.nch, nodes[S.node].dtype, S.groups, false, std::max<int64_t>(1, kSosSequences / chans));
             }
         B.desc_buf = raw_buf((B.members.size() + 1) * sizeof(SosDesc));
+        {
+            int off = 0;
+            for (int sid : B.members) {
+                B.bad_off.push_back(off);
+                off += stages[sid].sg.nch;
+            }
+            B.bad_buf = raw_buf((size_t)std::max(off, 1) * 4);
+        }
         for (int sid : B.members) stages[sid].batch = (int)batches.size();
         if (std::getenv("SIGOPS_DEBUG_PLAN"))
             std::fprintf(stderr, "[sigops] %zu IIR stages of %d sections share their launches\n", B.members.size(), B.nsec);

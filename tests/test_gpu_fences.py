@@ -148,3 +148,38 @@ def test_band_stop_up_to_nyquist_runs_in_the_reference_order(dt):
     # its neighbour with the edge at 0.49 fs stays on the time-parallel kernels, and is as close as ever
     t2 = so.Filt(x, so.Bandstop, 0.375 * fs * so.Hz, 0.49 * fs * so.Hz, method=so.Butterworth(5))
     assert relerr(so.sink(t2)[0], oracle_sink(t2)) <= (1e-11 if dt == np.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", ["one", "window", "scenes", "cascade16"])
+def test_a_filter_never_recovers_from_a_non_finite_sample(dt, shape):
+    """The reference's recurrence carries a NaN or Inf on in its state: from the first non-finite sample of a channel to
+    its end, everything is NaN (reference src/filters.jl:252-255 -> DSP.jl filt!).  The chunked form looks back K chunks
+    only and would return finite values again K chunks later -- values the reference never computes.  The output pass
+    notes the first chunk that ends in a non-finite state per channel and k_sos_poison fills what lies behind it."""
+    rng = np.random.default_rng(77)
+    fs = 44.1 * so.kHz
+
+    def noisy(n, nch, bad):
+        x = np.asfortranarray(rng.standard_normal((n, nch)).astype(dt))
+        for (i, c, v) in bad:
+            x[i, c] = v
+        return so.Signal(x, fs)
+
+    if shape == "one":
+        t = noisy(200000, 4, [(777, 1, np.nan), (150000, 3, np.inf)]) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    elif shape == "window":
+        t = noisy(200000, 3, [(60001, 0, np.nan)]) | so.Filt(so.Lowpass, 3 * so.kHz) | so.After(50000 * so.frames) | so.Until(120000 * so.frames)
+    elif shape == "scenes":  # a batch: the NaN of one scene stays in that scene
+        t = so.Append(*[noisy(50000 + 1000 * k, 2, [(20000, 1, np.nan)] if k == 2 else []) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+                        for k in range(5)])
+    else:  # two section groups filter one after the other in place
+        t = noisy(150000, 2, [(90000, 0, np.nan)]) | so.Filt(so.Bandpass, 1 * so.kHz, 4 * so.kHz, order=9)
+    from oracle_bridge import oracle_semantics
+    with oracle_semantics("intended"):  # (filtered children under an Append: every child its own filter, DESIGN.md section 4)
+        want = oracle_sink(t)
+    got = so.sink(t)[0]
+    assert got.shape == want.shape
+    gn, wn = ~np.isfinite(got), ~np.isfinite(want)
+    assert wn.any() and np.array_equal(gn, wn)
+    assert relerr(np.where(wn, 0, got), np.where(wn, 0, want)) <= (1e-9 if dt == np.float64 else 2e-6)
