@@ -919,6 +919,18 @@ void Plan::process_stage(int sid) {
         const int64_t bs = std::max(1, N.nd.i1);
         check_frames(child, (in_base + in_frames + bs - 1) / bs * bs);
     }
+    if (stages[sid].kind == ST_RESAMPLE && in_frames > 0) {
+        // ... and so does the resampler: it refills its input `rows` frames at a time, rows = trunc(max(1, min(N_out,
+        // blocksize) / ratio)) (reference src/filters.jl:185-199 init_length, :237-244 refill), so an error that sits in
+        // child frames the outputs asked for never depend on -- an indexing pad on a computed signal beyond them -- is
+        // raised all the same (tools/tree_soak_multirate.py seed 16046)
+        const RsGeom& rg = stages[sid].rg;
+        const int64_t bs = nodes[ni].nd.i3 > 0 ? nodes[ni].nd.i3 : 4096;
+        const double ratio = rg.arbitrary ? nodes[ni].nd.d0 : (double)rg.L / (double)rg.M;
+        const int64_t total = isinf_(nodes[ni].len) ? bs : nodes[ni].len.n;
+        const int64_t rows = (int64_t)std::trunc(std::max(1.0, (double)std::min<int64_t>(total, bs) / ratio));
+        if (rows > 0 && ratio > 0) check_frames(child, (in_base + in_frames + rows - 1) / rows * rows);
+    }
     if (stages[sid].out_buf >= 0) bufs[stages[sid].out_buf].frame0 = stages[sid].base;
     Stage& S = stages[sid];  // (re-taken: lower() may have appended stages)
     S.in_frames = in_frames;

@@ -183,3 +183,23 @@ def test_a_filter_never_recovers_from_a_non_finite_sample(dt, shape):
     gn, wn = ~np.isfinite(got), ~np.isfinite(want)
     assert wn.any() and np.array_equal(gn, wn)
     assert relerr(np.where(wn, 0, got), np.where(wn, 0, want)) <= (1e-9 if dt == np.float64 else 2e-6)
+
+
+def test_an_indexing_pad_on_a_computed_signal_is_refused_even_where_the_outputs_never_reach_it():
+    """`Pad(Signal(sin) |> Until, mirror)` is an error in the reference (src/padding.jl:169-181: a computed signal has
+    no `getindex`), raised when the pad region is first pulled.  A resampler above refills its input a block at a time
+    (src/filters.jl:185-199, 237-244), so the error comes even though the 265 outputs asked for depend on the first
+    ~200 input frames only (tools/tree_soak_multirate.py seed 16046: the engine used to accept the tree)."""
+    fs = 8 * so.kHz
+    x = so.Signal(so.sin, fs, ω=100 * so.Hz) | so.Until(354 * so.frames) | so.Pad(so.mirror) | so.Until(1412 * so.frames)
+    t = so.Amplify(x, 2.0) | so.ToFramerate(12 * so.kHz) | so.Until(265 * so.frames)
+    with pytest.raises(Exception) as oe:
+        oracle_sink(t)
+    with pytest.raises(Exception) as ee:
+        so.sink(t)
+    assert "indexing pad function" in str(oe.value) and "indexing pad function" in str(ee.value)
+    # the same tree with an array under the pad is fine on both sides
+    rng = np.random.default_rng(2)
+    y = so.Signal(np.asfortranarray(rng.standard_normal((354, 1))), fs) | so.Pad(so.mirror) | so.Until(1412 * so.frames)
+    t2 = so.Amplify(y, 2.0) | so.ToFramerate(12 * so.kHz) | so.Until(265 * so.frames)
+    assert relerr(so.sink(t2)[0], oracle_sink(t2)) <= 1e-9
