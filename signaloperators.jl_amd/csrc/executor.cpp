@@ -14,6 +14,11 @@ void Plan::finalize() {
             bufs[S.out_buf].bytes = 0;
             continue;
         }
+        if (S.out_buf >= 0 && S.fused_away) {  // (its consumer computes it on the fly: k_rsos)
+            bufs[S.out_buf].frames = 0;
+            bufs[S.out_buf].bytes = 64;
+            continue;
+        }
         if (S.out_buf >= 0) {
             Buf& b = bufs[S.out_buf];
             b.frames = S.need - S.base;
@@ -117,6 +122,8 @@ void Plan::finalize() {
         if (S.need <= 0) continue;
         if (S.kind == ST_SOS && S.qmat_buf >= 0)
             HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
+        if (S.kind == ST_SOS && S.rsos_src >= 0)
+            HIPCHECK(hipMemcpy(bufs[S.rsos_mats_buf].d, S.rsos_mats_host.data(), S.rsos_mats_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_SOS && S.onepass)
             HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_RESAMPLE) {
@@ -167,10 +174,12 @@ void Plan::finalize() {
             continue;
         }
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
-        const char* nm = S.kind == ST_SOS ? (S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
+        if (S.fused_away) continue;  // (runs inside its consumer's launch)
+        const char* nm = S.kind == ST_SOS ? (S.rsos_src >= 0 ? "k_rsos" : S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
-        if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
+        if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in + S.rs.n_out) * S.rs.nch * esz;
+        else if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
         else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
         else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
         steps.push_back(st);
@@ -227,8 +236,8 @@ void Plan::plan_lanes() {
             }
         } else {
             const Stage& S = stages[st.idx];
-            if (S.in_buf >= 0) rd[i].insert(S.in_buf);
-            for (auto& c : S.carriers) {
+            if (S.in_buf >= 0 && S.rsos_src < 0) rd[i].insert(S.in_buf);
+            for (auto& c : (S.rsos_src >= 0 ? stages[S.rsos_src].carriers : S.carriers)) {
                 if (c.buf >= 0) rd[i].insert(c.buf);
                 for (int k = 0; k < c.frame_len; ++k) {
                     const DOp& o = ops[c.frame_pc + k];
@@ -511,13 +520,50 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     if (s.idx == P->alias_stage && P->alias_narrow) g.out_dtype = SO_F32;
                     g.align_rows = S.pre_stage < 0 && !std::getenv("SIGOPS_SOS_NOALIGN");
                     g.bad = nullptr;
-                    if (S.bad_buf >= 0 && S.pre_stage < 0 && !S.onepass && !S.xscan && !g.exact && !std::getenv("SIGOPS_SOS_NOPOISON")) {
+                    if (S.bad_buf >= 0 && S.pre_stage < 0 && S.rsos_src < 0 && !S.onepass && !S.xscan && !g.exact && !std::getenv("SIGOPS_SOS_NOPOISON")) {
                         g.bad = (int32_t*)P->bufs[S.bad_buf].d;
                         HIPCHECK(hipMemsetAsync(g.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite chunk yet"
                     }
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
                     int nl = 0;
+                    if (S.rsos_src >= 0) {  // the resampler in front and this cascade in one launch (k_rsos)
+                        const Stage& S3 = P->stages[S.rsos_src];
+                        RsSos rs = S.rs;
+                        rs.out_pitch = ob.pitch;
+                        rs.out_f32 = g.out_dtype == SO_F32 && N.dtype == SO_F64;
+                        rs.mats = (const double*)P->bufs[S.rsos_mats_buf].d;
+                        rs.bad = nullptr;
+                        static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
+                        const bool rtracing = std::getenv("SIGOPS_RSOS_TRACE") != nullptr;
+                        const size_t rtrace_n = (size_t)16 * kRsosTraceIters * 8;
+                        if (rtracing) {
+                            if (!d_rtrace) HIPCHECK(hipMalloc(&d_rtrace, rtrace_n * 8));
+                            HIPCHECK(hipMemsetAsync(d_rtrace, 0, rtrace_n * 8, st));
+                            rs.trace = d_rtrace;
+                        }
+                        if (launch_rsos((const double*)P->bufs[S3.tab_buf].d, (const int*)P->bufs[S3.jend_buf].d, rs, ob.d,
+                                        RsGlobalTables{(const RsCtl*)P->bufs[S3.ctl_buf].d, (const DCarrier*)P->bufs[S3.car_buf].d, P->d_ops, P->d_leaves},
+                                        S.rsos_grid, st) != 0)
+                            fail(SO_ERR_RUNTIME, "internal: no fused resampler + IIR instantiation for this geometry");
+                        if (rtracing) {
+                            std::vector<long long> tr(rtrace_n);
+                            HIPCHECK(hipStreamSynchronize(st));
+                            HIPCHECK(hipMemcpy(tr.data(), d_rtrace, rtrace_n * 8, hipMemcpyDeviceToHost));
+                            long long t0 = 0;
+                            for (size_t i = 0; i < rtrace_n; ++i)
+                                if (tr[i] && (!t0 || tr[i] < t0)) t0 = tr[i];
+                            for (int w = 0; w < rs.nwaves; ++w)
+                                for (int it = 0; it < kRsosTraceIters; ++it) {
+                                    const long long* q = &tr[((size_t)w * kRsosTraceIters + it) * 8];
+                                    if (!q[0] && !q[2]) continue;
+                                    std::fprintf(stderr, "[rsos-trace] %s w%02d it%02d", w == 0 ? "C" : (w & 3) == 0 ? "L" : "Y", w, it);
+                                    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld", q[k] ? q[k] - t0 : -1);
+                                    std::fprintf(stderr, "\n");
+                                }
+                        }
+                        nl = 1;
+                    }
                     for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosOne o = S.so1;
@@ -548,7 +594,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         exact_done = launch_sos_exact(inp, ob.d, gg, S.groups[0], S.groups.size() > 1 ? S.groups[1] : SosCoefs{}, st) == 0;
                         if (exact_done) nl += 1;
                     }
-                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0 && !exact_done; ++gi) {
+                    for (size_t gi = 0; gi < S.groups.size() && !S.onepass && S.pre_stage < 0 && !exact_done && S.rsos_src < 0; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;
                         SosGeom gg = g;
                         if (gi > 0) gg.in_pitch = ob.pitch;

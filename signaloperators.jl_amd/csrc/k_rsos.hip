@@ -1,0 +1,780 @@
+// Hand-written HIP kernel for gfx950 (MI355X, CDNA4; wave64).  No CUDA shims, no dual paths.
+// K5 k_rsos: periodic polyphase resampler and the SOS IIR that consumes it, in ONE pass over HBM.
+//
+// Reference: `ToFramerate(Filt(x))` is rewritten to `Filt(ToFramerate(x))` (src/filters.jl:143-148) and the IIR's
+// nextblock pulls its resampling child block by block and filters the block in place (src/filters.jl:240-255): the
+// resampled signal never exists as a whole.  K3 + K2 wrote it to HBM, read it twice and wrote the result (9.2 GB
+// for 3.5 GB on the north-star pipeline); here it lives in MFMA accumulators and a few KB of LDS.
+//
+// Geometry.  A workgroup (one per CU, persistent) owns a *sequence group*: 16 rows = rgs time ranges x ct channels
+// of the signal, and walks all of them together, block by block (16 outputs per row and block).  The recurrence
+// only needs 16 independent sequences because it runs in block state-space form on the matrix cores:
+//     [ y ]   [ T   C    ] [ x ]      x: the block's 16 resampled samples, s: the cascade's 2*nsec DF2T states,
+//     [ s']   [ D   A^16 ] [ s ]      T: 16 x 16 lower-triangular Toeplitz of the impulse response
+// (entries from the DF2T recurrence itself, host-built).  Per block and 16 rows:
+//     y waves   X  = Tap_g^T . Win        ks MFMAs    (A: taps of phase group g from LDS, B: the rows' input windows
+//                                                      from the LDS ring; D[t][row] IS the B operand of what follows)
+//     chain     S' = D . X + A^16 . S     4 + 3 MFMAs (ONE wave carries the state of all 16 rows in registers; the
+//                                                      only serial dependency of the kernel is its 3 MFMAs per block)
+//     y waves   Y  = X^T . T^T + S^T . C^T  4 + 3 MFMAs  (D[row][t]: 16 lanes store one 128-byte line)
+// with v_mfma_f64_16x16x4_f64: A[l&15][k=l>>4], B[k=l>>4][l&15], D: col = l&15, row = (l>>4) + 4*reg -- so an
+// accumulator register v is at once k-step v of a B operand (k = time or state, col = row of the group) and, read
+// as an A operand, k-step v of the transposed product.  No transposes, no shuffles.
+// Waves: 0 chain | 4, 8, 12 loaders (LDS-DMA of 128-frame row chunks into a ring, fused `Mix`/`Amplify` source
+// applied in place) | the others y waves, blocks dealt round robin.  Waves meet through LDS sequence counters
+// (single writer each), never through barriers: the chain wave must not wait for anybody but its x block.
+// A range starts wp periods before its first output from zero state (||A^(wp L)|| < 2^-70: the planner's warm
+// start) and stores nothing there.
+#include "kcommon.h"
+#include "kstage.h"
+
+namespace so {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// LDS sequence counters: the accesses are asm so that the compiler neither caches nor reorders them.  The LDS executes
+// a wave's instructions in the order they were issued, so a counter written after the data it announces (and after the
+// reads whose completion it announces) needs no wait in front of it; a load is complete on return -- or, split in two,
+// issued early and waited for after the arithmetic it should hide behind.
+__device__ __forceinline__ int flag_ld(uint32_t a) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ int flag_ld_issue(uint32_t a) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ int flag_ld_wait(int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
+    return v;
+}
+__device__ __forceinline__ void flag_st(uint32_t a, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+// every wait of this kernel is for another wave of the same workgroup and lasts microseconds: a wait that does not end
+// is a bug of the protocol, and a trap (the launch fails) is better than a hung device
+__device__ __forceinline__ void spin_pause(int& spins, int sleep) {
+    if (++spins > (1 << 22)) __builtin_trap();
+    if (sleep == 1) __builtin_amdgcn_s_sleep(1);
+    else __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ int wave_min(int v, int n) {  // min of lanes [0, n), wave-uniform result
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int i = 1; i < 12; ++i)
+        if (i < n) m = min(m, __builtin_amdgcn_readlane(v, i));
+    return m;
+}
+// s_waitcnt vmcnt(n), wave-uniform runtime n up to 60 (rounded down: a stricter wait)
+__device__ __forceinline__ void wait_vmcnt_le60(int n) {
+#define SO_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    if (n < 8) {
+        switch (n < 0 ? 0 : n) { SO_W(0) SO_W(1) SO_W(2) SO_W(3) SO_W(4) SO_W(5) SO_W(6) SO_W(7) }
+    } else {
+        switch (n > 60 ? 15 : n >> 2) {
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+        }
+    }
+#undef SO_W
+}
+
+// (sin, cos)(2 pi phase) of a sine generator at 1-based frame i1 (phase as in func_eval; every operation rounded
+// on its own); out of line: ~40 live registers that must not add to the loader's loop
+__device__ __attribute__((noinline)) double2 rsos_sine_at(int64_t i1, double omega, double phi, double fs, int has_omega) {
+    const double t = __ddiv_rn((double)i1, fs);
+    const double ph = has_omega ? __dadd_rn(__dmul_rn(t, omega), phi) : __dadd_rn(t, phi);
+    double sb, cb;
+    sincospi_c(2.0 * ph, sb, cb);
+    return double2{sb, cb};
+}
+
+// general staging of one chunk of one unit (RU rows): edges of the signal and of carrier 0, Float32 arrays,
+// generated pieces, carriers with several steps -- everything the LDS-DMA fast path does not take
+template <int RU>
+__device__ __attribute__((noinline)) void rsos_stage_slow(int64_t n_in, int rpitch, const DCarrier* gcar, int ncar, const DOp* gops,
+                                                          const DLeaf* gleaves, int64_t n0, int lanes, int ch0, double* buf) {
+    const int lane = threadIdx.x & 63;
+    if (lane < lanes) stage_generic_impl<double, RU>(n_in, rpitch, gcar, ncar, gops, gleaves, n0 + 2 * lane, lane, 0, ch0, buf);
+}
+
+// in-place step of carrier 0 on one lane's 16 bytes of each of the RU rows of a landed chunk; OP: 0 v*m, 1 v+m, 2 v-m, 3 m-v
+template <int RU, int OP>
+__device__ __forceinline__ void rsos_rmw(uint32_t la, uint32_t row_bytes, v2d gn) {
+    if constexpr (RU > 4) {
+        rsos_rmw<4, OP>(la, row_bytes, gn);
+        rsos_rmw<RU - 4, OP>(la + 4 * row_bytes, row_bytes, gn);
+        return;
+    } else {
+        v2d raw[RU];
+#pragma unroll
+        for (int c = 0; c < RU; ++c) raw[c] = lds_ld16(la + (uint32_t)c * row_bytes);
+        lds_wait(raw);
+#pragma unroll
+        for (int c = 0; c < RU; ++c) raw[c] = OP == 0 ? raw[c] * gn : OP == 1 ? raw[c] + gn : OP == 2 ? raw[c] - gn : gn - raw[c];
+        lds_pin(raw);
+#pragma unroll
+        for (int c = 0; c < RU; ++c) lds_st16(la + (uint32_t)c * row_bytes, raw[c]);
+    }
+}
+
+// v += m on one lane's two frames of each of the RU rows of a landed chunk with the LDS's own adder (ds_add_f64: an
+// IEEE double add like v_add_f64): nothing for the vector ALU, which the chain wave's MFMAs keep busy
+template <int RU>
+__device__ __forceinline__ void rsos_add(uint32_t la, uint32_t row_bytes, v2d gn) {
+    const double g0 = gn[0], g1 = gn[1];
+#pragma unroll
+    for (int c = 0; c < RU; ++c) {
+        const uint32_t a = la + (uint32_t)c * row_bytes;
+        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(a), "v"(g0), "v"(g1) : "memory");
+    }
+}
+
+constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlags = 56;
+constexpr int kRsosMaxGroups = 256;
+
+// What the three roles share besides the dynamic LDS (taps, ring, exchange slots): a copy of the kernel's arguments
+// (the roles are out-of-line functions with register allocations of their own -- one kernel body for all three spilled
+// a hundred scalars and paid for it in every loop -- and read their geometry from here), the sequence counters, the
+// window ends of the period's blocks, the fused source's control block.
+struct RsosShared {
+    RsSos g;
+    const DCarrier* gcar;
+    const DOp* gops;
+    const DLeaf* gleaves;
+    void* y;
+    const double* tab;  // [ngroups][KS][64] taps in global memory (y waves that keep their phases' taps in registers)
+    int flags[kRsosFlags];
+    int jend[kRsosMaxGroups];
+    RsCtl ctl;
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// cycle stamp of workgroup 0 (tuning aid, SIGOPS_RSOS_TRACE); iterations [it0, it0 + kRsosTraceIters) are recorded
+__device__ __forceinline__ void rsos_stamp(long long* trace, int wave, int it, int k) {
+    constexpr int it0 = 400;
+    if (trace != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it >= it0 && it < it0 + kRsosTraceIters)
+        trace[(wave * kRsosTraceIters + (it - it0)) * 8 + k] = clock64();
+}
+
+// dynamic LDS: [ngroups][KS][64] taps | [16][rpitch] ring | [NX][4][64] x blocks | [NX][3][64] states | [16][16][2] sine bases
+#define SO_LDS __attribute__((address_space(3)))
+struct RsosLds {
+    SO_LDS double *taps, *ring, *xs, *ss, *gtab;
+};
+// The roles are called with generic pointers (in vector registers, as the calling convention has it): made wave-uniform
+// 32-bit LDS pointers again here, so that every access below is a ds_ instruction with a scalar base.
+__device__ __forceinline__ SO_LDS double* rsos_lds_ptr(const void* p) {
+    return (SO_LDS double*)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const SO_LDS void*)p);
+}
+__device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch, int nx) {  // tapd: doubles of the tap table in LDS
+    RsosLds l;
+    SO_LDS double* dyn = rsos_lds_ptr(dyn_);
+    l.taps = dyn;
+    l.ring = l.taps + tapd;
+    l.xs = l.ring + (size_t)16 * rpitch;
+    l.ss = l.xs + (size_t)nx * 256;
+    l.gtab = l.ss + (size_t)nx * 192;
+    return l;
+}
+
+// geometry of a sequence group that all roles derive the same way (wave-uniform)
+struct RsosGroup {
+    int cg;         // channel group
+    int64_t pb0;    // first input frame of the first period range 0 of the group walks (may be negative)
+    int64_t ob0;    // ... and its first output
+    int64_t prM, prL;  // inputs / outputs from one range to the next
+    int e0m, prMm;  // alignment of range ri's first staged frame: (e0m + ri prMm) & 15 frames above a 128-byte line
+};
+__device__ __forceinline__ RsosGroup rsos_group(const SO_LDS RsosShared* sh, int64_t G, bool single, int64_t base0_8, int64_t cs0, int64_t df0) {
+    const SO_LDS RsSos& g = sh->g;
+    const int ct = uni(g.ct), rgs = uni(g.rgs);
+    const int64_t ncg = uni(g.nch) / ct;
+    const int64_t pr = rfl64(g.pr), M = rfl64(g.M), L = rfl64(g.L);
+    const int wp = uni(g.wp), ulo = uni(g.ulo);
+    RsosGroup q;
+    q.cg = (int)(G % ncg);
+    const int64_t r0 = (G / ncg) * rgs;
+    q.pb0 = (r0 * pr - wp) * M;
+    q.ob0 = (r0 * pr - wp) * L;
+    q.prM = pr * M;
+    q.prL = pr * L;
+    if (single) {
+        const int64_t e = base0_8 + (int64_t)(q.cg * ct) * cs0 + df0 + q.pb0 + ulo;
+        q.e0m = (int)(((e % 16) + 16) % 16);
+        q.prMm = (int)(q.prM % 16);
+    } else
+        q.e0m = q.prMm = 0;
+    return q;
+}
+
+// =========================== chain wave ===========================
+template <int NY>
+__device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dyn) {
+    constexpr int NX = 2 * NY + 1;
+    const int lane = threadIdx.x & 63;
+    SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
+    const SO_LDS RsSos& g = sh->g;
+    const int ngroups = uni(g.ngroups);
+    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, uni(g.rpitch), NX);
+    const int NB = (uni(g.wp) + (int)rfl64(g.pr)) * ngroups;
+    const double* mats = (const double*)rfl64((int64_t)(uintptr_t)g.mats);
+    long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
+    const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
+    double Dk[4], Ak[3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Dk[v] = mats[v * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) Ak[v] = mats[(4 + v) * 64 + lane];
+    // Software pipeline: S(b) = the 3 MFMAs of the recurrence (the only serial chain of the kernel), X(b+1) = D . x of
+    // the next block (4 independent MFMAs that cover S(b)'s result latency), the x block after that already on its way
+    // from LDS, its counter polled behind the MFMAs.  Per block the wave issues 7 MFMAs and waits for nothing else
+    // while the y waves stay two blocks ahead.
+    v4d st = v4d{0.0, 0.0, 0.0, 0.0};
+    int spins = 0;
+    while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1) spin_pause(spins, 1);
+    v4d accx = v4d{0.0, 0.0, 0.0, 0.0};
+    double xr[4];
+    {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xr[v] = l.xs[v * 64 + lane];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], xr[v], accx, 0, 0, 0);
+    }
+    if (NB > 1) {
+        spins = 0;
+        while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2) spin_pause(spins, 1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xr[v] = l.xs[256 + v * 64 + lane];  // x_1
+    }
+    int s1 = 1 % NX, s2 = 2 % NX;  // slots of blocks b + 1 and b + 2
+    for (int b = 0; b < NB; ++b) {
+        rsos_stamp(trace, 0, b, 0);
+        v4d acc = accx;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[v], st[v], acc, 0, 0, 0);
+        int fl = 0x7fffffff;
+        if (b + 2 < NB) fl = flag_ld_issue(fl_base + 4 * (kRsosFlagXseq + s2));
+        if (b + 1 < NB) {
+            accx = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], xr[v], accx, 0, 0, 0);
+        }
+        st = acc;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) l.ss[s1 * 192 + v * 64 + lane] = acc[v];
+        flag_st(fl_base + 4 * kRsosFlagSseq, b + 1);
+        rsos_stamp(trace, 0, b, 1);
+        if (b + 2 < NB) {
+            fl = uni(flag_ld_wait(fl));
+            spins = 0;
+            while (fl < b + 3) {
+                spin_pause(spins, 1);
+                fl = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
+            }
+            rsos_stamp(trace, 0, b, 2);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xr[v] = l.xs[s2 * 256 + v * 64 + lane];
+        }
+        rsos_stamp(trace, 0, b, 3);
+        s1 = s2;
+        s2 = s2 + 1 == NX ? 0 : s2 + 1;
+    }
+}
+
+// =========================== loader waves ===========================
+template <int NY, int NL, int RU>
+__device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
+    constexpr int NX = 2 * NY + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
+    const int64_t G = rfl64(G_);
+    const int q = uni(q_);
+    const SO_LDS RsSos& g = sh->g;
+    const int ngroups = uni(g.ngroups), rpitch = uni(g.rpitch), RING = uni(g.ring), CH = uni(g.chunk);
+    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, rpitch, NX);
+    const int ct = uni(g.ct);
+    const int M = (int)rfl64(g.M);
+    const int NP = uni(g.wp) + (int)rfl64(g.pr);
+    const int ulo = uni(g.ulo);
+    const int64_t n_in = rfl64(g.n_in);
+    long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
+    const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
+    constexpr int nunits = 16 / RU;
+    const int lanes = CH >> 1;
+    const uint64_t dmask = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
+    const int total_rho = (NP - 1) * M + uni(sh->jend[ngroups - 1]) - ulo + 1 + 16;
+    const int NK = (total_rho + CH - 1) / CH;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)l.ring;
+    const uint32_t row_bytes = (uint32_t)rpitch * 8u;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    __builtin_amdgcn_s_setprio(3);
+    // carrier 0: the fast path's only source
+    const SO_LDS DCarrier& C0 = sh->ctl.car[0];
+    const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
+    const char* const base0 = (const char*)rfl64((int64_t)(uintptr_t)C0.base);
+    const int fuse = uni(g.fuse), fuse_sine = uni(g.fuse_sine), debug = uni(g.debug);
+    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) && !(df0 & 1) && fuse >= -1;
+    const int64_t lo_ok = a0 > 0 ? a0 : 0, hi_ok = b0 < n_in ? b0 : n_in;
+    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)((uintptr_t)base0 >> 3), cs0, df0);
+    // the fused step's gain: a constant, or a sine generator evaluated in two levels (share bases per chunk in gtab,
+    // per-lane (sin, cos) of the lane's two frame offsets)
+    const int kind0 = uni(C0.slot_kind[0]);
+    const DLeaf leaf0 = leaf_uniform(sh_->ctl.leaves[min(kCtlLeaves - 1, max(0, uni(C0.slot_leaf[0])))]);
+    double2 d0 = double2{0.0, 1.0}, d1 = double2{0.0, 1.0};
+    double gconst = 0.0;
+    if (fuse >= 0) {
+        if (fuse_sine) {
+            d0 = rsos_sine_at(2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+            d1 = rsos_sine_at(2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+        } else
+            gconst = slot_eval(kind0, leaf0, 0);
+    }
+    // unit u: rows [u RU, (u + 1) RU) of the group = RU channels of range ri.  What the loop needs of this wave's units
+    // (u = q + j NL) sits in lane j: first staged frame (ring position 0), its address in channel ch0's row, the unit's
+    // first ring row in LDS, and the chunks [klo, khi) that lie inside carrier 0 and the signal -- the LDS-DMA ones.
+    const int shift = CH == 128 ? 7 : 6;
+    int64_t Au_l = 0, rowb_l = 0;
+    int klo_l = 1, khi_l = 0, ch0_l = 0;
+    uint32_t lds_l = 0;
+    {
+        const int u = q + lane * NL;
+        if (u < nunits) {
+            const int ri = (u * RU) / ct, c0u = (u * RU) % ct;
+            ch0_l = grp.cg * ct + c0u;
+            Au_l = grp.pb0 + ri * grp.prM + ulo - ((grp.e0m + ri * grp.prMm) & 15);
+            rowb_l = (int64_t)(uintptr_t)base0 + ((int64_t)ch0_l * cs0 + df0 + Au_l) * 8;
+            lds_l = ring_b + (uint32_t)(u * RU) * row_bytes;
+            if (single) {
+                const int64_t lo = (lo_ok - Au_l + CH - 1) >> shift, hi = (hi_ok - Au_l) >> shift;
+                klo_l = (int)(lo < 0 ? 0 : (lo > 0x3fffffff ? 0x3fffffff : lo));
+                khi_l = (int)(hi < 0 ? 0 : (hi > 0x3fffffff ? 0x3fffffff : hi));
+            }
+        }
+    }
+    auto lane64 = [&](int64_t v, int j) __attribute__((always_inline)) {
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, j), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), j);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int MU = (nunits - q + NL - 1) / NL;  // units of this wave
+    // The first two units' facts in scalar registers (the tables above stay for the others): next to the chain wave's
+    // MFMA stream every VECTOR instruction of this wave -- a v_readlane as much as an fp64 add -- waits for a gap
+    // between two MFMAs (~64 cycles each, measured: 16 LDS-DMA instructions took 2 300 cycles to issue), so the
+    // per-chunk path of the common shapes (8 channels: two units, 16 channels: one) is scalar code + LDS-DMA only.
+    const int64_t rowb_s0 = lane64(rowb_l, 0), rowb_s1 = lane64(rowb_l, 1), Au_s0 = lane64(Au_l, 0), Au_s1 = lane64(Au_l, 1);
+    const int klo_s0 = __builtin_amdgcn_readlane(klo_l, 0), khi_s0 = __builtin_amdgcn_readlane(khi_l, 0);
+    const int klo_s1 = __builtin_amdgcn_readlane(klo_l, 1), khi_s1 = __builtin_amdgcn_readlane(khi_l, 1);
+    const int ch0_s0 = __builtin_amdgcn_readlane(ch0_l, 0), ch0_s1 = __builtin_amdgcn_readlane(ch0_l, 1);
+    const uint32_t lds_s0 = (uint32_t)__builtin_amdgcn_readlane((int)lds_l, 0), lds_s1 = (uint32_t)__builtin_amdgcn_readlane((int)lds_l, 1);
+    auto u_klo = [&](int j) __attribute__((always_inline)) { return j == 0 ? klo_s0 : j == 1 ? klo_s1 : __builtin_amdgcn_readlane(klo_l, j); };
+    auto u_khi = [&](int j) __attribute__((always_inline)) { return j == 0 ? khi_s0 : j == 1 ? khi_s1 : __builtin_amdgcn_readlane(khi_l, j); };
+    auto u_rowb = [&](int j) __attribute__((always_inline)) { return j == 0 ? rowb_s0 : j == 1 ? rowb_s1 : lane64(rowb_l, j); };
+    auto u_Au = [&](int j) __attribute__((always_inline)) { return j == 0 ? Au_s0 : j == 1 ? Au_s1 : lane64(Au_l, j); };
+    auto u_ch0 = [&](int j) __attribute__((always_inline)) { return j == 0 ? ch0_s0 : j == 1 ? ch0_s1 : __builtin_amdgcn_readlane(ch0_l, j); };
+    auto u_lds = [&](int j) __attribute__((always_inline)) { return j == 0 ? lds_s0 : j == 1 ? lds_s1 : (uint32_t)__builtin_amdgcn_readlane((int)lds_l, j); };
+    auto issue = [&](int k, int rho0) __attribute__((always_inline)) -> int {
+        int n = 0;
+        for (int j = 0; j < MU; ++j) {
+            const bool fast = k >= u_klo(j) && k < u_khi(j);
+            if (fast) {
+                const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + 3)));
+                dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
+                n += RU;
+            } else {
+                const int u = q + j * NL;
+                rsos_stage_slow<RU>(n_in, rpitch, (const DCarrier*)rfl64((int64_t)(uintptr_t)sh->gcar), uni(sh->ctl.ncar),
+                                    (const DOp*)rfl64((int64_t)(uintptr_t)sh->gops), (const DLeaf*)rfl64((int64_t)(uintptr_t)sh->gleaves),
+                                    u_Au(j) + ((int64_t)k << shift), lanes, u_ch0(j),
+                                    (double*)(l.ring + (size_t)(u * RU) * rpitch + rho0));
+            }
+        }
+        return n;
+    };
+    auto retire = [&](int k, int rho0, int allowed) __attribute__((always_inline)) {
+        rsos_stamp(trace, wave, k, 2);
+        wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
+        rsos_stamp(trace, wave, k, 3);
+        if (fuse >= 0 && !(debug & 2)) {
+            if (fuse_sine && (k & 15) == 0) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
+                for (int j4 = 0; j4 < MU; j4 += 4) {
+                    const int j = j4 + (lane >> 4);
+                    const int64_t Au = (int64_t)(((uint64_t)(uint32_t)__shfl((int)((uint64_t)Au_l >> 32), j, 64) << 32) |
+                                                 (uint32_t)__shfl((int)(uint32_t)Au_l, j, 64));
+                    if (j < MU) {
+                        const double2 bs = rsos_sine_at(Au + ((int64_t)(k + (lane & 15)) << shift) + leaf0.df + 1, leaf0.v0, leaf0.v1, leaf0.v2,
+                                                        leaf0.flag);
+                        const int u = q + j * NL;
+                        l.gtab[(u * 16 + (lane & 15)) * 2] = bs.x;
+                        l.gtab[(u * 16 + (lane & 15)) * 2 + 1] = bs.y;
+                    }
+                }
+            }
+            for (int j = 0; j < MU; ++j) {
+                if (!(k >= u_klo(j) && k < u_khi(j))) continue;
+                const int u = q + j * NL;
+                v2d gn;
+                if (fuse_sine) {
+                    const double2 bs = double2{l.gtab[(u * 16 + (k & 15)) * 2], l.gtab[(u * 16 + (k & 15)) * 2 + 1]};
+                    gn[0] = fma(bs.x, d0.y, bs.y * d0.x);
+                    gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
+                } else
+                    gn[0] = gn[1] = gconst;
+                if (lane < lanes) {
+                    const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
+                    switch (fuse) {
+                    case 0: rsos_rmw<RU, 0>(la, row_bytes, gn); break;
+                    case 1: rsos_add<RU>(la, row_bytes, gn); break;         // v + m: the LDS adds (no fp64 vector instruction)
+                    case 2: rsos_add<RU>(la, row_bytes, -gn); break;        // v - m
+                    default: rsos_rmw<RU, 3>(la, row_bytes, gn); break;
+                    }
+                }
+            }
+        }
+        flag_st(fl_base + 4 * (kRsosFlagLdp + q), (k + 1) * CH);
+        rsos_stamp(trace, wave, k, 4);
+    };
+    int issued = 0, retired = 0;
+    int rho_i = 0, rho_r = 0;       // ring positions of the next chunk to issue / to retire
+    int c0n = 0, c1n = 0, c2n = 0;  // DMA instructions of the youngest, second and third youngest chunk in flight
+    const int depth = uni(g.depth);
+    int minrd = 0;  // what the y waves no longer need (cached)
+    int spins = 0;
+    for (;;) {
+        bool can = issued < NK && issued - retired < depth;
+        if (can && (issued + 1) * CH > RING) {  // ring space: the chunk overwrites positions rho - ring
+            const int needrd = (issued + 1) * CH - RING;
+            if (minrd < needrd) {
+                const int v = lane < NY ? flag_ld(fl_base + 4 * (kRsosFlagYrd + lane)) : 0x7fffffff;
+                minrd = wave_min(v, NY);
+            }
+            can = minrd >= needrd;
+        }
+        if (can) {
+            spins = 0;
+            rsos_stamp(trace, wave, issued, 0);
+            const int n = issue(issued, rho_i);
+            rsos_stamp(trace, wave, issued, 1);
+            rho_i = rho_i + CH == RING ? 0 : rho_i + CH;
+            c2n = c1n;
+            c1n = c0n;
+            c0n = n;
+            ++issued;
+            continue;
+        }
+        if (retired < issued) {
+            const int inflight = issued - retired;
+            const int allowed = (inflight > 1 ? c0n : 0) + (inflight > 2 ? c1n : 0) + (inflight > 3 ? c2n : 0);
+            retire(retired, rho_r, allowed);
+            rho_r = rho_r + CH == RING ? 0 : rho_r + CH;
+            ++retired;
+            spins = 0;
+            continue;
+        }
+        if (issued >= NK) break;
+        spin_pause(spins, 2);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// =========================== y waves ===========================
+// CYC > 0: the wave's blocks cycle through CYC phase groups of the period (yi, yi + NY, ... modulo ngroups) and their
+// taps stay in registers for the whole kernel; CYC == 0: taps of any phase from the LDS table.
+template <int KS, int NY, int NL, typename TO, int CYC>
+__device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dyn, int64_t G_, int yi_) {
+    constexpr int NX = 2 * NY + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
+    const int64_t G = rfl64(G_);
+    const int yi = uni(yi_);
+    const SO_LDS RsSos& g = sh->g;
+    const int ngroups = uni(g.ngroups), rpitch = uni(g.rpitch), RING = uni(g.ring);
+    const RsosLds l = rsos_carve(dyn, CYC > 0 ? 0 : ngroups * KS * 64, rpitch, NX);
+    const int ct = uni(g.ct), wp = uni(g.wp), debug = uni(g.debug);
+    const int M = (int)rfl64(g.M);
+    const int NB = (wp + (int)rfl64(g.pr)) * ngroups;
+    constexpr int kw = 4 * KS;
+    const int ulo_kw = uni(g.ulo) + (kw - 1);
+    const int64_t n_out = rfl64(g.n_out), out_pitch = rfl64(g.out_pitch);
+    const double* mats = (const double*)rfl64((int64_t)(uintptr_t)g.mats);
+    long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
+    TO* const y = (TO*)rfl64((int64_t)(uintptr_t)sh->y);
+    const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
+    const SO_LDS DCarrier& C0 = sh->ctl.car[0];
+    const int64_t cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
+    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) && !(df0 & 1) && uni(g.fuse) >= -1;
+    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> 3), cs0, df0);
+    const int gq = lane >> 4, n16 = lane & 15;
+    double Tk[4], Ck[3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Tk[v] = mats[(7 + v) * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) Ck[v] = mats[(11 + v) * 64 + lane];
+    // this lane's B-operand row ...
+    int cl;   // its alignment shift + the lane's k offset
+    int nb0;  // blocks of this row before the signal's first output: their resampled samples do not exist (the cascade
+              // starts from rest at output 0, whatever the taps of "earlier outputs" would reach)
+    {
+        const int ri = n16 / ct;
+        cl = ((grp.e0m + ri * grp.prMm) & 15) + gq;
+        const int64_t ob = grp.ob0 + ri * grp.prL;
+        nb0 = ob < 0 ? (int)((-ob) / 16) : 0;
+    }
+    const SO_LDS char* const ringc = (const SO_LDS char*)l.ring + (uint32_t)n16 * (uint32_t)rpitch * 8u;
+    // ... and the four result rows it stores: row gq + 4v, time n16
+    TO* yp[4];
+    int64_t tl[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = gq + 4 * v;
+        const int ri = row / ct, cv = row % ct;
+        const int64_t ob = grp.ob0 + ri * grp.prL;
+        yp[v] = y + ((int64_t)(grp.cg * ct + cv) * out_pitch + ob + n16);
+        tl[v] = n_out - ob - n16;  // block b is stored where 16 b < tl
+    }
+    int pi = 0, gi = yi;
+    while (gi >= ngroups) {
+        gi -= ngroups;
+        ++pi;
+    }
+    int slot = yi % NX;
+    int avail = 0;
+    int wbm = -1;  // the block's window start modulo the ring
+    if (yi >= NB) flag_st(fl_base + 4 * (kRsosFlagYrd + yi), 0x7fffffff);  // (no block for this wave: it needs nothing of the ring)
+    const uint32_t f_sseq = fl_base + 4 * kRsosFlagSseq;
+    int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot, X^T T^T
+    v4d pay_ = v4d{0.0, 0.0, 0.0, 0.0};
+    auto back = [&]() __attribute__((always_inline)) {
+        int spins = 0;
+        int sq = uni(flag_ld(f_sseq));
+        while (sq < pb_) {
+            spin_pause(spins, 1);
+            sq = uni(flag_ld(f_sseq));
+        }
+        rsos_stamp(trace, wave, pb_ / NY, 4);
+        v4d ay = pay_;
+        {
+            double sv[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
+        }
+        if (ppi_ >= wp && !(debug & 1)) {
+            const int64_t t0 = (int64_t)16 * pb_;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (t0 < tl[v]) yp[v][t0] = (TO)ay[v];
+        }
+        rsos_stamp(trace, wave, pb_ / NY, 5);
+    };
+    auto block = [&](int b, const double (&at)[KS]) __attribute__((always_inline)) {
+        const int wb = pi * M + uni(sh->jend[gi]) - ulo_kw;
+        const int need = wb + kw + 16;
+        rsos_stamp(trace, wave, b / NY, 0);
+        int spins = 0;
+        while (avail < need) {
+            const int v = lane < NL ? flag_ld(fl_base + 4 * (kRsosFlagLdp + lane)) : 0x7fffffff;
+            avail = wave_min(v, NL);
+            if (avail < need) spin_pause(spins, 2);
+        }
+        rsos_stamp(trace, wave, b / NY, 1);
+        // ---- resample: X[t][row] = sum_k Tap[t][k] Win[k][row]; every operand of the block is requested before the
+        //      first MFMA (LDS returns in order: the MFMAs wait with counted lgkmcnt) ----
+        v4d ax = v4d{0.0, 0.0, 0.0, 0.0};
+        {
+            if (wbm < 0) wbm = wb % RING;
+            const int pos = wbm + cl;  // < RING + 20: one conditional subtraction per read wraps it
+            double bx[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p_ = pos + 4 * s;
+                bx[s] = *(const SO_LDS double*)(ringc + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 8u);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
+        }
+        if (b < nb0) ax = v4d{0.0, 0.0, 0.0, 0.0};
+        // next block of this wave: its window start is what this wave still needs of the ring
+        int pi2 = pi, gi2 = gi + NY;
+        while (gi2 >= ngroups) {
+            gi2 -= ngroups;
+            ++pi2;
+        }
+        const int wb2 = b + NY < NB ? pi2 * M + uni(sh->jend[gi2]) - ulo_kw : 0x7fffffff;
+        flag_st(fl_base + 4 * (kRsosFlagYrd + yi), wb2);
+        if (b + NY < NB) {
+            wbm += wb2 - wb;
+            while (wbm >= RING) wbm -= RING;
+        }
+        rsos_stamp(trace, wave, b / NY, 2);
+        // ---- hand X to the chain wave ----
+#pragma unroll
+        for (int v = 0; v < 4; ++v) l.xs[slot * 256 + v * 64 + lane] = ax[v];
+        flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
+        // ---- Y[row][t] = X^T T^T ... ----
+        v4d ay = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ay, 0, 0, 0);
+        rsos_stamp(trace, wave, b / NY, 3);
+        // ---- ... + S^T C^T with the state entering the block: for the PREVIOUS block of this wave.  The front part
+        //      above runs one block ahead of the back part below, so that the x blocks reach the chain wave a whole
+        //      round of the y waves before their states are needed: with front and back of one block back to back all
+        //      y waves ended up waiting for the chain together, and then the chain for all of them (a convoy:
+        //      1 200 cycles per block where the chain alone needs 450) ----
+        if (pb_ >= 0) back();
+        pb_ = b;
+        ppi_ = pi;
+        pslot_ = slot;
+        pay_ = ay;
+        pi = pi2;
+        gi = gi2;
+        slot += NY;  // (b + NY) mod (2 NY + 1)
+        if (slot >= NX) slot -= NX;
+    };
+    if constexpr (CYC > 0) {
+        const double* tab = (const double*)rfl64((int64_t)(uintptr_t)sh->tab);
+        double treg[CYC][KS];
+#pragma unroll
+        for (int c = 0; c < CYC; ++c) {
+            const int gc = (yi + c * NY) % ngroups;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) treg[c][s] = tab[((size_t)gc * KS + s) * 64 + lane];
+        }
+        for (int b = yi; b < NB;) {
+#pragma unroll
+            for (int c = 0; c < CYC; ++c) {
+                if (b < NB) block(b, treg[c]);
+                b += NY;
+            }
+        }
+        if (pb_ >= 0) back();
+    } else {
+        for (int b = yi; b < NB; b += NY) {
+            double at[KS];
+            const SO_LDS double* tp = l.taps + gi * KS * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) at[s] = tp[s * 64];
+            block(b, at);
+        }
+        if (pb_ >= 0) back();
+    }
+}
+
+
+template <int KS, int NW, typename TO, int CYC>
+__global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
+                                                  TO* __restrict__ y, RsGlobalTables gsrc) {
+    constexpr int NY = 3 * (NW / 4), NL = NW / 4 - 1, NX = 2 * NY + 1;
+    extern __shared__ double lds_raw[];
+    __shared__ RsosShared sh;
+    const int wave = uni(threadIdx.x >> 6);
+    // ---- once per workgroup: arguments, taps, window ends, control block ----
+    {
+        if (threadIdx.x == 0) {
+            sh.g = g;  // (member-wise from scalar registers: taking the argument's address would move it to scratch)
+            sh.gcar = gsrc.car;
+            sh.gops = gsrc.ops;
+            sh.gleaves = gsrc.leaves;
+            sh.y = (void*)y;
+            sh.tab = tab;
+        }
+    }
+    if constexpr (CYC == 0)
+        for (int i = threadIdx.x; i < g.ngroups * KS * 64; i += NW * 64) lds_raw[i] = tab[i];
+    for (int i = threadIdx.x; i < g.ngroups; i += NW * 64) sh.jend[i] = jend_g[i];
+    {
+        const int* src = reinterpret_cast<const int*>(gsrc.ctl);
+        int* dst = reinterpret_cast<int*>(&sh.ctl);
+        for (int i = threadIdx.x; i < (int)(sizeof(RsCtl) / 4); i += NW * 64) dst[i] = src[i];
+    }
+    const int64_t ncg = g.nch / g.ct;
+    const int64_t ngrp = ncg * ((g.nranges + g.rgs - 1) / g.rgs);
+    double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 256;
+    const int ru = g.ct < 8 ? g.ct : 8;
+    for (int64_t G = blockIdx.x; G < ngrp; G += gridDim.x) {
+        __syncthreads();  // (the previous group's LDS traffic is over; the first time: the tables are in place)
+        if (threadIdx.x < kRsosFlags) sh.flags[threadIdx.x] = 0;
+        if (threadIdx.x < 192) ss[threadIdx.x] = 0.0;  // s_0 = 0
+        __syncthreads();
+        if (wave == 0) rsos_chain<NY>(&sh, lds_raw);
+        else if ((wave & 3) == 0) {
+            const int q = (wave >> 2) - 1;
+            switch (ru) {
+            case 8: rsos_loader<NY, NL, 8>(&sh, lds_raw, G, q); break;
+            case 4: rsos_loader<NY, NL, 4>(&sh, lds_raw, G, q); break;
+            case 2: rsos_loader<NY, NL, 2>(&sh, lds_raw, G, q); break;
+            default: rsos_loader<NY, NL, 1>(&sh, lds_raw, G, q); break;
+            }
+        } else
+            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, (wave >> 2) * 3 + (wave & 3) - 1);
+    }
+}
+
+constexpr size_t kRsosStaticLds = sizeof(RsosShared) + 64;
+
+template <int KS, int NW, typename TO, int CYC>
+static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
+    const size_t lds = rsos_lds_bytes(g.ngroups, KS, g.rpitch, NW, CYC);
+    static bool seen[64];
+    if (first_use_on_device(seen))
+        (void)hipFuncSetAttribute((const void*)k_rsos<KS, NW, TO, CYC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsos_lds_budget());
+    hipLaunchKernelGGL((k_rsos<KS, NW, TO, CYC>), dim3((unsigned)grid), dim3(NW * 64), lds, st, tab, jend, g, (TO*)y, gsrc);
+}
+
+// LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
+size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
+    const int ny = 3 * (nwaves / 4), nx = 2 * ny + 1;
+    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 256 + (size_t)nx * 192 + 16 * 16 * 2) * 8;
+}
+size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
+
+// returns 0 when launched, -1 if no instantiation fits
+template <int KS, typename TO>
+static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
+    if (g.nwaves == 8) {
+        switch (g.cyc) {
+        case 0: launch_rsos_k<KS, 8, TO, 0>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 1: launch_rsos_k<KS, 8, TO, 1>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 2: launch_rsos_k<KS, 8, TO, 2>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 5:
+            if constexpr (KS <= 16) {
+                launch_rsos_k<KS, 8, TO, 5>(tab, jend, g, y, gsrc, grid, st);
+                return 0;
+            }
+            return -1;
+        default: return -1;
+        }
+    }
+    if (g.cyc != 0) return -1;
+    if (g.nwaves == 16) launch_rsos_k<KS, 16, TO, 0>(tab, jend, g, y, gsrc, grid, st);
+    else launch_rsos_k<KS, 12, TO, 0>(tab, jend, g, y, gsrc, grid, st);
+    return 0;
+}
+int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
+    if (g.n_out <= 0) return 0;
+    if (g.ngroups > kRsosMaxGroups) return -1;
+#define SO_RS(KS_) \
+    if (g.ks == KS_) return g.out_f32 ? launch_rsos_t<KS_, float>(tab, jend, g, y, gsrc, grid, st) : launch_rsos_t<KS_, double>(tab, jend, g, y, gsrc, grid, st);
+    SO_RS(12) SO_RS(14) SO_RS(16) SO_RS(20)
+#undef SO_RS
+    return -1;
+}
+
+}  // namespace so

@@ -167,6 +167,14 @@ struct Stage {
     int pre_stage = -1;
     int qmat_buf = -1;
     std::vector<double> qmat_host;
+    // fused resampler -> IIR (k_rsos): on the IIR stage, the periodic resampler stage it has absorbed; on that
+    // resampler stage, `fused_away` (no launch, no output buffer: its tables and carriers serve the fused kernel)
+    int rsos_src = -1;
+    bool fused_away = false;
+    RsSos rs{};
+    int rsos_grid = 0;
+    int rsos_mats_buf = -1;
+    std::vector<double> rsos_mats_host;
     // outputs DSP.jl's phase accumulator positions differently (recomputed by k_resample_fix)
     std::vector<RsFix> fix_host;
     int fix_buf = -1;
@@ -383,6 +391,7 @@ struct Plan {
     int add_leaf(const Expr& e);
     void count_array(int ni);
     void fuse_state_passes();
+    void fuse_resample_sos();
     void batch_sos_stages();
     void sos_chunking(int sid, int64_t need, int nch, int dtype, const std::vector<SosCoefs>& groups, bool exact, int64_t target);
     void finalize();

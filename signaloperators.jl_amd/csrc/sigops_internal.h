@@ -306,6 +306,46 @@ constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
 constexpr int kRsTwoBases = 128;                          // share bases per tile (tiles of up to 8192 frames)
 constexpr int kRsTwoDoubles = 128 + 2 * 2 * kRsTwoBases;  // per-lane (sin,cos) of the lane's phase offset + two buffers of share bases
 
+// ---------------------------------------------------------------------------
+// Fused periodic resampler -> SOS IIR (k_rsos.hip; reference src/filters.jl:143-148 puts the resampler under the
+// filter, and src/filters.jl:240-255 filters every block of the resampled child in place: the resampled signal
+// never exists as a whole).  One persistent workgroup walks a *sequence group* of 16 rows = rgs time ranges x ct
+// channels block by block (16 outputs per row and block):
+//   resampled block  X[16 t x 16 rows] = Tap_g^T[16 x 4 ks] . Win[4 ks x 16 rows]          (y waves, MFMA)
+//   next state       S'[12 x 16 rows]  = D[12 x 16] . X + A^16[12 x 12] . S                (ONE chain wave, MFMA)
+//   result block     Y[16 rows x 16 t] = X^T . T^T + S^T . C^T                              (y waves, MFMA)
+// (block state-space form of the DF2T cascade: T lower-triangular Toeplitz of its impulse response, C / D / A^16
+// from the same recurrence).  A range starts `wp` periods early from zero state (what earlier frames leave in the
+// state has decayed below 2^-70 by then) and stores nothing for those periods.
+struct RsSos {
+    int64_t n_in, n_out;  // stage input frames (zero outside); result frames
+    int64_t L, M;         // outputs / inputs per (super-)period, L % 16 == 0
+    int64_t pr;           // periods per range
+    int32_t wp;           // warm-up periods in front of every range
+    int32_t nranges;
+    int32_t ngroups;      // L / 16 blocks per period
+    int32_t ks;           // MFMA k-steps of a block's input window (kw / 4)
+    int32_t ulo;          // input frame (relative to a period's first input) of ring position 0, before the row's alignment shift
+    int32_t ct, rgs;      // channels x ranges per sequence group, ct * rgs == 16
+    int32_t nch;
+    int32_t nwaves;       // 8, 12 or 16: wave 0 chain, waves 4, 8, 12 loaders, the others y waves
+    int32_t ring;         // input ring per row in LDS, frames (power of two, multiple of chunk)
+    int32_t rpitch;       // doubles between ring rows (ring + 2: rows on different banks)
+    int32_t chunk;        // frames per row and LDS-DMA instruction: 128 or 64
+    int32_t depth;        // chunks in flight per loader wave (<= 4)
+    int32_t nsec;         // sections of the cascade (<= 6)
+    int32_t fuse;         // fast-path step of carrier 0 with frame slot 0: -1 none, 0 v*m, 1 v+m, 2 v-m, 3 m-v
+    int32_t fuse_sine;    // ... slot 0 is a sine generator (two-level evaluation); else a constant
+    int32_t out_f32;
+    int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain
+    int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
+    int64_t out_pitch;
+    const double* mats;   // [14][64] MFMA operands: D k-steps 0..3, A^16 k-steps 0..2, T^T k-steps 0..3, C^T k-steps 0..2
+    int32_t* bad;         // per channel: first range that ended in a non-finite state, or null
+    long long* trace;     // SIGOPS_RSOS_TRACE: [16 waves][kRsosTraceIters][8] cycle stamps of workgroup 0, or null
+};
+constexpr int kRsosTraceIters = 96;
+
 // Row-tiled variant for rational rates whose period does not fit the MFMA kernel's LDS ring or
 // tap registers (strong downsampling: many inputs per period, long filters), see k_resample_rows.
 struct RsRows {

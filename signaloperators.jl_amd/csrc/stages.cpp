@@ -1387,6 +1387,201 @@ void Plan::batch_sos_stages() {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Resampler -> IIR in one kernel (k_rsos.hip).  The reference never materialises the resampled signal: after
+// the rewrite src/filters.jl:143-148 the IIR pulls its resampling child block by block (src/filters.jl:240-255).
+// When an SOS stage is the only reader of a periodic resampler stage, both run as ONE launch: the signal is cut
+// into time ranges, 16 rows (ranges x channels) per workgroup, every range warm-started wp periods early from
+// zero state, the cascade in block state-space form on the matrix cores (see the kernel's header).
+// Values: the resampled samples are K3's (same products, same order); the IIR's differ from the sequential
+// recurrence by the rounding of a different association, ~1e-14 norm-wise for cascades that pass the planner's
+// conditioning probes (the others never get here: they run k_sos_exact).
+static void rsos_block_matrices(const SosCoefs& cf, std::vector<double>& mats) {
+    const int ns = cf.nsec, D = 2 * ns, B = 16;
+    // columns of [T C; D A^16]: the DF2T recurrence over one block from a unit input / a unit state
+    std::vector<double> Tm(B * B, 0.0), Cm(B * 12, 0.0), Dm(12 * B, 0.0), Am(12 * 12, 0.0);
+    for (int col = 0; col < B + D; ++col) {
+        std::vector<double> st(D, 0.0);
+        if (col >= B) st[col - B] = 1.0;
+        for (int t = 0; t < B; ++t) {
+            double v = col == t ? 1.0 : 0.0;
+            for (int f = 0; f < ns; ++f) {
+                const double xi = v;
+                v = st[2 * f] + cf.b0[f] * xi;
+                st[2 * f] = st[2 * f + 1] + cf.b1[f] * xi - cf.a1[f] * v;
+                st[2 * f + 1] = cf.b2[f] * xi - cf.a2[f] * v;
+            }
+            v *= cf.gain;
+            if (col < B) Tm[t * B + col] = v;
+            else Cm[t * 12 + (col - B)] = v;
+        }
+        for (int d = 0; d < D; ++d) {
+            if (col < B) Dm[d * B + col] = st[d];
+            else Am[d * 12 + (col - B)] = st[d];
+        }
+    }
+    // MFMA operand form: every matrix as Mat[lane & 15][4 v + (lane >> 4)] per k-step v
+    mats.assign((size_t)14 * 64, 0.0);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kq = lane >> 4;
+        for (int v = 0; v < 4; ++v) {
+            const int k = 4 * v + kq;
+            mats[(size_t)(0 + v) * 64 + lane] = i < 12 ? Dm[i * B + k] : 0.0;  // D[state i][time k]
+            mats[(size_t)(7 + v) * 64 + lane] = Tm[i * B + k];                 // T[time i][time k]
+            if (v < 3) {
+                mats[(size_t)(4 + v) * 64 + lane] = i < 12 ? Am[i * 12 + k] : 0.0;  // A^16[state i][state k]
+                mats[(size_t)(11 + v) * 64 + lane] = Cm[i * 12 + k];                // C[time i][state k]
+            }
+        }
+    }
+}
+
+void Plan::fuse_resample_sos() {
+    if (std::getenv("SIGOPS_NO_RSOS")) return;
+    auto env_int = [](const char* name, int dflt) {
+        const char* ev = std::getenv(name);
+        return ev ? std::atoi(ev) : dflt;
+    };
+    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+        Stage& S2 = stages[i2];
+        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.base > 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 ||
+            S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.exact || S2.xscan ||
+            S2.under_norm || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 || nodes[S2.node].dtype != SO_F64 ||
+            S2.in_frames != S2.need)
+            continue;
+        if ((int)i2 == alias_stage && alias_skip != 0) continue;
+        int i3 = -1;
+        for (size_t j = 0; j < stages.size(); ++j)
+            if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
+        if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
+        Stage& S3 = stages[i3];
+        const RsPeriodic& rp = S3.rp;
+        if (!S3.periodic || S3.base > 0 || rp.ga || rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
+            S3.need < S2.need || S3.carriers.empty() || (int)S3.carriers.size() > kCtlCar || rp.L % 16 != 0 ||
+            rp.ngroups * 16 != rp.L || rp.ngroups > 256 || rp.M >= (1 << 20))
+            continue;
+        const int ks = rp.kw / 4;
+        if (!(ks == 12 || ks == 14 || ks == 16 || ks == 20)) continue;
+        bool ok = true;
+        for (auto& c : S3.carriers)
+            if (c.pad_) ok = false;  // (GA carriers: Float32 arrays whose gain the K3 compute waves apply)
+        // nothing else may read the intermediate
+        for (auto& L : leaves)
+            if (L.buf == S2.in_buf) ok = false;
+        for (size_t j = 0; j < stages.size(); ++j) {
+            if (j != i2 && stages[j].in_buf == S2.in_buf) ok = false;
+            for (auto& c : stages[j].carriers)
+                if (c.buf == S2.in_buf) ok = false;
+        }
+        if (!ok) continue;
+        const SosCoefs& cf = S2.groups[0];
+        const int D = 2 * cf.nsec;
+        const int nch = nodes[S2.node].nch;
+        const int64_t need = S2.need, L = rp.L;
+        const int64_t nperiods = (need + L - 1) / L;
+        // warm-up: the first wp with ||A^(wp L)|| < 2^-70
+        int64_t wp = 1;
+        {
+            const double tol = std::ldexp(1.0, -70);
+            const Mat P = matpow(sos_state_matrix(cf), L, D);
+            Mat cur = P;
+            while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {
+                cur = matmul(cur, P, D);
+                ++wp;
+            }
+            if (!(maxabs(cur) < tol)) continue;
+        }
+        // rows of a sequence group: ct channels x rgs ranges
+        int ct = 1;
+        for (int c : {16, 8, 4, 2})
+            if (nch % c == 0) {
+                ct = c;
+                break;
+            }
+        const int rgs = 16 / ct;
+        const int64_t ncg = nch / ct;
+        // ranges: one sequence group per CU where the signal is long enough for the warm-up to stay below a fifth of
+        // a range; the last wave of groups of a longer grid would run on a draining machine
+        const int cus = env_int("SIGOPS_RSOS_GRID", 256);
+        int64_t rgroups = std::max<int64_t>(1, cus / ncg);  // range groups per channel group
+        int64_t nranges = rgroups * rgs;
+        const int64_t min_pr = 4 * wp;
+        if (nperiods / nranges < min_pr) nranges = std::max<int64_t>(rgs, nperiods / min_pr / rgs * rgs);
+        if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES")) nranges = std::max<int64_t>(1, std::atoll(ev));
+        const int64_t pr = (nperiods + nranges - 1) / nranges;
+        nranges = (nperiods + pr - 1) / pr;
+        const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
+        if (ngrp < env_int("SIGOPS_RSOS_MINGROUPS", 64) || (pr + wp) * rp.ngroups >= (1 << 30) || (pr + wp) * rp.M >= ((int64_t)1 << 30)) continue;
+        RsSos g{};
+        g.n_in = S3.rg.n_in;
+        g.n_out = need;
+        g.L = L;
+        g.M = rp.M;
+        g.pr = pr;
+        g.wp = (int32_t)wp;
+        g.nranges = (int32_t)nranges;
+        g.ngroups = rp.ngroups;
+        g.ks = ks;
+        g.ulo = rp.jlo;
+        g.ct = ct;
+        g.rgs = rgs;
+        g.nch = nch;
+        g.nwaves = env_int("SIGOPS_RSOS_NWAVES", 8);
+        if (g.nwaves != 8 && g.nwaves != 12 && g.nwaves != 16) g.nwaves = 8;
+        g.chunk = env_int("SIGOPS_RSOS_CHUNK", 128) == 64 ? 64 : 128;
+        g.depth = std::max(1, std::min(4, env_int("SIGOPS_RSOS_DEPTH", 4)));
+        g.nsec = cf.nsec;
+        g.debug = env_int("SIGOPS_RSOS_DEBUG", 0);
+        // taps in the y waves' registers where their blocks cycle through few phase groups of the period
+        {
+            const int ny = 3 * (g.nwaves / 4);
+            const int cyc = g.ngroups / std::__gcd(ny, g.ngroups);
+            if (g.nwaves == 8 && (cyc == 1 || cyc == 2 || cyc == 5) && cyc * ks <= 80 && !std::getenv("SIGOPS_RSOS_LDSTAPS")) g.cyc = cyc;
+        }
+        // input ring: as large as fits next to the tap table (if any) and the exchange slots
+        {
+            const int ny = 3 * (g.nwaves / 4);
+            const int64_t span = (int64_t)(ny - 1) * ((16 * rp.M + L - 1) / L + 1) + rp.kw + 16 + 2 * g.chunk;
+            int ring = 4096;  // (a multiple of 128: whole chunks, and rows of ring + 2 doubles fall on different banks)
+            while (ring >= 128 && rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc) > rsos_lds_budget()) ring -= 128;
+            if (const char* ev = std::getenv("SIGOPS_RSOS_RING")) ring = std::min(ring, std::max(128, std::atoi(ev) / 128 * 128));
+            if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                std::fprintf(stderr, "[sigops] k_rsos: ring %d frames (needs %lld), LDS %zu of %zu\n", ring, (long long)span,
+                             rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc), rsos_lds_budget());
+            if (ring < 128 || ring < span) continue;
+            g.ring = ring;
+            g.rpitch = ring + 2;
+        }
+        // carrier 0's step on the fast path
+        {
+            const DCarrier& c0 = S3.carriers[0];
+            g.fuse = -1;
+            if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 &&
+                (c0.op[0] == OP_MUL || c0.op[0] == OP_ADD || c0.op[0] == OP_SUB)) {
+                g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);
+                const DLeaf& L0 = leaves[c0.slot_leaf[0]];
+                const int kind = c0.slot_kind[0];
+                if (kind == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1) g.fuse_sine = 1;
+                else if (kind == OP_CONST || kind == OP_SCALAR) g.fuse_sine = 0;
+                else g.fuse = -2;
+            } else if (c0.nsteps > 0)
+                g.fuse = -2;  // (every chunk takes the general staging path)
+        }
+        S2.rs = g;
+        S2.rsos_src = i3;
+        S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);
+        rsos_block_matrices(cf, S2.rsos_mats_host);
+        S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);
+        S3.fused_away = true;
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr,
+                         "[sigops] resampler + IIR fused (k_rsos): %lld ranges of %lld periods (+%lld warm-up), %lld groups of %d ch x %d ranges, "
+                         "ks=%d ring=%d chunk=%d waves=%d cyc=%d fuse=%d/%d\n",
+                         (long long)nranges, (long long)pr, (long long)wp, (long long)ngrp, ct, rgs, ks, g.ring, g.chunk, g.nwaves, g.cyc,
+                         g.fuse, g.fuse_sine);
+    }
+}
+
 void Plan::fuse_state_passes() {
     if (!std::getenv("SIGOPS_FUSE_STATE")) return;
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {

@@ -395,7 +395,7 @@ def _streamable(x):
     if isinstance(x, S.RampSignal) and x.direction == "off":
         S.error("BlockStream: a ramp at the END of the signal (RampOff, Ramp, FadeTo) is anchored at a length the "
                 "stream does not know yet; not streamable")
-    if isinstance(x, S.PaddedSignal) and x.pad in (S.lastframe, S.cycle, S.mirror):
+    if isinstance(x, S.PaddedSignal) and any(x.pad is p for p in (S.lastframe, S.cycle, S.mirror)):  # (identity: a pad may be an ndarray)
         S.error("BlockStream: lastframe / cycle / mirror padding indexes the end of the input; not streamable")
     if isinstance(x, S.FilteredSignal) and isinstance(x.fn, S.ResamplerFn) and not isinstance(x.fn.ratio, tuple):
         fi, fo = x.signal.fs, x.fs

@@ -261,3 +261,14 @@ def test_block_stream_refuses_pipelines_that_need_the_total_length(name, pipelin
     bs = so.BlockStream(pipeline, fs=44.1 * so.kHz, nch=2)
     with pytest.raises(so.ErrorException, match="not streamable"):
         bs.push(np.zeros((5000, 2)))
+
+
+def test_block_stream_with_a_per_channel_padding_vector():
+    """`x.pad in (lastframe, cycle, mirror)` compared a NumPy padding vector with `==` and raised
+    "truth value of an array is ambiguous" at the first push; identity tests now, like the lowering's"""
+    rng = np.random.default_rng(73)
+    x = rng.standard_normal((30000, 2))
+    pipe = lambda s: s | so.Pad(np.array([1.0, 2.0])) | so.Until(40000 * so.frames) | so.Amplify(0.5)  # noqa: E731
+    bs = so.BlockStream(pipe, 44.1 * so.kHz, nch=2)
+    out = bs.push(x[:20000]).cpu().numpy()
+    assert out.shape[1] == 2 and np.array_equal(out, 0.5 * x[:out.shape[0]])

@@ -1,0 +1,37 @@
+"""Summary of a SIGOPS_RSOS_TRACE run (stderr of any sink through k_rsos): per role, the mean cycles between
+its stamps over the recorded iterations of workgroup 0's last execute."""
+import statistics
+import sys
+
+lines = [l.split() for l in open(sys.argv[1]) if l.startswith('[rsos-trace]')]
+waves = sorted({l[2] for l in lines})
+per_exec = len({(l[2], l[3]) for l in lines})
+last = lines[-per_exec:]
+
+
+def rows(w):
+    return [[int(x) for x in l[4:]] for l in last if l[2] == w]
+
+
+for w in waves:
+    R = rows(w)
+    kind = [l[1] for l in last if l[2] == w][0]
+    if len(R) < 3:
+        continue
+    if kind == 'L':
+        R = [r for r in R if r[0] >= 0 and r[4] >= 0]
+        per = statistics.mean(R[i + 1][0] - R[i][0] for i in range(len(R) - 1))
+        print(f"{w} loader: chunk period {per:.0f}  issue {statistics.mean(r[1]-r[0] for r in R):.0f}  "
+              f"landing wait {statistics.mean(r[3]-r[2] for r in R):.0f}  gain+publish {statistics.mean(r[4]-r[3] for r in R):.0f}  "
+              f"issue->retire {statistics.mean(r[2]-r[1] for r in R):.0f}")
+    elif kind == 'C':
+        R = [r for r in R if min(r[:4]) >= 0]
+        per = statistics.mean(R[i + 1][0] - R[i][0] for i in range(len(R) - 1))
+        print(f"{w} chain: block period {per:.0f}  S-part issue {statistics.mean(r[1]-r[0] for r in R):.0f}  "
+              f"wait for x {statistics.mean(r[2]-r[1] for r in R):.0f}  x read + D.x + publish {statistics.mean(r[3]-r[2] for r in R):.0f}")
+    else:
+        R = [r for r in R if min(r[:6]) >= 0]
+        per = statistics.mean(R[i + 1][0] - R[i][0] for i in range(len(R) - 1))
+        print(f"{w} y: block period {per:.0f}  input wait {statistics.mean(r[1]-r[0] for r in R):.0f}  "
+              f"resample {statistics.mean(r[2]-r[1] for r in R):.0f}  x out + T part {statistics.mean(r[3]-r[2] for r in R):.0f}  "
+              f"state wait {statistics.mean(r[4]-r[3] for r in R):.0f}  C part + store {statistics.mean(r[5]-r[4] for r in R):.0f}")
