@@ -32,27 +32,15 @@ namespace so {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// LDS sequence counters: the accesses are asm so that the compiler neither caches nor reorders them.  The LDS executes
-// a wave's instructions in the order they were issued, so a counter written after the data it announces (and after the
-// reads whose completion it announces) needs no wait in front of it; a load is complete on return -- or, split in two,
-// issued early and waited for after the arithmetic it should hide behind.
-__device__ __forceinline__ int flag_ld(uint32_t a) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
-__device__ __forceinline__ int flag_ld_issue(uint32_t a) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
-__device__ __forceinline__ int flag_ld_wait(int v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
-    return v;
-}
-__device__ __forceinline__ void flag_st(uint32_t a, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
+#define SO_LDS __attribute__((address_space(3)))
+// LDS sequence counters (single writer each) and the data they announce: VOLATILE accesses -- the compiler keeps them in
+// program order among themselves and never caches or speculates them, and the LDS executes a wave's instructions in the
+// order they were issued, so a counter written after its data (or after the reads whose completion it announces) needs
+// no wait in front of it.  Not inline asm: behind an asm LDS instruction the compiler no longer knows how many
+// operations are outstanding and every later wait becomes lgkmcnt(0) -- the chain wave then waited for its own
+// just-issued stores in every block.
+__device__ __forceinline__ int flag_ld(uint32_t a) { return *(const volatile SO_LDS int*)(uintptr_t)a; }
+__device__ __forceinline__ void flag_st(uint32_t a, int v) { *(volatile SO_LDS int*)(uintptr_t)a = v; }
 // every wait of this kernel is for another wave of the same workgroup and lasts microseconds: a wait that does not end
 // is a bug of the protocol, and a trap (the launch fails) is better than a hung device
 __device__ __forceinline__ void spin_pause(int& spins, int sleep) {
@@ -165,17 +153,26 @@ struct RsosShared {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Global-memory pointers rebuilt from values in LDS are GENERIC to the compiler: their loads and stores would be flat_
+// instructions, which count on lgkmcnt as well as vmcnt -- every wait for an LDS read would then also wait for the result
+// stores of the block before (a trip to HBM).  Typed as address space 1 they are global_ instructions.
+#define SO_GLB __attribute__((address_space(1)))
+
 // cycle stamp of workgroup 0 (tuning aid, SIGOPS_RSOS_TRACE); iterations [it0, it0 + kRsosTraceIters) are recorded
+#ifndef SO_RSOS_TRACE
+#define SO_RSOS_TRACE 0  // (build with -DSO_RSOS_TRACE=1: the stamps cost the y waves ~70 instructions per block even when off)
+#endif
 __device__ __forceinline__ void rsos_stamp(long long* trace, int wave, int it, int k) {
     constexpr int it0 = 400;
+    if constexpr (!SO_RSOS_TRACE) return;
     if (trace != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it >= it0 && it < it0 + kRsosTraceIters)
-        trace[(wave * kRsosTraceIters + (it - it0)) * 8 + k] = clock64();
+        ((long long SO_GLB*)trace)[(wave * kRsosTraceIters + (it - it0)) * 8 + k] = clock64();
 }
 
-// dynamic LDS: [ngroups][KS][64] taps | [16][rpitch] ring | [NX][4][64] x blocks | [NX][3][64] states | [16][16][2] sine bases
-#define SO_LDS __attribute__((address_space(3)))
+// dynamic LDS: [ngroups][KS][64] taps | [16][rpitch] ring | [NX][3][64] D.x blocks | [NX][3][64] states | [16][16][2] sine bases
 struct RsosLds {
-    SO_LDS double *taps, *ring, *xs, *ss, *gtab;
+    SO_LDS double *taps, *ring, *gtab;
+    volatile SO_LDS double *xs, *ss;  // what the waves hand each other
 };
 // The roles are called with generic pointers (in vector registers, as the calling convention has it): made wave-uniform
 // 32-bit LDS pointers again here, so that every access below is a ds_ instruction with a scalar base.
@@ -188,8 +185,8 @@ __device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch
     l.taps = dyn;
     l.ring = l.taps + tapd;
     l.xs = l.ring + (size_t)16 * rpitch;
-    l.ss = l.xs + (size_t)nx * 256;
-    l.gtab = l.ss + (size_t)nx * 192;
+    l.ss = l.xs + (size_t)nx * 192;
+    l.gtab = (SO_LDS double*)l.ss + (size_t)nx * 192;
     return l;
 }
 
@@ -233,68 +230,93 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     const int ngroups = uni(g.ngroups);
     const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, uni(g.rpitch), NX);
     const int NB = (uni(g.wp) + (int)rfl64(g.pr)) * ngroups;
-    const double* mats = (const double*)rfl64((int64_t)(uintptr_t)g.mats);
+    const double SO_GLB* mats = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)g.mats);
     long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
     const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
-    double Dk[4], Ak[3];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) Dk[v] = mats[v * 64 + lane];
+    const int debug = uni(g.debug);
+    double Ak[3];
 #pragma unroll
     for (int v = 0; v < 3; ++v) Ak[v] = mats[(4 + v) * 64 + lane];
-    // Software pipeline: S(b) = the 3 MFMAs of the recurrence (the only serial chain of the kernel), X(b+1) = D . x of
-    // the next block (4 independent MFMAs that cover S(b)'s result latency), the x block after that already on its way
-    // from LDS, its counter polled behind the MFMAs.  Per block the wave issues 7 MFMAs and waits for nothing else
-    // while the y waves stay two blocks ahead.
-    v4d st = v4d{0.0, 0.0, 0.0, 0.0};
+    // this wave IS the critical path: its three MFMAs per block must not queue behind the 25 of the y wave that shares
+    // the SIMD (measured: 500 cycles for the three without, next to a y wave in its MFMA phase)
+    __builtin_amdgcn_s_setprio(3);
+    // The only serial dependency of the kernel: S' = (D . X) + A^16 . S, three MFMAs per block on the state this wave
+    // carries in registers for all 16 rows.  D . X arrives from the y waves (they have X in registers); the block after
+    // the next is already on its way from LDS, its counter polled behind the MFMAs.
     int spins = 0;
-    while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1) spin_pause(spins, 1);
-    v4d accx = v4d{0.0, 0.0, 0.0, 0.0};
-    double xr[4];
-    {
+    while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1 && !(debug & 4)) spin_pause(spins, 1);
+    // Two steps per loop iteration with the roles of the register sets swapped: the state a step leaves is the next
+    // step's B operand where it is, the operand set a step has consumed is refilled (under its first MFMA) with the
+    // block two steps on, and the counter that guards that refill was requested two steps earlier still.
+    // What the loop looks like is dictated by three measurements (tools/micro/mfma64_chain.hip, one wave on a CU):
+    //   240 cycles per block  the bare recurrence: 3 x 64 for MFMAs that wait for each other + 48 before the next
+    //                         block's first one may read this block's result;
+    //   432                   the same with the block's LDS traffic in the natural places -- an in-order wave does
+    //                         nothing while it waits, so every round trip adds its latency to the kernel's only serial
+    //                         chain;
+    //   294                   with every LDS request UNDER a block's first MFMA, no wait between two MFMAs, and no
+    //                         VECTOR instruction under an MFMA either: an fp64 MFMA keeps the vector ALU for its 64
+    //                         cycles, a v_mov or v_readfirstlane "under" it waits for its end and pushes the chain back.
+    //                         Addresses, the counter's readfirstlane and the counter value therefore go into the gap
+    //                         in front of the first MFMA; under it are scalar and LDS instructions only.
+    v4d sA = v4d{0.0, 0.0, 0.0, 0.0}, sB = v4d{0.0, 0.0, 0.0, 0.0};  // state entering the even / odd block
+    double dA[3], dB[3] = {0.0, 0.0, 0.0};                            // D . x of the even / odd block
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xr[v] = l.xs[v * 64 + lane];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], xr[v], accx, 0, 0, 0);
-    }
+    for (int v = 0; v < 3; ++v) dA[v] = l.xs[v * 64 + lane];
     if (NB > 1) {
         spins = 0;
-        while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2) spin_pause(spins, 1);
+        while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2 && !(debug & 4)) spin_pause(spins, 1);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xr[v] = l.xs[256 + v * 64 + lane];  // x_1
+        for (int v = 0; v < 3; ++v) dB[v] = l.xs[192 + v * 64 + lane];
     }
-    int s1 = 1 % NX, s2 = 2 % NX;  // slots of blocks b + 1 and b + 2
-    for (int b = 0; b < NB; ++b) {
-        rsos_stamp(trace, 0, b, 0);
-        v4d acc = accx;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[v], st[v], acc, 0, 0, 0);
-        int fl = 0x7fffffff;
-        if (b + 2 < NB) fl = flag_ld_issue(fl_base + 4 * (kRsosFlagXseq + s2));
-        if (b + 1 < NB) {
-            accx = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], xr[v], accx, 0, 0, 0);
-        }
-        st = acc;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) l.ss[s1 * 192 + v * 64 + lane] = acc[v];
-        flag_st(fl_base + 4 * kRsosFlagSseq, b + 1);
-        rsos_stamp(trace, 0, b, 1);
-        if (b + 2 < NB) {
-            fl = uni(flag_ld_wait(fl));
-            spins = 0;
-            while (fl < b + 3) {
-                spin_pause(spins, 1);
-                fl = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
+    const uint32_t xs0 = (uint32_t)(uintptr_t)l.xs + (uint32_t)lane * 8u, ss0 = (uint32_t)(uintptr_t)l.ss + (uint32_t)lane * 8u;
+    int fA = NB > 2 ? flag_ld(fl_base + 4 * (kRsosFlagXseq + 2 % NX)) : 0x7fffffff;  // counters of blocks 2 and 3
+    int fB = NB > 3 ? flag_ld(fl_base + 4 * (kRsosFlagXseq + 3 % NX)) : 0x7fffffff;
+    int slot = 0;  // of block b
+    auto step = [&](int b, v4d& sin, v4d& sout, double (&din)[3], int& fpend) __attribute__((always_inline)) {
+        // ---- the gap in front of the first MFMA: vector instructions ----
+        int f = uni(fpend);  // counter of block b + 2's slot, requested two steps ago
+        const int s2 = slot + 2 >= NX ? slot + 2 - NX : slot + 2, s4 = s2 + 2 >= NX ? s2 + 2 - NX : s2 + 2;
+        uint32_t ax = xs0 + (uint32_t)s2 * 1536u, as = ss0 + (uint32_t)slot * 1536u;
+        uint32_t af = fl_base + 4u * (uint32_t)(kRsosFlagXseq + s4), ag = fl_base + 4u * (uint32_t)kRsosFlagSseq;
+        int bv = b;
+        asm volatile("" : "+v"(ax), "+v"(as), "+v"(af), "+v"(ag), "+v"(bv));  // (in vector registers NOW)
+        v4d acc = v4d{din[0], din[1], din[2], 0.0};
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[0], sin[0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- under it: scalar and LDS instructions ----
+        if (b + 2 < NB && !(debug & 512)) {
+            if (f < b + 3 && !(debug & 4)) {  // (the y waves are behind: wait here -- everybody waits for this wave anyway)
+                spins = 0;
+                do {
+                    spin_pause(spins, 1);
+                    f = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
+                } while (f < b + 3);
             }
-            rsos_stamp(trace, 0, b, 2);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xr[v] = l.xs[s2 * 256 + v * 64 + lane];
+            for (int v = 0; v < 3; ++v) din[v] = *(volatile SO_LDS double*)(uintptr_t)(ax + (uint32_t)v * 512u);
+            if (b + 4 < NB) fpend = *(volatile SO_LDS int*)(uintptr_t)af;
         }
+        if (!(debug & 1024)) {  // the state entering block b (the registers the MFMAs are reading) for its y wave
+#pragma unroll
+            for (int v = 0; v < 3; ++v) *(volatile SO_LDS double*)(uintptr_t)(as + (uint32_t)v * 512u) = sin[v];
+            *(volatile SO_LDS int*)(uintptr_t)ag = bv;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[1], sin[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[2], sin[2], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sout = acc;
+        slot = slot + 1 == NX ? 0 : slot + 1;
+    };
+    for (int b = 0; b < NB; b += 2) {
+        rsos_stamp(trace, 0, b, 0);
+        step(b, sA, sB, dA, fA);
+        if (b + 1 < NB) step(b + 1, sB, sA, dB, fB);
         rsos_stamp(trace, 0, b, 3);
-        s1 = s2;
-        s2 = s2 + 1 == NX ? 0 : s2 + 1;
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // =========================== loader waves ===========================
@@ -324,7 +346,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const uint32_t ring_b = (uint32_t)(uintptr_t)l.ring;
     const uint32_t row_bytes = (uint32_t)rpitch * 8u;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(2);
     // carrier 0: the fast path's only source
     const SO_LDS DCarrier& C0 = sh->ctl.car[0];
     const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
@@ -411,7 +433,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
         rsos_stamp(trace, wave, k, 3);
         if (fuse >= 0 && !(debug & 2)) {
-            if (fuse_sine && (k & 15) == 0) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
+            if (fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
                 for (int j4 = 0; j4 < MU; j4 += 4) {
                     const int j = j4 + (lane >> 4);
                     const int64_t Au = (int64_t)(((uint64_t)(uint32_t)__shfl((int)((uint64_t)Au_l >> 32), j, 64) << 32) |
@@ -463,7 +485,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                 const int v = lane < NY ? flag_ld(fl_base + 4 * (kRsosFlagYrd + lane)) : 0x7fffffff;
                 minrd = wave_min(v, NY);
             }
-            can = minrd >= needrd;
+            can = minrd >= needrd || (debug & 32);
         }
         if (can) {
             spins = 0;
@@ -512,16 +534,18 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     constexpr int kw = 4 * KS;
     const int ulo_kw = uni(g.ulo) + (kw - 1);
     const int64_t n_out = rfl64(g.n_out), out_pitch = rfl64(g.out_pitch);
-    const double* mats = (const double*)rfl64((int64_t)(uintptr_t)g.mats);
+    const double SO_GLB* mats = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)g.mats);
     long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
-    TO* const y = (TO*)rfl64((int64_t)(uintptr_t)sh->y);
+    TO SO_GLB* const y = (TO SO_GLB*)rfl64((int64_t)(uintptr_t)sh->y);
     const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
     const SO_LDS DCarrier& C0 = sh->ctl.car[0];
     const int64_t cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) && !(df0 & 1) && uni(g.fuse) >= -1;
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> 3), cs0, df0);
     const int gq = lane >> 4, n16 = lane & 15;
-    double Tk[4], Ck[3];
+    double Dk[4], Tk[4], Ck[3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Dk[v] = mats[v * 64 + lane];
 #pragma unroll
     for (int v = 0; v < 4; ++v) Tk[v] = mats[(7 + v) * 64 + lane];
 #pragma unroll
@@ -538,15 +562,32 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     }
     const SO_LDS char* const ringc = (const SO_LDS char*)l.ring + (uint32_t)n16 * (uint32_t)rpitch * 8u;
     // ... and the four result rows it stores: row gq + 4v, time n16
-    TO* yp[4];
-    int64_t tl[4];
+    TO SO_GLB* yp[4];
+    int nbs[4];      // block b of row gq + 4v is stored (by this lane: time n16 of the block) while b < nbs[v]
+    int nbs_all;     // ... and by every lane of the wave while b < nbs_all (no predicates then)
+    {
+        int m = 0x7fffffff;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int row = gq + 4 * v;
-        const int ri = row / ct, cv = row % ct;
-        const int64_t ob = grp.ob0 + ri * grp.prL;
-        yp[v] = y + ((int64_t)(grp.cg * ct + cv) * out_pitch + ob + n16);
-        tl[v] = n_out - ob - n16;  // block b is stored where 16 b < tl
+        for (int v = 0; v < 4; ++v) {
+            const int row = gq + 4 * v;
+            const int ri = row / ct, cv = row % ct;
+            const int64_t ob = grp.ob0 + ri * grp.prL;
+            yp[v] = y + ((int64_t)(grp.cg * ct + cv) * out_pitch + ob + n16);
+            const int64_t tl = n_out - ob - n16;  // 16 b < tl
+            const int64_t nb = tl <= 0 ? 0 : (tl + 15) / 16;
+            nbs[v] = (int)(nb > 0x3fffffff ? 0x3fffffff : nb);
+            m = min(m, nbs[v]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
+        nbs_all = uni(m);
+    }
+    int nb0_any;  // some lane's row starts before the signal: blocks below this need the zeroing
+    {
+        int m = nb0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        nb0_any = uni(m);
     }
     int pi = 0, gi = yi;
     while (gi >= ngroups) {
@@ -558,29 +599,43 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     int wbm = -1;  // the block's window start modulo the ring
     if (yi >= NB) flag_st(fl_base + 4 * (kRsosFlagYrd + yi), 0x7fffffff);  // (no block for this wave: it needs nothing of the ring)
     const uint32_t f_sseq = fl_base + 4 * kRsosFlagSseq;
-    int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot, X^T T^T
-    v4d pay_ = v4d{0.0, 0.0, 0.0, 0.0};
-    auto back = [&]() __attribute__((always_inline)) {
+    // Per block of this wave, in this order:
+    //   front(b)    one batch of LDS reads (the previous block's state counter and -- speculatively -- its state, then
+    //               the 4 KS window samples), KS MFMAs -> X, X to the chain wave;
+    //   back(prev)  Y(prev) = X^T T^T (kept since the previous round) + S^T C^T, stored;
+    //   T part(b)   X^T T^T of this block, kept for the next round.
+    // The front part of a block thus runs one block of this wave (NY blocks of the group) ahead of its back part: the
+    // x blocks reach the chain wave a whole round of the y waves before their states are needed.  (With front and back
+    // of one block back to back all y waves ended up waiting for the chain together, and then the chain for all of
+    // them: a convoy.)  An in-order wave does nothing while it waits, so what a block costs besides its 21 MFMAs is
+    // one LDS round trip, the hazard gaps behind three MFMA groups and ~100 other instructions.
+    int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot
+    v4d pay_ = v4d{0.0, 0.0, 0.0, 0.0};  // ... and its X^T T^T
+    auto back = [&](int sq, double (&sv)[3]) __attribute__((always_inline)) {
         int spins = 0;
-        int sq = uni(flag_ld(f_sseq));
-        while (sq < pb_) {
-            spin_pause(spins, 1);
-            sq = uni(flag_ld(f_sseq));
+        sq = uni(sq);
+        if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
+            do {
+                spin_pause(spins, 1);
+                sq = uni(flag_ld(f_sseq));
+            } while (sq < pb_);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
         }
         rsos_stamp(trace, wave, pb_ / NY, 4);
         v4d ay = pay_;
-        {
-            double sv[3];
 #pragma unroll
-            for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
-#pragma unroll
-            for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
-        }
+        for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
         if (ppi_ >= wp && !(debug & 1)) {
             const int64_t t0 = (int64_t)16 * pb_;
+            if (pb_ < nbs_all) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (t0 < tl[v]) yp[v][t0] = (TO)ay[v];
+                for (int v = 0; v < 4; ++v) yp[v][t0] = (TO)ay[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (pb_ < nbs[v]) yp[v][t0] = (TO)ay[v];
+            }
         }
         rsos_stamp(trace, wave, pb_ / NY, 5);
     };
@@ -589,28 +644,38 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         const int need = wb + kw + 16;
         rsos_stamp(trace, wave, b / NY, 0);
         int spins = 0;
-        while (avail < need) {
+        while (avail < need && !(debug & 16)) {
             const int v = lane < NL ? flag_ld(fl_base + 4 * (kRsosFlagLdp + lane)) : 0x7fffffff;
             avail = wave_min(v, NL);
             if (avail < need) spin_pause(spins, 2);
         }
         rsos_stamp(trace, wave, b / NY, 1);
-        // ---- resample: X[t][row] = sum_k Tap[t][k] Win[k][row]; every operand of the block is requested before the
-        //      first MFMA (LDS returns in order: the MFMAs wait with counted lgkmcnt) ----
-        v4d ax = v4d{0.0, 0.0, 0.0, 0.0};
-        {
-            if (wbm < 0) wbm = wb % RING;
-            const int pos = wbm + cl;  // < RING + 20: one conditional subtraction per read wraps it
-            double bx[KS];
+        // ---- the block's LDS reads, all at once ----
+        int sq = 0;
+        double sv[3] = {0.0, 0.0, 0.0};
+        if (pb_ >= 0) {
+            sq = flag_ld(f_sseq);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
+        }
+        if (wbm < 0) wbm = wb % RING;
+        const int pos = wbm + cl;  // < RING + 20: one conditional subtraction per read wraps it
+        double bx[KS];
+        if (wbm + 20 + kw <= RING) {  // (no lane's window wraps: one address, immediate offsets)
+            const SO_LDS double* p0 = (const SO_LDS double*)(ringc + (uint32_t)pos * 8u);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bx[s] = p0[4 * s];
+        } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int p_ = pos + 4 * s;
                 bx[s] = *(const SO_LDS double*)(ringc + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 8u);
             }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
         }
-        if (b < nb0) ax = v4d{0.0, 0.0, 0.0, 0.0};
+        // ---- resample: X[t][row] = sum_k Tap[t][k] Win[k][row] (LDS returns in order: counted lgkmcnt waits) ----
+        v4d ax = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
         // next block of this wave: its window start is what this wave still needs of the ring
         int pi2 = pi, gi2 = gi + NY;
         while (gi2 >= ngroups) {
@@ -623,33 +688,43 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             wbm += wb2 - wb;
             while (wbm >= RING) wbm -= RING;
         }
+        if (b < nb0_any) {
+            if (b < nb0) ax = v4d{0.0, 0.0, 0.0, 0.0};
+        }
         rsos_stamp(trace, wave, b / NY, 2);
-        // ---- hand X to the chain wave ----
+        // ---- D . X for the chain wave (its share of the recurrence that does not depend on the state) ----
+        v4d dx = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) l.xs[slot * 256 + v * 64 + lane] = ax[v];
+        for (int v = 0; v < 4; ++v) dx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], ax[v], dx, 0, 0, 0);
+        // ---- X^T T^T of this block (kept for the next round) ----
+        v4d ty = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ty = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ty, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
         flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
-        // ---- Y[row][t] = X^T T^T ... ----
-        v4d ay = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ay, 0, 0, 0);
+        // ---- the previous block's result ----
+        if (pb_ >= 0) back(sq, sv);
+        pay_ = ty;
         rsos_stamp(trace, wave, b / NY, 3);
-        // ---- ... + S^T C^T with the state entering the block: for the PREVIOUS block of this wave.  The front part
-        //      above runs one block ahead of the back part below, so that the x blocks reach the chain wave a whole
-        //      round of the y waves before their states are needed: with front and back of one block back to back all
-        //      y waves ended up waiting for the chain together, and then the chain for all of them (a convoy:
-        //      1 200 cycles per block where the chain alone needs 450) ----
-        if (pb_ >= 0) back();
         pb_ = b;
         ppi_ = pi;
         pslot_ = slot;
-        pay_ = ay;
         pi = pi2;
         gi = gi2;
         slot += NY;  // (b + NY) mod (2 NY + 1)
         if (slot >= NX) slot -= NX;
     };
+    auto last_back = [&]() __attribute__((always_inline)) {
+        if (pb_ < 0) return;
+        double sv[3];
+        const int sq = flag_ld(f_sseq);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
+        back(sq, sv);
+    };
     if constexpr (CYC > 0) {
-        const double* tab = (const double*)rfl64((int64_t)(uintptr_t)sh->tab);
+        const double SO_GLB* tab = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)sh->tab);
         double treg[CYC][KS];
 #pragma unroll
         for (int c = 0; c < CYC; ++c) {
@@ -664,7 +739,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
                 b += NY;
             }
         }
-        if (pb_ >= 0) back();
+        last_back();
     } else {
         for (int b = yi; b < NB; b += NY) {
             double at[KS];
@@ -673,7 +748,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             for (int s = 0; s < KS; ++s) at[s] = tp[s * 64];
             block(b, at);
         }
-        if (pb_ >= 0) back();
+        last_back();
     }
 }
 
@@ -681,7 +756,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 template <int KS, int NW, typename TO, int CYC>
 __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
                                                   TO* __restrict__ y, RsGlobalTables gsrc) {
-    constexpr int NY = 3 * (NW / 4), NL = NW / 4 - 1, NX = 2 * NY + 1;
+    constexpr int NY = NW - 2, NL = 1, NX = 2 * NY + 1;  // wave 0: chain, wave 4: loader, the others: y waves
     extern __shared__ double lds_raw[];
     __shared__ RsosShared sh;
     const int wave = uni(threadIdx.x >> 6);
@@ -706,24 +781,26 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
     }
     const int64_t ncg = g.nch / g.ct;
     const int64_t ngrp = ncg * ((g.nranges + g.rgs - 1) / g.rgs);
-    double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 256;
+    double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 192;
     const int ru = g.ct < 8 ? g.ct : 8;
     for (int64_t G = blockIdx.x; G < ngrp; G += gridDim.x) {
         __syncthreads();  // (the previous group's LDS traffic is over; the first time: the tables are in place)
         if (threadIdx.x < kRsosFlags) sh.flags[threadIdx.x] = 0;
         if (threadIdx.x < 192) ss[threadIdx.x] = 0.0;  // s_0 = 0
         __syncthreads();
-        if (wave == 0) rsos_chain<NY>(&sh, lds_raw);
-        else if ((wave & 3) == 0) {
-            const int q = (wave >> 2) - 1;
+        if (wave == 0) {
+            if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw);
+        } else if (wave == 4) {
+            const int q = 0;
+            if (g.debug & 256) continue;
             switch (ru) {
             case 8: rsos_loader<NY, NL, 8>(&sh, lds_raw, G, q); break;
             case 4: rsos_loader<NY, NL, 4>(&sh, lds_raw, G, q); break;
             case 2: rsos_loader<NY, NL, 2>(&sh, lds_raw, G, q); break;
             default: rsos_loader<NY, NL, 1>(&sh, lds_raw, G, q); break;
             }
-        } else
-            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, (wave >> 2) * 3 + (wave & 3) - 1);
+        } else if (!(g.debug & 128))
+            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, wave - (wave > 4 ? 2 : 1));
     }
 }
 
@@ -740,19 +817,40 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
 
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
-    const int ny = 3 * (nwaves / 4), nx = 2 * ny + 1;
-    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 256 + (size_t)nx * 192 + 16 * 16 * 2) * 8;
+    const int ny = nwaves - 2, nx = 2 * ny + 1;
+    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)nx * 192 + 16 * 16 * 2) * 8;
 }
 size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 
 // returns 0 when launched, -1 if no instantiation fits
 template <int KS, typename TO>
 static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
+    // (register taps: cyc * KS doubles per y wave -- up to 32 of them at 12 waves per workgroup (168 registers each), up
+    //  to 80 at 8 waves (256 registers))
+    if (g.nwaves == 12) {
+        switch (g.cyc) {
+        case 0: launch_rsos_k<KS, 12, TO, 0>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 1: launch_rsos_k<KS, 12, TO, 1>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 2:
+            if constexpr (KS <= 16) {
+                launch_rsos_k<KS, 12, TO, 2>(tab, jend, g, y, gsrc, grid, st);
+                return 0;
+            }
+            return -1;
+        default: return -1;
+        }
+    }
     if (g.nwaves == 8) {
         switch (g.cyc) {
         case 0: launch_rsos_k<KS, 8, TO, 0>(tab, jend, g, y, gsrc, grid, st); return 0;
         case 1: launch_rsos_k<KS, 8, TO, 1>(tab, jend, g, y, gsrc, grid, st); return 0;
         case 2: launch_rsos_k<KS, 8, TO, 2>(tab, jend, g, y, gsrc, grid, st); return 0;
+        case 3:
+            if constexpr (KS <= 20) {
+                launch_rsos_k<KS, 8, TO, 3>(tab, jend, g, y, gsrc, grid, st);
+                return 0;
+            }
+            return -1;
         case 5:
             if constexpr (KS <= 16) {
                 launch_rsos_k<KS, 8, TO, 5>(tab, jend, g, y, gsrc, grid, st);
@@ -762,10 +860,7 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
         default: return -1;
         }
     }
-    if (g.cyc != 0) return -1;
-    if (g.nwaves == 16) launch_rsos_k<KS, 16, TO, 0>(tab, jend, g, y, gsrc, grid, st);
-    else launch_rsos_k<KS, 12, TO, 0>(tab, jend, g, y, gsrc, grid, st);
-    return 0;
+    return -1;
 }
 int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
     if (g.n_out <= 0) return 0;

@@ -337,7 +337,7 @@ struct RsSos {
     int32_t fuse;         // fast-path step of carrier 0 with frame slot 0: -1 none, 0 v*m, 1 v+m, 2 v-m, 3 m-v
     int32_t fuse_sine;    // ... slot 0 is a sine generator (two-level evaluation); else a constant
     int32_t out_f32;
-    int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain
+    int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space
     int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
     int64_t out_pitch;
     const double* mats;   // [14][64] MFMA operands: D k-steps 0..3, A^16 k-steps 0..2, T^T k-steps 0..3, C^T k-steps 0..2

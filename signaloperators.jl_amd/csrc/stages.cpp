@@ -1526,22 +1526,29 @@ void Plan::fuse_resample_sos() {
         g.ct = ct;
         g.rgs = rgs;
         g.nch = nch;
-        g.nwaves = env_int("SIGOPS_RSOS_NWAVES", 8);
-        if (g.nwaves != 8 && g.nwaves != 12 && g.nwaves != 16) g.nwaves = 8;
         g.chunk = env_int("SIGOPS_RSOS_CHUNK", 128) == 64 ? 64 : 128;
         g.depth = std::max(1, std::min(4, env_int("SIGOPS_RSOS_DEPTH", 4)));
         g.nsec = cf.nsec;
         g.debug = env_int("SIGOPS_RSOS_DEBUG", 0);
-        // taps in the y waves' registers where their blocks cycle through few phase groups of the period
+        // waves: one chain, one loader, nwaves - 2 y waves that take the blocks round robin.  A y wave keeps the taps of
+        // the phase groups its blocks cycle through in registers where they fit (10 y waves and the 10 groups of
+        // 44.1 -> 48 kHz: one group each); otherwise the tap table goes to LDS and the input ring shrinks
         {
-            const int ny = 3 * (g.nwaves / 4);
-            const int cyc = g.ngroups / std::__gcd(ny, g.ngroups);
-            if (g.nwaves == 8 && (cyc == 1 || cyc == 2 || cyc == 5) && cyc * ks <= 80 && !std::getenv("SIGOPS_RSOS_LDSTAPS")) g.cyc = cyc;
+            auto cyc_of = [&](int nw) { return g.ngroups / std::__gcd(nw - 2, g.ngroups); };
+            auto fits = [&](int nw) {
+                const int c = cyc_of(nw);
+                return nw == 12 ? ((c == 1 || c == 2) && c * ks <= 32) : ((c == 1 || c == 2 || c == 3 || c == 5) && c * ks <= 80);
+            };
+            int nw = fits(12) ? 12 : fits(8) ? 8 : 12;
+            if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : 12;
+            g.nwaves = nw;
+            g.cyc = fits(nw) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
         }
         // input ring: as large as fits next to the tap table (if any) and the exchange slots
         {
-            const int ny = 3 * (g.nwaves / 4);
-            const int64_t span = (int64_t)(ny - 1) * ((16 * rp.M + L - 1) / L + 1) + rp.kw + 16 + 2 * g.chunk;
+            const int ny = g.nwaves - 2;
+            // (a y wave's front part runs up to one of its own blocks ahead: the windows in use span 2 ny - 1 blocks)
+            const int64_t span = (int64_t)(2 * ny - 1) * ((16 * rp.M + L - 1) / L + 1) + rp.kw + 16 + 2 * g.chunk;
             int ring = 4096;  // (a multiple of 128: whole chunks, and rows of ring + 2 doubles fall on different banks)
             while (ring >= 128 && rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc) > rsos_lds_budget()) ring -= 128;
             if (const char* ev = std::getenv("SIGOPS_RSOS_RING")) ring = std::min(ring, std::max(128, std::atoi(ev) / 128 * 128));
