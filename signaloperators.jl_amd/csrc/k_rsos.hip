@@ -374,6 +374,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int shift = CH == 128 ? 7 : 6;
     int64_t Au_l = 0, rowb_l = 0;
     int klo_l = 1, khi_l = 0, ch0_l = 0;
+    int kzl_l = 0, kzh_l = 0x3fffffff;  // chunks below kzl / from kzh on lie wholly outside the signal: zeros
     uint32_t lds_l = 0;
     {
         const int u = q + lane * NL;
@@ -383,6 +384,11 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             Au_l = grp.pb0 + ri * grp.prM + ulo - ((grp.e0m + ri * grp.prMm) & 15);
             rowb_l = (int64_t)(uintptr_t)base0 + ((int64_t)ch0_l * cs0 + df0 + Au_l) * 8;
             lds_l = ring_b + (uint32_t)(u * RU) * row_bytes;
+            {
+                const int64_t zl = (-Au_l) >> shift, zh = (n_in - Au_l + CH - 1) >> shift;  // (k + 1) CH <= -Au ; k CH >= n_in - Au
+                kzl_l = (int)(zl < 0 ? 0 : (zl > 0x3fffffff ? 0x3fffffff : zl));
+                kzh_l = (int)(zh < 0 ? 0 : (zh > 0x3fffffff ? 0x3fffffff : zh));
+            }
             if (single) {
                 const int64_t lo = (lo_ok - Au_l + CH - 1) >> shift, hi = (hi_ok - Au_l) >> shift;
                 klo_l = (int)(lo < 0 ? 0 : (lo > 0x3fffffff ? 0x3fffffff : lo));
@@ -414,11 +420,22 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         int n = 0;
         for (int j = 0; j < MU; ++j) {
             const bool fast = k >= u_klo(j) && k < u_khi(j);
+            if (fast && (debug & 8192)) continue;
             if (fast) {
                 const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + 3)));
                 dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
                 n += RU;
-            } else {
+            } else if (k < __builtin_amdgcn_readlane(kzl_l, j) || k >= __builtin_amdgcn_readlane(kzh_l, j)) {
+                // wholly before the signal's first frame (the warm-up of the first range) or behind its last: zeros
+                // (Pad(x.signal, zero), reference src/filters.jl:240) -- the general path below costs ~30 000 cycles
+                // per chunk, and the workgroup that walks range 0 held the whole kernel up by 0.46 ms with it
+                if (lane < lanes) {
+                    const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
+                    const v2d z = v2d{0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < RU; ++c) lds_st16(la + (uint32_t)c * row_bytes, z);
+                }
+            } else if (!(debug & 4096)) {
                 const int u = q + j * NL;
                 rsos_stage_slow<RU>(n_in, rpitch, (const DCarrier*)rfl64((int64_t)(uintptr_t)sh->gcar), uni(sh->ctl.ncar),
                                     (const DOp*)rfl64((int64_t)(uintptr_t)sh->gops), (const DLeaf*)rfl64((int64_t)(uintptr_t)sh->gleaves),
@@ -756,7 +773,9 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 template <int KS, int NW, typename TO, int CYC>
 __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
                                                   TO* __restrict__ y, RsGlobalTables gsrc) {
-    constexpr int NY = NW - 2, NL = 1, NX = 2 * NY + 1;  // wave 0: chain, wave 4: loader, the others: y waves
+    constexpr int NY = NW == 16 ? 10 : NW - 2, NL = NW == 16 ? 2 : 1, NX = 2 * NY + 1;
+    // wave 0: chain; wave 4 (and 8 at 16 waves): loaders; the others: y waves (at 16 waves: ten of them -- one more on the
+    // chain's SIMD, three on each of the others --, waves 13..15 have nothing to do)
     extern __shared__ double lds_raw[];
     __shared__ RsosShared sh;
     const int wave = uni(threadIdx.x >> 6);
@@ -790,8 +809,8 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
         __syncthreads();
         if (wave == 0) {
             if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw);
-        } else if (wave == 4) {
-            const int q = 0;
+        } else if (wave == 4 || (NW == 16 && wave == 8)) {
+            const int q = wave == 4 ? 0 : 1;
             if (g.debug & 256) continue;
             switch (ru) {
             case 8: rsos_loader<NY, NL, 8>(&sh, lds_raw, G, q); break;
@@ -800,7 +819,10 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
             default: rsos_loader<NY, NL, 1>(&sh, lds_raw, G, q); break;
             }
         } else if (!(g.debug & 128))
-            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, wave - (wave > 4 ? 2 : 1));
+            {
+            if (NW == 16 && wave > 12) continue;
+            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, NW == 16 ? (wave < 4 ? wave - 1 : wave < 8 ? wave - 2 : wave < 12 ? wave - 3 : 9) : wave - (wave > 4 ? 2 : 1));
+        }
     }
 }
 
@@ -817,7 +839,7 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
 
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
-    const int ny = nwaves - 2, nx = 2 * ny + 1;
+    const int ny = nwaves == 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
     return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)nx * 192 + 16 * 16 * 2) * 8;
 }
 size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
@@ -839,6 +861,11 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
             return -1;
         default: return -1;
         }
+    }
+    if (g.nwaves == 16) {
+        if (g.cyc != 1) return -1;
+        launch_rsos_k<KS, 16, TO, 1>(tab, jend, g, y, gsrc, grid, st);
+        return 0;
     }
     if (g.nwaves == 8) {
         switch (g.cyc) {

@@ -1534,19 +1534,19 @@ void Plan::fuse_resample_sos() {
         // the phase groups its blocks cycle through in registers where they fit (10 y waves and the 10 groups of
         // 44.1 -> 48 kHz: one group each); otherwise the tap table goes to LDS and the input ring shrinks
         {
-            auto cyc_of = [&](int nw) { return g.ngroups / std::__gcd(nw - 2, g.ngroups); };
+            auto cyc_of = [&](int nw) { return g.ngroups / std::__gcd(nw == 16 ? 10 : nw - 2, g.ngroups); };
             auto fits = [&](int nw) {
                 const int c = cyc_of(nw);
                 return nw == 12 ? ((c == 1 || c == 2) && c * ks <= 32) : ((c == 1 || c == 2 || c == 3 || c == 5) && c * ks <= 80);
             };
             int nw = fits(12) ? 12 : fits(8) ? 8 : 12;
-            if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : 12;
+            if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : std::atoi(ev) == 16 && cyc_of(16) == 1 && ks <= 16 ? 16 : 12;
             g.nwaves = nw;
-            g.cyc = fits(nw) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
+            g.cyc = (nw == 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
         }
         // input ring: as large as fits next to the tap table (if any) and the exchange slots
         {
-            const int ny = g.nwaves - 2;
+            const int ny = g.nwaves == 16 ? 10 : g.nwaves - 2;
             // (a y wave's front part runs up to one of its own blocks ahead: the windows in use span 2 ny - 1 blocks)
             const int64_t span = (int64_t)(2 * ny - 1) * ((16 * rp.M + L - 1) / L + 1) + rp.kw + 16 + 2 * g.chunk;
             int ring = 4096;  // (a multiple of 128: whole chunks, and rows of ring + 2 doubles fall on different banks)
