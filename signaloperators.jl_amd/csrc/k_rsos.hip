@@ -629,6 +629,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot
     v4d pay_ = v4d{0.0, 0.0, 0.0, 0.0};  // ... and its X^T T^T
     auto back = [&](int sq, double (&sv)[3]) __attribute__((always_inline)) {
+        // (the wait below is also what keeps this wave from running away from the chain wave: the exchange slots are
+        //  reused on the strength of it, so it stays for warm-up blocks, whose result is not computed)
         int spins = 0;
         sq = uni(sq);
         if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
@@ -639,11 +641,12 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #pragma unroll
             for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
         }
+        if (ppi_ < wp) return;  // (a warm-up block: nothing to store)
         rsos_stamp(trace, wave, pb_ / NY, 4);
         v4d ay = pay_;
 #pragma unroll
         for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
-        if (ppi_ >= wp && !(debug & 1)) {
+        if (!(debug & 1)) {
             const int64_t t0 = (int64_t)16 * pb_;
             if (pb_ < nbs_all) {
 #pragma unroll
@@ -715,8 +718,10 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int v = 0; v < 4; ++v) dx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], ax[v], dx, 0, 0, 0);
         // ---- X^T T^T of this block (kept for the next round) ----
         v4d ty = v4d{0.0, 0.0, 0.0, 0.0};
+        if (pi >= wp) {  // (a warm-up block's result is not stored: only its D . x matters)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) ty = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ty, 0, 0, 0);
+            for (int v = 0; v < 4; ++v) ty = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ty, 0, 0, 0);
+        }
 #pragma unroll
         for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
         flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
