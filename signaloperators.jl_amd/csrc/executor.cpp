@@ -534,6 +534,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rs.out_f32 = g.out_dtype == SO_F32 && N.dtype == SO_F64;
                         rs.mats = (const double*)P->bufs[S.rsos_mats_buf].d;
                         rs.bad = nullptr;
+                        if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
+                            rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
+                            HIPCHECK(hipMemsetAsync(rs.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite range yet"
+                        }
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
                         const bool rtracing = std::getenv("SIGOPS_RSOS_TRACE") != nullptr;
                         const size_t rtrace_n = (size_t)16 * kRsosTraceIters * 8;
@@ -563,6 +567,15 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                 }
                         }
                         nl = 1;
+                        if (rs.bad) {  // behind a non-finite sample the reference stays NaN: everything after the first bad range
+                            SosGeom pg = g;
+                            pg.n = rs.n_out;
+                            pg.chunk = rs.pr * rs.L;
+                            pg.nchunks = rs.nranges;
+                            pg.store_lo = 0;
+                            pg.bad = rs.bad;
+                            nl += launch_sos_poison(ob.d, pg, st);
+                        }
                     }
                     for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {
                         const void* x = gi == 0 ? (const void*)inp : (const void*)ob.d;

@@ -222,7 +222,7 @@ __device__ __forceinline__ RsosGroup rsos_group(const SO_LDS RsosShared* sh, int
 
 // =========================== chain wave ===========================
 template <int NY>
-__device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dyn) {
+__device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dyn, int64_t G_) {
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
     SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
@@ -317,6 +317,24 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
         rsos_stamp(trace, 0, b, 3);
     }
     __builtin_amdgcn_s_setprio(0);
+    // A filter never recovers from a non-finite sample: the reference's recurrence carries a NaN or Inf on in its state
+    // to the end of the channel (k_sos_poison).  Here the next range starts from rest wp periods early and
+    // would be finite again: a range whose walk ends in a non-finite state is noted per channel (the smallest such
+    // range), and the launch behind this kernel fills NaN into everything that follows it.
+    int32_t* bad = (int32_t*)rfl64((int64_t)(uintptr_t)g.bad);
+    if (bad != nullptr) {
+        const v4d sE = (NB & 1) ? sB : sA;  // the state the last block left
+        const bool nf = !(isfinite(sE[0]) && isfinite(sE[1]) && isfinite(sE[2]));
+        const uint64_t m = __ballot(nf);
+        const uint32_t rows = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu);  // row = lane & 15
+        if (rows != 0 && lane < 16 && ((rows >> lane) & 1u)) {
+            const int ct = uni(g.ct), rgs = uni(g.rgs);
+            const int64_t G = rfl64(G_);
+            const int64_t ncg = uni(g.nch) / ct;
+            const int64_t r = (G / ncg) * rgs + lane / ct;
+            if (r < uni(g.nranges)) atomicMin(bad + ((int)(G % ncg) * ct + lane % ct), (int32_t)r);
+        }
+    }
 }
 
 // =========================== loader waves ===========================
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
         if (threadIdx.x < 192) ss[threadIdx.x] = 0.0;  // s_0 = 0
         __syncthreads();
         if (wave == 0) {
-            if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw);
+            if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw, G);
         } else if (wave == 4 || (NW == 16 && wave == 8)) {
             const int q = wave == 4 ? 0 : 1;
             if (g.debug & 256) continue;

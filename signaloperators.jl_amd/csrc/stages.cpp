@@ -1579,6 +1579,7 @@ void Plan::fuse_resample_sos() {
         S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);
         rsos_block_matrices(cf, S2.rsos_mats_host);
         S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);
+        if (S2.bad_buf < 0) S2.bad_buf = raw_buf((size_t)nch * 4);  // first range per channel that ended in a non-finite state
         S3.fused_away = true;
         if (std::getenv("SIGOPS_DEBUG_PLAN"))
             std::fprintf(stderr,

@@ -1,0 +1,194 @@
+"""The fused resampler -> IIR kernel (k_rsos.hip; reference src/filters.jl:143-148 puts the resampler under the
+filter, src/filters.jl:240-255 filters every block of the resampled child in place) against the CPU oracle and
+against the engine's own two-kernel path (K3 + K2, `SIGOPS_NO_RSOS=1` at plan creation) on identical inputs.
+
+`SIGOPS_RSOS_MINGROUPS=1` lets signals of a few seconds take the fused kernel (by default the planner only fuses
+where there are at least 64 sequence groups, i.e. from about 45 s x 8 channels on); the last tests run without it.
+Tolerances: Float64 1e-9 against the oracle (what the accumulated-alpha drift of DSP.jl's phase accumulator leaves,
+as for K3), 1e-11 between the two engine paths (the fused sine source is evaluated in two levels with different
+base frames: ~4e-12)."""
+import os
+
+import numpy as np
+import pytest
+
+import sigops_amd as so
+from oracle_bridge import oracle_sink, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def F(a):
+    return np.asfortranarray(a)
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def steps_of(x, dtype=np.float64):
+    """kernel names of the plan `sink(x)` would run (host result)"""
+    n, nch = so.nframes(x), so.nchannels(x)
+    p = so.Plan(so.ToChannels(x, nch), (n, nch), dtype, (1, n), False)
+    names = [s["name"] for s in p.steps()]
+    p.close()
+    return names
+
+
+def both(x, to=None):
+    """(fused result, two-kernel result, fused?)"""
+    with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_RSOS=None):
+        fused = "k_rsos" in steps_of(x)
+        a = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
+    with env(SIGOPS_NO_RSOS=1):
+        b = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
+    return a, b, fused
+
+
+def pipeline(src, lo=0.5, hi=2.0, fs_out=48.0, order=5):
+    return src | so.Filt(so.Bandstop, lo * so.kHz, hi * so.kHz, order=order) | so.ToFramerate(fs_out * so.kHz)
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4, 8, 16, 24])
+def test_channel_counts(nch):
+    """rows of a sequence group = ranges x channels for every divisor of 16 (and 3 -> one channel per group, 24 ->
+    groups of 8)"""
+    rng = np.random.default_rng(10 + nch)
+    n = 400000 if nch <= 8 else 200000
+    x = pipeline(so.Signal(F(rng.standard_normal((n, nch))), 44.1 * so.kHz))
+    a, b, fused = both(x)
+    assert fused
+    assert a.shape == b.shape and relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["mix_sine", "amplify_sine", "amplify_const", "sine_minus", "ramp_in_front", "padded_tail", "append"])
+def test_fused_sources(kind):
+    """carrier steps of the resampler's source: the LDS-add path (Mix), the in-place multiply (Amplify), a constant, a
+    subtraction from the generator, and shapes whose first / last chunks or whole ranges take the general staging path"""
+    rng = np.random.default_rng(21)
+    n = 300000
+    noise = so.Signal(F(rng.standard_normal((n, 2))), 44.1 * so.kHz)
+    tone = so.Signal(so.sin, ω=1 * so.kHz)
+    src = {
+        "mix_sine": lambda: so.Mix(tone, noise) | so.Until(n * so.frames),
+        "amplify_sine": lambda: noise | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(n * so.frames),
+        "amplify_const": lambda: noise | so.Amplify(0.25),
+        "sine_minus": lambda: so.OperateOn(np.subtract, tone, noise) | so.Until(n * so.frames),
+        "ramp_in_front": lambda: noise | so.RampOn(50 * so.ms),
+        "padded_tail": lambda: noise | so.Pad(so.zero) | so.Until((n + 50000) * so.frames),
+        "append": lambda: so.Append(noise | so.Until(100000 * so.frames), so.Signal(F(rng.standard_normal((150000, 2))), 44.1 * so.kHz)),
+    }[kind]()
+    x = pipeline(src)
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+
+
+@pytest.mark.parametrize("design", ["lowpass3", "highpass4", "bandpass6", "bandstop2"])
+def test_cascades(design):
+    rng = np.random.default_rng(33)
+    src = so.Signal(F(rng.standard_normal((350000, 4))), 44.1 * so.kHz)
+    x = {
+        "lowpass3": lambda: src | so.Filt(so.Lowpass, 3 * so.kHz, order=5),      # 3 sections
+        "highpass4": lambda: src | so.Filt(so.Highpass, 200 * so.Hz, order=7),   # 4
+        "bandpass6": lambda: src | so.Filt(so.Bandpass, 1 * so.kHz, 4 * so.kHz, order=6),  # 6
+        "bandstop2": lambda: src | so.Filt(so.Bandstop, 1 * so.kHz, 3 * so.kHz, order=2),  # 2
+    }[design]() | so.ToFramerate(48 * so.kHz)
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+
+
+@pytest.mark.parametrize("fs_in,fs_out", [(44.1, 48.0), (32.0, 48.0), (22.05, 48.0), (44.1, 88.2), (8.0, 16.0)])
+def test_rates(fs_in, fs_out):
+    """other periodic rates whose period splits into whole blocks of 16 outputs; where the geometry does not fit the
+    engine keeps the two kernels and the result is theirs"""
+    rng = np.random.default_rng(44)
+    src = so.Signal(F(rng.standard_normal((300000, 2))), fs_in * so.kHz)
+    x = src | so.Filt(so.Lowpass, 2 * so.kHz) | so.ToFramerate(fs_out * so.kHz)
+    a, b, fused = both(x)
+    assert relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+
+
+def test_float32_result_of_a_float64_pipeline():
+    """`sink(x, Float32)` of a Float64 signal: the kernel rounds in its own store (reference src/sink.jl:262-266)"""
+    rng = np.random.default_rng(55)
+    x = pipeline(so.Signal(F(rng.standard_normal((300000, 8))), 44.1 * so.kHz))
+    want = oracle_sink(x).astype(np.float32)
+    got = np.empty(want.shape, dtype=np.float32, order="F")
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        so.sink_into(got, x)
+    assert relerr(got, want) < 1e-6
+    assert np.mean(got == want) > 0.999  # (what differs: values within the accumulated-alpha drift of a rounding boundary)
+
+
+def test_a_non_finite_sample_poisons_the_rest_of_its_channel():
+    """the reference's recurrence stays NaN from the first non-finite sample of a channel to its end; a later time range
+    of the fused kernel starts from rest and would be finite again (k_sos_poison behind the kernel fills it)"""
+    rng = np.random.default_rng(66)
+    a = rng.standard_normal((400000, 4))
+    a[123456, 1] = np.nan
+    a[300000, 3] = np.inf
+    x = pipeline(so.Signal(F(a), 44.1 * so.kHz))
+    got, ref, fused = both(x)
+    assert fused
+    for ch, first in ((1, 123456), (3, 300000)):
+        m = int(first * 160 / 147)
+        assert np.isnan(got[m + 200:, ch]).all() and np.isnan(ref[m + 200:, ch]).all()
+        assert np.isfinite(got[:m - 200, ch]).all()
+        assert relerr(got[:m - 200, ch], ref[:m - 200, ch]) < 1e-11
+    for ch in (0, 2):
+        assert np.isfinite(got[:, ch]).all() and relerr(got[:, ch], ref[:, ch]) < 1e-11
+
+
+def test_windows_and_streams_keep_the_two_kernel_path():
+    """a window of the result (After, a later block of `so.stream`) warm-starts its stages: not fused (yet), same values"""
+    rng = np.random.default_rng(77)
+    x = pipeline(so.Signal(F(rng.standard_normal((400000, 2))), 44.1 * so.kHz))
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        whole = so.sink(x)[0]
+        part = so.sink(x | so.After(200000 * so.frames) | so.Until(50000 * so.frames))[0]
+    assert relerr(part, whole[200000:250000]) < 1e-11
+
+
+def test_run_to_run_identical():
+    rng = np.random.default_rng(88)
+    x = pipeline(so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(F(rng.standard_normal((500000, 8))), 44.1 * so.kHz))
+                 | so.Until(500000 * so.frames))
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        a = so.sink(x)[0]
+        b = so.sink(x)[0]
+    assert np.array_equal(a, b)
+
+
+def test_default_policy_fuses_long_signals_only():
+    rng = np.random.default_rng(99)
+    short = pipeline(so.Signal(F(rng.standard_normal((100000, 8))), 44.1 * so.kHz))
+    long_ = pipeline(so.Signal(F(rng.standard_normal((3000000, 8))), 44.1 * so.kHz))
+    with env(SIGOPS_RSOS_MINGROUPS=None, SIGOPS_NO_RSOS=None):
+        assert "k_rsos" not in steps_of(short)
+        assert steps_of(long_) == ["k_rsos"]
+        got = so.sink(long_)[0]
+    with env(SIGOPS_NO_RSOS=1):
+        ref = so.sink(long_)[0]
+    assert relerr(got, ref) < 1e-11
