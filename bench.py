@@ -12,8 +12,11 @@ SOS IIR at 48 kHz).  A step is one `so_plan_execute` of that tree with the noise
 result both resident in HBM.  BASELINE config 3 (the Filt-less resampler run)
 is timed in the same process and reported as the "config3" object of the same JSON line.
 
-N>1: one process per GPU (torch.distributed / RCCL).  `ns` / `config3`: every rank sinks its own
-independent signal (weak scaling, no collective).  `config4`: the 64 scenes of an Append are
+N>1: one process per GPU (torch.distributed / RCCL).  Started under `torch.distributed.run` (RANK / WORLD_SIZE set) the
+process is one rank; started plainly with `--gpus N` it launches N fresh children of itself -- before anything touches a
+GPU -- and relays rank 0's line.  `ns` / `config3`: every rank sinks its own independent signal (weak scaling, no
+collective); at N > 1 over RCCL the default line also carries a "config4" object (the sharded Append with its device-
+to-device gather).  `config4`: the 64 scenes of an Append are
 sharded over the ranks and the result slabs are all-gathered device to device.  `config5`: each
 rank owns a 128-channel slab of the 1024-channel signal; no exchange step.
 
@@ -79,19 +82,99 @@ def cpu_model():
     return "unknown"
 
 
+def lib_sha16():
+    import hashlib
+
+    p = os.path.join(ROOT, "signaloperators.jl_amd", "csrc", "libsigops.so")
+    if not os.path.exists(p):
+        return None
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(stage_name):
     """HBM bytes per execute of a stage from the committed rocprofv3 PMC passes of this command
-    (profiles/r03/bench_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
-    MI355X_MICROARCH.md prescribes).  A file read, NOT a measurement of this run."""
-    path = os.path.join(ROOT, "profiles", "r03", "bench_pmc_hbm.json")
+    (profiles/r04/bench_pmc_hbm.json, written by tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    corrected as MI355X_MICROARCH.md prescribes).  A file read, NOT a measurement of this run -- and only quoted while
+    the kernel sources it was collected on are the ones in the tree (their hash is recorded next to the counters): after
+    any change to them the line carries null and says so, instead of a number gone stale."""
+    path = os.path.join(ROOT, "profiles", "r04", "bench_pmc_hbm.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
+    if d.get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, "profiles/r04/bench_pmc_hbm.json is from other kernel sources (%s, now %s): not quoted" % (
+            d.get("kernel_sources_sha16"), kernel_sources_sha16())
     for key, val in d.get("stages", {}).items():
         if stage_name.startswith(key):
-            return val.get("corrected_bytes_per_execute"), "profiles/r03/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command; not this run)"
+            return val.get("corrected_bytes_per_execute"), "profiles/r04/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command on these kernel sources; not this run)"
     return None, None
+
+
+def kernel_sources_sha16():
+    """hash of the device code's sources (what the PMC numbers depend on; the .so itself differs from build to build)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "signaloperators.jl_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "k*.h")) + [os.path.join(d, "sigops_internal.h")]):
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N children of this script, one rank each (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set), started BEFORE this process imports torch or touches a device; rank 0's JSON line is
+    relayed, a failing child fails the run."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    for line in out0.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+    if any(codes):
+        raise SystemExit("bench.py: ranks exited with %s" % codes)
+
+
+def launch_path_only(args, torch, dist, rank, world):
+    """No HIP device (a build container): the engine has no CPU path, so nothing can be timed -- what runs is the N-rank
+    path around it (rendezvous, barriers, max over ranks, rank 0 prints), with a line that says so."""
+    t = torch.zeros(1, dtype=torch.float64)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t[0] = el
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "data": "none", "valid": False,
+                          "config": {"workload": "NO HIP DEVICE: launch path only (rendezvous over gloo, barriers, max over ranks); "
+                                                 "the sink engine has no CPU path and nothing was measured",
+                                     "ranks_seen": dist.get_world_size() if dist is not None else 1},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def timed_loop(plan, optr, stream, steps, warmup, torch, dist, dev, series=None, profile=False):
@@ -288,6 +371,8 @@ def main():
                          "is ~10-20 s of CPU work on one core")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 object")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     import numpy as np
     import torch
@@ -304,6 +389,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() == 0:
+            dist.init_process_group("gloo")
+            return launch_path_only(args, torch, dist, rank, world)
         if torch.cuda.device_count() >= world:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -317,12 +405,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the sink engine has no CPU path")
+    rccl_ranks = dist.get_world_size() if dist is not None and dist.get_backend() == "nccl" else None
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if args.workload in ("config4", "config5", "ns_time"):
         import bench_multi
 
         return bench_multi.run(args, so, torch, dist, rank, local_rank, world, dev)
+    config4 = None
 
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     ndt = np.float64 if args.dtype == "f64" else np.float32
@@ -390,6 +480,15 @@ def main():
         p3.close()
         del o3_t, o3
 
+    # ---- N > 1 over RCCL: the path that has an exchange step, next to the headline (every rank takes part) ----
+    if dist is not None and dist.get_backend() == "nccl" and args.workload == "ns":
+        import bench_multi
+
+        a4 = argparse.Namespace(**vars(args))
+        a4.workload = "config4"
+        a4.steps, a4.warmup = max(5, args.steps // 4), max(2, args.warmup // 2)
+        config4 = bench_multi.run(a4, so, torch, dist, rank, local_rank, world, dev, emit=False)
+
     # ---- correctness gate (rank 0, same device noise, a prefix); the whole length: parity_full below ----
     gate = None
     if rank == 0:
@@ -429,6 +528,10 @@ def main():
                               "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
                               "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},
             "stages": stages,
+            "steady_state_ms": (sum(series[-10:]) / len(series[-10:])) if series else None,
+            "steady_state_note": "mean device time of the last 10 executes of step_ms_series (the kernel once the chip's "
+                                 "power management has settled); ms_per_step is the whole timed loop on the host clock",
+            "rccl_ranks": rccl_ranks,
             "step_ms_series": series,
             "host_side": host_side,
             "step_ms_series_note": "device time of every execute, the --warmup ones first (events on the launch stream, no "
@@ -437,6 +540,7 @@ def main():
                                    "short runs (20 / 5) sit inside that transient, long ones (200 / 30) mostly outside.",
             "parity_gate": gate,
             "config3": secondary,
+            "config4": config4,
         }
         if args.cpu_seconds > 0 and world == 1:
             noise_host = np.asfortranarray(noise_t.t().cpu().numpy())

@@ -39,7 +39,8 @@ def _sync_time(fn, steps, warmup, torch, dist, dev):
     return el
 
 
-def run(args, so, torch, dist, rank, local_rank, world, dev):
+def run(args, so, torch, dist, rank, local_rank, world, dev, emit=True):
+    """emit=False: returns rank 0's result object instead of printing it, and leaves the process group alone"""
     from bench import HBM_PEAK_GBS, METRIC, scene, tree_config5
     from sigops_amd import sharding
 
@@ -48,6 +49,7 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
     esz = 8 if args.dtype == "f64" else 4
     stream = torch.cuda.current_stream().cuda_stream
     steps, warmup = args.steps, args.warmup
+    result = None
     # measurement aid on a one-GPU box: evaluate the shard rank R of W would get, without a process group
     # (SIGOPS_BENCH_AS=R/W; compute-only time of that rank, no gather)
     import os
@@ -139,7 +141,7 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
             cfg.update(extra)
             if shard_world != world:
                 cfg["measured_as"] = f"rank {shard_rank} of {shard_world} on one GPU: its shard only ({count} frames), no gather"
-            print(json.dumps({
+            result = ({
                 "metric": METRIC, "value": total / (ms_g * 1e-3), "unit": "frames/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": ms_g, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": args.dtype, "data": "synthetic", "config": cfg,
@@ -147,7 +149,10 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
                 "roofline": {"bound": "hbm", "achieved": algo / (ms_c * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": algo / (ms_c * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
                              "kernel": "whole sink per GPU, compute only (timed loop)"},
-                "cpu_baseline": None}), flush=True)
+                "rccl_ranks": dist.get_world_size() if dist is not None and dist.get_backend() == "nccl" else None,
+                "cpu_baseline": None})
+            if emit:
+                print(json.dumps(result), flush=True)
     else:  # config5
         cpg = 128
         n = int(round(args.seconds / 600.0 * 10_000_000))
@@ -192,6 +197,10 @@ def run(args, so, torch, dist, rank, local_rank, world, dev):
                                   "from": "timed loop, per GPU"},
                 "cpu_baseline": None}), flush=True)
         plan.close()
+    if not emit:
+        if plan is not None and args.workload != "config5":
+            plan.close()
+        return result if rank == 0 else None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

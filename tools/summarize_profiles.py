@@ -17,13 +17,15 @@ if stats:
             row[0] = row[0][:200]  # torch's RNG kernel has a 4 KB mangled name
             w.writerow(row)
 
-STAGES = {"k_resample_periodic": ["k_resample_periodic"], "k_sos": ["k_sos_tiled", "k_sos_scan", "k_sos_onepass"],
-          "k_pointwise": ["k_pointwise"]}
+STAGES = {"k_rsos": ["k_rsos", "k_sos_poison"], "k_resample_periodic": ["k_resample_periodic"],
+          "k_sos": ["k_sos_tiled", "k_sos_scan", "k_sos_onepass"], "k_pointwise": ["k_pointwise"]}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_sources_sha16: bench.py quotes these counters only while the kernel sources are the same)
 res = {"note": ("separate --pmc passes of `python3 bench.py --workload W --no-secondary --steps 100 --warmup 10 "
                 "--cpu-seconds 0`.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and "
                 "WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950, WRITE_SIZE is "
                 "exact; corrected HBM traffic = 2*FETCH + WRITE.  Per execute = summed over the stage's kernels / number of "
-                "executes."), "stages": {}}
+                "executes."), "kernel_sources_sha16": bench.kernel_sources_sha16(), "stages": {}}
 for wl in ("ns", "config3"):
     per = {}
     for name, sub in (("FETCH_SIZE", f"fetch_{wl}"), ("WRITE_SIZE", f"write_{wl}")):
@@ -45,7 +47,7 @@ for wl in ("ns", "config3"):
     for stage, d in per.items():
         if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
             continue
-        nexec = min(v[0] for v in d["FETCH_SIZE"].values())  # the kernel launched once per execute
+        nexec = max(v[0] for v in d["FETCH_SIZE"].values()) if stage == "k_rsos" else min(v[0] for v in d["FETCH_SIZE"].values())  # launched once per execute
         fetch_kb = sum(v[1] for v in d["FETCH_SIZE"].values()) / nexec
         write_kb = sum(v[1] for v in d["WRITE_SIZE"].values()) / nexec
         res["stages"][f"{wl}:{stage}"] = {
