@@ -88,9 +88,33 @@ def oracle_nframes(x):
     return oracle_lib().so_oracle_nframes(lw.nodes, lw.n, lw.root)
 
 
+_RELERR_LOG = {}
+
+
+def _relerr_dump():
+    import json
+
+    path = os.environ.get("SIGOPS_RECORD_RELERR")
+    if path and _RELERR_LOG:
+        with open(path, "w") as f:
+            json.dump({k: {"max": v[0], "calls": v[1]} for k, v in sorted(_RELERR_LOG.items())}, f, indent=1)
+
+
 def relerr(a, b):
-    """norm-wise relative error, Julia isapprox semantics (runtests.jl:356)"""
+    """norm-wise relative error, Julia isapprox semantics (runtests.jl:356).  SIGOPS_RECORD_RELERR=<file>: the largest
+    value every test saw, per result dtype, is written there at exit (profiles/r04/relerr_maxima.json: what the
+    tolerances of the suite are set against)."""
+    dt = getattr(a, "dtype", None)
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     nb = np.linalg.norm(b)
-    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+    r = np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+    if os.environ.get("SIGOPS_RECORD_RELERR"):
+        if not _RELERR_LOG:
+            import atexit
+
+            atexit.register(_relerr_dump)
+        key = "%s [%s]" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], dt)
+        old = _RELERR_LOG.get(key, (0.0, 0))
+        _RELERR_LOG[key] = (max(old[0], float(r)) if np.isfinite(r) else old[0], old[1] + 1)
+    return r

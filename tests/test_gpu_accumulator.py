@@ -106,7 +106,7 @@ def test_tiled_resampler_for_rates_without_a_period(fs_in, fs_out, nch, n, dt):
     want = oracle_sink(tree)
     assert got.shape == want.shape and got.dtype == want.dtype
     assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
-    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 2e-6) * np.abs(want).max()
+    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 1e-6) * np.abs(want).max()
 
 
 def test_tiled_resampler_equals_the_thread_per_output_kernel(monkeypatch):
@@ -140,7 +140,7 @@ def test_two_outputs_per_lane_form_of_the_tiled_resampler(fs_in, fs_out, nch, n,
     want = oracle_sink(tree)
     assert got.shape == want.shape and got.dtype == want.dtype
     assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
-    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 2e-6) * np.abs(want).max()
+    assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 1e-6) * np.abs(want).max()
     monkeypatch.setenv("SIGOPS_RS_NOPAIR", "1")
     one = so.sink(tree)[0]
     assert np.array_equal(got, one)

@@ -182,7 +182,7 @@ def test_a_filter_never_recovers_from_a_non_finite_sample(dt, shape):
     assert got.shape == want.shape
     gn, wn = ~np.isfinite(got), ~np.isfinite(want)
     assert wn.any() and np.array_equal(gn, wn)
-    assert relerr(np.where(wn, 0, got), np.where(wn, 0, want)) <= (1e-9 if dt == np.float64 else 2e-6)
+    assert relerr(np.where(wn, 0, got), np.where(wn, 0, want)) <= (1e-9 if dt == np.float64 else 1e-6)
 
 
 def test_an_indexing_pad_on_a_computed_signal_is_refused_even_where_the_outputs_never_reach_it():

@@ -77,7 +77,7 @@ def test_random_iir_geometries(seed):
         want = oracle_sink(tree)
         got = so.sink(tree)[0]
         assert got.shape == want.shape
-        tol = 2e-6 if got.dtype == np.float32 else 1e-8
+        tol = 1e-6 if got.dtype == np.float32 else 1e-8
         assert relerr(got, want) <= tol, (fs, nch, n, dt.__name__, typ, order)
 
 
@@ -189,7 +189,7 @@ def test_random_operator_trees(seed):
         if want.size:
             ok = np.isfinite(want).all()
             # Float32 anywhere in the tree (even under a Float64 result): Float32 bound
-            tol = 2e-6 if info.get("f32") else 1e-9
+            tol = 1e-6 if info.get("f32") else 1e-9
             if ok:
                 assert relerr(got, want) <= tol, repr(tree)[:400]
             else:
@@ -256,5 +256,5 @@ def test_random_multirate_multiblock_trees(seed):
             want = oracle_sink(tree)
         got = so.sink(tree)[0]
         assert got.shape == want.shape and got.dtype == want.dtype, repr(tree)[:300]
-        tol = 2e-6 if (info.get("f32") or got.dtype == np.float32) else 1e-8
+        tol = 1e-6 if (info.get("f32") or got.dtype == np.float32) else 1e-8
         assert relerr(got, want) <= tol, repr(tree)[:400]

@@ -63,9 +63,13 @@ def test_filter_memory_and_section_groups(spec):
     tree = spec[1](so.Signal(x, 44.1 * so.kHz))
     got = so.sink(tree)[0]
     want = oracle_sink(tree)
-    # (2 Hz high-pass at 44.1 kHz: poles at 1 - 1e-4, where the chunked forms and the sequential
-    #  recurrence differ by their rounding, amplified by the filter's memory)
-    assert relerr(got, want) < (1e-7 if "2 Hz" in spec[0] else 1e-9), spec[0]
+    # (2 Hz high-pass at 44.1 kHz: poles at 1 - 1e-4.  The one Float64 bound of the suite above 1e-8 (observed 1.3e-8,
+    #  profiles/r04/relerr_maxima.json): this filter's memory is longer than the signal, and its own Float64 recurrence
+    #  -- DSP.jl's `filt!`, the call at reference src/filters.jl:252-255 -- is that far from its 80-bit evaluation
+    #  ("what remains above 1e-8"), so any other association of the same sums differs from it by as
+    #  much; the sequential kernel that reproduces the reference's order bit for bit is kept for cascades whose
+    #  conditioning probe fails, not for every DC blocker.)
+    assert relerr(got, want) < (2e-8 if "2 Hz" in spec[0] else 1e-9), spec[0]
 
 
 def test_onepass_equals_three_pass(monkeypatch):

@@ -45,7 +45,7 @@ def test_soak_operator_trees(seed):
         if not want.size:
             continue
         if np.isfinite(want).all():
-            assert relerr(got, want) <= (2e-6 if info.get("f32") else 1e-9), (seed, i, repr(tree)[:400])
+            assert relerr(got, want) <= (1e-6 if info.get("f32") else 1e-9), (seed, i, repr(tree)[:400])
         else:
             assert np.array_equal(np.isfinite(got), np.isfinite(want)), (seed, i, repr(tree)[:400])
 
@@ -70,7 +70,7 @@ def test_soak_multirate_multiblock_trees(seed):
             os.environ.pop("SIGOPS_NO_WINDOW_ALIAS", None)
         assert got.shape == want.shape and got.dtype == want.dtype, (seed, i)
         assert np.array_equal(got, ref), (seed, i, "window aliasing changed the result")
-        assert relerr(got, want) <= (2e-6 if (info.get("f32") or got.dtype == np.float32) else 1e-8), (seed, i, repr(tree)[:400])
+        assert relerr(got, want) <= (1e-6 if (info.get("f32") or got.dtype == np.float32) else 1e-8), (seed, i, repr(tree)[:400])
 
 
 RATES = [8000.0, 12000.0, 16000.0, 44100.0, 48000.0]
@@ -127,7 +127,7 @@ def test_soak_windows_of_stateful_trees(seed):
         except so.ErrorException:
             continue
         whole = so.sink(t, so.Array)
-        tol = 2e-6 if (info.get("f32") or whole.dtype == np.float32) else 1e-8
+        tol = 1e-6 if (info.get("f32") or whole.dtype == np.float32) else 1e-8
         for j in range(3):
             a = int(rng.integers(N // 4, N - 10))
             m = int(rng.integers(1, N - a + 1)) if rng.random() < 0.5 else N - a
@@ -169,14 +169,14 @@ def test_soak_filter_designs(seed):
         pytest.skip("the design is rejected by the host layer (same for the oracle)")
     if not np.isfinite(want).all() or np.abs(want).max() > 1e6:
         pytest.skip("an unstable design: nothing to compare")
-    tol = 5e-6 if dt == np.float32 else 1e-7
+    tol = 1e-6 if dt == np.float32 else 1e-8  # (north_star: 1e-6 for Float32; observed: profiles/r04/relerr_maxima.json)
     got = so.sink(t, so.Array)
     assert relerr(got, want) <= tol, (k, order, method, f1 / fs)
     a = int(rng.integers(N // 2, N - 1000))
     m = int(rng.integers(500, N - a))
     w = so.sink(t | so.After(a * so.frames) | so.Until(m * so.frames), so.Array)
     if np.abs(want[a:a + m]).max() > 0:
-        assert relerr(w, want[a:a + m]) <= 10 * tol, (k, order, method, f1 / fs, a, m)
+        assert relerr(w, want[a:a + m]) <= tol, (k, order, method, f1 / fs, a, m)
 
 
 LONG_RATES = [(44100, 48000), (48000, 44100), (44100, 16000), (32000, 48000), (22050, 44100)]
@@ -204,7 +204,7 @@ def test_soak_long_fused_resamplers(seed):
     else:
         t = x | so.ToEltype(np.float64) | so.Amplify(so.Signal(so.cos, ω=2 * so.Hz)) | so.Until(N * so.frames) | so.ToFramerate(fo * so.Hz)
     want = oracle_sink(t)
-    tol = 2e-6 if want.dtype == np.float32 else 1e-8
+    tol = 1e-6 if want.dtype == np.float32 else 1e-8
     for _ in range(2):  # (twice: the ring protocols are timing dependent)
         assert relerr(so.sink(t, so.Array), want) <= tol, (fi, fo, nch, dt.__name__, N, k)
 
@@ -230,7 +230,7 @@ def test_soak_channel_counts(nch):
         want = oracle_sink(t)
         got = so.sink(t, so.Array)
         assert got.shape == want.shape, (nch, name)
-        assert relerr(got, want) <= (2e-6 if dt == np.float32 else 1e-9), (nch, dt.__name__, name)
+        assert relerr(got, want) <= (1e-6 if dt == np.float32 else 1e-9), (nch, dt.__name__, name)
 
 
 @pytest.mark.parametrize("nch", [1, 2, 8])
@@ -255,7 +255,7 @@ def test_soak_sizes_around_the_planner_switch_points(nch, base):
             want = oracle_sink(t)
             got = so.sink(t, so.Array)
             assert got.shape == want.shape, (nch, N, name)
-            assert relerr(got, want) <= (2e-6 if dt == np.float32 else 1e-9), (nch, N, dt.__name__, name)
+            assert relerr(got, want) <= (1e-6 if dt == np.float32 else 1e-9), (nch, N, dt.__name__, name)
 
 
 @pytest.mark.parametrize("block", range(4))

@@ -68,7 +68,7 @@ def test_scenes_of_ragged_lengths(nch, dt):
     rng = np.random.default_rng(100 + nch)
     kids = [so.Signal(_noise(rng, n, nch, dt), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
             for n in (50001, 17, 7777, 123456, 3, 64, 65, 30000)]
-    _check(so.Append(*kids), tol=2e-6 if dt == np.float32 else 1e-9)
+    _check(so.Append(*kids), tol=1e-6 if dt == np.float32 else 1e-9)
 
 
 def test_the_batch_is_one_step_of_four_launches():
@@ -209,6 +209,6 @@ def test_result_rows_off_the_cache_line(dt, off, pad):
         for c in range(nch):
             mask[off + c * (m + pad): off + c * (m + pad) + m] = False
         assert np.all(np.isnan(host[mask]))
-        assert relerr(got, want) <= (1e-9 if dt == np.float64 else 2e-6)
+        assert relerr(got, want) <= (1e-9 if dt == np.float64 else 1e-6)
         res.append(got)
     assert np.array_equal(res[0], res[1])

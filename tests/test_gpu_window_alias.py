@@ -45,7 +45,7 @@ def test_append_of_filtered_children_odd_lengths(nch, dt):
     rng = np.random.default_rng(11 + nch)
     kids = [so.Signal(_noise(rng, n, nch, dt), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
             for n in (5001, 7777, 12345, 3)]
-    _check(so.Append(*kids), tol=2e-6 if dt == np.float32 else 1e-9)
+    _check(so.Append(*kids), tol=1e-6 if dt == np.float32 else 1e-9)
 
 
 def test_scenes_filter_then_ramp():

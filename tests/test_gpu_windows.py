@@ -55,7 +55,7 @@ def test_cascaded_groups_and_chained_filters():
 def test_float32_and_mixed_consumers():
     rng = np.random.default_rng(23)
     x = so.Signal(_noise(rng, 80000, 2, np.float32), 44.1 * so.kHz)
-    _check(x | so.Filt(so.Lowpass, 3 * so.kHz) | so.After(60000 * so.frames), tol=2e-6)
+    _check(x | so.Filt(so.Lowpass, 3 * so.kHz) | so.After(60000 * so.frames), tol=1e-6)
     y = so.Signal(_noise(rng, 80000, 2), 44.1 * so.kHz)
     f = y | so.Filt(so.Lowpass, 3 * so.kHz)
     # the same stage read at two offsets: the earlier one decides where it starts
