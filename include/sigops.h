@@ -31,6 +31,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The entry points below are the library's whole dynamic symbol table: libsigops.so is built with
+ * -fvisibility=hidden, and everything declared between here and the matching pop is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SO_ABI_VERSION 1
 
@@ -276,8 +281,8 @@ int64_t so_plan_counter(const so_plan_t* plan, int32_t which);
 int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity);
 
 /* Large pointwise steps the interpreter CAN run are specialised too, but never at the caller's expense: the plan
- * uses the specialised kernel if this process or the on-disk cache of code objects ($SIGOPS_CACHE_DIR, default
- * $XDG_CACHE_HOME/sigops-hip or ~/.cache/sigops-hip; an empty SIGOPS_CACHE_DIR disables it) has it, otherwise it
+ * uses the specialised kernel if this process has it -- or, where the host sets SIGOPS_CACHE_DIR, that directory of
+ * code objects (the library writes nowhere on its own) --, otherwise it
  * keeps the interpreter -- same values, operation for operation -- while a background thread compiles the kernel
  * for the plans to come.  so_rtc_wait_idle returns when every compile queued so far has finished (a service
  * warming up; tests).  SIGOPS_RTC_NOASYNC=1 switches the background path off. */
@@ -313,6 +318,12 @@ int32_t so_comm_create(const void* id128, int32_t world, int32_t rank, int32_t d
  * `full`: then nothing is copied locally); slabs[world]: every rank's share; full: device buffer */
 int32_t so_comm_allgather(so_comm_t* comm, const void* mine, int64_t src_row_stride, void* full,
                           const so_slab_t* slabs, int32_t dtype, void* stream);
+/* The operands of a root Mix(xs...) = OperateOn(+, xs...) (reference src/mapsignal.jl:307-308) evaluated on
+ * different ranks: every rank holds a partial sum in a buffer of the result's shape -- `rows` runs of `row_elems`
+ * elements, `row_stride` elements apart -- and one grouped reduction adds the buffers up IN PLACE: into every rank's
+ * (root < 0) or into rank `root`'s (the other buffers are then unspecified). */
+int32_t so_comm_reduce_sum(so_comm_t* comm, void* buf, int64_t rows, int64_t row_elems, int64_t row_stride,
+                           int32_t dtype, int32_t root, void* stream);
 const char* so_comm_last_error(void);
 void so_comm_destroy(so_comm_t* comm);
 
@@ -368,6 +379,9 @@ int32_t so_resample_positions(double fs_in, double fs_out, double rate, int32_t 
                               int32_t hlen, int64_t n_out, int64_t* j, int32_t* p, double* alpha,
                               int64_t* nfix, int64_t* nbaked);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,7 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
            "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_plan_counter",
-           "so_rtc_compile_check", "so_rtc_wait_idle", "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_last_error", "so_comm_destroy"]
+           "so_rtc_compile_check", "so_rtc_wait_idle", "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_reduce_sum", "so_comm_last_error", "so_comm_destroy"]
 
 _lib = None
 
@@ -135,6 +135,8 @@ def lib():
     L.so_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.so_comm_allgather.restype = C.c_int32
     L.so_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(so_slab_t), C.c_int32, C.c_void_p]
+    L.so_comm_reduce_sum.restype = C.c_int32
+    L.so_comm_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     L.so_comm_last_error.restype = C.c_char_p
     L.so_comm_destroy.restype = None
     L.so_comm_destroy.argtypes = [C.c_void_p]

@@ -33,6 +33,8 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
@@ -62,6 +64,8 @@ Rccl& rccl() {
         r.GroupEnd = (int (*)())sym("ncclGroupEnd");
         r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
         r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+        r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
+        r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))sym("ncclReduce");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     });
     return r;
@@ -162,6 +166,41 @@ int32_t so_comm_allgather(so_comm_t* c, const void* mine, int64_t src_row_stride
     }
     const int rc2 = r.GroupEnd();
     if (rc != 0 || rc2 != 0) return fail(SO_ERR_RUNTIME, std::string("RCCL exchange: ") + r.GetErrorString(rc ? rc : rc2));
+    return SO_OK;
+}
+
+// The other exchange the path has (BASELINE.json north_star: "RCCL ... only for the final concatenate/sum"): the
+// operands of a root `Mix(xs...) = OperateOn(+, xs...)` (reference src/mapsignal.jl:307-308) evaluated on different
+// ranks, every rank's partial sum in a buffer of the result's shape, and ONE grouped reduction adds them up in place --
+// into every rank's buffer (root < 0: ncclAllReduce) or into `root`'s (ncclReduce; the others' buffers are then
+// unspecified).  `rows` runs of `row_elems` elements, `row_stride` elements apart (a planar result whose channel
+// rows are padded; rows = 1 for a contiguous one).  Floating-point note: the reference folds its operands left to
+// right; a reduction over ranks associates them as the collective's algorithm does -- the same values for two ranks,
+// a different rounding of the same sum (<= 1 ulp per addition) beyond.
+int32_t so_comm_reduce_sum(so_comm_t* c, void* buf, int64_t rows, int64_t row_elems, int64_t row_stride, int32_t dtype,
+                           int32_t root, void* stream) {
+    if (!c || (!buf && rows > 0 && row_elems > 0)) return fail(SO_ERR_INVALID, "so_comm_reduce_sum: null argument");
+    if (dtype != SO_F32 && dtype != SO_F64) return fail(SO_ERR_INVALID, "so_comm_reduce_sum: Float32 / Float64 only");
+    if (rows < 0 || row_elems < 0 || root >= c->world) return fail(SO_ERR_INVALID, "so_comm_reduce_sum: bad shape or root");
+    Rccl& r = rccl();
+    if (!r.err.empty()) return fail(SO_ERR_UNSUPPORTED, r.err);
+    if (rows == 0 || row_elems == 0) return SO_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(SO_ERR_NODEVICE, "so_comm_reduce_sum: device");
+    const size_t esz = dtype == SO_F32 ? 4 : 8;
+    const int nt = dtype == SO_F32 ? 7 : 8;  // ncclFloat32 / ncclFloat64
+    const int sum = 0;                        // ncclSum
+    hipStream_t st = (hipStream_t)stream;
+    if (row_stride == row_elems) {  // contiguous: one collective
+        row_elems *= rows;
+        rows = 1;
+    }
+    int rc = rows > 1 ? r.GroupStart() : 0;
+    for (int64_t row = 0; row < rows && rc == 0; ++row) {
+        char* p = (char*)buf + (size_t)(row * row_stride) * esz;
+        rc = root < 0 ? r.AllReduce(p, p, (size_t)row_elems, nt, sum, c->comm, st) : r.Reduce(p, p, (size_t)row_elems, nt, sum, root, c->comm, st);
+    }
+    const int rc2 = rows > 1 ? r.GroupEnd() : 0;
+    if (rc != 0 || rc2 != 0) return fail(SO_ERR_RUNTIME, std::string("RCCL reduction: ") + r.GetErrorString(rc ? rc : rc2));
     return SO_OK;
 }
 

@@ -308,4 +308,40 @@ function sink_blocks(f, x, blocksize::Integer; T=Float64)
     end
 end
 
+# ---- the exchange steps of a sharded sink (include/sigops.h so_comm_*; one process per GPU, RCCL bound at run time) ----
+struct SoSlab
+    rows::Int64; row_elems::Int64
+    dst_offset::Int64; dst_row_stride::Int64
+end
+
+"rank 0 makes the 128-byte id; the host's launcher (MPI.jl, a file, a socket) hands it to every rank"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:so_comm_unique_id, libsigops), Int32, (Ptr{UInt8},), id))
+    id
+end
+
+function comm_create(id::Vector{UInt8}, world::Integer, rank::Integer, device::Integer=0)
+    comm = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:so_comm_create, libsigops), Int32, (Ptr{UInt8}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+                id, world, rank, device, comm))
+    comm[]
+end
+
+"every rank's share (`mine`: device pointer, rows `src_row_stride` elements apart) into every rank's `full` buffer"
+function comm_allgather!(comm::Ptr{Cvoid}, mine::Ptr{Cvoid}, src_row_stride::Integer, full::Ptr{Cvoid},
+                         slabs::Vector{SoSlab}, dtype::Integer=SO_F64, stream::Ptr{Cvoid}=C_NULL)
+    check(ccall((:so_comm_allgather, libsigops), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{SoSlab}, Int32, Ptr{Cvoid}),
+                comm, mine, src_row_stride, full, slabs, dtype, stream))
+end
+
+"the operands of a root `Mix` evaluated on different ranks: the ranks' partial sums added up in place (root < 0: on every rank)"
+function comm_reduce_sum!(comm::Ptr{Cvoid}, buf::Ptr{Cvoid}, rows::Integer, row_elems::Integer, row_stride::Integer,
+                          dtype::Integer=SO_F64, root::Integer=-1, stream::Ptr{Cvoid}=C_NULL)
+    check(ccall((:so_comm_reduce_sum, libsigops), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int32, Int32, Ptr{Cvoid}),
+                comm, buf, rows, row_elems, row_stride, dtype, root, stream))
+end
+
+comm_destroy(comm::Ptr{Cvoid}) = ccall((:so_comm_destroy, libsigops), Cvoid, (Ptr{Cvoid},), comm)
+
 end # module

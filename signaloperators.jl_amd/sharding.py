@@ -162,6 +162,20 @@ class NativeComm:
         if st != 0:
             raise S.ErrorException(K.lib().so_comm_last_error().decode())
 
+    def reduce_sum(self, buf, root=-1, stream=None):
+        """so_comm_reduce_sum: the ranks' buffers (one planar [nch][pitch] tensor each) added up in place, into every
+        rank's buffer (root < 0) or into `root`'s"""
+        import ctypes as C
+
+        from . import _capi as K
+
+        rows, row_elems = (1, buf.numel()) if buf.is_contiguous() else (buf.shape[0], buf.shape[1])
+        dt = K.SO_F32 if buf.element_size() == 4 else K.SO_F64
+        st = K.lib().so_comm_reduce_sum(self.handle, C.c_void_p(buf.data_ptr()), int(rows), int(row_elems),
+                                        int(buf.stride(0)) if rows > 1 else int(row_elems), dt, int(root), C.c_void_p(stream or 0))
+        if st != 0:
+            raise S.ErrorException(K.lib().so_comm_last_error().decode())
+
     def close(self):
         from . import _capi as K
 
@@ -174,6 +188,81 @@ class NativeComm:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def shard_mix(x, rank, world):
+    """Operands of a root `Mix(xs...) = OperateOn(+, xs...)` (reference src/mapsignal.jl:307-308) in contiguous blocks per
+    rank -> this rank's partial sum as a signal of the WHOLE result's length (shorter operands are zero-extended, as the
+    Mix itself extends them: src/mapsignal.jl:26), or None for a rank without operands."""
+    from .units import frames
+
+    x = S._assignal(x)
+    if not (isinstance(x, S.MapSignal) and x.fn == S.ADD and x.bychannel and len(x.signals) >= 2):
+        raise S.ErrorException("shard_mix needs a Mix(...) root")
+    n = S.nframes(x)
+    if n is None or S.isknowninf(n):
+        raise S.ErrorException("Cannot shard a Mix of infinite or unknown length")
+    lo, hi = block_range(len(x.signals), rank, world)
+    if hi <= lo:
+        return None
+    mine = list(x.signals[lo:hi])
+    sub = mine[0] if len(mine) == 1 else S._OperateOn(S.ADD, mine)
+    sub = S.ToChannels(sub, x.nch)
+    m = S.nframes(sub)
+    if m is None or S.isknowninf(m) or int(m) > int(n):
+        sub = S.Until(sub, int(n) * frames)
+    elif int(m) < int(n):
+        sub = S.Until(S.Pad(sub, S.zero), int(n) * frames)
+    return sub
+
+
+def sink_mix_sharded(x, *, rank=None, world=None, root=-1, compute=None, device=0, comm=None):
+    """Evaluate Mix(operands...) with the operands sharded over the ranks: every rank sinks the sum of its block of
+    operands into a device buffer of the result's shape, and ONE reduction adds the buffers up (the only exchange
+    step; BASELINE.json north_star: "RCCL ... only for the final concatenate/sum").  `comm` (a NativeComm): the
+    library's own so_comm_reduce_sum; otherwise torch.distributed's all_reduce / reduce.  `compute` (tests: the CPU
+    oracle under gloo) switches to the NumPy path.  Returns the full result on every rank (root < 0) or on `root`
+    (None elsewhere).  The reference folds the operands left to right; the reduction associates the ranks' partial
+    sums as the collective does: the same values for two ranks, <= 1 ulp per addition beyond."""
+    rank, world = _dist_info(rank, world)
+    x = S._assignal(x)
+    sub = shard_mix(x, rank, world)
+    n, nch = int(S.nframes(x)), x.nch
+    dt = S.float_type(x.dtype)
+    if compute is not None:
+        import torch
+        import torch.distributed as dist
+
+        local = np.zeros((n, nch), dtype=dt, order="F") if sub is None else np.asfortranarray(np.asarray(compute(sub), dtype=dt))
+        if world == 1:
+            return local
+        t = torch.from_numpy(np.ascontiguousarray(local.T))
+        if dist.get_backend() == "nccl":
+            t = t.cuda(device)
+        if root < 0:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+        return np.asfortranarray(t.cpu().numpy().T) if (root < 0 or rank == root) else None
+    import torch
+    import torch.distributed as dist
+
+    from .engine import sink_into
+
+    tdt = torch.float32 if dt == S.F32 else torch.float64
+    buf = torch.zeros((nch, max(n, 1)), dtype=tdt, device=f"cuda:{device}")
+    if sub is not None and n > 0:
+        sink_into(buf.t()[:n], sub, device=device)
+    if comm is not None:
+        torch.cuda.synchronize(device)
+        comm.reduce_sum(buf, root, torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+    elif world > 1:
+        if root < 0:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
+    return buf.t()[:n] if (root < 0 or rank == root) else None
 
 
 def sink_append_sharded(x, *, rank=None, world=None, gather=True, compute=None, device=0, comm=None, force_gather=False):

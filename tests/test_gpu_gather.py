@@ -116,3 +116,35 @@ def test_native_exchange_through_rccl_on_one_rank(monkeypatch):
     tree = _scenes(rng, k=3)
     assert np.array_equal(sh.sink_append_sharded(tree, rank=0, world=1, comm=comm).cpu().numpy(), so.sink(tree, so.Array))
     comm.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_mix_operands_on_ranks_add_up_to_the_unsharded_sink(world):
+    """sink_mix_sharded on ONE GPU: every rank's partial sum evaluated by the engine, the partial sums added by hand where
+    there are several (what the reduction does), and for world = 1 through the library's own so_comm_reduce_sum on a
+    one-rank RCCL communicator and through torch.distributed's all_reduce"""
+    rng = np.random.default_rng(60)
+    ops = []
+    for k in range(3):
+        n = 30000 + 4000 * k
+        ops.append(so.Signal(np.asfortranarray(rng.standard_normal((n, 2))), 44.1 * so.kHz)
+                   | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz))
+    tree = so.Mix(*ops)
+    whole = so.sink(tree, so.Array)
+    if world == 1:
+        comm = sh.NativeComm.single()
+        try:
+            got = sh.sink_mix_sharded(tree, rank=0, world=1, comm=comm)
+            assert got.is_cuda and np.array_equal(got.cpu().numpy(), whole)
+            only = sh.sink_mix_sharded(tree, rank=0, world=1, comm=comm, root=0)
+            assert np.array_equal(only.cpu().numpy(), whole)
+        finally:
+            comm.close()
+        return
+    acc = None
+    for r in range(world):
+        sub = sh.shard_mix(tree, r, world)
+        part = np.zeros_like(whole) if sub is None else so.sink(sub, so.Array)
+        assert part.shape == whole.shape
+        acc = part if acc is None else acc + part
+    assert relerr(acc, whole) < 1e-15

@@ -1,0 +1,110 @@
+"""The Julia glue (signaloperators.jl_amd/julia/SignalOperatorsHIP.jl) cannot run here (no Julia in the image), so the
+parts of it a typo would break silently are checked as text against the C side:
+  * every `struct` that mirrors a C-ABI struct (SoNode <-> so_node_t, SoOutDesc <-> so_out_desc_t, SoSlab <-> so_slab_t)
+    has the fields of the C struct in the same order at the same offsets -- the C offsets come from a tiny program
+    compiled here with gcc against include/sigops.h, the Julia offsets from Julia's own layout rule for isbits structs
+    (C layout: every field aligned to its size);
+  * every `ccall((:name, lib), ...)` names a symbol include/sigops.h declares, with as many argument types as the
+    prototype has parameters."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = os.path.join(ROOT, "signaloperators.jl_amd", "julia", "SignalOperatorsHIP.jl")
+HDR = os.path.join(ROOT, "include", "sigops.h")
+
+SIZES = {"Int32": 4, "UInt32": 4, "Cint": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Float32": 4, "Cdouble": 8}
+PAIRS = {"SoNode": "so_node_t", "SoOutDesc": "so_out_desc_t", "SoSlab": "so_slab_t"}
+
+
+def julia_structs():
+    src = open(JL).read()
+    out = {}
+    for m in re.finditer(r"^struct\s+(\w+)\b(.*?)\bend\b", src, re.S | re.M):
+        name, body = m.group(1), re.sub(r"#.*", "", m.group(2))
+        if name not in PAIRS:
+            continue
+        out[name] = [(fm.group(1), fm.group(2)) for fm in re.finditer(r"(\w+)::([\w{}.]+)", body)]
+    return out
+
+
+def layout(fields):
+    off, res, maxal = 0, [], 1
+    for name, typ in fields:
+        size = 8 if typ.startswith("Ptr{") else SIZES[typ]
+        off = (off + size - 1) // size * size
+        res.append((name, off, size))
+        off += size
+        maxal = max(maxal, size)
+    return res, (off + maxal - 1) // maxal * maxal
+
+
+def c_layout(tmp_path):
+    fields = {"so_node_t": ["kind", "dtype", "nch", "n_children", "children", "nframes", "fs", "i0", "i1", "i2", "i3", "l0", "l1",
+                            "d0", "d1", "d2", "d3", "p0", "p1", "s0", "s1"],
+              "so_out_desc_t": ["dtype", "nch", "nframes", "frame_stride", "chan_stride", "is_device", "reserved"],
+              "so_slab_t": ["rows", "row_elems", "dst_offset", "dst_row_stride"]}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "sigops.h"', 'int main(void) {']
+    for t, fs in fields.items():
+        prog.append(f'printf("{t} size %zu\\n", sizeof({t}));')
+        for f in fs:
+            prog.append(f'printf("{t} {f} %zu %zu\\n", offsetof({t}, {f}), sizeof((({t}*)0)->{f}));')
+    prog += ['return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    res = {}
+    for line in out:
+        p = line.split()
+        if len(p) == 3 and p[1] == "size":
+            res.setdefault(p[0], {"fields": []})["size"] = int(p[2])
+        elif len(p) == 4:
+            res.setdefault(p[0], {"fields": []})["fields"].append((p[1], int(p[2]), int(p[3])))
+    return res
+
+
+def test_julia_structs_have_the_c_layout(tmp_path):
+    js, cs = julia_structs(), c_layout(tmp_path)
+    assert set(js) == set(PAIRS), "every mirrored struct is found in the Julia file"
+    for jname, cname in PAIRS.items():
+        jl, jsize = layout(js[jname])
+        assert [(n, o, s) for n, o, s in jl] == cs[cname]["fields"], (jname, jl, cs[cname]["fields"])
+        assert jsize == cs[cname]["size"]
+
+
+def c_prototypes():
+    src = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(so_\w+)\s*\(([^;{}]*?)\)\s*;", src):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",")])
+    return protos
+
+
+def test_ccalls_name_declared_symbols_with_the_right_arity():
+    src = open(JL).read()
+    protos = c_prototypes()
+    calls = re.findall(r"ccall\(\(:(\w+),\s*\w+\),\s*[\w{}.]+,\s*\((.*?)\)\s*,", src, re.S)
+    assert len(calls) >= 10
+    for name, argt in calls:
+        assert name in protos, f"ccall of {name}: not declared in include/sigops.h"
+        depth, n, cur = 0, 0, ""
+        for ch in argt:  # count top-level commas (Ptr{...} has none inside, Tuple types could)
+            if ch in "{(":
+                depth += 1
+            elif ch in "})":
+                depth -= 1
+            if ch == "," and depth == 0:
+                if cur.strip():
+                    n += 1
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            n += 1
+        assert n == protos[name], f"ccall of {name}: {n} argument types, the prototype has {protos[name]}"
