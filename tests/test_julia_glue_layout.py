@@ -86,25 +86,42 @@ def c_prototypes():
     return protos
 
 
-def test_ccalls_name_declared_symbols_with_the_right_arity():
-    src = open(JL).read()
-    protos = c_prototypes()
-    calls = re.findall(r"ccall\(\(:(\w+),\s*\w+\),\s*[\w{}.]+,\s*\((.*?)\)\s*,", src, re.S)
-    assert len(calls) >= 10
-    for name, argt in calls:
-        assert name in protos, f"ccall of {name}: not declared in include/sigops.h"
-        depth, n, cur = 0, 0, ""
-        for ch in argt:  # count top-level commas (Ptr{...} has none inside, Tuple types could)
-            if ch in "{(":
-                depth += 1
-            elif ch in "})":
-                depth -= 1
+def _ccalls(src):
+    """(name, [argument types]) of every `ccall((:name, lib), Ret, (ArgTypes...), args...)`"""
+    out = []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*\w+\),", src):
+        i = m.end()
+        depth, j = 0, i
+        while not (src[j] == "," and depth == 0):  # the return type
+            depth += src[j] in "{(["
+            depth -= src[j] in "})]"
+            j += 1
+        j = src.index("(", j)  # the tuple of argument types
+        depth, k = 0, j
+        while True:
+            depth += src[k] in "{(["
+            depth -= src[k] in "})]"
+            if depth == 0:
+                break
+            k += 1
+        body, args, cur, depth = src[j + 1:k], [], "", 0
+        for ch in body:
+            depth += ch in "{(["
+            depth -= ch in "})]"
             if ch == "," and depth == 0:
-                if cur.strip():
-                    n += 1
+                args.append(cur.strip())
                 cur = ""
             else:
                 cur += ch
-        if cur.strip():
-            n += 1
-        assert n == protos[name], f"ccall of {name}: {n} argument types, the prototype has {protos[name]}"
+        args.append(cur.strip())
+        out.append((m.group(1), [a for a in args if a]))
+    return out
+
+
+def test_ccalls_name_declared_symbols_with_the_right_arity():
+    protos = c_prototypes()
+    calls = _ccalls(open(JL).read())
+    assert len(calls) >= 10
+    for name, args in calls:
+        assert name in protos, f"ccall of {name}: not declared in include/sigops.h"
+        assert len(args) == protos[name], f"ccall of {name}: {len(args)} argument types {args}, the prototype has {protos[name]}"
