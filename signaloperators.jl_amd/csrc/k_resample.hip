@@ -1048,7 +1048,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ytile[yoff[q][i] + gi * 16] = (TO)acc[q][i];
+                        for (int i = 0; i < 4; ++i) {
+                            if (g.pad & 256) __builtin_nontemporal_store((TO)acc[q][i], &ytile[yoff[q][i] + gi * 16]);
+                            else ytile[yoff[q][i] + gi * 16] = (TO)acc[q][i];
+                        }
                 } else {
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
