@@ -520,7 +520,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     if (s.idx == P->alias_stage && P->alias_narrow) g.out_dtype = SO_F32;
                     g.align_rows = S.pre_stage < 0 && !std::getenv("SIGOPS_SOS_NOALIGN");
                     g.bad = nullptr;
-                    if (S.bad_buf >= 0 && S.pre_stage < 0 && S.rsos_src < 0 && !S.onepass && !S.xscan && !g.exact && !std::getenv("SIGOPS_SOS_NOPOISON")) {
+                    if (S.bad_buf >= 0 && S.pre_stage < 0 && S.rsos_src < 0 && !S.onepass && !S.xscan && !g.exact &&
+                        !std::getenv("SIGOPS_SOS_NOPOISON")) {
                         g.bad = (int32_t*)P->bufs[S.bad_buf].d;
                         HIPCHECK(hipMemsetAsync(g.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite chunk yet"
                     }

@@ -256,13 +256,16 @@ def _demand(x, n, out, skip=0):
 
 
 def _apply_host(fn, args):
-    """fn over whole arrays if it broadcasts like a ufunc, else element by element"""
-    try:
+    """An opaque closure over host arrays, as the reference applies it: once per frame (src/functions.jl:53-56,
+    src/mapsignal.jl:249-272).  Only a NumPy ufunc -- elementwise by construction, so one call over the whole array IS
+    the per-frame calls -- or a closure that says so itself (`fn.vectorized = True`) is called once with the arrays;
+    anything else (a stateful or random closure, `x / abs(x).max()`, `cumsum`: same shape, different values) runs
+    element by element, exactly once per element."""
+    if isinstance(fn, np.ufunc) or getattr(fn, "vectorized", False):
         out = np.asarray(fn(*args))
         if out.shape == np.asarray(args[0]).shape:
             return out
-    except Exception:  # noqa: BLE001
-        pass
+        S.error("a closure marked `vectorized` must return one value per frame")
     return np.frompyfunc(fn, len(args), 1)(*args).astype(np.float64)
 
 

@@ -203,3 +203,20 @@ def test_an_indexing_pad_on_a_computed_signal_is_refused_even_where_the_outputs_
     y = so.Signal(np.asfortranarray(rng.standard_normal((354, 1))), fs) | so.Pad(so.mirror) | so.Until(1412 * so.frames)
     t2 = so.Amplify(y, 2.0) | so.ToFramerate(12 * so.kHz) | so.Until(265 * so.frames)
     assert relerr(so.sink(t2)[0], oracle_sink(t2)) <= 1e-9
+
+
+def test_a_cascade_without_feedback_stays_nan_too():
+    """ADVICE r3 suggested sparing sections with a1 = a2 = 0 the poison pass ("their state forgets a NaN two samples
+    later").  It does not in IEEE arithmetic: DF2T forms s1 = s2 + b1 x - a1 y with y = NaN, and 0 * NaN is NaN -- the
+    reference's recurrence (DSP.jl `filt!`, call site src/filters.jl:252-255) stays NaN to the end of the channel for
+    such a cascade as for any other, and so do the oracle and the engine."""
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal((300000, 2))
+    x[100000, 0] = np.nan
+    sos = np.array([[0.5, 0.25, 0.125, 1.0, 0.0, 0.0], [1.0, -0.5, 0.25, 1.0, 0.0, 0.0]])
+    t = so.Filt(so.Signal(np.asfortranarray(x), 44.1 * so.kHz), sos=sos, gain=1.0)
+    got, want = so.sink(t, so.Array), oracle_sink(t)
+    assert np.isnan(want[100000:, 0]).all() and np.isfinite(want[:100000, 0]).all()
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    fin = np.isfinite(want)
+    assert relerr(np.where(fin, got, 0), np.where(fin, want, 0)) <= 1e-12

@@ -201,3 +201,24 @@ def test_stream_of_plain_data_yields_consecutive_slices():
     assert np.array_equal(np.concatenate(blocks, axis=0), data)
     with pytest.raises(so.ErrorException):
         next(so.stream(so.Signal(data, 10 * so.Hz), 0))
+
+
+def test_opaque_closures_run_once_per_frame_on_the_host():
+    """the host evaluation of a closure the engine has no kernel for used to call it once with the whole
+    array and keep any result of the right shape -- a stateful closure, or one that is not elementwise (x / max|x|),
+    silently gave other values than the reference's per-frame calls (src/functions.jl:53-56, src/mapsignal.jl:249-272)"""
+    from sigops_amd.lowering import _apply_host
+
+    x = np.array([1.0, -4.0, 2.0])
+    calls = []
+
+    def counting(v):
+        calls.append(v)
+        return v / abs(v)  # elementwise only when called per element; over the array `abs(v).max()`-style code would not be
+
+    assert np.array_equal(_apply_host(counting, (x,)), np.array([1.0, -1.0, 1.0])) and len(calls) == 3
+    assert np.array_equal(_apply_host(lambda v: v / np.abs(v).max(), (x,)), np.ones(3) * np.sign(x))  # per frame: v / |v|
+    assert np.array_equal(_apply_host(np.maximum, (x, np.zeros(3))), np.maximum(x, 0))  # a ufunc: one call
+    vec = lambda v: 2 * v  # noqa: E731
+    vec.vectorized = True
+    assert np.array_equal(_apply_host(vec, (x,)), 2 * x)
