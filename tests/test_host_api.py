@@ -177,6 +177,19 @@ def test_cabi_exports_every_declared_symbol():
     assert _capi.lib().so_abi_version() == 1
 
 
+def test_cabi_exports_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table defines the header's so_* entry points and
+    nothing of the engine's C++ (no kernel launchers, no STL instantiations another library could bind to)"""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    syms -= {"_init", "_fini", "_edata", "_end", "__bss_start"}
+    assert syms == set(_capi.EXPORTS), sorted(syms ^ set(_capi.EXPORTS))[:10]
+
+
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.so_node_t) == 4 * 4 + 8 + 8 + 8 + 4 * 4 + 2 * 8 + 4 * 8 + 2 * 8 + 2 * 8
     assert ctypes.sizeof(_capi.so_out_desc_t) == 40
