@@ -359,6 +359,21 @@ int32_t so_design_iir_zpk(int32_t type, double f1, double f2, double fs, int32_t
 int32_t so_zpk_to_sos(const double* z, int32_t nz, const double* p, int32_t np, double k, double* sos,
                       int32_t sos_capacity, int32_t* nsections, double* gain);
 
+/* DF2TFilter(::PolynomialRatio) for the engine: `filt(b, a, x[, si])` and `Filt(x, PolynomialRatio(b, a))` of any order
+ * (reference src/filters.jl:68-95 hand DSP.jl's direct-form recurrence the coefficients; the device runs cascades of
+ * second-order sections).  Both polynomials are factored in Float64 (Aberth-Ehrlich; multiple roots by clustering), conjugates made
+ * exact and paired as so_zpk_to_sos pairs them; leading zeros of `b` become delay sections, surplus zeros FIR sections.
+ * `*residual` (may be NULL) = relative l2 distance between the impulse responses of the direct form and of the cascade
+ * over the filter's memory: the caller's gate for ill-conditioned polynomials.  sos must hold 6 * (max(nb, na) + 1) / 2
+ * doubles at least. */
+int32_t so_tf_to_sos(const double* b, int32_t nb, const double* a, int32_t na, double* sos, int32_t sos_capacity,
+                     int32_t* nsections, double* gain, double* residual);
+/* The zero-input response of the direct form from initial state `si` (max(nb, na) - 1 entries, DSP.jl's layout): what
+ * `filt(b, a, x, si)` adds to the response from rest.  Writes up to `capacity` frames; `*nframes` = the frames after
+ * which the state is below 2^-80 of the response's peak (capacity where it has not decayed). */
+int32_t so_tf_zero_input(const double* b, int32_t nb, const double* a, int32_t na, const double* si, int32_t nsi,
+                         double* out, int64_t capacity, int64_t* nframes);
+
 /* resample_filter(ratio): rational (num/den, Nphi=num) or arbitrary (rate, nphi).
  * Call with h==NULL to get the length in *hlen. */
 int32_t so_design_resample_rational(int64_t num, int64_t den, double* h, int32_t capacity,

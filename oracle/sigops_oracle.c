@@ -147,6 +147,37 @@ void so_oracle_set_positions(int mode) { g_position_mode = mode; }
    engine implements).  Used by the multi-rate fuzz tests. */
 void so_oracle_set_semantics(int mode) { g_intended = mode; }
 
+/* DSP.filt(b, a, x::AbstractSignal, si) (reference src/filters.jl:68-87): `filt!(data, b, a, sink(x, Array), si)`,
+   i.e. DSP.jl 0.6.10's direct-form II transposed recurrence of order max(|b|, |a|) - 1 on the sunk samples, one
+   channel after the other (`_filt_iir!`: coefficients divided by a[1] first; per sample
+       y = si[1] + b[1] x;  si[j] = si[j+1] + b[j+1] x - a[j+1] y;  si[end] = b[end] x - a[end] y).
+   x, y: n frames x nch channels, channel-major (chan_stride frames apart); si: `ord` entries per channel
+   (si_stride apart; 0 = the same vector for every channel; NULL = rest).  Pinned against scipy.signal.lfilter in
+   tests/test_oracle_dsp.py (the same recurrence). */
+int so_oracle_filt_direct(const double* b, int nb, const double* a, int na, const double* x, double* y, int64_t n,
+                          int nch, int64_t chan_stride, const double* si, int64_t si_stride) {
+    int sz = nb > na ? nb : na, ord = sz - 1;
+    if (nb < 1 || na < 1 || a[0] == 0.0) return -1;
+    double* bn = (double*)calloc((size_t)sz * 3, sizeof(double));
+    double *an = bn + sz, *st = an + sz;
+    for (int i = 0; i < nb; ++i) bn[i] = b[i] / a[0];
+    for (int i = 0; i < na; ++i) an[i] = a[i] / a[0];
+    for (int ch = 0; ch < nch; ++ch) {
+        for (int j = 0; j < ord; ++j) st[j] = si ? si[(int64_t)ch * si_stride + j] : 0.0;
+        const double* xc = x + (int64_t)ch * chan_stride;
+        double* yc = y + (int64_t)ch * chan_stride;
+        for (int64_t i = 0; i < n; ++i) {
+            double xi = xc[i];
+            double yi = (ord ? st[0] : 0.0) + bn[0] * xi;
+            for (int j = 0; j + 1 < ord; ++j) st[j] = st[j + 1] + bn[j + 1] * xi - an[j + 1] * yi;
+            if (ord) st[ord - 1] = bn[ord] * xi - an[ord] * yi;
+            yc[i] = yi;
+        }
+    }
+    free(bn);
+    return 0;
+}
+
 static double sinpi_(double x) {
     /* Julia sinpi: exact argument reduction, src/functions.jl:57-60 use it */
     double r = fmod(x, 2.0);

@@ -58,7 +58,7 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
-           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_plan_counter",
+           "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_tf_to_sos", "so_tf_zero_input", "so_plan_counter",
            "so_rtc_compile_check", "so_rtc_wait_idle", "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_reduce_sum", "so_comm_last_error", "so_comm_destroy"]
 
 _lib = None
@@ -125,6 +125,13 @@ def lib():
     L.so_zpk_to_sos.restype = C.c_int32
     L.so_zpk_to_sos.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_double,
                                 C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.so_tf_to_sos.restype = C.c_int32
+    L.so_tf_to_sos.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double),
+                               C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.so_tf_zero_input.restype = C.c_int32
+    L.so_tf_zero_input.argtypes = [C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                   C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int64,
+                                   C.POINTER(C.c_int64)]
     L.so_rtc_compile_check.restype = C.c_int32
     L.so_rtc_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.so_rtc_wait_idle.restype = C.c_int32

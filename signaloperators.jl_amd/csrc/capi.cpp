@@ -155,6 +155,33 @@ int32_t so_zpk_to_sos(const double* z, int32_t nz, const double* p, int32_t np, 
     return SO_OK;
 }
 
+int32_t so_tf_to_sos(const double* b, int32_t nb, const double* a, int32_t na, double* sos, int32_t sos_capacity,
+                     int32_t* nsections, double* gain, double* residual) {
+    std::vector<double> s;
+    double g = 1.0, r = 0.0;
+    std::string err;
+    int st = so::tf_to_sos(b, nb, a, na, s, g, r, err);
+    if (st != SO_OK) return set_err(st, err);
+    if (!sos || !nsections || !gain || (int)s.size() > sos_capacity)
+        return set_err(SO_ERR_INVALID, "so_tf_to_sos: output buffer too small");
+    std::memcpy(sos, s.data(), s.size() * sizeof(double));
+    *nsections = (int32_t)(s.size() / 6);
+    *gain = g;
+    if (residual) *residual = r;
+    return SO_OK;
+}
+
+int32_t so_tf_zero_input(const double* b, int32_t nb, const double* a, int32_t na, const double* si, int32_t nsi,
+                         double* out, int64_t capacity, int64_t* nframes) {
+    std::string err;
+    int64_t used = 0;
+    if (!out || !nframes || capacity < 0) return set_err(SO_ERR_INVALID, "so_tf_zero_input: null output");
+    int st = so::tf_zero_input(b, nb, a, na, si, nsi, out, capacity, used, err);
+    if (st != SO_OK) return set_err(st, err);
+    *nframes = used;
+    return SO_OK;
+}
+
 static int32_t copy_taps(const std::vector<double>& h, double* out, int32_t capacity, int32_t* hlen) {
     if (!hlen) return set_err(SO_ERR_INVALID, "null hlen");
     *hlen = (int32_t)h.size();

@@ -14,6 +14,10 @@ int design_iir_zpk(int type, double f1, double f2, double fs, int method, int or
                    std::vector<double>& z, std::vector<double>& p, double& k, std::string& err);
 int zpk_to_sos(const double* z, int nz, const double* p, int np, double k, std::vector<double>& sos, double& gain,
                std::string& err);
+int tf_to_sos(const double* b, int nb, const double* a, int na, std::vector<double>& sos, double& gain, double& resid,
+              std::string& err);
+int tf_zero_input(const double* b, int nb, const double* a, int na, const double* si0, int nsi, double* out, int64_t cap,
+                  int64_t& used, std::string& err);
 int design_resample_rational(int64_t num, int64_t den, std::vector<double>& h, std::string& err);
 int design_resample_arbitrary(double rate, int nphi, std::vector<double>& h, std::string& err);
 

@@ -409,20 +409,57 @@ def _streamable(x):
 
 
 def filt(b, a, x, si=None, *, device=0):
-    """DSP.filt(b, a, x::AbstractSignal[, si]) (reference src/filters.jl:68-79): the signal is sunk
-    (HIP engine) and filtered with direct-form coefficients.  FIR (a scalar / [a0]) and orders <= 2
-    from zero state run as a `Filt` node on the device; anything else -- higher orders, a given
-    initial state `si` -- follows the reference literally: `sink(x, Array)` on the engine, then the
-    array method of `filt!`."""
+    """DSP.filt(b, a, x::AbstractSignal[, si]) (reference src/filters.jl:68-79: `sink(x, Array)`, then DSP.jl's
+    direct-form `filt!`).  Here the filter is a `Filt` node of the signal's own plan, whatever its order: FIR for a
+    scalar `a`, else second-order sections factored from the two polynomials (`so_tf_to_sos`).  An initial state `si`
+    (max(|a|, |b|) - 1 entries, per channel if a matrix) enters by linearity: the direct form's zero-input response
+    from `si` is computed until it has decayed (`so_tf_zero_input`) and mixed in on the device.  Only a filter whose
+    polynomials are too ill-conditioned to factor (the gate of `signals.TF_RESIDUAL_MAX`: the cascade would no longer
+    be the reference's filter) follows the reference literally -- `sink(x, Array)` on the engine, then the direct-form
+    recurrence on the host array."""
+    from .units import frames
+
     x = S._assignal(x)
+
+    def ftype(v):  # (eltype of a coefficient argument: Julia literals are Float64 / Int)
+        dt = getattr(v, "dtype", None)
+        return dt if dt is not None and np.issubdtype(dt, np.floating) else np.dtype(np.float64)
+
+    rt = np.result_type(ftype(b), ftype(a), S.float_type(x.dtype), *([ftype(si)] if si is not None else []))
     b = np.atleast_1d(np.asarray(b, dtype=np.float64))
     a = np.atleast_1d(np.asarray(a, dtype=np.float64))
-    if si is None and (len(a) == 1 or (len(a) <= 3 and len(b) <= 3)):
-        y = sink(S.Filt(x, S.PolynomialRatio(b, a)), Array, device=device)
-        return _like_root(y, x)
+    if len(a) > 1 and max(len(a), len(b)) > 3 and not S.tf_to_sos(b, a)[2] <= S.TF_RESIDUAL_MAX:
+        return _filt_direct_host(b, a, x, si, rt, device)
+    n, nch = S.nframes(x), x.nch
+    # (`filt!` runs in R = promote_type(coefficients, samples) over the sunk samples: a Float32 signal under Float64
+    #  coefficients is filtered in Float64, src/filters.jl:73-76)
+    y = S.Filt(x if S.float_type(x.dtype) == rt else S.ToEltype(x, rt), S.PolynomialRatio(b, a))
+    if n is None or S.isknowninf(n):
+        S.error("filt: the signal must have a finite length")
+    if si is not None:
+        zi = np.asarray(si, dtype=np.float64)
+        if zi.ndim == 1:
+            zi = np.repeat(zi[:, None], nch, axis=1)
+        if zi.ndim != 2 or zi.shape[1] != nch:
+            S.error("filt: the initial state must be a vector or have one column per channel")
+        cols = [S.tf_zero_input(b, a, zi[:, c], n) for c in range(nch)]
+        m = max([len(c) for c in cols] + [1])
+        zir = np.zeros((min(m, n), nch), order="F")
+        for c, col in enumerate(cols):
+            zir[: min(len(col), n), c] = col[:n]
+        if zir.shape[0] and np.any(zir):
+            y = S.Mix(y, S.Signal(zir, x.fs)) | S.Until(n * frames)
+    out = np.empty((n, nch), dtype=rt, order="F")
+    sink_into(out, y, device=device)
+    return _like_root(out, x)
+
+
+def _filt_direct_host(b, a, x, si, rt, device):
+    """the reference's own sequence for a filter the cascade form cannot represent: the engine sinks the signal, the
+    direct-form recurrence runs over the host array (reference src/filters.jl:74-76)"""
     from scipy import signal as sps
 
-    data = np.asarray(sink(x, Array, device=device), dtype=np.result_type(b.dtype, a.dtype, S.float_type(x.dtype)))
+    data = np.asarray(sink(x, Array, device=device), dtype=rt)
     if si is None:
         y = sps.lfilter(b, a, data, axis=0)
     else:
@@ -430,7 +467,7 @@ def filt(b, a, x, si=None, *, device=0):
         if zi.ndim == 1:
             zi = np.repeat(zi[:, None], data.shape[1], axis=1)
         y, _ = sps.lfilter(b, a, data, axis=0, zi=zi)
-    return _like_root(np.asfortranarray(y), x)
+    return _like_root(np.asfortranarray(y, dtype=rt), x)
 
 
 def filt_into(data, b, a, x, si=None, *, device=0):

@@ -254,6 +254,19 @@ function lower_node!(lw, x::FilteredSignal)
         h = Float64.(coefb(hobj) ./ coefa(hobj)[1])
         push!(lw.keep, h)
         push_node!(lw, x, RESAMPLE; kids=Int32[c], i0=2, i1=1, l0=1, l1=1, p0=pointer(h), i2=length(h), i3=x.blocksize)
+    elseif hobj isa PolynomialRatio
+        # DF2TFilter(::PolynomialRatio) is DSP.jl's direct form; the engine runs second-order sections.  The library
+        # factors the polynomials and reports how far the two impulse responses are apart (ill-conditioned ones: refuse)
+        b, a = Float64.(coefb(hobj)), Float64.(coefa(hobj))
+        sos = zeros(Float64, 6 * (max(length(a), length(b)) ÷ 2 + 2))
+        nsec, gain, resid = Ref{Int32}(0), Ref{Float64}(0), Ref{Float64}(0)
+        check(ccall((:so_tf_to_sos, libsigops), Int32,
+                    (Ptr{Float64}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Ref{Int32}, Ref{Float64}, Ref{Float64}),
+                    b, length(b), a, length(a), sos, length(sos), nsec, gain, resid))
+        resid[] <= 1e-9 || error("PolynomialRatio: too ill-conditioned to factor into second-order sections " *
+                                 "(impulse responses differ by $(resid[])); pass SecondOrderSections or ZeroPoleGain")
+        push!(lw.keep, sos)
+        push_node!(lw, x, FILT_SOS; kids=Int32[c], i0=nsec[], p0=pointer(sos), d0=gain[], i1=x.blocksize)
     else                                            # reference src/filters.jl:10-11,94
         f = convert(SecondOrderSections, x.fn(framerate(x)))
         sos = Float64[c for b in f.biquads for c in (b.b0, b.b1, b.b2, 1.0, b.a1, b.a2)]
@@ -267,7 +280,7 @@ lower_node!(lw, x::NormedSignal) = push_node!(lw, x, NORMPOWER; kids=Int32[lower
 check(st) = st == 0 || error(unsafe_string(ccall((:so_last_error, libsigops), Cstring, ())))
 
 # Large map nests are specialised by hipRTC off the caller's path (first sink of a shape: interpreter kernel; later
-# sinks, and later sessions through ~/.cache/sigops-hip: the compiled one, same values).  A long-running service
+# sinks, and later sessions where ENV["SIGOPS_CACHE_DIR"] names a directory: the compiled one, same values).  A long-running service
 # can wait for the queue once it has seen its workload:
 warmup_done() = check(ccall((:so_rtc_wait_idle, libsigops), Int32, ()))
 

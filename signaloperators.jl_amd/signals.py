@@ -1039,8 +1039,14 @@ class Biquad:
         self.row = [float(b0), float(b1), float(b2), 1.0, float(a1), float(a2)]
 
 
+# largest relative l2 distance between the impulse responses of a PolynomialRatio's direct form and of its factored
+# cascade the engine accepts (so_tf_to_sos's residual; the suite holds Float64 results to 1e-8)
+TF_RESIDUAL_MAX = 1e-9
+
+
 class PolynomialRatio:
-    """DSP.jl PolynomialRatio(b, a); lowered for FIR (a == [1]) and for orders <= 2 (one section)"""
+    """DSP.jl PolynomialRatio(b, a): FIR for a == [a0], one section for orders <= 2, otherwise factored into
+    second-order sections by the library (so_tf_to_sos)"""
 
     def __init__(self, b, a):
         self.b = np.asarray(b, dtype=np.float64).ravel()
@@ -1069,6 +1075,42 @@ def digitalfilter(response, method):
     zz = np.array(z[: 2 * nz.value]).view(np.complex128)
     pp = np.array(p[: 2 * npl.value]).view(np.complex128)
     return ZeroPoleGain(zz, pp, k.value)
+
+
+def tf_to_sos(b, a):
+    """(sos rows, gain, residual) of so_tf_to_sos: the direct-form coefficients factored into second-order sections"""
+    from . import _capi as K
+    import ctypes as C
+
+    b = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    a = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    cap = 6 * (max(len(a), len(b)) // 2 + 2)
+    sos = (C.c_double * cap)()
+    nsec, gain, resid = C.c_int32(0), C.c_double(0), C.c_double(0)
+    dp = C.POINTER(C.c_double)
+    st = K.lib().so_tf_to_sos(b.ctypes.data_as(dp), len(b), a.ctypes.data_as(dp), len(a), sos, cap, C.byref(nsec),
+                              C.byref(gain), C.byref(resid))
+    if st != 0:
+        error(K.last_error())
+    return np.array(sos[: 6 * nsec.value]).reshape(-1, 6), gain.value, resid.value
+
+
+def tf_zero_input(b, a, si, nmax):
+    """zero-input response of the direct form from state `si` (so_tf_zero_input), cut where it has decayed"""
+    from . import _capi as K
+    import ctypes as C
+
+    b = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    a = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    si = np.ascontiguousarray(si, dtype=np.float64).ravel()
+    out = np.empty(max(int(nmax), 0), dtype=np.float64)
+    used = C.c_int64(0)
+    dp = C.POINTER(C.c_double)
+    st = K.lib().so_tf_zero_input(b.ctypes.data_as(dp), len(b), a.ctypes.data_as(dp), len(a), si.ctypes.data_as(dp),
+                                  len(si), out.ctypes.data_as(dp), len(out), C.byref(used))
+    if st != 0:
+        error(K.last_error())
+    return out[: used.value]
 
 
 def _raw_filter(h):
@@ -1104,8 +1146,12 @@ def _raw_filter(h):
             b = np.concatenate([b, np.zeros(3 - len(b))])
             a = np.concatenate([a, np.zeros(3 - len(a))])
             return RawFilterFn([[b[0], b[1], b[2], 1.0, a[1], a[2]]], 1.0)
-        error("PolynomialRatio filters of order > 2 are not lowered by the HIP engine: pass SecondOrderSections "
-              "or ZeroPoleGain")
+        sos, gain, resid = tf_to_sos(b, a)
+        if not resid <= TF_RESIDUAL_MAX:
+            error("PolynomialRatio: the polynomials of this filter are too ill-conditioned to be factored into "
+                  f"second-order sections (impulse responses differ by {resid:.1e}): pass SecondOrderSections or "
+                  "ZeroPoleGain")
+        return RawFilterFn(sos, gain)
     arr = np.asarray(h, dtype=np.float64)
     if arr.ndim == 1 and arr.size >= 1:  # FIR coefficient vector
         return RawFirFn(arr)

@@ -83,6 +83,28 @@ def oracle_sink(x, nframes=None, blocksize=0, rng=None, dtype=None):
     return oracle_sink_lowered(lw, n, x.nch, dtype, blocksize)
 
 
+def oracle_filt(b, a, x, si=None):
+    """DSP.filt(b, a, x::AbstractSignal[, si]) on the CPU oracle (reference src/filters.jl:68-79): the signal sunk by the
+    oracle, then DSP.jl's direct-form recurrence (so_oracle_filt_direct)"""
+    L = oracle_lib()
+    dp = C.POINTER(C.c_double)
+    L.so_oracle_filt_direct.restype = C.c_int
+    L.so_oracle_filt_direct.argtypes = [dp, C.c_int, dp, C.c_int, dp, dp, C.c_int64, C.c_int, C.c_int64, dp, C.c_int64]
+    data = np.asfortranarray(x if isinstance(x, np.ndarray) else oracle_sink(x), dtype=np.float64)
+    b = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    a = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    n, nch = data.shape
+    y = np.empty((n, nch), order="F")
+    zi, zs = None, 0
+    if si is not None:
+        zi = np.asfortranarray(si, dtype=np.float64)
+        zs = zi.shape[0] if zi.ndim == 2 else 0
+    st = L.so_oracle_filt_direct(b.ctypes.data_as(dp), len(b), a.ctypes.data_as(dp), len(a), data.ctypes.data_as(dp),
+                                 y.ctypes.data_as(dp), n, nch, max(n, 1), zi.ctypes.data_as(dp) if zi is not None else None, zs)
+    assert st == 0
+    return y
+
+
 def oracle_nframes(x):
     lw = lower(S._assignal(x))
     return oracle_lib().so_oracle_nframes(lw.nodes, lw.n, lw.root)
