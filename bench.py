@@ -276,7 +276,7 @@ def roofline_of(stage, traffic=None, source=None):
 def parity_gate(so, tree_fn, noise_host, tol=1e-6):
     """engine vs oracle on a prefix of the same input (BASELINE.md §2's correctness gate).  Runs AFTER the
     timed loops: freeing this one-shot plan's device buffers right before them stalled the device for
-    40-70 ms somewhere in the next ~100 ms on one run in three (round 3, tools/stall_probe.sh: 0 of 5
+    40-70 ms somewhere in the next ~100 ms on one run in three (round 3, profiles/r03/stall_probe.txt: 0 of 5
     runs without the gate or with a 1 s pause after it, 5 of 12 with it directly in front)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_bridge import oracle_sink, relerr
@@ -454,6 +454,9 @@ def main():
     host_side = series.pop() if series and isinstance(series[-1], dict) else None
     stages = stage_means(plan)  # per-kernel means over the timed executes themselves
     st = plan.stats()
+    issue = dict(plan.counters(), profiling="deferred: per-kernel events recorded during the timed executes, never "
+                 "synchronising; a plan in this mode issues direct launches (plans of four or more steps replay a HIP "
+                 "graph outside the bench -- the headline is one or two launches either way)")
     secondary = None
     if do_secondary:
         steps3 = max(20, args.steps // 2)
@@ -533,6 +536,7 @@ def main():
                               "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
                               "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},
             "stages": stages,
+            "issue": issue,
             "steady_state_ms": (sum(series[-10:]) / len(series[-10:])) if series else None,
             "steady_state_note": "mean device time of the last 10 executes of step_ms_series (the kernel once the chip's "
                                  "power management has settled); ms_per_step is the whole timed loop on the host clock",
