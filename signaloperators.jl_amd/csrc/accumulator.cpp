@@ -58,13 +58,14 @@ static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
 // The replay is sequential by nature (~5 ns per output: 160 ms for config 3's 28.8 M outputs) and
 // depends only on the geometry, so a process keeps the last few results (plans of the same
 // resampler -- a bench's second workload, a re-created plan -- get it for free).
-// Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate, and the
-// fix-up list comes back in the window's own coordinates (output m - from, input j - from/L*M).
+// Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate (any output of a rate
+// without a period), and the fix-up list comes back in the window's own coordinates (output m - from, input
+// j - from/L*M, or j - g.j0).
 void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
                                      std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from) {
     struct Key {
         double delta, c0, hsum;
-        int64_t c0i, L, M, need, from;
+        int64_t c0i, L, M, need, from, j0;
         int32_t nphi, taps, exact, hlen, bake;
         bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
     };
@@ -84,6 +85,7 @@ void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_
     k.M = g.M;
     k.need = need;
     k.from = from;
+    k.j0 = g.j0;
     k.nphi = g.nphi;
     k.taps = g.taps;
     k.exact = g.exact;
@@ -378,7 +380,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     }
     std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
     if (from > 0) {
-        const int64_t jin = exact ? from / L * g.M : 0;
+        const int64_t jin = exact ? from / L * g.M : g.j0;  // (what the stage's first staged input frame is)
         for (auto& f : fix) {
             f.m -= from;
             f.j -= jin;

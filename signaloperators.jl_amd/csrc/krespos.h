@@ -28,10 +28,10 @@ __device__ __forceinline__ void rs_pos(const RsGeom& g, int64_t m, int64_t& j, i
         const int64_t qi = (int64_t)fl;
         alpha = q - fl;
         if (g.nphi == 32) {  // (DSP.jl's N_phi; positions are never negative: a shift, not a 64-bit division)
-            j = qi >> 5;
+            j = (qi >> 5) - g.j0;
             p = (int)(qi & 31);
         } else {
-            j = qi / g.nphi;
+            j = qi / g.nphi - g.j0;
             p = (int)(qi % g.nphi);
         }
     } else {

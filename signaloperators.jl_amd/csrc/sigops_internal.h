@@ -202,6 +202,7 @@ struct SosOne {
 struct RsGeom {
     int64_t n_in, n_out;
     int64_t m0;          // first output index produced (outputs m0 .. m0+n_out)
+    int64_t j0;          // first input frame staged: rs_pos returns j relative to it (warm start of a rate without a period)
     int64_t L, M;        // rational
     double delta, c0;    // arbitrary: q_m = c0 + m*delta  (two roundings)
     int64_t c0i;         // rational: q_m = c0i + m*M

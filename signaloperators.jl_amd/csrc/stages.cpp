@@ -396,14 +396,30 @@ void Plan::process_stage(int sid) {
                 g.n_out = need;
             }
         }
+        // ... and a rate without a period (no integer frame rates) has nothing to be aligned with: output m sits at
+        // q_m = c0 + m delta whatever came before it (the accumulator's deviations from that are listed from the
+        // nearest checkpoint of an earlier replay, accumulator.cpp), so the stage starts at the first frame anybody
+        // reads -- g.m0 -- and stages its input from taps + 2 frames before that output's newest input -- g.j0
+        if (g.arbitrary && !g.exact && stages[sid].lo >= 8192 && stages[sid].lo < need && !std::getenv("SIGOPS_NO_WARM_START")) {
+            rbase = stages[sid].lo / 64 * 64;  // (whole lines for the kernels' stores)
+            const double q = g.c0 + (double)rbase * g.delta;
+            const int64_t jf = (int64_t)std::floor(q) / g.nphi;
+            const int64_t ib = std::max<int64_t>(0, jf - g.taps - 2) / 16 * 16;
+            stages[sid].base = rbase;
+            stages[sid].in_base = ib;
+            g.m0 = rbase;
+            g.j0 = ib;
+            need -= rbase;
+            g.n_out = need;
+        }
         // newest input of the last needed output
         int64_t jl;
         if (g.arbitrary && g.exact) {
             int64_t Nn = (need - 1) * ((int64_t)g.nphi * g.M);
             jl = (g.c0i + Nn / g.L) / g.nphi;
         } else if (g.arbitrary) {
-            double q = g.c0 + (double)(need - 1) * g.delta;
-            jl = (int64_t)std::floor(q) / g.nphi;
+            double q = g.c0 + (double)(g.m0 + need - 1) * g.delta;
+            jl = (int64_t)std::floor(q) / g.nphi - g.j0;
         } else jl = (g.c0i + (need - 1) * g.M) / g.L;
         int64_t nin = jl + 2;  // +1 slack: host rounding of q may differ from the device's at ties
         if (!isinf_(C.len)) nin = std::min(nin, C.len.n - stages[sid].in_base);

@@ -221,10 +221,9 @@ def stream(x, blocksize, to=None, *, device=0):
     buffers.  Results do not depend on `blocksize` (the reference's `blocksize` contract,
     src/filters.jl:3).  Stateful stages do not start over for every block: a filter starts a decay
     time before the block and a resampler a few periods before it (warm start), and the
-    resampler's DSP.jl phase accumulator resumes from the previous block's end.  (Resamplers between
-    rational rates or integer frame rates, that is: a rate without a period -- non-integer frame rates --
-    has no warm start, its stage begins at input frame 0 for every block and work per block grows with
-    the block's position.)  Host arrays of the tree are uploaded once.  `Normpower` needs its whole child for every block and `randn` leaves
+    resampler's DSP.jl phase accumulator resumes from the previous block's end (a rate without a period -- non-integer
+    frame rates, x pi -- starts exactly at the block: its stage stages taps + 2 input frames before the block's first
+    output and lists the accumulator's deviations from the nearest checkpoint of an earlier replay).  Host arrays of the tree are uploaded once.  `Normpower` needs its whole child for every block and `randn` leaves
     draw new numbers for every block: neither is meant for streaming."""
     from . import lowering as LW
     from .units import frames
@@ -397,13 +396,6 @@ def _streamable(x):
                 "stream does not know yet; not streamable")
     if isinstance(x, S.PaddedSignal) and any(x.pad is p for p in (S.lastframe, S.cycle, S.mirror)):  # (identity: a pad may be an ndarray)
         S.error("BlockStream: lastframe / cycle / mirror padding indexes the end of the input; not streamable")
-    if isinstance(x, S.FilteredSignal) and isinstance(x.fn, S.ResamplerFn) and not isinstance(x.fn.ratio, tuple):
-        fi, fo = x.signal.fs, x.fs
-        if fi is None or fo is None or float(fi) != int(fi) or float(fo) != int(fo):
-            # (warm starts exist for rational rates and integer frame rates only: DSP.jl's phase accumulator of
-            #  any other rate is replayed from output 0, which needs the whole input resident -- ADVICE r2)
-            S.error("BlockStream: a resampler between non-integer frame rates has no period to restart from; "
-                    "not streamable with a bounded history")
     for c in getattr(x, "children", ()) or ():
         _streamable(c)
 

@@ -272,3 +272,84 @@ def test_block_stream_with_a_per_channel_padding_vector():
     bs = so.BlockStream(pipe, 44.1 * so.kHz, nch=2)
     out = bs.push(x[:20000]).cpu().numpy()
     assert out.shape[1] == 2 and np.array_equal(out, 0.5 * x[:out.shape[0]])
+
+
+# ---- rates without a period: warm start (round 4) ----------------------------------------------------------------
+IRR = 44100 * np.pi / 3
+
+
+def test_window_of_an_irrational_rate_starts_at_the_window():
+    """`After` over a resampler between non-integer frame rates: the stage starts at the window's first output (g.m0)
+    and stages its input from taps + 2 frames before it (g.j0) instead of evaluating everything from output 0
+    (reference src/filters.jl:221-262: the outputs are the same whatever block they are asked in)"""
+    rng = np.random.default_rng(81)
+    x = np.asfortranarray(rng.standard_normal((600000, 2)))
+    tree = so.Signal(x, 44100 * so.Hz) | so.ToFramerate(IRR * so.Hz)
+    whole = so.sink(tree)[0]
+    import torch
+
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).cuda().t()   # (a device leaf: scratch is what the stages allocate)
+    dtree = so.Signal(xd, 44100 * so.Hz) | so.ToFramerate(IRR * so.Hz)
+    for a, n in ((8192, 5000), (100000, 70000), (400001, 12345), (600000, 20000)):
+        part = so.sink(tree | so.After(a * so.frames) | so.Until(n * so.frames))[0]
+        assert np.array_equal(part, whole[a:a + n]), (a, n)
+        p = so.Plan(so.ToChannels(dtree | so.After(a * so.frames) | so.Until(n * so.frames), 2), (n, 2), np.float64, (1, n), False)
+        st = p.stats()
+        p.close()
+        assert st["scratch_bytes"] < 8 * 2 * (2 * n + 50000)  # (nothing of the frames before the window is evaluated)
+    from oracle_bridge import oracle_sink
+
+    ref = oracle_sink(tree)
+    assert relerr(whole, ref) < 1e-9
+
+
+def test_stream_of_an_irrational_rate_costs_the_same_everywhere():
+    """`so.stream` at x pi/3: a block at position 10^8 stages and evaluates what a block at position 0 does (the
+    accumulator's deviations come from the checkpoint the previous block left)"""
+    import time
+
+    import torch
+
+    tone = so.Signal(so.sin, 44100 * so.Hz, ω=440 * so.Hz) | so.ToFramerate(IRR * so.Hz)   # infinite: any position exists
+    nblk = 1 << 20
+
+    def block_at(pos, reps=3):
+        blk = tone | so.After(pos * so.frames) | so.Until(nblk * so.frames)
+        out = torch.empty((1, nblk), dtype=torch.float64, device="cuda").t()
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            so.sink_into(out, blk)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return out.cpu().numpy(), best
+
+    y0, t0 = block_at(0)
+    block_at(10 ** 8 - nblk, reps=1)            # (the block before: leaves the checkpoint a stream would have)
+    y1, t1 = block_at(10 ** 8)
+    assert t1 < 3 * t0 + 0.02, (t0, t1)
+    # values: the sine at the resampled positions (amplitude error of the interpolation filter << 1e-3); frame i (from 1)
+    # of a signal is at time i / fs on both sides of the resampler
+    def err(y, pos):
+        t = (pos + np.arange(2000, 3000) + 1) / float(IRR)
+        return np.abs(y[2000:3000, 0] - np.sin(2 * np.pi * 440 * t)).max()
+
+    assert err(y0, 0) < 1e-3 and err(y1, 10 ** 8) < 1e-3, (err(y0, 0), err(y1, 10 ** 8))
+    from oracle_bridge import oracle_sink
+
+    ref = oracle_sink(tone | so.Until(20000 * so.frames))
+    assert relerr(y0[:20000], ref) < 1e-9
+
+
+def test_block_stream_at_an_irrational_rate():
+    """BlockStream no longer refuses a resampler between non-integer frame rates: bounded history, same frames"""
+    rng = np.random.default_rng(82)
+    x = rng.standard_normal((300000, 2))
+    pipe = lambda s: s | so.ToFramerate(IRR * so.Hz)  # noqa: E731
+    whole = so.sink(so.Signal(np.asfortranarray(x), 44100 * so.Hz) | so.ToFramerate(IRR * so.Hz))[0]
+    bs = so.BlockStream(pipe, 44100 * so.Hz, nch=2, history=20000)
+    outs = [bs.push(x[k:k + 30000]).cpu().numpy() for k in range(0, 300000, 30000)]
+    outs.append(bs.finish().cpu().numpy())
+    got = np.concatenate(outs)
+    assert got.shape == whole.shape and relerr(got, whole) < 1e-12
+    assert bs.cap <= 2 * (20000 + 30000)
