@@ -175,7 +175,7 @@ void Plan::finalize() {
         }
         if (S.pw_step >= 0) push_pw_step(S.pw_step);
         if (S.fused_away) continue;  // (runs inside its consumer's launch)
-        const char* nm = S.kind == ST_SOS ? (S.rsos_src >= 0 ? "k_rsos" : S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
+        const char* nm = S.kind == ST_SOS ? (S.rsos_src >= 0 ? "k_rsos" : S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.arbk ? "k_resample_arb" : S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
         int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
         if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in + S.rs.n_out) * S.rs.nch * esz;
@@ -704,7 +704,16 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsTiled rt = S.rt;
                         rt.g.in_pitch = in_pitch;
                         rt.g.out_pitch = ob.pitch;
-                        if (rt.pair)
+                        bool done = false;
+                        if (S.arbk) {
+                            RsArb ra = S.ra;
+                            ra.g.in_pitch = in_pitch;
+                            ra.g.out_pitch = ob.pitch;
+                            done = launch_resample_arb(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
+                                                       (const double*)P->bufs[S.dpfbt_buf].d, ra, st) == 0;
+                        }
+                        if (done) {
+                        } else if (rt.pair)
                             launch_resample_tiled2(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
                                                   (const double*)P->bufs[S.dpfbt_buf].d, rt, st);
                         else

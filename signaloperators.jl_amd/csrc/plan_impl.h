@@ -145,6 +145,8 @@ struct Stage {
     RsPeriodic rp{};
     bool tiled = false;  // tiled resampler without a period (k_resample_tiled)
     RsTiled rt{};
+    bool arbk = false;   // ... its persistent form (k_resample_arb), geometry in ra
+    RsArb ra{};
     int pfbt_buf = -1, dpfbt_buf = -1;
     std::vector<double> pfbt_host, dpfbt_host;
     bool rows = false;  // row-tiled resampler (k_resample_rows)

@@ -227,6 +227,21 @@ struct RsTiled {
     int32_t pad_;
 };
 
+// Persistent form of the same (k_resample_arb.hip): a workgroup walks one contiguous range of batches of 128 outputs for
+// ct channels, a loader wave stages the input through an LDS ring, nc compute waves evaluate.
+struct RsArb {
+    RsGeom g;
+    int32_t ct;       // channels per workgroup
+    int32_t nc;       // compute waves
+    int32_t ringf;    // ring frames per channel row (a power of two)
+    int32_t zrows;    // rows of zeros on either side of the tap tables
+    int32_t nranges;  // ranges along time (grid = nranges * nch / ct)
+    int32_t dma_ok, vec_out, depth, debug;  // depth: loader chunks in flight; debug: ablation bits (SIGOPS_ARB_DEBUG)
+    int32_t no, pad_;  // outputs per lane (2 or 4); a batch is 64 * no outputs
+    int64_t bpr;       // batches per range
+    int64_t nbatches;  // ceil(n_out / (64 no))
+};
+
 // DSP.jl's FIRArbitrary positions its outputs with a floating-point phase accumulator
 // (ϕAccumulator += Δ once per output; reference call site
 // src/reformatting.jl:92-98 + src/filters.jl:248-255).  The kernels position outputs in closed

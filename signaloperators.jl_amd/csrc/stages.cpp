@@ -5,6 +5,11 @@
 
 namespace so {
 
+static int env_int(const char* name, int dflt) {  // tuning knobs
+    const char* ev = std::getenv(name);
+    return ev ? std::atoi(ev) : dflt;
+}
+
 // ---------------------------------------------------------------------------
 // small dense matrices for the SOS state propagation
 Mat matmul(const Mat& a, const Mat& b, int D) {
@@ -774,6 +779,48 @@ void Plan::process_stage(int sid) {
                         }
                     stages[sid].pfbt_buf = raw_buf(stages[sid].pfbt_host.size() * 8);
                     stages[sid].dpfbt_buf = raw_buf(stages[sid].dpfbt_host.size() * 8);
+                    // ---- the persistent form (k_resample_arb): Float64, DSP.jl's 32 phases, windows of a pair close ----
+                    if (pair && g.nphi == 32 && N.dtype == SO_F64 && need >= 16384 && !std::getenv("SIGOPS_RS_NOARB")) {
+                        RsArb ra{};
+                        ra.g = g;
+                        int cta = 1;
+                        for (int c : {8, 4, 2})
+                            if (N.nch % c == 0) {
+                                cta = c;
+                                break;
+                            }
+                        ra.ct = cta;
+                        const int dmax = (int)std::ceil(step) + 1;  // newest inputs of two consecutive outputs, at most this far apart
+                        // four outputs per lane where their windows stay close and all eight channels are in the
+                        // workgroup: the LDS reads of a frame serve four outputs (the kernel is bound by them)
+                        int no = (cta == 8 && step <= 1.5) ? 4 : 2;
+                        no = env_int("SIGOPS_ARB_NO", no);
+                        if (no != 4 || cta != 8) no = 2;
+                        ra.no = no;
+                        ra.zrows = (no - 1) * dmax + 3;
+                        int ringf = 4096;
+                        while (ringf >= 512 && resample_arb_lds_bytes(g.taps, ra.zrows, cta, ringf) + 1024 > (size_t)160 * 1024) ringf >>= 1;
+                        ringf = env_int("SIGOPS_ARB_RING", ringf);
+                        ra.depth = env_int("SIGOPS_ARB_DEPTH", no == 4 ? 3 : 6);
+                        ra.debug = env_int("SIGOPS_ARB_DEBUG", 0);
+                        const int per_batch = (int)std::ceil(64.0 * no * step) + 2;
+                        // a batch's own span + what the loader has in flight must fit next to NC batches in progress
+                        int nc = (ringf - (ra.depth * 128 + 127 + g.taps + no * dmax + 32)) / per_batch;
+                        nc = std::min(nc, no == 4 ? 7 : 11);
+                        nc = std::min(nc, env_int("SIGOPS_ARB_NC", nc));
+                        ra.nc = nc;
+                        ra.ringf = ringf;
+                        ra.nbatches = (need + 64 * no - 1) / (64 * no);
+                        const int64_t ncg = N.nch / cta;
+                        int64_t nr = std::max<int64_t>(1, env_int("SIGOPS_ARB_GRID", 256) / ncg);
+                        nr = std::min(nr, std::max<int64_t>(1, ra.nbatches / (2 * std::max(nc, 1))));
+                        ra.bpr = (ra.nbatches + nr - 1) / nr;
+                        ra.nranges = (int32_t)((ra.nbatches + ra.bpr - 1) / ra.bpr);
+                        if (nc >= 4 && ringf >= 1024 && ringf >= 512 && ncg * ra.nranges < (1ll << 31)) {
+                            stages[sid].arbk = true;
+                            stages[sid].ra = ra;
+                        }
+                    }
                     break;
                 }
             }

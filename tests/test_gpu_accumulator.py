@@ -4,6 +4,8 @@ ratio)` + `setphase!`, src/filters.jl:252-255 `filt!`).  The oracle's default mo
 that; the engine's kernels use closed-form positions whose tap tables are built from a host
 replay of the accumulator, plus a sparse fix-up pass (k_resample_fix) for what a periodic table
 cannot express.  Bound: 1e-6 norm-wise (BASELINE.json north_star); observed ~1e-9 or better."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,6 +143,11 @@ def test_two_outputs_per_lane_form_of_the_tiled_resampler(fs_in, fs_out, nch, n,
     assert got.shape == want.shape and got.dtype == want.dtype
     assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
     assert np.abs(got.astype(np.float64) - want).max() < (1e-8 if dt == np.float64 else 1e-6) * np.abs(want).max()
+    # (long Float64 signals take the persistent form, k_resample_arb, which forms the interpolated tap once per output:
+    #  another association of the same sums, test below; the tiles themselves are compared with it switched off)
+    monkeypatch.setenv("SIGOPS_RS_NOARB", "1")
+    got = so.sink(tree)[0]
+    assert relerr(got, want) < (1e-9 if dt == np.float64 else 2e-7)
     monkeypatch.setenv("SIGOPS_RS_NOPAIR", "1")
     one = so.sink(tree)[0]
     assert np.array_equal(got, one)
@@ -152,9 +159,48 @@ def test_two_outputs_per_lane_form_is_the_one_that_runs():
     tree = so.Signal(x.t(), 1000 * so.Hz) | so.ToFramerate(1000 * np.pi * so.Hz)
     n = so.nframes(tree)
     out = torch.empty((8, n), dtype=torch.float64, device="cuda")
-    p = so.Plan(so.ToChannels(tree, 8), (n, 8), np.float64, (1, n), True)
-    p.set_profiling(True)
-    p.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert [s["name"] for s in p.steps()] == ["k_resample_tiled2"]
+    for env, name in (("1", "k_resample_tiled2"), (None, "k_resample_arb")):
+        if env:
+            os.environ["SIGOPS_RS_NOARB"] = env
+        else:
+            os.environ.pop("SIGOPS_RS_NOARB", None)
+        p = so.Plan(so.ToChannels(tree, 8), (n, 8), np.float64, (1, n), True)
+        p.set_profiling(True)
+        p.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert [s["name"] for s in p.steps()] == [name]
+        p.close()
+
+
+@pytest.mark.parametrize("fs_in,fs_out,nch,n,arb", [
+    (1000.0, 1000.0 * np.pi, 8, 300000, True),          # benchmarks.jl "resampling-irrational"
+    (44100.0, 44100.0 * np.pi / 3, 8, 700001, True),    # tools/bench_irrational.py's rate; several ranges, odd length
+    (1000.0, 1000.0 * np.pi / 3, 16, 150000, True),     # two channel groups
+    (44100.5, 48000.0, 3, 200000, True),                # non-integer frame rate, one channel per workgroup
+    (44100.5, 48000.0, 4, 123457, True),
+    (48000.0, 44100.5, 2, 260000, True),                # down
+    (1000.0, 1000.0 / np.e, 8, 400000, None),           # x 0.37: a long filter (whichever kernel its tables leave room for)
+    (48000.0, 9000.5, 4, 500000, None),                 # x 0.19: windows of a pair five or six frames apart
+    (999.0, 16000.0, 8, 40000, True)])                  # x 16: many outputs per input
+def test_persistent_form_of_the_arbitrary_rate_resampler(fs_in, fs_out, nch, n, arb, monkeypatch):
+    """k_resample_arb (k_resample_arb.hip): loader wave + LDS ring + compute waves that form DSP.jl's interpolated tap
+    h[p + 32 k] + alpha dh[p + 32 k] once per output -- against the oracle (yLower + alpha yUpper per output: 1e-9 as for
+    every resampler, the accumulated-alpha drift) and against the tiled kernel (the two associations of the same sum:
+    1e-14), windows included (warm start: g.m0 / g.j0)"""
+    rng = np.random.default_rng(207)
+    x = np.asfortranarray(rng.standard_normal((n, nch)))
+    x[n // 3, 0] = 0.0
+    tree = so.Signal(x, fs_in * so.Hz) | so.ToFramerate(fs_out * so.Hz)
+    nout = so.nframes(tree)
+    p = so.Plan(so.ToChannels(tree, nch), (nout, nch), np.float64, (1, nout), False)
+    names = [s["name"] for s in p.steps()]
     p.close()
+    assert names == ["k_resample_arb"] or (arb is None and names == ["k_resample_tiled2"]), names
+    got = so.sink(tree)[0]
+    assert relerr(got, oracle_sink(tree)) < 1e-9
+    part = so.sink(tree | so.After(nout // 2 * so.frames) | so.Until(20000 * so.frames))[0]
+    assert np.array_equal(part, got[nout // 2:nout // 2 + 20000])
+    monkeypatch.setenv("SIGOPS_RS_NOARB", "1")
+    ref = so.sink(tree)[0]
+    assert relerr(got, ref) < 1e-14
+    assert np.abs(got - ref).max() < 1e-13 * np.abs(ref).max()

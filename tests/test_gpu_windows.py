@@ -292,7 +292,8 @@ def test_window_of_an_irrational_rate_starts_at_the_window():
     dtree = so.Signal(xd, 44100 * so.Hz) | so.ToFramerate(IRR * so.Hz)
     for a, n in ((8192, 5000), (100000, 70000), (400001, 12345), (600000, 20000)):
         part = so.sink(tree | so.After(a * so.frames) | so.Until(n * so.frames))[0]
-        assert np.array_equal(part, whole[a:a + n]), (a, n)
+        # (short windows run the tiled kernel, long signals the persistent one: two associations of the same sums)
+        assert relerr(part, whole[a:a + n]) < 1e-14 and np.abs(part - whole[a:a + n]).max() < 1e-13, (a, n)
         p = so.Plan(so.ToChannels(dtree | so.After(a * so.frames) | so.Until(n * so.frames), 2), (n, 2), np.float64, (1, n), False)
         st = p.stats()
         p.close()

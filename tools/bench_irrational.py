@@ -1,33 +1,48 @@
-"""Timing of the irrational-rate resampler (reference test/benchmarks.jl "resampling-irrational",
-x pi) on a config-3-sized signal: k_resample_tiled vs the thread-per-output fallback."""
-import os, sys, time, json
+"""Timing of the irrational-rate resampler (reference test/benchmarks.jl "resampling-irrational", x pi / 3) on a quarter of
+a config-3-sized signal: the persistent kernel (k_resample_arb), the tiled kernel it replaced (SIGOPS_RS_NOARB=1) and
+the thread-per-output fallback (SIGOPS_RS_NOTILED=1).  Device time between two events over `reps` executes."""
+import json
+import os
+import sys
+
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
 import sigops_amd as so
 
+reps = int(os.environ.get("REPS", "100"))
 n, nch = 26_460_000 // 4, 8
-g = torch.Generator(device="cuda"); g.manual_seed(1)
+g = torch.Generator(device="cuda")
+g.manual_seed(1)
 x = torch.randn((nch, n), dtype=torch.float64, device="cuda", generator=g).t()
 tree = so.Signal(x, 44100 * so.Hz) | so.ToFramerate(44100 * np.pi / 3 * so.Hz)
 n_out = so.nframes(tree)
-out_t = torch.empty((nch, n_out), dtype=torch.float64, device="cuda"); out = out_t.t()
-for env in ("", "1"):
-    if env:
-        os.environ["SIGOPS_RS_NOTILED"] = "1"
+out_t = torch.empty((nch, n_out), dtype=torch.float64, device="cuda")
+out = out_t.t()
+which = os.environ.get("ONLY", "arb,tiled,plain").split(",")
+for name, env in (("arb", {}), ("tiled", {"SIGOPS_RS_NOARB": "1"}), ("plain", {"SIGOPS_RS_NOTILED": "1"})):
+    if name not in which:
+        continue
+    os.environ.update(env)
     plan = so.Plan(so.ToChannels(tree, nch), (n_out, nch), np.float64, (out.stride(0), out.stride(1)), True)
     st = torch.cuda.current_stream().cuda_stream
+    for _ in range(20):
+        plan.execute(out.data_ptr(), st)
+    torch.cuda.synchronize()
+    best = 1e9
     for _ in range(3):
-        plan.execute(out.data_ptr(), st)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10):
-        plan.execute(out.data_ptr(), st)
-    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps if name != "plain" else 10):
+            plan.execute(out.data_ptr(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / (reps if name != "plain" else 10))
     algo = 8 * nch * (n + n_out)
-    print(json.dumps({"kernel": "k_resample" if env else "k_resample_tiled", "in_frames": n, "out_frames": n_out, "channels": nch,
-                      "ms": ms, "algorithmic_GBps": algo / ms / 1e6, "frac_of_8TBps": algo / ms / 1e6 / 8000}))
-    plan.set_profiling(True)
-    for _ in range(3):
-        plan.execute(out.data_ptr(), st); torch.cuda.synchronize()
-    print("   steps:", [(s_["name"], round(s_["ms"], 4), s_["launches"]) for s_ in plan.steps()])
+    print(json.dumps({"kernel": [s_["name"] for s_ in plan.steps()][-1], "in_frames": n, "out_frames": n_out, "channels": nch,
+                      "ms": best, "algorithmic_GBps": algo / best / 1e6, "frac_of_8TBps": algo / best / 1e6 / 8000}), flush=True)
     plan.close()
+    for k in env:
+        os.environ.pop(k, None)
