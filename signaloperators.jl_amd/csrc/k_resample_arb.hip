@@ -134,6 +134,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
         const char* const xb = (const char*)(x + (int64_t)c0 * g.in_pitch);
         const uint32_t lane16 = (uint32_t)lane * 16u;
         int minrd = 0, spins = 0;
+        __builtin_amdgcn_s_setprio(3);  // (a handful of scalar instructions and DMAs per chunk: never behind the compute waves' arithmetic)
         const int depth = a.depth;
         const int debug = a.debug;
         int cnt[kArbMaxDepth] = {0};  // DMA instructions of the chunks in flight, youngest first

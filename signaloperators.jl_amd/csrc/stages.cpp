@@ -793,20 +793,22 @@ void Plan::process_stage(int sid) {
                         const int dmax = (int)std::ceil(step) + 1;  // newest inputs of two consecutive outputs, at most this far apart
                         // four outputs per lane where their windows stay close and all eight channels are in the
                         // workgroup: the LDS reads of a frame serve four outputs (the kernel is bound by them)
-                        int no = (cta == 8 && step <= 1.5) ? 4 : 2;
-                        no = env_int("SIGOPS_ARB_NO", no);
-                        if (no != 4 || cta != 8) no = 2;
+                        // (four outputs per lane -- the LDS reads of a frame serve four outputs -- is built and measured:
+                        //  compute waves alone 0.204 ms instead of 0.185, its 32-byte-strided stores cost what the
+                        //  reads save; opt-in)
+                        int no = env_int("SIGOPS_ARB_NO", 2);
+                        if (no != 4 || cta != 8 || step > 1.5) no = 2;
                         ra.no = no;
                         ra.zrows = (no - 1) * dmax + 3;
                         int ringf = 4096;
                         while (ringf >= 512 && resample_arb_lds_bytes(g.taps, ra.zrows, cta, ringf) + 1024 > (size_t)160 * 1024) ringf >>= 1;
                         ringf = env_int("SIGOPS_ARB_RING", ringf);
-                        ra.depth = env_int("SIGOPS_ARB_DEPTH", no == 4 ? 3 : 6);
+                        ra.depth = env_int("SIGOPS_ARB_DEPTH", no == 4 ? 2 : 4);
                         ra.debug = env_int("SIGOPS_ARB_DEBUG", 0);
                         const int per_batch = (int)std::ceil(64.0 * no * step) + 2;
                         // a batch's own span + what the loader has in flight must fit next to NC batches in progress
                         int nc = (ringf - (ra.depth * 128 + 127 + g.taps + no * dmax + 32)) / per_batch;
-                        nc = std::min(nc, no == 4 ? 7 : 11);
+                        nc = std::min(nc, no == 4 ? 7 : 8);  // (pairs: 4 waves 0.268 ms, 6 0.242, 8 0.231, 11 0.235 on the x pi / 3 bench)
                         nc = std::min(nc, env_int("SIGOPS_ARB_NC", nc));
                         ra.nc = nc;
                         ra.ringf = ringf;

@@ -204,3 +204,7 @@ def test_persistent_form_of_the_arbitrary_rate_resampler(fs_in, fs_out, nch, n, 
     ref = so.sink(tree)[0]
     assert relerr(got, ref) < 1e-14
     assert np.abs(got - ref).max() < 1e-13 * np.abs(ref).max()
+    monkeypatch.delenv("SIGOPS_RS_NOARB")
+    monkeypatch.setenv("SIGOPS_ARB_NO", "4")   # four outputs per lane (opt-in; eight-channel groups at rates near 1)
+    four = so.sink(tree)[0]
+    assert relerr(four, ref) < 1e-14
