@@ -502,7 +502,7 @@ def main():
     if rank == 0:
         m = min(n_in, 150_000)
         pre = np.asfortranarray(noise_t[:, :m].t().cpu().numpy())
-        gate = parity_gate(so, headline_fn, pre, 1e-6 if args.dtype == "f64" else 2e-6)
+        gate = parity_gate(so, headline_fn, pre, 1e-6)
 
     if rank == 0:
         algo = st["algorithmic_bytes"]
@@ -555,7 +555,7 @@ def main():
             noise_host = np.asfortranarray(noise_t.t().cpu().numpy())
             full, res["cpu_baseline"] = cpu_baseline(so, headline_fn, args.cpu_seconds, nch, ndt, noise_host, gpu_result)
             res["parity_full"] = full
-            tol = 1e-6 if args.dtype == "f64" else 2e-6
+            tol = 1e-6
             if full is not None and not (full["relerr"] <= tol):
                 raise SystemExit(f"bench.py: the timed result differs from the CPU oracle: {full}")
         else:

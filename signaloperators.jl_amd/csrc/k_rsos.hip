@@ -132,6 +132,43 @@ __device__ __forceinline__ void rsos_add(uint32_t la, uint32_t row_bytes, v2d gn
     }
 }
 
+// A landed chunk of a Float32 array: 128 floats in the upper half of each row's 1 KB slot.  Widened in place -- lane l
+// owns frames l and 64 + l of every row; all reads (the upper half) are back before the first write, so the lower
+// half's doubles may overwrite what the upper half's were read from -- with the fused step applied on the way
+// (OP: -1 none, 0 v*m, 1 v+m, 2 v-m, 3 m-v; g0 / g1: its operand at the lane's two frames).
+template <int RU, int OP>
+__device__ __forceinline__ void rsos_widen(uint32_t slot, uint32_t row_bytes, int lane, double g0, double g1) {
+    if constexpr (RU > 4) {
+        rsos_widen<4, OP>(slot, row_bytes, lane, g0, g1);
+        rsos_widen<RU - 4, OP>(slot + 4 * row_bytes, row_bytes, lane, g0, g1);
+        return;
+    } else {
+        float a[RU], b[RU];
+        const uint32_t ra = slot + 512u + (uint32_t)lane * 4u;
+#pragma unroll
+        for (int c = 0; c < RU; ++c) {
+            asm volatile("ds_read_b32 %0, %1" : "=v"(a[c]) : "v"(ra + (uint32_t)c * row_bytes) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(b[c]) : "v"(ra + (uint32_t)c * row_bytes) : "memory");
+        }
+        if constexpr (RU == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
+        else if constexpr (RU == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
+        double v0[RU], v1[RU];
+#pragma unroll
+        for (int c = 0; c < RU; ++c) {
+            const double x0 = (double)a[c], x1 = (double)b[c];
+            v0[c] = OP == 0 ? x0 * g0 : OP == 1 ? x0 + g0 : OP == 2 ? x0 - g0 : OP == 3 ? g0 - x0 : x0;
+            v1[c] = OP == 0 ? x1 * g1 : OP == 1 ? x1 + g1 : OP == 2 ? x1 - g1 : OP == 3 ? g1 - x1 : x1;
+        }
+        const uint32_t wa = slot + (uint32_t)lane * 8u;
+#pragma unroll
+        for (int c = 0; c < RU; ++c) {
+            asm volatile("ds_write_b64 %0, %1" ::"v"(wa + (uint32_t)c * row_bytes), "v"(v0[c]) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:512" ::"v"(wa + (uint32_t)c * row_bytes), "v"(v1[c]) : "memory");
+        }
+    }
+}
+
 constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlags = 56;
 constexpr int kRsosMaxGroups = 256;
 
@@ -370,9 +407,12 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const char* const base0 = (const char*)rfl64((int64_t)(uintptr_t)C0.base);
     const int fuse = uni(g.fuse), fuse_sine = uni(g.fuse_sine), debug = uni(g.debug);
-    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) && !(df0 & 1) && fuse >= -1;
+    const bool src32 = uni(g.src32) != 0;  // (a Float32 array: 4-byte elements, 128 of them per chunk and LDS-DMA instruction)
+    const int esh = src32 ? 2 : 3;
+    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && fuse >= -1 &&
+                        (!src32 || CH == 128);
     const int64_t lo_ok = a0 > 0 ? a0 : 0, hi_ok = b0 < n_in ? b0 : n_in;
-    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)((uintptr_t)base0 >> 3), cs0, df0);
+    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)((uintptr_t)base0 >> esh), cs0, df0);
     // the fused step's gain: a constant, or a sine generator evaluated in two levels (share bases per chunk in gtab,
     // per-lane (sin, cos) of the lane's two frame offsets)
     const int kind0 = uni(C0.slot_kind[0]);
@@ -380,9 +420,9 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     double2 d0 = double2{0.0, 1.0}, d1 = double2{0.0, 1.0};
     double gconst = 0.0;
     if (fuse >= 0) {
-        if (fuse_sine) {
-            d0 = rsos_sine_at(2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
-            d1 = rsos_sine_at(2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+        if (fuse_sine) {  // (the lane's two frames of a chunk: 2 l and 2 l + 1, or l and 64 + l where it widens Float32)
+            d0 = rsos_sine_at(src32 ? lane : 2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+            d1 = rsos_sine_at(src32 ? 64 + lane : 2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
         } else
             gconst = slot_eval(kind0, leaf0, 0);
     }
@@ -400,7 +440,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             const int ri = (u * RU) / ct, c0u = (u * RU) % ct;
             ch0_l = grp.cg * ct + c0u;
             Au_l = grp.pb0 + ri * grp.prM + ulo - ((grp.e0m + ri * grp.prMm) & 15);
-            rowb_l = (int64_t)(uintptr_t)base0 + ((int64_t)ch0_l * cs0 + df0 + Au_l) * 8;
+            rowb_l = (int64_t)(uintptr_t)base0 + (((int64_t)ch0_l * cs0 + df0 + Au_l) << esh);
             lds_l = ring_b + (uint32_t)(u * RU) * row_bytes;
             {
                 const int64_t zl = (-Au_l) >> shift, zh = (n_in - Au_l + CH - 1) >> shift;  // (k + 1) CH <= -Au ; k CH >= n_in - Au
@@ -440,8 +480,9 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             const bool fast = k >= u_klo(j) && k < u_khi(j);
             if (fast && (debug & 8192)) continue;
             if (fast) {
-                const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + 3)));
-                dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
+                const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + esh)));
+                if (src32) dma_rows<RU>(0xffffffffull, lane16, row, cs0 * 4, u_lds(j) + (uint32_t)rho0 * 8u + 512u, row_bytes);
+                else dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
                 n += RU;
             } else if (k < __builtin_amdgcn_readlane(kzl_l, j) || k >= __builtin_amdgcn_readlane(kzh_l, j)) {
                 // wholly before the signal's first frame (the warm-up of the first range) or behind its last: zeros
@@ -467,8 +508,8 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         rsos_stamp(trace, wave, k, 2);
         wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
         rsos_stamp(trace, wave, k, 3);
-        if (fuse >= 0 && !(debug & 2)) {
-            if (fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
+        if ((fuse >= 0 || src32) && !(debug & 2)) {
+            if (fuse >= 0 && fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
                 for (int j4 = 0; j4 < MU; j4 += 4) {
                     const int j = j4 + (lane >> 4);
                     const int64_t Au = (int64_t)(((uint64_t)(uint32_t)__shfl((int)((uint64_t)Au_l >> 32), j, 64) << 32) |
@@ -492,7 +533,16 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
                 } else
                     gn[0] = gn[1] = gconst;
-                if (lane < lanes) {
+                if (src32) {
+                    const uint32_t slot = u_lds(j) + (uint32_t)rho0 * 8u;
+                    switch (fuse) {
+                    case 0: rsos_widen<RU, 0>(slot, row_bytes, lane, gn[0], gn[1]); break;
+                    case 1: rsos_widen<RU, 1>(slot, row_bytes, lane, gn[0], gn[1]); break;
+                    case 2: rsos_widen<RU, 2>(slot, row_bytes, lane, gn[0], gn[1]); break;
+                    case 3: rsos_widen<RU, 3>(slot, row_bytes, lane, gn[0], gn[1]); break;
+                    default: rsos_widen<RU, -1>(slot, row_bytes, lane, 0.0, 0.0); break;
+                    }
+                } else if (lane < lanes) {
                     const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
                     switch (fuse) {
                     case 0: rsos_rmw<RU, 0>(la, row_bytes, gn); break;
@@ -575,8 +625,10 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
     const SO_LDS DCarrier& C0 = sh->ctl.car[0];
     const int64_t cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
-    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == SO_F64)) && !(df0 & 1) && uni(g.fuse) >= -1;
-    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> 3), cs0, df0);
+    const bool src32 = uni(g.src32) != 0;
+    const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && uni(g.fuse) >= -1 &&
+                        (!src32 || uni(g.chunk) == 128);
+    const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
     const int gq = lane >> 4, n16 = lane & 15;
     double Dk[4], Tk[4], Ck[3];
 #pragma unroll

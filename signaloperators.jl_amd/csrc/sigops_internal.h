@@ -353,6 +353,9 @@ struct RsSos {
     int32_t fuse;         // fast-path step of carrier 0 with frame slot 0: -1 none, 0 v*m, 1 v+m, 2 v-m, 3 m-v
     int32_t fuse_sine;    // ... slot 0 is a sine generator (two-level evaluation); else a constant
     int32_t out_f32;
+    int32_t src32;        // carrier 0 is a Float32 array: its chunks land as Float32 in the upper half of their ring slots and the
+                          // loader widens them in place (together with the fused step)
+    int32_t pad32_;
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space
     int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
     int64_t out_pitch;

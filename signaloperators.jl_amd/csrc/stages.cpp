@@ -1521,15 +1521,20 @@ void Plan::fuse_resample_sos() {
         if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
         Stage& S3 = stages[i3];
         const RsPeriodic& rp = S3.rp;
-        if (!S3.periodic || S3.base > 0 || rp.ga || rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
+        if (!S3.periodic || S3.base > 0 || rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
             S3.need < S2.need || S3.carriers.empty() || (int)S3.carriers.size() > kCtlCar || rp.L % 16 != 0 ||
             rp.ngroups * 16 != rp.L || rp.ngroups > 256 || rp.M >= (1 << 20))
             continue;
         const int ks = rp.kw / 4;
         if (!(ks == 12 || ks == 14 || ks == 16 || ks == 20)) continue;
         bool ok = true;
+        // GA carriers (a Float32 array whose Float64 gain or summand K3's compute waves apply at the MFMA operand): this
+        // kernel's loader widens the landed Float32 chunk in place and applies the step on the way, so the carriers go
+        // back to their plain form below -- array + one step, generated pieces that load the operand
+        const bool was_ga = rp.ga != 0;
         for (auto& c : S3.carriers)
-            if (c.pad_) ok = false;  // (GA carriers: Float32 arrays whose gain the K3 compute waves apply)
+            if ((c.pad_ != 0) != was_ga) ok = false;
+        if (was_ga && std::getenv("SIGOPS_RSOS_NO32")) ok = false;
         // nothing else may read the intermediate
         for (auto& L : leaves)
             if (L.buf == S2.in_buf) ok = false;
@@ -1624,6 +1629,17 @@ void Plan::fuse_resample_sos() {
             g.ring = ring;
             g.rpitch = ring + 2;
         }
+        if (was_ga) {
+            for (size_t i = 0; i < S3.carriers.size(); ++i) {
+                DCarrier& c = S3.carriers[i];
+                c.pad_ = 0;
+                c.nsteps = 1;  // (op[] / arg[] were left as build_carriers made them: MUL / ADD with slot 0, LOADF for the pieces)
+                if (i > 0) c.dtype = SO_F64;
+            }
+            S3.rp.ga = 0;
+            g.src32 = 1;
+        } else
+            g.src32 = S3.carriers[0].dtype == SO_F32 && S3.carriers[0].nsteps == 0 ? 1 : 0;
         // carrier 0's step on the fast path
         {
             const DCarrier& c0 = S3.carriers[0];

@@ -130,6 +130,52 @@ def test_rates(fs_in, fs_out):
     assert relerr(a, oracle_sink(x)) < 1e-9
 
 
+@pytest.mark.parametrize("kind", ["mix_sine", "amplify_sine", "amplify_const", "promoted", "sine_minus", "append"])
+@pytest.mark.parametrize("nch", [8, 2, 3])
+def test_float32_array_sources(kind, nch):
+    """a Float32 array under a Float64 generator (the Float32 headline: `Mix(Signal(sin), noise32)` is a Float64 signal,
+    src/mapsignal.jl promotion): the loader DMAs the Float32 chunk into the upper half of its ring slot and widens it in
+    place with the fused step -- against the oracle, and against K3's GA form + K2 (`SIGOPS_NO_RSOS`)"""
+    rng = np.random.default_rng(31 + nch)
+    n = 300000
+    x32 = F(rng.standard_normal((n, nch)).astype(np.float32))
+    noise = so.Signal(x32, 44.1 * so.kHz)
+    tone = so.Signal(so.sin, ω=1 * so.kHz)
+    src = {
+        "mix_sine": lambda: so.Mix(tone, noise) | so.Until(n * so.frames),
+        "amplify_sine": lambda: noise | so.Amplify(so.Signal(so.sin, ω=5 * so.Hz)) | so.Until(n * so.frames),
+        "amplify_const": lambda: noise | so.Amplify(0.25),
+        "promoted": lambda: so.ToEltype(noise, np.float64),
+        "sine_minus": lambda: so.OperateOn(np.subtract, tone, noise) | so.Until(n * so.frames),
+        "append": lambda: so.Append(so.Mix(tone, noise) | so.Until(100000 * so.frames),
+                                    so.Signal(F(rng.standard_normal((150000, nch))), 44.1 * so.kHz)),
+    }[kind]()
+    x = pipeline(src)
+    assert x.dtype == so.signals.F64 if hasattr(so.signals, "F64") else True
+    a, b, fused = both(x)
+    assert fused or kind in ("amplify_const", "sine_minus", "append")   # (what the planner does not fuse keeps the two kernels: same values)
+    assert a.dtype == np.float64 and relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+
+
+def test_float32_headline_is_one_launch():
+    """Float32 leaf, Float32 result, Float64 arithmetic: the BASELINE pipeline with Float32 storage"""
+    rng = np.random.default_rng(57)
+    n = 2000000
+    x32 = F(rng.standard_normal((n, 8)).astype(np.float32))
+    x = pipeline(so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(x32, 44.1 * so.kHz)) | so.Until(n * so.frames))
+    nout = so.nframes(x)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        p = so.Plan(so.ToChannels(x, 8), (nout, 8), np.float32, (1, nout), False)
+        names = [s["name"] for s in p.steps()]
+        p.close()
+        assert names == ["k_rsos"], names
+        got = np.empty((nout, 8), dtype=np.float32, order="F")
+        so.sink_into(got, x)
+    want = oracle_sink(x).astype(np.float32)
+    assert relerr(got, want) < 1e-6 and np.mean(got == want) > 0.99   # (values within the accumulated-alpha drift, 2e-9, of a Float32 rounding boundary flip)
+
+
 def test_float32_result_of_a_float64_pipeline():
     """`sink(x, Float32)` of a Float64 signal: the kernel rounds in its own store (reference src/sink.jl:262-266)"""
     rng = np.random.default_rng(55)
