@@ -375,7 +375,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
 }
 
 // =========================== loader waves ===========================
-template <int NY, int NL, int RU>
+template <int NY, int NL, int RU, bool SRC32>
 __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
@@ -407,8 +407,9 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const char* const base0 = (const char*)rfl64((int64_t)(uintptr_t)C0.base);
     const int fuse = uni(g.fuse), fuse_sine = uni(g.fuse_sine), debug = uni(g.debug);
-    const bool src32 = uni(g.src32) != 0;  // (a Float32 array: 4-byte elements, 128 of them per chunk and LDS-DMA instruction)
-    const int esh = src32 ? 2 : 3;
+    constexpr bool src32 = SRC32;  // (a Float32 array: 4-byte elements, 128 of them per chunk and LDS-DMA instruction; its own
+                                   //  instantiation: the Float64 loader's per-chunk path stays what it was)
+    constexpr int esh = src32 ? 2 : 3;
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && fuse >= -1 &&
                         (!src32 || CH == 128);
     const int64_t lo_ok = a0 > 0 ? a0 : 0, hi_ok = b0 < n_in ? b0 : n_in;
@@ -481,7 +482,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             if (fast && (debug & 8192)) continue;
             if (fast) {
                 const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + esh)));
-                if (src32) dma_rows<RU>(0xffffffffull, lane16, row, cs0 * 4, u_lds(j) + (uint32_t)rho0 * 8u + 512u, row_bytes);
+                if constexpr (src32) dma_rows<RU>(0xffffffffull, lane16, row, cs0 * 4, u_lds(j) + (uint32_t)rho0 * 8u + 512u, row_bytes);
                 else dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
                 n += RU;
             } else if (k < __builtin_amdgcn_readlane(kzl_l, j) || k >= __builtin_amdgcn_readlane(kzh_l, j)) {
@@ -533,7 +534,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
                 } else
                     gn[0] = gn[1] = gconst;
-                if (src32) {
+                if constexpr (src32) {
                     const uint32_t slot = u_lds(j) + (uint32_t)rho0 * 8u;
                     switch (fuse) {
                     case 0: rsos_widen<RU, 0>(slot, row_bytes, lane, gn[0], gn[1]); break;
@@ -888,10 +889,22 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
             const int q = wave == 4 ? 0 : 1;
             if (g.debug & 256) continue;
             switch (ru) {
-            case 8: rsos_loader<NY, NL, 8>(&sh, lds_raw, G, q); break;
-            case 4: rsos_loader<NY, NL, 4>(&sh, lds_raw, G, q); break;
-            case 2: rsos_loader<NY, NL, 2>(&sh, lds_raw, G, q); break;
-            default: rsos_loader<NY, NL, 1>(&sh, lds_raw, G, q); break;
+            case 8:
+                if (g.src32) rsos_loader<NY, NL, 8, true>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 8, false>(&sh, lds_raw, G, q);
+                break;
+            case 4:
+                if (g.src32) rsos_loader<NY, NL, 4, true>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 4, false>(&sh, lds_raw, G, q);
+                break;
+            case 2:
+                if (g.src32) rsos_loader<NY, NL, 2, true>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 2, false>(&sh, lds_raw, G, q);
+                break;
+            default:
+                if (g.src32) rsos_loader<NY, NL, 1, true>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 1, false>(&sh, lds_raw, G, q);
+                break;
             }
         } else if (!(g.debug & 128))
             {
