@@ -270,3 +270,17 @@ def test_soak_round3_paths(block):
     spec.loader.exec_module(mod)
     checks, bad = mod.run(2000 + 10 * block, 2010 + 10 * block)
     assert checks >= 20 and bad == 0
+
+
+def test_soak_round4_kernels():
+    """tools/soak_arb.py, a slice: the persistent kernel of rates without a period against the tiled one and the oracle
+    over random rates / channel counts / lengths / windows, Float32 array sources of the fused resampler + IIR kernel
+    against K3-GA + K2 and the oracle (600 + 75 cases ran clean on the final round-4 code: profiles/r04/soak_arb.txt)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_arb.py"), "4040", "48"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "'on_k_resample_arb':" in r.stdout
