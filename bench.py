@@ -273,6 +273,25 @@ def roofline_of(stage, traffic=None, source=None):
             "launches": stage["launches"], "kernel_algorithmic_bytes": stage["algorithmic_bytes"]}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD's FP64 matrix figure for MI355X (256 CUs x 4 SIMDs x 32 FMA / clock x 2.4 GHz); the guide under
+                               # /opt/skills has no fp64 row.  tools/micro/mfma64.hip reaches 64-69 on a loaded chip (profiles/r04/mfma64.txt)
+
+
+def mfma_roofline_of(stage, n_out, nch, plan_steps):
+    """The fused resampler + IIR kernel is bound by the fp64 matrix pipe, not by HBM: the MFMA
+    flops its launch issues for the outputs it stores -- 28 v_mfma_f64_16x16x4 (2 048 flops each) per block of 16 outputs x
+    16 rows for the headline's 14 k-step windows, warm-up blocks not counted -- over the kernel's measured time.  Reported
+    NEXT TO `roofline` (which stays the HBM one the contract's per-unit figure is stated in)."""
+    if not stage["name"].startswith("k_rsos"):
+        return None
+    ks = 14  # (the headline's and config-3-rate windows; other rates: 12 / 16 / 20, DESIGN.md)
+    blocks = n_out * nch / 256.0
+    tflops = blocks * (ks + 14) * 2048 / (stage["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS,
+            "kernel": stage["name"], "kernel_ms": stage["ms"],
+            "note": "issued fp64 MFMA flops of the stored outputs (28 MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure"}
+
+
 def parity_gate(so, tree_fn, noise_host, tol=1e-6):
     """engine vs oracle on a prefix of the same input (BASELINE.md §2's correctness gate).  Runs AFTER the
     timed loops: freeing this one-shot plan's device buffers right before them stalled the device for
@@ -532,6 +551,7 @@ def main():
                        "note": "warm-up is exactly --warmup steps; the first ~15 launches after an idle gap run up to 20% slower"},
             "algorithmic_bytes_per_step": algo,
             "roofline": roofline_of(dom, traffic, tsrc),
+            "roofline_mfma": mfma_roofline_of(dom, n_out, nch, stages),
             "roofline_sink": {"bound": "hbm", "achieved": sink_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
                               "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},

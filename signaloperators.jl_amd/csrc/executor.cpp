@@ -533,6 +533,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsSos rs = S.rs;
                         rs.out_pitch = ob.pitch;
                         rs.out_f32 = g.out_dtype == SO_F32 && N.dtype == SO_F64;
+                        // the kernel's output m is frame m - store_lo of this stage's buffer (a window: the resampler's warm
+                        // start lies store_lo frames before the cascade's); the sink's own skipped frames come on top
+                        char* const yk = (char*)ob.d - (size_t)S.rs.store_lo * (rs.out_f32 ? 4 : 8);
+                        rs.store_lo = S.rs.store_lo + g.store_lo;
                         rs.mats = (const double*)P->bufs[S.rsos_mats_buf].d;
                         rs.bad = nullptr;
                         if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
@@ -547,7 +551,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             HIPCHECK(hipMemsetAsync(d_rtrace, 0, rtrace_n * 8, st));
                             rs.trace = d_rtrace;
                         }
-                        if (launch_rsos((const double*)P->bufs[S3.tab_buf].d, (const int*)P->bufs[S3.jend_buf].d, rs, ob.d,
+                        if (launch_rsos((const double*)P->bufs[S3.tab_buf].d, (const int*)P->bufs[S3.jend_buf].d, rs, yk,
                                         RsGlobalTables{(const RsCtl*)P->bufs[S3.ctl_buf].d, (const DCarrier*)P->bufs[S3.car_buf].d, P->d_ops, P->d_leaves},
                                         S.rsos_grid, st) != 0)
                             fail(SO_ERR_RUNTIME, "internal: no fused resampler + IIR instantiation for this geometry");
@@ -573,9 +577,9 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             pg.n = rs.n_out;
                             pg.chunk = rs.pr * rs.L;
                             pg.nchunks = rs.nranges;
-                            pg.store_lo = 0;
+                            pg.store_lo = rs.store_lo;
                             pg.bad = rs.bad;
-                            nl += launch_sos_poison(ob.d, pg, st);
+                            nl += launch_sos_poison(yk, pg, st);
                         }
                     }
                     for (size_t gi = 0; gi < S.groups.size() && S.onepass; ++gi) {

@@ -233,6 +233,7 @@ struct RsosGroup {
     int64_t pb0;    // first input frame of the first period range 0 of the group walks (may be negative)
     int64_t ob0;    // ... and its first output
     int64_t prM, prL;  // inputs / outputs from one range to the next
+    int64_t r0;     // first range of the group
     int e0m, prMm;  // alignment of range ri's first staged frame: (e0m + ri prMm) & 15 frames above a 128-byte line
 };
 __device__ __forceinline__ RsosGroup rsos_group(const SO_LDS RsosShared* sh, int64_t G, bool single, int64_t base0_8, int64_t cs0, int64_t df0) {
@@ -244,6 +245,7 @@ __device__ __forceinline__ RsosGroup rsos_group(const SO_LDS RsosShared* sh, int
     RsosGroup q;
     q.cg = (int)(G % ncg);
     const int64_t r0 = (G / ncg) * rgs;
+    q.r0 = r0;
     q.pb0 = (r0 * pr - wp) * M;
     q.ob0 = (r0 * pr - wp) * L;
     q.prM = pr * M;
@@ -670,6 +672,14 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
         nbs_all = uni(m);
     }
+    // a window's warm-up (RsSos::store_lo): outputs below it are not stored.  Only the first blocks of the first ranges
+    // can lie below it: from block nbl_max on every row of the group stores -- the common path
+    const int64_t slo = rfl64(g.store_lo);
+    int nbl_max = 0;
+    if (slo > grp.ob0) {
+        const int64_t nb = (slo - grp.ob0 + 15) / 16;
+        nbl_max = (int)(nb > 0x3fffffff ? 0x3fffffff : nb);
+    }
     int nb0_any;  // some lane's row starts before the signal: blocks below this need the zeroing
     {
         int m = nb0;
@@ -719,7 +729,13 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
         if (!(debug & 1)) {
             const int64_t t0 = (int64_t)16 * pb_;
-            if (pb_ < nbs_all) {
+            if (pb_ < nbl_max) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t m = grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16;
+                    if (pb_ < nbs[v] && m >= slo) yp[v][t0] = (TO)ay[v];
+                }
+            } else if (pb_ < nbs_all) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) yp[v][t0] = (TO)ay[v];
             } else {

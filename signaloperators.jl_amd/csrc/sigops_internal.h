@@ -359,6 +359,8 @@ struct RsSos {
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space
     int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
     int64_t out_pitch;
+    int64_t store_lo;     // outputs below this one are not stored (a window's warm-up: the kernel's output 0 is where the
+                          // resampler stage's warm start begins, the result where the window does)
     const double* mats;   // [14][64] MFMA operands: D k-steps 0..3, A^16 k-steps 0..2, T^T k-steps 0..3, C^T k-steps 0..2
     int32_t* bad;         // per channel: first range that ended in a non-finite state, or null
     long long* trace;     // SIGOPS_RSOS_TRACE: [16 waves][kRsosTraceIters][8] cycle stamps of workgroup 0, or null

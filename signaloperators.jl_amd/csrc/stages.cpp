@@ -1509,19 +1509,24 @@ void Plan::fuse_resample_sos() {
     };
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {
         Stage& S2 = stages[i2];
-        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.base > 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 ||
-            S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != 0 || S2.pw_step >= 0 || S2.sg.exact || S2.xscan ||
+        if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 ||
+            S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != S2.base || S2.pw_step >= 0 || S2.sg.exact || S2.xscan ||
             S2.under_norm || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 || nodes[S2.node].dtype != SO_F64 ||
-            S2.in_frames != S2.need)
+            S2.in_frames != S2.need - S2.base)
             continue;
-        if ((int)i2 == alias_stage && alias_skip != 0) continue;
+        if (S2.base > 0 && std::getenv("SIGOPS_RSOS_NOWINDOWS")) continue;
         int i3 = -1;
         for (size_t j = 0; j < stages.size(); ++j)
             if (stages[j].kind == ST_RESAMPLE && stages[j].out_buf == S2.in_buf) i3 = (int)j;
         if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
         Stage& S3 = stages[i3];
         const RsPeriodic& rp = S3.rp;
-        if (!S3.periodic || S3.base > 0 || rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
+        // A window (After, a block of so.stream, a rank's time range): both stages are warm-started -- the cascade a decay
+        // time before the window (S2.base), the resampler a few periods before that (S3.base, whole periods).  The fused
+        // kernel's coordinates are the resampler stage's: its output 0 is frame S3.base, the cascade starts from rest
+        // there (earlier than the cascade stage alone would: a longer warm-up), and nothing below S2.base is stored.
+        if (!S3.periodic || rp.L <= 0 || S3.base > S2.base || S3.base % rp.L != 0) continue;
+        if (rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
             S3.need < S2.need || S3.carriers.empty() || (int)S3.carriers.size() > kCtlCar || rp.L % 16 != 0 ||
             rp.ngroups * 16 != rp.L || rp.ngroups > 256 || rp.M >= (1 << 20))
             continue;
@@ -1547,7 +1552,8 @@ void Plan::fuse_resample_sos() {
         const SosCoefs& cf = S2.groups[0];
         const int D = 2 * cf.nsec;
         const int nch = nodes[S2.node].nch;
-        const int64_t need = S2.need, L = rp.L;
+        const int64_t need = S2.need - S3.base, L = rp.L;
+        const int64_t store_lo = S2.base - S3.base;
         const int64_t nperiods = (need + L - 1) / L;
         // warm-up: the first wp with ||A^(wp L)|| < 2^-70
         int64_t wp = 1;
@@ -1570,21 +1576,38 @@ void Plan::fuse_resample_sos() {
             }
         const int rgs = 16 / ct;
         const int64_t ncg = nch / ct;
-        // ranges: one sequence group per CU where the signal is long enough for the warm-up to stay below a fifth of
-        // a range; the last wave of groups of a longer grid would run on a draining machine
+        // ranges: one sequence group per CU (the last wave of groups of a longer grid would run on a draining machine),
+        // fewer where a range would otherwise be shorter than its own warm-up
         const int cus = env_int("SIGOPS_RSOS_GRID", 256);
         int64_t rgroups = std::max<int64_t>(1, cus / ncg);  // range groups per channel group
         int64_t nranges = rgroups * rgs;
-        const int64_t min_pr = 4 * wp;
+        const int64_t min_pr = std::max<int64_t>(1, wp);
         if (nperiods / nranges < min_pr) nranges = std::max<int64_t>(rgs, nperiods / min_pr / rgs * rgs);
         if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES")) nranges = std::max<int64_t>(1, std::atoll(ev));
         const int64_t pr = (nperiods + nranges - 1) / nranges;
         nranges = (nperiods + pr - 1) / pr;
         const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
-        if (ngrp < env_int("SIGOPS_RSOS_MINGROUPS", 64) || (pr + wp) * rp.ngroups >= (1 << 30) || (pr + wp) * rp.M >= ((int64_t)1 << 30)) continue;
+        if ((pr + wp) * rp.ngroups >= (1 << 30) || (pr + wp) * rp.M >= ((int64_t)1 << 30)) continue;
+        // Worth it?  A workgroup walks its (pr + wp) periods block by block -- 0.30 us per block of 16 outputs x 16 rows
+        // with 14 k-step windows -- however few workgroups there are, while the two kernels use the whole chip for any
+        // length: 8 ps per output sample + 95 us of launches, scans and tails (tools/rsos_len_sweep.sh, 8 channels at
+        // 44.1 -> 48 kHz: fused 0.176 / 0.189 / 0.241 / 0.466 ms for 20 / 46 / 75 / 200 s, two kernels 0.159 / 0.226 /
+        // 0.306 / 0.710).  Short signals and short windows keep the two kernels (8 channels: below ~30 s).
+        // SIGOPS_RSOS_MINGROUPS=n replaces the estimate by "at least n sequence groups" (tests, measurements).
+        if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
+            if (ngrp < std::atoll(ev)) continue;
+        } else {
+            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * rp.ngroups) * 0.30 * (ks + 14) / 28.0 + 15.0;
+            const double t_two = 8.0e-6 * (double)need * nch + 95.0;
+            if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                std::fprintf(stderr, "[sigops] k_rsos estimate: fused %.0f us (%lld groups, %lld + %lld periods), two kernels %.0f us\n", t_fused,
+                             (long long)ngrp, (long long)pr, (long long)wp, t_two);
+            if (t_fused > t_two) continue;
+        }
         RsSos g{};
         g.n_in = S3.rg.n_in;
         g.n_out = need;
+        g.store_lo = store_lo;
         g.L = L;
         g.M = rp.M;
         g.pr = pr;

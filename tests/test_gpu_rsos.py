@@ -2,8 +2,8 @@
 filter, src/filters.jl:240-255 filters every block of the resampled child in place) against the CPU oracle and
 against the engine's own two-kernel path (K3 + K2, `SIGOPS_NO_RSOS=1` at plan creation) on identical inputs.
 
-`SIGOPS_RSOS_MINGROUPS=1` lets signals of a few seconds take the fused kernel (by default the planner only fuses
-where there are at least 64 sequence groups, i.e. from about 45 s x 8 channels on); the last tests run without it.
+`SIGOPS_RSOS_MINGROUPS=1` lets signals of a few seconds take the fused kernel (by default the planner fuses where its time
+estimate says the one launch is faster than the two: from about 30 s x 8 channels on); the last test runs without it.
 Tolerances: Float64 1e-9 against the oracle (what the accumulated-alpha drift of DSP.jl's phase accumulator leaves,
 as for K3), 1e-11 between the two engine paths (the fused sine source is evaluated in two levels with different
 base frames: ~4e-12)."""
@@ -207,14 +207,49 @@ def test_a_non_finite_sample_poisons_the_rest_of_its_channel():
         assert np.isfinite(got[:, ch]).all() and relerr(got[:, ch], ref[:, ch]) < 1e-11
 
 
-def test_windows_and_streams_keep_the_two_kernel_path():
-    """a window of the result (After, a later block of `so.stream`) warm-starts its stages: not fused (yet), same values"""
+@pytest.mark.parametrize("a,n", [(200000, 50000), (8192, 300000), (123457, 1), (350001, 85000), (20000, 410000)])
+def test_windows_run_fused_too(a, n):
+    """a window of the result (After, a later block of `so.stream`, a rank's time range) warm-starts both stages; the
+    fused kernel takes the resampler stage's coordinates and stores nothing below the window (RsSos::store_lo)"""
     rng = np.random.default_rng(77)
     x = pipeline(so.Signal(F(rng.standard_normal((400000, 2))), 44.1 * so.kHz))
+    win = x | so.After(a * so.frames) | so.Until(n * so.frames)
+    with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_RSOS=None):
+        whole = so.sink(x)[0]
+        fused = "k_rsos" in steps_of(win)
+        part = so.sink(win)[0]
+        out32 = np.empty((n, 2), dtype=np.float32, order="F")
+        so.sink_into(out32, win)
+    assert fused or n < 20000
+    assert part.shape == (n, 2) and relerr(part, whole[a:a + n]) < 1e-11
+    assert relerr(out32, whole[a:a + n].astype(np.float32)) < 1e-6
+    with env(SIGOPS_NO_RSOS=1):
+        ref = so.sink(win)[0]
+    assert relerr(part, ref) < 1e-11
+
+
+def test_stream_blocks_and_time_shards_through_the_fused_kernel():
+    rng = np.random.default_rng(78)
+    x = pipeline(so.Mix(so.Signal(so.sin, ω=1 * so.kHz), so.Signal(F(rng.standard_normal((600000, 8))), 44.1 * so.kHz))
+                 | so.Until(600000 * so.frames))
+    from sigops_amd import sharding
+
     with env(SIGOPS_RSOS_MINGROUPS=1):
         whole = so.sink(x)[0]
-        part = so.sink(x | so.After(200000 * so.frames) | so.Until(50000 * so.frames))[0]
-    assert relerr(part, whole[200000:250000]) < 1e-11
+        blocks = [b for b, _ in so.stream(x, 150000)]
+        got = np.concatenate([np.asarray(b) for b in blocks])
+        assert got.shape == whole.shape and relerr(got, whole) < 1e-11
+        parts = [so.sink(sharding.shard_time(x, r, 3)[0])[0] for r in range(3)]
+        assert relerr(np.concatenate(parts), whole) < 1e-11
+    a = rng.standard_normal((500000, 2))
+    a[400000, 1] = np.nan                      # non-finite behind the window's start: the rest of that channel is NaN
+    y = pipeline(so.Signal(F(a), 44.1 * so.kHz)) | so.After(300000 * so.frames)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        got = so.sink(y)[0]
+    with env(SIGOPS_NO_RSOS=1):
+        ref = so.sink(y)[0]
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[200000:, 1]).all() and np.isfinite(got[:, 0]).all()
+    assert relerr(got[:, 0], ref[:, 0]) < 1e-11
 
 
 def test_run_to_run_identical():
