@@ -780,7 +780,10 @@ void Plan::process_stage(int sid) {
                     stages[sid].pfbt_buf = raw_buf(stages[sid].pfbt_host.size() * 8);
                     stages[sid].dpfbt_buf = raw_buf(stages[sid].dpfbt_host.size() * 8);
                     // ---- the persistent form (k_resample_arb): Float64, DSP.jl's 32 phases, windows of a pair close ----
-                    if (pair && g.nphi == 32 && N.dtype == SO_F64 && need >= 16384 && !std::getenv("SIGOPS_RS_NOARB")) {
+                    // (a persistent workgroup zeroes its ring and builds its tables first: ~22 us before the first output, 15
+                    //  for the tiled kernel; from 1.5 M output samples on the pipelined walk is ahead -- tools/arb_len_sweep.py)
+                    const int64_t arb_min = env_int("SIGOPS_ARB_MIN", 1500000);
+                    if (pair && g.nphi == 32 && N.dtype == SO_F64 && need >= 16384 && need * N.nch >= arb_min && !std::getenv("SIGOPS_RS_NOARB")) {
                         RsArb ra{};
                         ra.g = g;
                         int cta = 1;

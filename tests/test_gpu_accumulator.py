@@ -187,6 +187,7 @@ def test_persistent_form_of_the_arbitrary_rate_resampler(fs_in, fs_out, nch, n, 
     h[p + 32 k] + alpha dh[p + 32 k] once per output -- against the oracle (yLower + alpha yUpper per output: 1e-9 as for
     every resampler, the accumulated-alpha drift) and against the tiled kernel (the two associations of the same sum:
     1e-14), windows included (warm start: g.m0 / g.j0)"""
+    monkeypatch.setenv("SIGOPS_ARB_MIN", "1")   # (by default from 1.5 M output samples on: below, the tiled kernel's shorter start wins)
     rng = np.random.default_rng(207)
     x = np.asfortranarray(rng.standard_normal((n, nch)))
     x[n // 3, 0] = 0.0

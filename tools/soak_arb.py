@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sigops_amd as so
 from oracle_bridge import oracle_sink, relerr
 
+os.environ.setdefault("SIGOPS_ARB_MIN", "1")  # (the persistent kernel for every length it can run, not only where it pays)
 base = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 
