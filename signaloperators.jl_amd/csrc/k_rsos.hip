@@ -153,6 +153,7 @@ __device__ __forceinline__ void rsos_widen(uint32_t slot, uint32_t row_bytes, in
         if constexpr (RU == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
         else if constexpr (RU == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
+        // (the LDS adder for v + m, as the Float64 path uses it, is slower here: 1.36 ms against 1.33 with the vector add)
         double v0[RU], v1[RU];
 #pragma unroll
         for (int c = 0; c < RU; ++c) {
@@ -708,8 +709,10 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     // them: a convoy.)  An in-order wave does nothing while it waits, so what a block costs besides its 21 MFMAs is
     // one LDS round trip, the hazard gaps behind three MFMA groups and ~100 other instructions.
     int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot
-    v4d pay_ = v4d{0.0, 0.0, 0.0, 0.0};  // ... and its X^T T^T
-    auto back = [&](int sq, double (&sv)[3]) __attribute__((always_inline)) {
+    // ... and its X^T T^T: two register sets that swap roles from block to block (the set a block fills is the one the
+    // next block's back part accumulates into and stores from: no copy between them)
+    v4d payA = v4d{0.0, 0.0, 0.0, 0.0}, payB = v4d{0.0, 0.0, 0.0, 0.0};
+    auto back = [&](int sq, double (&sv)[3], v4d& pay_) __attribute__((always_inline)) {
         // (the wait below is also what keeps this wave from running away from the chain wave: the exchange slots are
         //  reused on the strength of it, so it stays for warm-up blocks, whose result is not computed)
         int spins = 0;
@@ -746,7 +749,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         }
         rsos_stamp(trace, wave, pb_ / NY, 5);
     };
-    auto block = [&](int b, const double (&at)[KS]) __attribute__((always_inline)) {
+    auto block = [&](int b, const double (&at)[KS], v4d& pin, v4d& pout) __attribute__((always_inline)) {
         const int wb = pi * M + uni(sh->jend[gi]) - ulo_kw;
         const int need = wb + kw + 16;
         rsos_stamp(trace, wave, b / NY, 0);
@@ -795,8 +798,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             wbm += wb2 - wb;
             while (wbm >= RING) wbm -= RING;
         }
-        if (b < nb0_any) {
+        if (b < nb0_any) {  // (a real branch -- the first blocks of the signal's first range only: if-converted it is eight
+                            //  selects behind an MFMA-result hazard in every block of the kernel)
+            asm volatile("" ::: "memory");
             if (b < nb0) ax = v4d{0.0, 0.0, 0.0, 0.0};
+            asm volatile("" : "+v"(ax));
         }
         rsos_stamp(trace, wave, b / NY, 2);
         // ---- D . X for the chain wave (its share of the recurrence that does not depend on the state) ----
@@ -804,17 +810,17 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #pragma unroll
         for (int v = 0; v < 4; ++v) dx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], ax[v], dx, 0, 0, 0);
         // ---- X^T T^T of this block (kept for the next round) ----
-        v4d ty = v4d{0.0, 0.0, 0.0, 0.0};
-        if (pi >= wp) {  // (a warm-up block's result is not stored: only its D . x matters)
+        // (also for a warm-up block, whose result is not stored: 7 % of the blocks; skipping the four products there makes
+        //  the set a conditional value, and the register allocator pays for that with four copies behind an MFMA-result
+        //  hazard in every block)
+        pout = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0], Tk[0], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) ty = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], ty, 0, 0, 0);
-        }
+        for (int v = 1; v < 4; ++v) pout = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], pout, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
         flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
         // ---- the previous block's result ----
-        if (pb_ >= 0) back(sq, sv);
-        pay_ = ty;
+        if (pb_ >= 0) back(sq, sv, pin);
         rsos_stamp(trace, wave, b / NY, 3);
         pb_ = b;
         ppi_ = pi;
@@ -824,13 +830,15 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         slot += NY;  // (b + NY) mod (2 NY + 1)
         if (slot >= NX) slot -= NX;
     };
+    int cur = 0;  // the set the pending block's T part is in: 0 payA, 1 payB
     auto last_back = [&]() __attribute__((always_inline)) {
         if (pb_ < 0) return;
         double sv[3];
         const int sq = flag_ld(f_sseq);
 #pragma unroll
         for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
-        back(sq, sv);
+        if (cur) back(sq, sv, payB);
+        else back(sq, sv, payA);
     };
     if constexpr (CYC > 0) {
         const double SO_GLB* tab = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)sh->tab);
@@ -843,8 +851,12 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         }
         for (int b = yi; b < NB;) {
 #pragma unroll
-            for (int c = 0; c < CYC; ++c) {
-                if (b < NB) block(b, treg[c]);
+            for (int k = 0; k < 2 * CYC; ++k) {
+                if (b < NB) {
+                    if ((k & 1) == 0) block(b, treg[k % CYC], payA, payB);
+                    else block(b, treg[k % CYC], payB, payA);
+                    cur = (k & 1) ^ 1;
+                }
                 b += NY;
             }
         }
@@ -855,7 +867,9 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             const SO_LDS double* tp = l.taps + gi * KS * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) at[s] = tp[s * 64];
-            block(b, at);
+            if (cur == 0) block(b, at, payA, payB);
+            else block(b, at, payB, payA);
+            cur ^= 1;
         }
         last_back();
     }
