@@ -107,4 +107,57 @@ for i in range(max(8, cases // 8)):
         eo = relerr(got, oracle_sink(tree))
         assert eo < 1e-9, (i, names, eo)
         worst["rsos32_vs_oracle"] = max(worst["rsos32_vs_oracle"], eo)
-print({"base": base, "cases": cases, "on_k_resample_arb": narb, "fused_float32": nf, **worst})
+# the fused kernel at large: rates whose period splits into blocks of 16 outputs, random cascades, channel counts,
+# lengths, sources and WINDOWS (warm starts: RsSos::store_lo), every structurally possible case forced onto it
+ng = 0
+worst["rsos_vs_two"] = worst["rsos_vs_oracle"] = 0.0
+for i in range(max(12, cases // 2)):
+    rng = np.random.default_rng(base * 104729 + i)
+    nch = int(rng.choice([1, 2, 3, 4, 6, 8, 8, 12, 16, 24]))
+    fs_in, fs_out = [(44100.0, 48000.0), (22050.0, 48000.0), (44100.0, 96000.0), (11025.0, 48000.0), (44100.0, 48000.0)][int(rng.integers(0, 5))]
+    n = int(rng.integers(60000, 500000) * (fs_in / 44100.0))
+    if nch > 8:
+        n = min(n, 150000)
+    dt = np.float64
+    x = np.asfortranarray(rng.standard_normal((n, nch)))
+    src = so.Signal(x, fs_in * so.Hz)
+    k = int(rng.integers(0, 4))
+    if k == 1:
+        src = so.Mix(so.Signal(so.sin, ω=float(rng.uniform(50, 3000)) * so.Hz), src) | so.Until(n * so.frames)
+    elif k == 2:
+        src = src | so.Amplify(so.Signal(so.sin, ω=float(rng.uniform(1, 20)) * so.Hz)) | so.Until(n * so.frames)
+    elif k == 3:
+        src = src | so.Amplify(float(rng.uniform(0.1, 2.0)))
+    nyq = 0.5 * fs_in / 1000.0
+    kind = int(rng.integers(0, 4))
+    order = int(rng.integers(1, 7 if kind < 2 else 4))
+    f1 = float(rng.uniform(0.02, 0.6)) * nyq
+    f2 = min(f1 + float(rng.uniform(0.05, 0.3)) * nyq, 0.95 * nyq)
+    filt = [lambda s: s | so.Filt(so.Lowpass, f1 * so.kHz, order=order), lambda s: s | so.Filt(so.Highpass, f1 * so.kHz, order=order),
+            lambda s: s | so.Filt(so.Bandpass, f1 * so.kHz, f2 * so.kHz, order=order),
+            lambda s: s | so.Filt(so.Bandstop, f1 * so.kHz, f2 * so.kHz, order=order)][kind]
+    tree = filt(src) | so.ToFramerate(fs_out * so.Hz)
+    nout = so.nframes(tree)
+    if rng.random() < 0.6 and nout > 60000:
+        a = int(rng.integers(1, nout - 20000))
+        m = int(rng.integers(1, nout - a))
+        tree = tree | so.After(a * so.frames) | so.Until(m * so.frames)
+        nout = m
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        p = so.Plan(so.ToChannels(tree, nch), (nout, nch), np.float64, (1, nout), False)
+        names = [s["name"] for s in p.steps()]
+        p.close()
+        got = so.sink(tree)[0]
+    with env(SIGOPS_NO_RSOS=1):
+        ref = so.sink(tree)[0]
+    nrm = np.linalg.norm(ref)
+    e = relerr(got, ref) if nrm > 1e-200 else float(np.abs(got - ref).max())
+    assert got.shape == ref.shape and e < 1e-9, (i, names, e, nch, n, fs_in, fs_out, kind, order, f1, f2)
+    if "k_rsos" in names:
+        ng += 1
+        worst["rsos_vs_two"] = max(worst["rsos_vs_two"], e)
+    if i % 6 == 0:
+        eo = relerr(got, oracle_sink(tree))
+        assert eo < 1e-8, (i, names, eo)
+        worst["rsos_vs_oracle"] = max(worst["rsos_vs_oracle"], eo)
+print({"base": base, "cases": cases, "on_k_resample_arb": narb, "fused_float32": nf, "fused_random": ng, **worst})
