@@ -514,7 +514,10 @@ def main():
         a4 = argparse.Namespace(**vars(args))
         a4.workload = "config4"
         a4.steps, a4.warmup = max(5, args.steps // 4), max(2, args.warmup // 2)
-        config4 = bench_multi.run(a4, so, torch, dist, rank, local_rank, world, dev, emit=False)
+        try:
+            config4 = bench_multi.run(a4, so, torch, dist, rank, local_rank, world, dev, emit=False)
+        except Exception as exc:  # (the headline line must not depend on the secondary workload)
+            config4 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # ---- correctness gate (rank 0, same device noise, a prefix); the whole length: parity_full below ----
     gate = None
