@@ -112,9 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
                                 if (v0 + j * 64 < nv) {
-                                    const int e0 = 2 * (v0 + j * 64);
-                                    const bool p2 = (nb & (nb - 1)) == 0;
-                                    const int f = f0w + (p2 ? e0 >> (31 - __builtin_clz(nb)) : e0 / nb), cc = p2 ? (e0 & (nb - 1)) : e0 % nb;
+                                    const int e0 = 2 * (v0 + j * 64), f = f0w + e0 / nb, cc = e0 % nb;
                                     il_tile[f * kIlPitch + cc] = w[j].x;
                                     il_tile[f * kIlPitch + cc + 1] = w[j].y;
                                 }
@@ -198,19 +196,6 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
                     if (!(out.pad & 1) && out64 && nb == out.fstride && !(nb & 1) && ((((uintptr_t)out.base) + ooff0 * 8) & 15) == 0) {
                         double2* dst = reinterpret_cast<double2*>((double*)out.base + ooff0);
                         const int nv = 64 * E * nb / 2;
-                        // (frame and channel of a vector by shifts for the usual widths: a runtime division per vector cost
-                        //  more instructions than the copy itself)
-                        const int sh = nb == 8 ? 3 : nb == 4 ? 2 : nb == 2 ? 1 : -1;
-                        if (sh > 0) {
-#pragma unroll 4
-                            for (int v0 = ln; v0 < nv; v0 += 64) {
-                                const int e0 = 2 * v0, f = f0w + (e0 >> sh), cc = e0 & (nb - 1);
-                                double2 w;
-                                w.x = il_tile[f * kIlPitch + cc];
-                                w.y = il_tile[f * kIlPitch + cc + 1];
-                                dst[v0] = w;
-                            }
-                        } else
                         for (int v0 = ln; v0 < nv; v0 += 64) {
                             const int e0 = 2 * v0, f = f0w + e0 / nb, cc = e0 % nb;
                             double2 w;
