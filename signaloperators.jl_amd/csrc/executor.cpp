@@ -122,8 +122,13 @@ void Plan::finalize() {
         if (S.need <= 0) continue;
         if (S.kind == ST_SOS && S.qmat_buf >= 0)
             HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
-        if (S.kind == ST_SOS && S.rsos_src >= 0)
+        if (S.kind == ST_SOS && S.rsos_src >= 0) {
             HIPCHECK(hipMemcpy(bufs[S.rsos_mats_buf].d, S.rsos_mats_host.data(), S.rsos_mats_host.size() * 8, hipMemcpyHostToDevice));
+            if (S.rsos_tab_buf >= 0) {
+                HIPCHECK(hipMemcpy(bufs[S.rsos_tab_buf].d, S.rsos_tab_host.data(), S.rsos_tab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(bufs[S.rsos_jend_buf].d, S.rsos_jend_host.data(), S.rsos_jend_host.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
         if (S.kind == ST_SOS && S.onepass)
             HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
         if (S.kind == ST_RESAMPLE) {
@@ -551,7 +556,9 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             HIPCHECK(hipMemsetAsync(d_rtrace, 0, rtrace_n * 8, st));
                             rs.trace = d_rtrace;
                         }
-                        if (launch_rsos((const double*)P->bufs[S3.tab_buf].d, (const int*)P->bufs[S3.jend_buf].d, rs, yk,
+                        const double* rtab = (const double*)P->bufs[S.rsos_tab_buf >= 0 ? S.rsos_tab_buf : S3.tab_buf].d;
+                        const int* rjend = (const int*)P->bufs[S.rsos_jend_buf >= 0 ? S.rsos_jend_buf : S3.jend_buf].d;
+                        if (launch_rsos(rtab, rjend, rs, yk,
                                         RsGlobalTables{(const RsCtl*)P->bufs[S3.ctl_buf].d, (const DCarrier*)P->bufs[S3.car_buf].d, P->d_ops, P->d_leaves},
                                         S.rsos_grid, st) != 0)
                             fail(SO_ERR_RUNTIME, "internal: no fused resampler + IIR instantiation for this geometry");

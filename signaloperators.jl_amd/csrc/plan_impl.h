@@ -145,6 +145,9 @@ struct Stage {
     RsPeriodic rp{};
     bool tiled = false;  // tiled resampler without a period (k_resample_tiled)
     RsTiled rt{};
+    std::vector<double> rsos_tab_host;  // fused kernel: tap operands of a super-period of its own (small rational ratios)
+    std::vector<int> rsos_jend_host;
+    int rsos_tab_buf = -1, rsos_jend_buf = -1;
     bool arbk = false;   // ... its persistent form (k_resample_arb), geometry in ra
     RsArb ra{};
     int pfbt_buf = -1, dpfbt_buf = -1;

@@ -482,6 +482,14 @@ void Plan::process_stage(int sid) {
             int64_t t = std::max<int64_t>(1, 1100 / (pt * Mb));
             t = std::max<int64_t>(tmin, t / tmin * tmin);
             if (Lb * t > 4096) t = std::max<int64_t>(1, 4096 / Lb);
+            // ... and (c) at most twelve blocks of 16 outputs where tmin allows it: a compute wave keeps ONE block's taps
+            // in registers.  Upsampling by small ratios (x 2, x 3, x 4: few inputs per period) used to get super-periods of
+            // 30 - 70 blocks from (b), for which no instantiation exists -- the stage fell to the row-tiled kernel at a
+            // tenth of the speed (x 2 of 8 channels x 300 s: 11 ms; tools/ratio_probe.py)
+            if (!std::getenv("SIGOPS_RS_NOBLOCKCAP")) {
+                const int64_t tcap = std::max<int64_t>(tmin, (12 * 16 / Lb) / tmin * tmin);
+                t = std::min(t, tcap);
+            }
             const int64_t Ls = Lb * t, Ms = Mb * t;
             auto pos = [&](int64_t r, int64_t& j, int& p, double& alpha) {
                 int64_t qi;
@@ -1528,12 +1536,84 @@ void Plan::fuse_resample_sos() {
         // time before the window (S2.base), the resampler a few periods before that (S3.base, whole periods).  The fused
         // kernel's coordinates are the resampler stage's: its output 0 is frame S3.base, the cascade starts from rest
         // there (earlier than the cascade stage alone would: a longer warm-up), and nothing below S2.base is stored.
-        if (!S3.periodic || rp.L <= 0 || S3.base > S2.base || S3.base % rp.L != 0) continue;
-        if (rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() ||
-            S3.need < S2.need || S3.carriers.empty() || (int)S3.carriers.size() > kCtlCar || rp.L % 16 != 0 ||
-            rp.ngroups * 16 != rp.L || rp.ngroups > 256 || rp.M >= (1 << 20))
+        if (S3.base > S2.base) continue;
+        if (rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
             continue;
-        const int ks = rp.kw / 4;
+        // (a stage that does not run the periodic kernel -- long super-periods: x 2 of eight channels -- has no carriers:
+        //  its plain source, an array or a stage buffer, becomes one below)
+        const bool plain_src = S3.carriers.empty() && (S3.in_buf >= 0 || S3.in_array_node >= 0);
+        if (S3.carriers.empty() && !plain_src) continue;
+        // The period the kernel walks: blocks of 16 outputs, each with its own [k-steps x 16] tap operand.  The resampler
+        // stage's own (44.1 -> 48 kHz: 160 outputs, ten blocks) where it splits into whole blocks -- or, for the small
+        // rational ratios (x 2, x 3, x 3/2 ...: DSP.jl's FIRInterpolator / FIRRational, reference src/reformatting.jl:103-111)
+        // whose stage runs on super-periods sized for K3's tiles, the shortest super-period of whole blocks, with a tap
+        // table of this stage's own.
+        int64_t Lp = rp.L, Mp = rp.M;
+        int ngp = rp.ngroups, kwp = rp.kw, jlop = rp.jlo;
+        bool own_tab = false;
+        std::vector<double> own_taps;
+        std::vector<int> own_jend;
+        const bool blocks_ok = S3.periodic && Lp > 0 && Lp % 16 == 0 && (int64_t)ngp * 16 == Lp && ngp <= 256;
+        if (!S3.rg.arbitrary && (!blocks_ok || ngp > 10) && !std::getenv("SIGOPS_RSOS_NOOWNTAB")) {
+            const RsGeom& rg = S3.rg;
+            const so_node_t& nd3 = nodes[S3.node].nd;
+            const double* h = (const double*)nd3.p0;
+            const int hlen = nd3.i2;
+            const int64_t tmin = 16 / std::__gcd<int64_t>(rg.L, 16);
+            bool found = false;
+            for (int64_t m : {1, 2, 3, 5}) {
+                const int64_t Ls = rg.L * tmin * m, Ms = rg.M * tmin * m;
+                const int ng = (int)(Ls / 16);
+                if (Ls > 4096 || (ng != 1 && ng != 2 && ng != 3 && ng != 5 && ng != 6 && ng != 10)) continue;
+                std::vector<int64_t> jr((size_t)Ls);
+                std::vector<int> prr((size_t)Ls);
+                for (int64_t r = 0; r < Ls; ++r) {
+                    const int64_t qi = rg.c0i + r * rg.M;  // (rational: nphi == L, no interpolation between phases)
+                    jr[(size_t)r] = qi / rg.nphi;
+                    prr[(size_t)r] = (int)(qi % rg.nphi);
+                }
+                std::vector<int> jend((size_t)ng);
+                int64_t maxspan = 0;
+                for (int gi = 0; gi < ng; ++gi) {
+                    jend[(size_t)gi] = (int)jr[(size_t)gi * 16 + 15];
+                    maxspan = std::max(maxspan, jr[(size_t)gi * 16 + 15] - jr[(size_t)gi * 16]);
+                }
+                const int ksneed = (int)((rg.taps + maxspan + 3) / 4);
+                int ksc = 0;
+                for (int k : {12, 14, 16, 20})
+                    if (!ksc && k >= ksneed) ksc = k;
+                if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                    std::fprintf(stderr, "[sigops] k_rsos own taps: L %lld M %lld x %lld -> %d blocks, taps %d span %lld: %d k-steps (%d)\n",
+                                 (long long)rg.L, (long long)rg.M, (long long)(tmin * m), ng, rg.taps, (long long)maxspan, ksneed, ksc);
+                if (!ksc) break;  // (a longer super-period does not shorten the windows)
+                const int kw = 4 * ksc;
+                int jlo = jend[0] - (kw - 1);
+                jlo -= ((jlo % 4) + 4) % 4;
+                std::vector<double> tab((size_t)ng * kw * 16, 0.0);
+                for (int gi = 0; gi < ng; ++gi)
+                    for (int rr = 0; rr < 16; ++rr)
+                        for (int kk = 0; kk < kw; ++kk) {
+                            const int64_t r = (int64_t)gi * 16 + rr;
+                            const int64_t age = jr[(size_t)r] - ((int64_t)jend[(size_t)gi] - (kw - 1) + kk);
+                            if (age < 0 || age >= rg.taps) continue;
+                            const int64_t hi = prr[(size_t)r] + (int64_t)rg.nphi * age;
+                            tab[((size_t)gi * kw + kk) * 16 + rr] = hi < hlen ? h[hi] : 0.0;
+                        }
+                Lp = Ls;
+                Mp = Ms;
+                ngp = ng;
+                kwp = kw;
+                jlop = jlo;
+                own_taps.swap(tab);
+                own_jend.swap(jend);
+                own_tab = found = true;
+                break;
+            }
+            (void)found;
+        }
+        if (!own_tab && (!blocks_ok || !S3.periodic)) continue;
+        if (S3.base % Lp != 0 || Mp >= (1 << 20)) continue;
+        const int ks = kwp / 4;
         if (!(ks == 12 || ks == 14 || ks == 16 || ks == 20)) continue;
         bool ok = true;
         // GA carriers (a Float32 array whose Float64 gain or summand K3's compute waves apply at the MFMA operand): this
@@ -1555,7 +1635,7 @@ void Plan::fuse_resample_sos() {
         const SosCoefs& cf = S2.groups[0];
         const int D = 2 * cf.nsec;
         const int nch = nodes[S2.node].nch;
-        const int64_t need = S2.need - S3.base, L = rp.L;
+        const int64_t need = S2.need - S3.base, L = Lp;
         const int64_t store_lo = S2.base - S3.base;
         const int64_t nperiods = (need + L - 1) / L;
         // warm-up: the first wp with ||A^(wp L)|| < 2^-70
@@ -1590,7 +1670,7 @@ void Plan::fuse_resample_sos() {
         const int64_t pr = (nperiods + nranges - 1) / nranges;
         nranges = (nperiods + pr - 1) / pr;
         const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
-        if ((pr + wp) * rp.ngroups >= (1 << 30) || (pr + wp) * rp.M >= ((int64_t)1 << 30)) continue;
+        if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * Mp >= ((int64_t)1 << 30)) continue;
         // Worth it?  A workgroup walks its (pr + wp) periods block by block -- 0.30 us per block of 16 outputs x 16 rows
         // with 14 k-step windows -- however few workgroups there are, while the two kernels use the whole chip for any
         // length: 8 ps per output sample + 95 us of launches, scans and tails (tools/rsos_len_sweep.sh, 8 channels at
@@ -1600,7 +1680,7 @@ void Plan::fuse_resample_sos() {
         if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
             if (ngrp < std::atoll(ev)) continue;
         } else {
-            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * rp.ngroups) * 0.30 * (ks + 14) / 28.0 + 15.0;
+            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.30 * (ks + 14) / 28.0 + 15.0;
             const double t_two = 8.0e-6 * (double)need * nch + 95.0;
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] k_rsos estimate: fused %.0f us (%lld groups, %lld + %lld periods), two kernels %.0f us\n", t_fused,
@@ -1612,13 +1692,13 @@ void Plan::fuse_resample_sos() {
         g.n_out = need;
         g.store_lo = store_lo;
         g.L = L;
-        g.M = rp.M;
+        g.M = Mp;
         g.pr = pr;
         g.wp = (int32_t)wp;
         g.nranges = (int32_t)nranges;
-        g.ngroups = rp.ngroups;
+        g.ngroups = ngp;
         g.ks = ks;
-        g.ulo = rp.jlo;
+        g.ulo = jlop;
         g.ct = ct;
         g.rgs = rgs;
         g.nch = nch;
@@ -1644,7 +1724,7 @@ void Plan::fuse_resample_sos() {
         {
             const int ny = g.nwaves == 16 ? 10 : g.nwaves - 2;
             // (a y wave's front part runs up to one of its own blocks ahead: the windows in use span 2 ny - 1 blocks)
-            const int64_t span = (int64_t)(2 * ny - 1) * ((16 * rp.M + L - 1) / L + 1) + rp.kw + 16 + 2 * g.chunk;
+            const int64_t span = (int64_t)(2 * ny - 1) * ((16 * Mp + L - 1) / L + 1) + kwp + 16 + 2 * g.chunk;
             int ring = 4096;  // (a multiple of 128: whole chunks, and rows of ring + 2 doubles fall on different banks)
             while (ring >= 128 && rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc) > rsos_lds_budget()) ring -= 128;
             if (const char* ev = std::getenv("SIGOPS_RSOS_RING")) ring = std::min(ring, std::max(128, std::atoi(ev) / 128 * 128));
@@ -1654,6 +1734,19 @@ void Plan::fuse_resample_sos() {
             if (ring < 128 || ring < span) continue;
             g.ring = ring;
             g.rpitch = ring + 2;
+        }
+        if (plain_src) {
+            DCarrier c{};
+            c.a = 0;
+            c.b = S3.in_frames;
+            c.dtype = nodes[nodes[S3.node].kids[0]].dtype == SO_F32 ? SO_F32 : SO_F64;
+            c.array_node = S3.in_array_node;
+            c.buf = S3.in_array_node >= 0 ? -1 : S3.in_buf;
+            c.df = S3.in_offset;
+            c.cstride = S3.in_array_node >= 0 ? (nch == 1 ? 0 : S3.in_pitch) : -1;  // -1: buffer pitch
+            S3.carriers.push_back(c);
+            S3.car_buf = raw_buf(sizeof(DCarrier));
+            S3.ctl_buf = raw_buf(sizeof(RsCtl));
         }
         if (was_ga) {
             for (size_t i = 0; i < S3.carriers.size(); ++i) {
@@ -1683,6 +1776,12 @@ void Plan::fuse_resample_sos() {
         }
         S2.rs = g;
         S2.rsos_src = i3;
+        if (own_tab) {
+            S2.rsos_tab_host.swap(own_taps);
+            S2.rsos_jend_host.swap(own_jend);
+            S2.rsos_tab_buf = raw_buf(S2.rsos_tab_host.size() * 8);
+            S2.rsos_jend_buf = raw_buf(S2.rsos_jend_host.size() * 4);
+        }
         S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);
         rsos_block_matrices(cf, S2.rsos_mats_host);
         S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);

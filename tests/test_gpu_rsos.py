@@ -176,6 +176,27 @@ def test_float32_headline_is_one_launch():
     assert relerr(got, want) < 1e-6 and np.mean(got == want) > 0.99   # (values within the accumulated-alpha drift, 2e-9, of a Float32 rounding boundary flip)
 
 
+@pytest.mark.parametrize("fs_in,fs_out,nch", [(24.0, 48.0, 8), (16.0, 48.0, 2), (32.0, 48.0, 8), (8.0, 16.0, 3), (22.05, 44.1, 4),
+                                              (48.0, 24.0, 8), (48.0, 32.0, 2)])
+def test_small_rational_ratios(fs_in, fs_out, nch):
+    """x 2, x 3, x 3/2 (and the downsampling ones where the windows fit 20 k-steps): DSP.jl's FIRInterpolator / FIRRational
+    rates (reference src/reformatting.jl:103-111).  Their resampler stage runs on super-periods sized for K3's tiles; the
+    fused kernel walks the shortest super-period of whole 16-output blocks with a tap table of its own"""
+    rng = np.random.default_rng(91)
+    n = int(300000 * fs_in / 44.1)
+    src = so.Mix(so.Signal(so.sin, ω=0.3 * so.kHz), so.Signal(F(rng.standard_normal((n, nch))), fs_in * so.kHz)) | so.Until(n * so.frames)
+    x = src | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(fs_out * so.kHz)
+    a, b, fused = both(x)
+    assert fused or fs_out < fs_in, (fs_in, fs_out)
+    assert a.shape == b.shape and relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-9
+    nout = a.shape[0]
+    win = x | so.After((nout // 2) * so.frames) | so.Until(20000 * so.frames)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        part = so.sink(win)[0]
+    assert relerr(part, a[nout // 2:nout // 2 + 20000]) < 1e-11
+
+
 def test_float32_result_of_a_float64_pipeline():
     """`sink(x, Float32)` of a Float64 signal: the kernel rounds in its own store (reference src/sink.jl:262-266)"""
     rng = np.random.default_rng(55)

@@ -114,7 +114,9 @@ worst["rsos_vs_two"] = worst["rsos_vs_oracle"] = 0.0
 for i in range(max(12, cases // 2)):
     rng = np.random.default_rng(base * 104729 + i)
     nch = int(rng.choice([1, 2, 3, 4, 6, 8, 8, 12, 16, 24]))
-    fs_in, fs_out = [(44100.0, 48000.0), (22050.0, 48000.0), (44100.0, 96000.0), (11025.0, 48000.0), (44100.0, 48000.0)][int(rng.integers(0, 5))]
+    fs_in, fs_out = [(44100.0, 48000.0), (22050.0, 48000.0), (44100.0, 96000.0), (11025.0, 48000.0), (44100.0, 48000.0),
+                     (24000.0, 48000.0), (16000.0, 48000.0), (32000.0, 48000.0), (12000.0, 48000.0), (8000.0, 16000.0),
+                     (48000.0, 24000.0), (48000.0, 32000.0)][int(rng.integers(0, 12))]
     n = int(rng.integers(60000, 500000) * (fs_in / 44100.0))
     if nch > 8:
         n = min(n, 150000)
@@ -128,7 +130,7 @@ for i in range(max(12, cases // 2)):
         src = src | so.Amplify(so.Signal(so.sin, ω=float(rng.uniform(1, 20)) * so.Hz)) | so.Until(n * so.frames)
     elif k == 3:
         src = src | so.Amplify(float(rng.uniform(0.1, 2.0)))
-    nyq = 0.5 * fs_in / 1000.0
+    nyq = 0.5 * min(fs_in, fs_out) / 1000.0   # (the filter moves behind the resampler: reference src/filters.jl:143-148)
     kind = int(rng.integers(0, 4))
     order = int(rng.integers(1, 7 if kind < 2 else 4))
     f1 = float(rng.uniform(0.02, 0.6)) * nyq
@@ -137,6 +139,8 @@ for i in range(max(12, cases // 2)):
             lambda s: s | so.Filt(so.Bandpass, f1 * so.kHz, f2 * so.kHz, order=order),
             lambda s: s | so.Filt(so.Bandstop, f1 * so.kHz, f2 * so.kHz, order=order)][kind]
     tree = filt(src) | so.ToFramerate(fs_out * so.Hz)
+    if rng.random() < 0.15:
+        tree = src | so.ToFramerate(fs_out * so.Hz)   # (the resampler alone: K3's own super-periods of the small ratios)
     nout = so.nframes(tree)
     if rng.random() < 0.6 and nout > 60000:
         a = int(rng.integers(1, nout - 20000))
