@@ -617,7 +617,13 @@ void Plan::process_stage(int sid) {
         // ---- row-tiled variant: rational rates the MFMA kernel's geometry does not cover -------
         if (!stages[sid].periodic && (!g.arbitrary || g.exact) && need >= 2048 && g.m0 == 0 &&
             !std::getenv("SIGOPS_RS_NOROWS")) {
-            const int64_t Lb = g.L, Mb = g.M;
+            // (periods of fewer than 16 outputs -- decimation by 3, 4, 6 ...: L = 1 -- are walked as super-periods of
+            //  whole 16-output blocks: a tile row is a (super-)period, and a row of ONE output left fifteen sixteenths of
+            //  every MFMA tile and most of the staged window unused: 192 -> 48 kHz of 8 channels x 120 s took 12.3 ms,
+            //  0.15 TB/s; tools/rate_matrix.py)
+            const int64_t L1 = g.L, M1 = g.M;
+            const int64_t tsup = (L1 < 16 && !std::getenv("SIGOPS_RR_NOSUPER")) ? 16 / std::__gcd<int64_t>(L1, 16) : 1;
+            const int64_t Lb = L1 * tsup, Mb = M1 * tsup;
             const double* h = (const double*)nd.p0;
             std::vector<int> jr(Lb);
             std::vector<double> ctab((size_t)Lb * g.taps, 0.0);
@@ -626,10 +632,10 @@ void Plan::process_stage(int sid) {
                 int64_t qi;
                 double alpha = 0.0;
                 if (g.arbitrary) {
-                    const int64_t Nn = r * ((int64_t)g.nphi * Mb);
-                    qi = g.c0i + Nn / Lb;
-                    alpha = (double)(Nn % Lb) / (double)Lb;
-                } else qi = g.c0i + r * Mb;
+                    const int64_t Nn = r * ((int64_t)g.nphi * M1);
+                    qi = g.c0i + Nn / L1;
+                    alpha = (double)(Nn % L1) / (double)L1;
+                } else qi = g.c0i + r * M1;
                 if (wrap_at(r)) {
                     qi -= 1;
                     alpha = 1.0;
