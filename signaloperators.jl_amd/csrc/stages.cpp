@@ -1686,7 +1686,12 @@ void Plan::fuse_resample_sos() {
         if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
             if (ngrp < std::atoll(ev)) continue;
         } else {
-            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.30 * (ks + 14) / 28.0 + 15.0;
+            // (groups of fewer than eight channels have 4, 8 or 16 loader units per chunk instead of 2, each with its own
+            //  lane-table reads next to the chain wave's MFMAs: the loader sets the pace there -- 1e8 samples: 0.65 ms
+            //  for 8 channels per group, 0.78 / 1.22 / 2.07 for 4 / 2 / 1 (tools/channel_matrix.py, tools/rsos_ct_abl.sh;
+            //  an affine, table-free addressing of unaligned rows was built and is slower still) -- two kernels: 1.0)
+            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.2 : ct == 2 ? 1.9 : 3.2;
+            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.30 * unit_cost * (ks + 14) / 28.0 + 15.0;
             const double t_two = 8.0e-6 * (double)need * nch + 95.0;
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] k_rsos estimate: fused %.0f us (%lld groups, %lld + %lld periods), two kernels %.0f us\n", t_fused,
