@@ -1,6 +1,8 @@
 // Hand-written HIP kernels for gfx950 (MI355X, CDNA4; wave64).  No CUDA shims, no dual paths.
 // K2 k_sos_*: second-order-sections IIR, time-parallel by exact chunked state propagation
 // (reference src/filters.jl:252-255 + DSP.jl DF2T)
+#include <type_traits>
+
 #include "kcommon.h"
 
 namespace so {
@@ -39,15 +41,15 @@ constexpr int kTT = 16;
 
 // One tile step of a lane's row through the cascade: kTT frames from LDS, outputs back in place (APPLY).
 // HEAD: the row's first `head` columns lie before its chunk and are left alone (see sos_tiled_body).
-template <int NS, bool APPLY, bool HEAD>
-__device__ __forceinline__ void sos_row_steps(double* __restrict__ row, double (&s)[2 * NS], const SosGeom& g, const SosCoefs& cf,
+template <int NS, bool APPLY, bool HEAD, int TT, typename E>
+__device__ __forceinline__ void sos_row_steps(E* __restrict__ row, double (&s)[2 * NS], const SosGeom& g, const SosCoefs& cf,
                                               double& gs, double& gc, const int head) {
     if (g.src_op == 0) {
 #pragma unroll
-        for (int t = 0; t < kTT; ++t) {
+        for (int t = 0; t < TT; ++t) {
             if (HEAD && t < head) continue;
-            const double yv = sos_step<NS>(row[t], s, cf);
-            if (APPLY) row[t] = yv * cf.gain;
+            const double yv = sos_step<NS>((double)row[t], s, cf);
+            if (APPLY) row[t] = (E)(yv * cf.gain);
             // (frames past a short row's end are zeros and never stored; their effect on
             //  the state is irrelevant: only full chunks feed pass 1)
         }
@@ -58,14 +60,14 @@ __device__ __forceinline__ void sos_row_steps(double* __restrict__ row, double (
         // its row in time, so the sine advances by one rotation per frame from the exact value at
         // the row's first frame (gs, gc).
 #pragma unroll
-        for (int t = 0; t < kTT; ++t) {
+        for (int t = 0; t < TT; ++t) {
             if (HEAD && t < head) continue;
-            const double xin = g.src_op == 1 ? row[t] + gs : row[t] * gs;
+            const double xin = g.src_op == 1 ? (double)row[t] + gs : (double)row[t] * gs;
             const double ns_ = fma(gs, g.src_cd, gc * g.src_sd), nc_ = fma(gc, g.src_cd, -(gs * g.src_sd));
             gs = ns_;
             gc = nc_;
             const double yv = sos_step<NS>(xin, s, cf);
-            if (APPLY) row[t] = yv * cf.gain;
+            if (APPLY) row[t] = (E)(yv * cf.gain);
         }
     }
 }
@@ -76,7 +78,14 @@ template <int NS, typename T, bool APPLY>
 __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __restrict__ y,
                                                const double* __restrict__ s0, double* __restrict__ v,
                                                const SosGeom& g, const SosCoefs& cf, const int64_t blk) {
-    __shared__ double tile[kBlock / 64][64 * (kTT + 1)];
+    // Float32 signals: steps of 32 frames, two per lane and load / store instruction -- 128 bytes per row segment as for
+    // Float64 (with 16-frame steps a Float32 row segment was 64 bytes: twice the memory requests per byte, and the
+    // Float32 filter took 1.0 ms where the Float64 one took 0.55: tools/channel_matrix.py) -- in a tile of floats (the
+    // cascade computes in Float64 either way; a value is rounded once, where it used to be rounded by the store)
+    constexpr int TT = sizeof(T) == 4 ? 2 * kTT : kTT;
+    constexpr int VE = TT / 16;  // elements per lane and row of a load / store instruction
+    typedef typename std::conditional<sizeof(T) == 4, float, double>::type E;
+    __shared__ E tile[kBlock / 64][64 * (TT + 1)];
     __shared__ int64_t rowbase[kBlock / 64][64];  // frame of column 0 of the row's first tile step
     __shared__ int64_t rowmin[kBlock / 64][64];   // first frame the row stores
     __shared__ int rowlen[kBlock / 64][64];       // columns the row spans (head + frames to process)
@@ -95,7 +104,7 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     // them: a filter that forgets within 8 frames (W = 1 ... 8; a first-order Butterworth at fs/4 has its pole at 0)
     // handed on the state of 16 - W frames later, i.e. nothing (tools/soak_kernels.py seed 10102: 7 % off)
     if (!APPLY) {
-        const int64_t w16 = (g.warm + (kTT - 1)) / kTT * kTT;
+        const int64_t w16 = (g.warm + (TT - 1)) / TT * TT;
         beg = end - (w16 < g.chunk ? w16 : g.chunk);
     }
     // Pass 3 stores whole cache lines whatever the alignment of the result's channel rows (SosGeom::align_rows): the
@@ -106,7 +115,7 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
     // rows of 3 628 118 frames (what an n x 128 Array has): pass 3 2.6 ms against 1.65 ms with aligned rows.
     int head = 0;
     if (APPLY && g.align_rows && live)
-        head = (int)(((uintptr_t)y / (g.out_dtype == SO_F32 ? 4 : 8) + (uint64_t)ch * (uint64_t)g.out_pitch + (uint64_t)beg) % kTT);
+        head = (int)(((uintptr_t)y / (g.out_dtype == SO_F32 ? 4 : 8) + (uint64_t)ch * (uint64_t)g.out_pitch + (uint64_t)beg) % TT);
     const int len = live ? head + (int)(end - beg) : 0;
     rowbase[w][lane] = beg - head;  // (the row's channel is kept in rowch)
     rowmin[w][lane] = beg > g.store_lo ? beg : g.store_lo;
@@ -130,8 +139,8 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
     const bool anyhead = APPLY && __any(head != 0);
-    double* tl = tile[w];
-    const int rsub = lane >> 4, col = lane & 15;  // load/store role: 4 rows x 16 columns
+    E* tl = tile[w];
+    const int rsub = lane >> 4, col = (lane & 15) * VE;  // load/store role: 4 rows x 16 lanes x VE columns
     // The passes are latency-bound (a few waves per CU, each a chain of tile round trips): all 16
     // loads of a tile are issued together and the NEXT tile's loads are issued before this tile's
     // arithmetic, so a wave always has one tile (8 KB) in flight.
@@ -143,10 +152,24 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
         xlen[j] = rowlen[w][r];
         xrow[j] = x + ((int64_t)rowch[w][r] * g.in_pitch + rowbase[w][r] + col);
     }
-    double xv[16];
+    E xv[16][VE];
+    // (lo: first column of the row this lane may read; hi: one past the last)
+    auto load_cols = [&](int j, int t0, int lo) __attribute__((always_inline)) {
+        if constexpr (VE == 2) {
+            if (t0 + col >= lo && t0 + col + 1 < xlen[j]) {  // both columns: one 8-byte load (any 4-byte address)
+                typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+                const f2 w2 = *reinterpret_cast<const f2*>(xrow[j] + t0);
+                xv[j][0] = w2[0];
+                xv[j][1] = w2[1];
+                return;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) xv[j][e] = (t0 + col + e < xlen[j] && t0 + col + e >= lo) ? (E)xrow[j][t0 + e] : (E)0;
+    };
 #pragma unroll
     for (int j = 0; j < 16; ++j)  // (head columns hold frames of the chunk before, or of nothing: not this row's to read)
-        xv[j] = col < xlen[j] && (!APPLY || col >= rowhead[w][j * 4 + rsub]) ? (double)xrow[j][0] : 0.0;
+        load_cols(j, 0, APPLY ? rowhead[w][j * 4 + rsub] : 0);
     // fused sine source: (sin, cos) of the generator's phase at this lane's first frame, evaluated like
     // func_eval (every operation rounded on its own, first frame t = 1/fs)
     double gs = 0.0, gc = 1.0;
@@ -155,31 +178,46 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
         const double ph = g.src_has_omega ? __dadd_rn(__dmul_rn(tt, g.src_omega), g.src_phi) : __dadd_rn(tt, g.src_phi);
         sincospi_c(2.0 * ph, gs, gc);
     }
-    for (int t0 = 0; t0 < maxlen; t0 += kTT) {
+    for (int t0 = 0; t0 < maxlen; t0 += TT) {
         // ---- tile t0 (loaded one iteration ago: 16 instructions x (4 rows x 128 B)) -> LDS ----
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tl[(j * 4 + rsub) * (kTT + 1) + col] = xv[j];
-        __builtin_amdgcn_wave_barrier();
-        if (t0 + kTT < maxlen) {
+        for (int j = 0; j < 16; ++j)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xv[j] = t0 + kTT + col < xlen[j] ? (double)xrow[j][t0 + kTT] : 0.0;
+            for (int e = 0; e < VE; ++e) tl[(j * 4 + rsub) * (TT + 1) + col + e] = xv[j][e];
+        __builtin_amdgcn_wave_barrier();
+        if (t0 + TT < maxlen) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) load_cols(j, t0 + TT, 0);
         }
         // ---- every lane: its own row through the cascade ----
-        double* row = tl + lane * (kTT + 1);
-        if (t0 == 0 && anyhead) sos_row_steps<NS, APPLY, true>(row, s, g, cf, gs, gc, head);
-        else sos_row_steps<NS, APPLY, false>(row, s, g, cf, gs, gc, 0);
+        E* row = tl + lane * (TT + 1);
+        if (t0 == 0 && anyhead) sos_row_steps<NS, APPLY, true, TT, E>(row, s, g, cf, gs, gc, head);
+        else sos_row_steps<NS, APPLY, false, TT, E>(row, s, g, cf, gs, gc, 0);
         __builtin_amdgcn_wave_barrier();
         if (APPLY) {
             // ---- coalesced store ----
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const int r = j * 4 + rsub;
-                if (t0 + col < rowlen[w][r] && rowbase[w][r] + t0 + col >= rowmin[w][r]) {
-                    const int64_t o = (int64_t)rowch[w][r] * g.out_pitch + rowbase[w][r] + t0 + col;
-                    // (a Float64 filter writing a Float32 result itself: `convert` on store, src/sink.jl:262-266)
-                    if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o] = (float)tl[r * (kTT + 1) + col];
-                    else y[o] = (T)tl[r * (kTT + 1) + col];
+                const int64_t f0 = rowbase[w][r] + t0 + col;  // frame of this lane's first column
+                const int64_t o = (int64_t)rowch[w][r] * g.out_pitch + f0;
+                if constexpr (VE == 2) {
+                    if (t0 + col + 1 < rowlen[w][r] && f0 >= rowmin[w][r]) {  // both columns: one 8-byte store
+                        typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+                        f2 w2;
+                        w2[0] = tl[r * (TT + 1) + col];
+                        w2[1] = tl[r * (TT + 1) + col + 1];
+                        *reinterpret_cast<f2*>(y + o) = w2;
+                        continue;
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < VE; ++e)
+                    if (t0 + col + e < rowlen[w][r] && f0 + e >= rowmin[w][r]) {
+                        // (a Float64 filter writing a Float32 result itself: `convert` on store, src/sink.jl:262-266)
+                        if (sizeof(T) == 8 && g.out_dtype == SO_F32) reinterpret_cast<float*>(y)[o + e] = (float)tl[r * (TT + 1) + col + e];
+                        else y[o + e] = (T)tl[r * (TT + 1) + col + e];
+                    }
             }
             __builtin_amdgcn_wave_barrier();
         }
