@@ -1688,9 +1688,9 @@ void Plan::fuse_resample_sos() {
         } else {
             // (groups of fewer than eight channels have 4, 8 or 16 loader units per chunk instead of 2, each with its own
             //  lane-table reads next to the chain wave's MFMAs: the loader sets the pace there -- 1e8 samples: 0.65 ms
-            //  for 8 channels per group, 0.78 / 1.22 / 2.07 for 4 / 2 / 1 (tools/channel_matrix.py, tools/rsos_ct_abl.sh;
+            //  for 8 channels per group, 0.78 / 1.01 / 2.07 for 4 / 2 (two loader waves) / 1 (tools/channel_matrix.py, tools/rsos_ct_abl.sh;
             //  an affine, table-free addressing of unaligned rows was built and is slower still) -- two kernels: 1.0)
-            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.2 : ct == 2 ? 1.9 : 3.2;
+            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.2 : ct == 2 ? 1.55 : 3.2;  // (ct == 2: with its second loader wave)
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.30 * unit_cost * (ks + 14) / 28.0 + 15.0;
             const double t_two = 8.0e-6 * (double)need * nch + 95.0;
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
@@ -1727,6 +1727,9 @@ void Plan::fuse_resample_sos() {
                 return nw == 12 ? ((c == 1 || c == 2) && c * ks <= 32) : ((c == 1 || c == 2 || c == 3 || c == 5) && c * ks <= 80);
             };
             int nw = fits(12) ? 12 : fits(8) ? 8 : 12;
+            // (groups of two channels: eight loader units per chunk -- a second loader wave pays: 1.22 -> 1.01 ms for 1e8
+            //  samples, tools/rsos_nw16.sh; for four and more channels it costs what it saves)
+            if (ct == 2 && nw == 12 && cyc_of(16) == 1 && ks <= 16) nw = 16;
             if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : std::atoi(ev) == 16 && cyc_of(16) == 1 && ks <= 16 ? 16 : 12;
             g.nwaves = nw;
             g.cyc = (nw == 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
