@@ -487,7 +487,10 @@ void Plan::process_stage(int sid) {
             // 30 - 70 blocks from (b), for which no instantiation exists -- the stage fell to the row-tiled kernel at a
             // tenth of the speed (x 2 of 8 channels x 300 s: 11 ms; tools/ratio_probe.py)
             if (!std::getenv("SIGOPS_RS_NOBLOCKCAP")) {
-                const int64_t tcap = std::max<int64_t>(tmin, (12 * 16 / Lb) / tmin * tmin);
+                // (twenty-four -- a compute wave keeps two blocks' taps -- for x 2 and x 3, whose twelve-block super-period is
+                //  under a hundred input frames: tiles of 400 frames instead of 800, 0.64 ms instead of 0.39)
+                const int64_t nblk = env_int("SIGOPS_RS_BLOCKCAP", (Lb <= 3 && Mb * (192 / Lb) < 100) ? 24 : 12);
+                const int64_t tcap = std::max<int64_t>(tmin, (nblk * 16 / Lb) / tmin * tmin);
                 t = std::min(t, tcap);
             }
             const int64_t Ls = Lb * t, Ms = Mb * t;
