@@ -33,7 +33,6 @@ namespace so {
 
 namespace {
 
-constexpr int kArbChunk = 128;  // frames per loader chunk (one LDS-DMA instruction per channel row)
 constexpr int kArbMaxDepth = 8;  // chunks in flight, at most
 constexpr int kArbMaxNC = 11;  // + the loader: twelve waves, 168 registers each
 
@@ -79,8 +78,8 @@ __device__ __forceinline__ void wait_vmcnt_le60a(int n) {
 }  // namespace
 
 // ring: CT rows of RINGF frames (a power of two), row c at ring + c RINGF; taps: 32 phases x ((taps + 2 Z) | 1) x (h, dh)
-template <int CT, int NO>
-__global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const double* __restrict__ x, double* __restrict__ y,
+template <int CT, int NO, typename T>
+__global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const T* __restrict__ x, T* __restrict__ y,
                                                        const double* __restrict__ pfbt, const double* __restrict__ dpfbt,
                                                        RsArb a) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];  // (16-byte reads of the ring: an 8-byte aligned base splits every one)
@@ -91,7 +90,9 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
     const int RINGF = a.ringf;
     const int NC = a.nc;
     SO_LDS double* const tab = (SO_LDS double*)lds_raw;  // tab[(p * trows + k + Z) * 2 + {0: h, 1: dh}]
-    SO_LDS double* const ring = tab + (size_t)trows * 64;
+    SO_LDS T* const ring = (SO_LDS T*)(tab + (size_t)trows * 64);  // (Float32 signals: a ring of floats, widened where they are read)
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int CHF = 1024 / ESZ;  // frames per loader chunk: one LDS-DMA instruction (1 KB) per channel row
     const int tid = threadIdx.x, lane = tid & 63, wave = a_uni(tid >> 6);
     const bool arb = g.arbitrary != 0;
     // ---- set-up, all waves: tables with their zero rows, a zeroed ring (stale LDS may hold NaN patterns, and a zero
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
         tab[2 * i] = real ? pfbt[k * 32 + p] : 0.0;
         tab[2 * i + 1] = (real && arb) ? dpfbt[k * 32 + p] : 0.0;
     }
-    for (int i = tid; i < CT * RINGF; i += blockDim.x) ring[i] = 0.0;
+    for (int i = tid; i < CT * RINGF; i += blockDim.x) ring[i] = (T)0;
     if (tid == 0) sh.ldp = sh.next = 0;
     if (tid < kArbMaxNC) sh.rd[tid] = 0;
     // ---- this workgroup's range ----
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
     }
     const int64_t F0 = ((jf - (taps - 1)) & ~(int64_t)1) & ~(int64_t)15;  // first staged frame: 128-byte aligned
     const int E = (int)(jl + 4 - F0);                                      // frames to stage (a pair beyond the last window)
-    const int NK = (E + kArbChunk - 1) / kArbChunk;
+    const int NK = (E + CHF - 1) / CHF;
     __syncthreads();
     if (mhi <= mlo) return;
     SO_LDS int* const f_ldp = (SO_LDS int*)&sh.ldp;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
     if (wave == NC) {
         // =========================== loader ===========================
         const uint32_t ring_b = (uint32_t)(uintptr_t)ring;
-        const uint32_t row_bytes = (uint32_t)RINGF * 8u;
+        const uint32_t row_bytes = (uint32_t)RINGF * (uint32_t)ESZ;
         const char* const xb = (const char*)(x + (int64_t)c0 * g.in_pitch);
         const uint32_t lane16 = (uint32_t)lane * 16u;
         int minrd = 0, spins = 0;
@@ -145,28 +146,29 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
         for (int k = 0; k < NK + depth - 1; ++k) {
             if (k < NK) {
                 // ring space: chunk k overwrites frames [128 (k + 1) - RINGF - 128, ...)
-                const int needrd = (k + 1) * kArbChunk - RINGF;
+                const int needrd = (k + 1) * CHF - RINGF;
                 while (needrd > 0 && minrd < needrd && !(debug & 1)) {
                     int v = lane < NC ? a_flag_ld(f_rd + lane) : 0x7fffffff;
                     minrd = a_wave_min(v);
                     if (minrd < needrd) a_pause(spins);
                 }
                 spins = 0;
-                const int64_t fa = F0 + (int64_t)k * kArbChunk;  // absolute first frame of the chunk
-                const uint32_t rho = (uint32_t)((k * kArbChunk) & (RINGF - 1));
+                const int64_t fa = F0 + (int64_t)k * CHF;  // absolute first frame of the chunk
+                const uint32_t rho = (uint32_t)((k * CHF) & (RINGF - 1));
                 int n = 0;
-                if (fa >= 0 && fa + kArbChunk <= g.n_in && a.dma_ok) {
-                    dma_rows<CT>(~0ull, lane16, xb + fa * 8, g.in_pitch * 8, ring_b + rho * 8u, row_bytes);
+                if (fa >= 0 && fa + CHF <= g.n_in && a.dma_ok) {
+                    dma_rows<CT>(~0ull, lane16, xb + fa * ESZ, g.in_pitch * ESZ, ring_b + rho * (uint32_t)ESZ, row_bytes);
                     n = CT;
-                } else {  // an end of the signal (or an array the DMA cannot read 16 bytes at a time): guarded loads
+                } else {  // an end of the signal: guarded loads, 16 bytes' worth of frames per lane
+                    constexpr int FPL = 16 / ESZ;
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
-                        const int64_t f = fa + 2 * lane;
-                        const double* row = x + (int64_t)(c0 + c) * g.in_pitch;
-                        const double v0 = (f >= 0 && f < g.n_in) ? row[f] : 0.0;
-                        const double v1 = (f + 1 >= 0 && f + 1 < g.n_in) ? row[f + 1] : 0.0;
-                        ring[(size_t)c * RINGF + rho + 2 * lane] = v0;
-                        ring[(size_t)c * RINGF + rho + 2 * lane + 1] = v1;
+                        const T* row = x + (int64_t)(c0 + c) * g.in_pitch;
+#pragma unroll
+                        for (int e = 0; e < FPL; ++e) {
+                            const int64_t f = fa + FPL * lane + e;
+                            ring[(size_t)c * RINGF + rho + FPL * lane + e] = (f >= 0 && f < g.n_in) ? row[f] : (T)0;
+                        }
                     }
                 }
 #pragma unroll
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
                 for (int i = 0; i < kArbMaxDepth - 1; ++i)
                     if (i < depth - 1) younger += cnt[i];
                 wait_vmcnt_le60a(younger);
-                a_flag_st(f_ldp, min(E, (done + 1) * kArbChunk));
+                a_flag_st(f_ldp, min(E, (done + 1) * CHF));
             }
         }
         return;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
     // =========================== compute waves ===========================
     const bool vec_out = a.vec_out != 0;
     const uint32_t tab_b = (uint32_t)(uintptr_t)tab;
-    const uint32_t ring_mask = (uint32_t)RINGF * 8u - 1u;
+    const uint32_t ring_mask = (uint32_t)RINGF * (uint32_t)ESZ - 1u;
     constexpr int BO = 64 * NO;  // outputs per batch
     int spins = 0;
     // Batches are handed out in order to whichever wave is free (an LDS counter): the waves of a SIMD that also runs
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
         uint32_t q[NO];  // the tap of the pair's SECOND frame; the first frame's is the next granule
 #pragma unroll
         for (int o = 0; o < NO; ++o) q[o] = tab_b + (uint32_t)((pp[o] * trows + r[o] - sA - 1 + Z) * 16);
-        uint32_t xo = ((uint32_t)sA * 8u) & ring_mask;
+        uint32_t xo = ((uint32_t)sA * (uint32_t)ESZ) & ring_mask;
         double acc[NO][CT];
 #pragma unroll
         for (int o = 0; o < NO; ++o)
@@ -247,7 +249,14 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
             }
             v2d xv[CT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) xv[c] = *(const SO_LDS v2d*)((const SO_LDS char*)ring + (size_t)c * RINGF * 8 + xo);
+            for (int c = 0; c < CT; ++c) {
+                if constexpr (ESZ == 8) xv[c] = *(const SO_LDS v2d*)((const SO_LDS char*)ring + (size_t)c * RINGF * 8 + xo);
+                else {
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    const v2f w2 = *(const SO_LDS v2f*)((const SO_LDS char*)ring + (size_t)c * RINGF * 4 + xo);
+                    xv[c] = v2d{(double)w2[0], (double)w2[1]};
+                }
+            }
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
 #pragma unroll
@@ -255,50 +264,47 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const doub
 #pragma unroll
                 for (int o = 0; o < NO; ++o) acc[o][c] = fma(c1v[o], xv[c][1], acc[o][c]);
             }
-            xo = (xo + 16u) & ring_mask;
+            xo = (xo + 2u * (uint32_t)ESZ) & ring_mask;
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            double SO_GLB* op = (double SO_GLB*)(y + (int64_t)(c0 + c) * g.out_pitch + m_);
+            T SO_GLB* op = (T SO_GLB*)(y + (int64_t)(c0 + c) * g.out_pitch + m_);
             if (nv >= NO && vec_out) {
+                typedef T v2t __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int o = 0; o < NO; o += 2) *(v2d SO_GLB*)(op + o) = v2d{acc[o][c], acc[o + 1][c]};
+                for (int o = 0; o < NO; o += 2) *(v2t SO_GLB*)(op + o) = v2t{(T)acc[o][c], (T)acc[o + 1][c]};
             } else {
 #pragma unroll
                 for (int o = 0; o < NO; ++o)
-                    if (o < nv) op[o] = acc[o][c];
+                    if (o < nv) op[o] = (T)acc[o][c];
             }
         }
     }
     if (lane == 0) a_flag_st(f_rd + wave, 0x7fffffff);
 }
 
-// LDS the kernel needs besides its small static block
-size_t resample_arb_lds_bytes(int taps, int zrows, int ct, int ringf) {
-    return ((size_t)2 * ((taps + 2 * zrows) | 1) * 32 + (size_t)ct * ringf) * 8;
+// LDS the kernel needs besides its small static block (esz: bytes per ring element)
+size_t resample_arb_lds_bytes(int taps, int zrows, int ct, int ringf, int esz) {
+    return (size_t)2 * ((taps + 2 * zrows) | 1) * 32 * 8 + (size_t)ct * ringf * esz;
 }
 
-// returns 0 when launched, -1 if this geometry is not covered (the caller falls back to k_resample_tiled2)
-int launch_resample_arb(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsArb& a_, hipStream_t st) {
-    RsArb a = a_;
+template <typename T>
+static int launch_resample_arb_t(const void* x, void* y, const double* pfbt, const double* dpfbt, RsArb a, hipStream_t st) {
     const RsGeom& g = a.g;
-    if (g.n_out <= 0) return 0;
-    if ((a.no != 2 && a.no != 4) || g.in_dtype != SO_F64 || g.out_dtype != SO_F64 || g.nphi != 32 || a.nc < 1 || a.nc > kArbMaxNC || (a.ringf & (a.ringf - 1)) ||
-        a.ringf < 4 * kArbChunk)
-        return -1;
-    a.dma_ok = ((uintptr_t)x & 15) == 0 && (g.in_pitch & 1) == 0;
-    a.vec_out = ((uintptr_t)y & 15) == 0 && (g.out_pitch & 1) == 0;
+    constexpr int esz = (int)sizeof(T);
+    a.dma_ok = 1;  // (any element-aligned address: executor.cpp carrier_vec_ok)
+    a.vec_out = ((uintptr_t)y & (2 * esz - 1)) == 0 && (g.out_pitch & 1) == 0;
     a.depth = a.depth < 2 ? 2 : (a.depth > kArbMaxDepth ? kArbMaxDepth : a.depth);
-    const size_t lds = resample_arb_lds_bytes(g.taps, a.zrows, a.ct, a.ringf);
+    const size_t lds = resample_arb_lds_bytes(g.taps, a.zrows, a.ct, a.ringf, esz);
     if (lds + 1024 > 160 * 1024) return -1;
     const unsigned grid = (unsigned)((int64_t)a.nranges * (g.nch / a.ct));
     const unsigned threads = (unsigned)(a.nc + 1) * 64u;
-#define SO_ARB(CTV, NOV)                                                                                                                   \
-    {                                                                                                                                       \
-        static bool seen[64];                                                                                                               \
-        if (first_use_on_device(seen))                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)k_resample_arb<CTV, NOV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
-        hipLaunchKernelGGL((k_resample_arb<CTV, NOV>), dim3(grid), dim3(threads), lds, st, (const double*)x, (double*)y, pfbt, dpfbt, a);   \
+#define SO_ARB(CTV, NOV)                                                                                                                      \
+    {                                                                                                                                          \
+        static bool seen[64];                                                                                                                  \
+        if (first_use_on_device(seen))                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)k_resample_arb<CTV, NOV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+        hipLaunchKernelGGL((k_resample_arb<CTV, NOV, T>), dim3(grid), dim3(threads), lds, st, (const T*)x, (T*)y, pfbt, dpfbt, a);             \
     }
     if (a.no == 4) {
         if (a.ct != 8 || a.nc > 7) return -1;
@@ -314,6 +320,18 @@ int launch_resample_arb(const void* x, void* y, const double* pfbt, const double
     }
 #undef SO_ARB
     return 0;
+}
+
+// returns 0 when launched, -1 if this geometry is not covered (the caller falls back to k_resample_tiled2)
+int launch_resample_arb(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsArb& a, hipStream_t st) {
+    const RsGeom& g = a.g;
+    if (g.n_out <= 0) return 0;
+    if ((a.no != 2 && a.no != 4) || g.in_dtype != g.out_dtype || g.nphi != 32 || a.nc < 1 || a.nc > kArbMaxNC || (a.ringf & (a.ringf - 1)) ||
+        a.ringf < 4 * 256)
+        return -1;
+    if (g.in_dtype == SO_F64) return launch_resample_arb_t<double>(x, y, pfbt, dpfbt, a, st);
+    if (g.in_dtype == SO_F32) return launch_resample_arb_t<float>(x, y, pfbt, dpfbt, a, st);
+    return -1;
 }
 
 }  // namespace so

@@ -34,7 +34,7 @@ void launch_sos_onepass(const void* x, void* y, const SosOne& g, const SosCoefs&
 void launch_resample(const void* x, void* y, const double* pfb, const double* dpfb,
                      const RsGeom& g, hipStream_t st);
 // pfbt / dpfbt: polyphase tables transposed to [taps][nphi]
-size_t resample_arb_lds_bytes(int taps, int zrows, int ct, int ringf);
+size_t resample_arb_lds_bytes(int taps, int zrows, int ct, int ringf, int esz);
 int launch_resample_arb(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsArb& a, hipStream_t st);
 void launch_resample_tiled2(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g, hipStream_t st);
 void launch_resample_tiled(const void* x, void* y, const double* pfbt, const double* dpfbt, const RsTiled& g,

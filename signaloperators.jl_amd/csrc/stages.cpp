@@ -800,7 +800,9 @@ void Plan::process_stage(int sid) {
                     // (a persistent workgroup zeroes its ring and builds its tables first: ~22 us before the first output, 15
                     //  for the tiled kernel; from 1.5 M output samples on the pipelined walk is ahead -- tools/arb_len_sweep.py)
                     const int64_t arb_min = env_int("SIGOPS_ARB_MIN", 1500000);
-                    if (pair && g.nphi == 32 && N.dtype == SO_F64 && need >= 16384 && need * N.nch >= arb_min && !std::getenv("SIGOPS_RS_NOARB")) {
+                    if (pair && g.nphi == 32 && (N.dtype == SO_F64 || N.dtype == SO_F32) && need >= 16384 && need * N.nch >= arb_min &&
+                        !std::getenv("SIGOPS_RS_NOARB")) {
+                        const int esz_a = (int)dsize(N.dtype), chf = 1024 / esz_a;  // (ring element bytes; frames per loader chunk)
                         RsArb ra{};
                         ra.g = g;
                         int cta = 1;
@@ -821,13 +823,13 @@ void Plan::process_stage(int sid) {
                         ra.no = no;
                         ra.zrows = (no - 1) * dmax + 3;
                         int ringf = 4096;
-                        while (ringf >= 512 && resample_arb_lds_bytes(g.taps, ra.zrows, cta, ringf) + 1024 > (size_t)160 * 1024) ringf >>= 1;
+                        while (ringf >= 512 && resample_arb_lds_bytes(g.taps, ra.zrows, cta, ringf, esz_a) + 1024 > (size_t)160 * 1024) ringf >>= 1;
                         ringf = env_int("SIGOPS_ARB_RING", ringf);
                         ra.depth = env_int("SIGOPS_ARB_DEPTH", no == 4 ? 2 : 4);
                         ra.debug = env_int("SIGOPS_ARB_DEBUG", 0);
                         const int per_batch = (int)std::ceil(64.0 * no * step) + 2;
                         // a batch's own span + what the loader has in flight must fit next to NC batches in progress
-                        int nc = (ringf - (ra.depth * 128 + 127 + g.taps + no * dmax + 32)) / per_batch;
+                        int nc = (ringf - (ra.depth * chf + chf - 1 + g.taps + no * dmax + 32)) / per_batch;
                         nc = std::min(nc, no == 4 ? 7 : 8);  // (pairs: 4 waves 0.268 ms, 6 0.242, 8 0.231, 11 0.235 on the x pi / 3 bench)
                         nc = std::min(nc, env_int("SIGOPS_ARB_NC", nc));
                         ra.nc = nc;

@@ -153,6 +153,30 @@ def test_two_outputs_per_lane_form_of_the_tiled_resampler(fs_in, fs_out, nch, n,
     assert np.array_equal(got, one)
 
 
+def test_persistent_form_takes_float32_signals_too(monkeypatch):
+    """Float32 samples: a ring of floats (256 frames per LDS-DMA instruction), widened where the compute waves read them,
+    Float32 stores -- against the oracle at the Float32 bar and against the tiled kernel (the same Float64 sums up to
+    their last bits: a Float32 rounding flip here and there)"""
+    monkeypatch.setenv("SIGOPS_ARB_MIN", "1")
+    rng = np.random.default_rng(208)
+    for nch, n, fs_in, fs_out in ((8, 400001, 44100.0, 44100.0 * np.pi / 3), (3, 250000, 44100.5, 48000.0), (2, 300002, 1000.0, 1000.0 * np.pi)):
+        x = np.asfortranarray(rng.standard_normal((n, nch)).astype(np.float32))
+        tree = so.Signal(x, fs_in * so.Hz) | so.ToFramerate(fs_out * so.Hz)
+        nout = so.nframes(tree)
+        p = so.Plan(so.ToChannels(tree, nch), (nout, nch), np.float32, (1, nout), False)
+        names = [s["name"] for s in p.steps()]
+        p.close()
+        assert names == ["k_resample_arb"], names
+        got = so.sink(tree)[0]
+        assert got.dtype == np.float32 and relerr(got, oracle_sink(tree)) < 1e-6
+        part = so.sink(tree | so.After(nout // 3 * so.frames) | so.Until(30000 * so.frames))[0]
+        assert np.array_equal(part, got[nout // 3:nout // 3 + 30000])
+        monkeypatch.setenv("SIGOPS_RS_NOARB", "1")
+        ref = so.sink(tree)[0]
+        monkeypatch.delenv("SIGOPS_RS_NOARB")
+        assert relerr(got, ref) < 2e-8 and np.mean(got == ref) > 0.999
+
+
 def test_two_outputs_per_lane_form_is_the_one_that_runs():
     import torch
     x = torch.randn((8, 100000), dtype=torch.float64, device="cuda")

@@ -14,19 +14,20 @@ import sigops_amd as so
 
 reps = int(os.environ.get("REPS", "100"))
 n, nch = 26_460_000 // 4, 8
+tdt, ndt = (torch.float32, np.float32) if os.environ.get("F32") else (torch.float64, np.float64)
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
-x = torch.randn((nch, n), dtype=torch.float64, device="cuda", generator=g).t()
+x = torch.randn((nch, n), dtype=tdt, device="cuda", generator=g).t()
 tree = so.Signal(x, 44100 * so.Hz) | so.ToFramerate(44100 * np.pi / 3 * so.Hz)
 n_out = so.nframes(tree)
-out_t = torch.empty((nch, n_out), dtype=torch.float64, device="cuda")
+out_t = torch.empty((nch, n_out), dtype=tdt, device="cuda")
 out = out_t.t()
 which = os.environ.get("ONLY", "arb,tiled,plain").split(",")
 for name, env in (("arb", {}), ("tiled", {"SIGOPS_RS_NOARB": "1"}), ("plain", {"SIGOPS_RS_NOTILED": "1"})):
     if name not in which:
         continue
     os.environ.update(env)
-    plan = so.Plan(so.ToChannels(tree, nch), (n_out, nch), np.float64, (out.stride(0), out.stride(1)), True)
+    plan = so.Plan(so.ToChannels(tree, nch), (n_out, nch), ndt, (out.stride(0), out.stride(1)), True)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(20):
         plan.execute(out.data_ptr(), st)
@@ -40,8 +41,8 @@ for name, env in (("arb", {}), ("tiled", {"SIGOPS_RS_NOARB": "1"}), ("plain", {"
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / (reps if name != "plain" else 10))
-    algo = 8 * nch * (n + n_out)
-    print(json.dumps({"kernel": [s_["name"] for s_ in plan.steps()][-1], "in_frames": n, "out_frames": n_out, "channels": nch,
+    algo = (8 if ndt == np.float64 else 4) * nch * (n + n_out)
+    print(json.dumps({"kernel": [s_["name"] for s_ in plan.steps()][-1], "dtype": ndt.__name__, "in_frames": n, "out_frames": n_out, "channels": nch,
                       "ms": best, "algorithmic_GBps": algo / best / 1e6, "frac_of_8TBps": algo / best / 1e6 / 8000}), flush=True)
     plan.close()
     for k in env:

@@ -48,7 +48,8 @@ for i in range(cases):
     fs_in = float(rng.choice([1000.0, 44100.0, 44100.5, 48000.0, 22050.25, 8000.0]))
     ratio = float(np.exp(rng.uniform(np.log(0.3), np.log(4.0)))) * (1 + 1e-3 * rng.standard_normal())
     fs_out = fs_in * ratio
-    x = np.asfortranarray(rng.standard_normal((n, nch)))
+    dt = np.float32 if rng.random() < 0.35 else np.float64
+    x = np.asfortranarray(rng.standard_normal((n, nch)).astype(dt))
     if rng.random() < 0.2:
         x[int(rng.integers(0, n)), int(rng.integers(0, nch))] = 0.0
     tree = so.Signal(x, fs_in * so.Hz) | so.ToFramerate(fs_out * so.Hz)
@@ -58,21 +59,24 @@ for i in range(cases):
         m = int(rng.integers(17000, nout - a))
         tree = tree | so.After(a * so.frames) | so.Until(m * so.frames)
         nout = m
-    p = so.Plan(so.ToChannels(tree, nch), (nout, nch), np.float64, (1, nout), False)
+    p = so.Plan(so.ToChannels(tree, nch), (nout, nch), dt, (1, nout), False)
     names = [s["name"] for s in p.steps()]
     p.close()
     got = so.sink(tree)[0]
     with env(SIGOPS_RS_NOARB=1):
         ref = so.sink(tree)[0]
     e = relerr(got, ref)
-    assert got.shape == ref.shape and np.isfinite(got).all() and e < 1e-13, (i, names, e, nch, n, fs_in, fs_out)
+    # (Float32 results: both kernels round the same Float64 sums, which differ in their last bits: a rounding flip here and there)
+    assert got.shape == ref.shape and got.dtype == dt and np.isfinite(got).all() and e < (1e-13 if dt == np.float64 else 2e-8), (i, names, e, nch, n, fs_in, fs_out)
     if "k_resample_arb" in names:
         narb += 1
-        worst["arb_vs_tiled"] = max(worst["arb_vs_tiled"], e)
+        if dt == np.float64:
+            worst["arb_vs_tiled"] = max(worst["arb_vs_tiled"], e)
     if i % 8 == 0:
         eo = relerr(got, oracle_sink(tree))
-        assert eo < 1e-9, (i, names, eo)
-        worst["arb_vs_oracle"] = max(worst["arb_vs_oracle"], eo)
+        assert eo < (1e-9 if dt == np.float64 else 1e-6), (i, names, eo)
+        if dt == np.float64:
+            worst["arb_vs_oracle"] = max(worst["arb_vs_oracle"], eo)
 
 # Float32 sources of the fused resampler + IIR kernel
 nf = 0
