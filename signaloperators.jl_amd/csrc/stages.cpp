@@ -625,7 +625,7 @@ void Plan::process_stage(int sid) {
             //  every MFMA tile and most of the staged window unused: 192 -> 48 kHz of 8 channels x 120 s took 12.3 ms,
             //  0.15 TB/s; tools/rate_matrix.py)
             const int64_t L1 = g.L, M1 = g.M;
-            const int64_t tsup = (L1 < 16 && !std::getenv("SIGOPS_RR_NOSUPER")) ? 16 / std::__gcd<int64_t>(L1, 16) : 1;
+            const int64_t tsup = (L1 < 16 && !std::getenv("SIGOPS_RR_NOSUPER")) ? 16 / std::__gcd<int64_t>(L1, 16) * env_int("SIGOPS_RR_SUPERK", 2) : 1;  // (32 outputs per row: 20-38 % over 16, 64 no better)
             const int64_t Lb = L1 * tsup, Mb = M1 * tsup;
             const double* h = (const double*)nd.p0;
             std::vector<int> jr(Lb);
