@@ -287,6 +287,10 @@ int32_t so_rtc_compile_check(const char* body, char* log, int32_t log_capacity);
  * for the plans to come.  so_rtc_wait_idle returns when every compile queued so far has finished (a service
  * warming up; tests).  SIGOPS_RTC_NOASYNC=1 switches the background path off. */
 int32_t so_rtc_wait_idle(void);
+/* Ends the background compiles in an orderly way: queued ones are dropped, the one in flight is waited for, the thread is
+ * joined (a later plan starts a new one).  For a host about to tear the GPU runtime down -- interpreter shutdown hooks:
+ * `atexit` in the Python mirror and in the Julia glue --; the library also runs it from the C atexit chain. */
+int32_t so_rtc_shutdown(void);
 
 /* When enabled, so_plan_execute brackets every kernel with hipEvents (on the stream
  * the kernels are launched on) and fills so_stats_t.*_ms.  Off by default.

@@ -59,7 +59,7 @@ EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
            "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_tf_to_sos", "so_tf_zero_input", "so_plan_counter",
-           "so_rtc_compile_check", "so_rtc_wait_idle", "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_reduce_sum", "so_comm_last_error", "so_comm_destroy"]
+           "so_rtc_compile_check", "so_rtc_wait_idle", "so_rtc_shutdown", "so_comm_unique_id", "so_comm_create", "so_comm_allgather", "so_comm_reduce_sum", "so_comm_last_error", "so_comm_destroy"]
 
 _lib = None
 
@@ -136,6 +136,11 @@ def lib():
     L.so_rtc_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.so_rtc_wait_idle.restype = C.c_int32
     L.so_rtc_wait_idle.argtypes = []
+    L.so_rtc_shutdown.restype = C.c_int32
+    L.so_rtc_shutdown.argtypes = []
+    import atexit
+
+    atexit.register(L.so_rtc_shutdown)  # (before the interpreter tears torch's GPU state down: include/sigops.h)
     L.so_comm_unique_id.restype = C.c_int32
     L.so_comm_unique_id.argtypes = [C.c_void_p]
     L.so_comm_create.restype = C.c_int32

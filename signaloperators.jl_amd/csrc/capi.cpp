@@ -89,6 +89,11 @@ int32_t so_rtc_wait_idle(void) {
     return SO_OK;
 }
 
+int32_t so_rtc_shutdown(void) {
+    so::rtc_shutdown();
+    return SO_OK;
+}
+
 int64_t so_plan_counter(const so_plan_t* plan, int32_t which) {
     if (!plan) return -1;
     return so::plan_counter(plan->p, which);

@@ -26,6 +26,7 @@ int resample_positions(double fs_in, double fs_out, double rate, int nphi, const
 
 int rtc_compile_check(const std::string& body, std::string& err);  // rtc.cpp
 void rtc_wait_idle();                                                // rtc.cpp
+void rtc_shutdown();                                                 // rtc.cpp
 
 struct Plan;
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,

@@ -355,6 +355,27 @@ void Plan::process_stage(int sid) {
     Node& N = nodes[ni];
     const so_node_t& nd = N.nd;
     int child = N.kids[0];
+    // `Filt(Filt(x))` in Float64 (a band-pass written as low-pass |> high-pass): ONE cascade of all the sections -- the inner
+    // filter's first, the gains multiplied -- as long as it fits one launch group: one run of the filter kernels instead of
+    // two, no intermediate signal in HBM (reference src/filters.jl:240-255 filters the inner filter's blocks in place: the
+    // same sections in the same order, rounded as one cascade instead of two).  Frames are one to one, so every bound below
+    // holds for the innermost child; each skipped filter still pulls whole blocks of ITS child (error parity).
+    std::vector<double> merged_sos;
+    double merged_gain = nd.d0;
+    std::vector<int64_t> merged_bs;
+    if (stages[sid].kind == ST_SOS && N.dtype == SO_F64 && !std::getenv("SIGOPS_SOS_NOMERGE")) {
+        int tot = nd.i0;
+        while (nodes[child].nd.kind == SO_NODE_FILT_SOS && nodes[child].dtype == SO_F64 && nodes[child].nch == N.nch &&
+               nodes[child].fs == N.fs && tot + nodes[child].nd.i0 <= kMaxSec && nodes[child].nd.i0 >= 1) {
+            const so_node_t& cn = nodes[child].nd;
+            if (merged_sos.empty()) merged_sos.assign((const double*)nd.p0, (const double*)nd.p0 + 6 * (size_t)nd.i0);
+            merged_sos.insert(merged_sos.begin(), (const double*)cn.p0, (const double*)cn.p0 + 6 * (size_t)cn.i0);
+            merged_gain *= cn.d0;
+            merged_bs.push_back(std::max(1, cn.i1));
+            tot += cn.i0;
+            child = nodes[child].kids[0];
+        }
+    }
     Node& C = nodes[child];
     int64_t need = stages[sid].need;
     stages[sid].processed = true;
@@ -855,8 +876,9 @@ void Plan::process_stage(int sid) {
         if (!stages[sid].fix_host.empty()) stages[sid].fix_buf = raw_buf(stages[sid].fix_host.size() * sizeof(RsFix));
     } else if (stages[sid].kind == ST_SOS) {
         if (!isinf_(C.len)) in_frames = std::min(need, C.len.n);
-        int nsec = nd.i0;
-        const double* sos = (const double*)nd.p0;
+        int nsec = merged_sos.empty() ? nd.i0 : (int)(merged_sos.size() / 6);
+        const double* sos = merged_sos.empty() ? (const double*)nd.p0 : merged_sos.data();
+        const double gain_all = merged_gain;
         std::vector<SosCoefs> groups;
         for (int s0 = 0; s0 < nsec; s0 += kMaxSec) {
             SosCoefs cf{};
@@ -870,7 +892,7 @@ void Plan::process_stage(int sid) {
                 cf.a1[f] = b[4];
                 cf.a2[f] = b[5];
             }
-            cf.gain = (s0 + kMaxSec >= nsec) ? nd.d0 : 1.0;
+            cf.gain = (s0 + kMaxSec >= nsec) ? gain_all : 1.0;
             groups.push_back(cf);
         }
         // ---- ill-conditioned cascade: the reference's own order of operations (see above) ----
@@ -879,7 +901,7 @@ void Plan::process_stage(int sid) {
             const char* ev = std::getenv("SIGOPS_SOS_EXACT");  // 1: always, 0: never (measurement aid)
             if (ev) exact = std::atoi(ev) != 0;
             else {
-                exact = nsec >= 3 && sos_rounding_sensitivity(sos, nsec, nd.d0) > kSosExactTol;
+                exact = nsec >= 3 && sos_rounding_sensitivity(sos, nsec, gain_all) > kSosExactTol;
                 if (!exact && nsec >= 2) {  // ... or the chunked form itself, at the chunk length this signal would get
                     const int64_t tgt = kSosSequences / std::max(1, N.nch);
                     const int64_t nck = std::max<int64_t>(1, std::min<int64_t>(tgt, need / 64));
@@ -888,7 +910,7 @@ void Plan::process_stage(int sid) {
                     exact = cs > kSosExactTol;
                     if (std::getenv("SIGOPS_DEBUG_PLAN"))
                         std::fprintf(stderr, "[sigops] IIR of %d sections: rounding sensitivity %.3g, chunked (L = %lld) %.3g -> %s\n", nsec,
-                                     nsec >= 3 ? sos_rounding_sensitivity(sos, nsec, nd.d0) : 0.0, (long long)Lp, cs, exact ? "sequential" : "time-parallel");
+                                     nsec >= 3 ? sos_rounding_sensitivity(sos, nsec, gain_all) : 0.0, (long long)Lp, cs, exact ? "sequential" : "time-parallel");
                 }
             }
         }
@@ -1004,7 +1026,9 @@ void Plan::process_stage(int sid) {
     }
     if (stages[sid].kind == ST_SOS && in_frames > 0) {  // the reference filters whole blocks of its input
         const int64_t bs = std::max(1, N.nd.i1);
-        check_frames(child, (in_base + in_frames + bs - 1) / bs * bs);
+        int64_t fr = (in_base + in_frames + bs - 1) / bs * bs;
+        for (int64_t b2 : merged_bs) fr = (fr + b2 - 1) / b2 * b2;  // (... and so does every filter merged into this one)
+        check_frames(child, fr);
     }
     if (stages[sid].kind == ST_RESAMPLE && in_frames > 0) {
         // ... and so does the resampler: it refills its input `rows` frames at a time, rows = trunc(max(1, min(N_out,

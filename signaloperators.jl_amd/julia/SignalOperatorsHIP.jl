@@ -283,6 +283,8 @@ check(st) = st == 0 || error(unsafe_string(ccall((:so_last_error, libsigops), Cs
 # sinks, and later sessions where ENV["SIGOPS_CACHE_DIR"] names a directory: the compiled one, same values).  A long-running service
 # can wait for the queue once it has seen its workload:
 warmup_done() = check(ccall((:so_rtc_wait_idle, libsigops), Int32, ()))
+# (the compile thread ends before the session tears the GPU runtime down)
+atexit(() -> ccall((:so_rtc_shutdown, libsigops), Int32, ()))
 
 # The method the engine plugs into: reference src/sink.jl:225-226 dispatch point.
 function SignalOperators.sink!(result::HIPSink{T}, x, ::IsSignal) where T

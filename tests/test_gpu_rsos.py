@@ -323,3 +323,28 @@ def test_device_tensor_with_an_odd_number_of_frames():
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert times[0] < 3 * times[1] + 0.005, times
+
+
+@pytest.mark.parametrize("n", [5000, 400000])
+def test_consecutive_filters_run_as_one_cascade(n):
+    """`x |> Filt(Lowpass) |> Filt(Highpass)` in Float64: one cascade of all the sections (the inner filter's first, gains
+    multiplied) -- one run of the filter kernels, and with a resampler behind it one launch of the fused kernel; against
+    the oracle (which filters twice, as the reference does) and against the engine filtering twice (SIGOPS_SOS_NOMERGE)"""
+    rng = np.random.default_rng(93)
+    src = so.Signal(F(rng.standard_normal((n, 4))), 44.1 * so.kHz)
+    two = src | so.Filt(so.Lowpass, 3 * so.kHz, order=5) | so.Filt(so.Highpass, 200 * so.Hz, order=3)
+    three = two | so.Filt(so.Bandstop, 1 * so.kHz, 1.2 * so.kHz, order=1)
+    for x in (two, three, two | so.After(n // 2 * so.frames), two | so.ToFramerate(48 * so.kHz)):
+        with env(SIGOPS_RSOS_MINGROUPS=1):
+            names = steps_of(x)
+            got = so.sink(x)[0]
+        with env(SIGOPS_SOS_NOMERGE=1, SIGOPS_NO_RSOS=1):
+            names2 = steps_of(x)
+            ref = so.sink(x)[0]
+        assert sum(nm.startswith("k_sos") or nm == "k_rsos" for nm in names) == 1, names
+        assert sum(nm.startswith("k_sos") for nm in names2) >= 2, names2
+        assert relerr(got, ref) < 1e-11
+        assert relerr(got, oracle_sink(x)) < 1e-9
+    x32 = so.Signal(F(rng.standard_normal((n, 2)).astype(np.float32)), 44.1 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) | so.Filt(so.Highpass, 200 * so.Hz)
+    assert sum(nm.startswith("k_sos") for nm in steps_of(x32, np.float32)) == 2   # (Float32: the reference rounds in between)
+    assert relerr(so.sink(x32)[0], oracle_sink(x32)) < 1e-6
