@@ -9,11 +9,12 @@ import torch
 
 import sigops_amd as so
 
-nch, n = 8, 12_500_000
+nch, n = int(os.environ.get("NCH", "8")), int(float(os.environ.get("FRAMES", "12.5e6")))
 fs = 44.1 * so.kHz
-x = torch.randn((nch, n), dtype=torch.float64, device="cuda").t()
-y = torch.randn((nch, n), dtype=torch.float64, device="cuda").t()
-z = torch.randn((nch, n // 2), dtype=torch.float64, device="cuda").t()
+TDT, NDT = (torch.float32, np.float32) if os.environ.get("F32") else (torch.float64, np.float64)
+x = torch.randn((nch, n), dtype=TDT, device="cuda").t()
+y = torch.randn((nch, n), dtype=TDT, device="cuda").t()
+z = torch.randn((nch, n // 2), dtype=TDT, device="cuda").t()
 X, Y, Z = so.Signal(x, fs), so.Signal(y, fs), so.Signal(z, fs)
 tone = so.Signal(so.sin, ω=1 * so.kHz)
 cases = {
@@ -53,7 +54,7 @@ for name, mk in cases.items():
     try:
         tree = mk()
         nout, co = so.nframes(tree), so.nchannels(tree)
-        odt = np.float32 if "Float32" in name else np.float64
+        odt = np.float32 if ("Float32" in name or NDT == np.float32) else np.float64
         tdt = torch.float32 if odt == np.float32 else torch.float64
         out = torch.empty((co, nout), dtype=tdt, device="cuda").t()
         plan = so.Plan(so.ToChannels(tree, co), (nout, co), odt, (out.stride(0), out.stride(1)), True)
