@@ -107,6 +107,7 @@ struct Stage {
     int64_t base = 0;  // first frame the stage computes (warm start, see process_stage): its buffer holds [base, need)
     int64_t in_base = 0;  // first frame of the child the stage consumes
     bool processed = false;
+    bool norm_alias = false;  // Normpower whose `vals` is its child stage's output buffer (no copy)
     bool under_norm = false;  // a Normpower consumes this stage (directly or through further stages)
     int out_buf = -1, in_buf = -1, aux_buf = -1;
     int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)

@@ -1101,7 +1101,13 @@ void Plan::process_stage(int sid) {
             }
         }
     }
-    if (S.kind == ST_NORM) {
+    if (S.kind == ST_NORM && S.norm_alias) {
+        // `vals` is the child stage's buffer (planner.cpp): lowering the child above registered the frames it needs
+        if (ps.size() != 1 || exprs[ps[0].e].op != E_LOAD || exprs[ps[0].e].leaf.buf != S.out_buf)
+            fail(SO_ERR_RUNTIME, "internal: Normpower over a stage buffer expected that buffer");
+        S.in_buf = S.out_buf;
+        S.in_pitch = -1;
+    } else if (S.kind == ST_NORM) {
         // materialise the child straight into `vals` (the stage's own output buffer)
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
         S.in_buf = S.out_buf;
