@@ -24,7 +24,7 @@ void Plan::finalize() {
             bufs[S.out_buf].bytes = 0;
             continue;
         }
-        if (S.out_buf >= 0 && S.fused_away) {  // (its consumer computes it on the fly: k_rsos)
+        if (S.out_buf >= 0 && (S.fused_away || S.norm_direct)) {  // (its consumer computes it on the fly: k_rsos; Normpower reading an array in place)
             bufs[S.out_buf].frames = 0;
             bufs[S.out_buf].bytes = 64;
             continue;
@@ -773,8 +773,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         launches++;
                     }
                 } else {
-                    launch_rms(ob.d, N.dtype, S.need, N.nch, ob.pitch, (double*)P->bufs[S.partial_buf].d,
-                               S.nparts, (double*)P->bufs[S.rms_buf].d, st);
+                    launch_rms(S.norm_direct ? (const void*)inp : ob.d, N.dtype, S.need, N.nch, S.norm_direct ? in_pitch : ob.pitch,
+                               (double*)P->bufs[S.partial_buf].d, S.nparts, (double*)P->bufs[S.rms_buf].d, st);
                     s.launches = 2;
                     launches += 2;
                 }

@@ -312,12 +312,36 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_partial(const T* __restrict__ 
                                                           double* __restrict__ partial) {
     __shared__ double red[kBlock / 64];
     const int64_t total = n * nch;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * kBlock) {
-        const int64_t ch = i / n, f = i - ch * n;
+    // (channel, frame) of this thread's elements kept by increments: a 64-bit division per element cost more than its load
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t ch = i / n, f = i - ch * n;
+    constexpr int U = 4;  // loads in flight; the sums stay in element order
+    for (; i + (U - 1) * stride < total; i += U * stride) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = (double)x[ch * pitch + f];
+            f += stride;
+            if (f >= n) {
+                const int64_t k = f / n;
+                f -= k * n;
+                ch += k;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u] * v[u];
+    }
+    for (; i < total; i += stride) {
         const double v = (double)x[ch * pitch + f];
         acc += v * v;
+        f += stride;
+        if (f >= n) {
+            const int64_t k = f / n;
+            f -= k * n;
+            ch += k;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -349,29 +373,140 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_final(const double* __restrict
 // 1024 values (Base.mapreduce_impl).  The same order as the oracle's restatement
 // (oracle/sigops_oracle.c, NORMPOWER): every block summed front to back in Float32 (separate
 // multiply and add), then neighbours folded level by level; rms = sqrt(sum / count) in Float32.
-__global__ __launch_bounds__(kBlock) void k_sumsq32_blocks(const float* __restrict__ x, int64_t n, int nch,
-                                                           int64_t pitch, float* __restrict__ part, int64_t nb) {
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= nb) return;
+// One lane per block of 1024 (its sum is a chain of 1024 dependent adds), one wave per workgroup: the wave's 64 blocks are
+// 256 KB of the signal in a row, read 64 values of every block at a time with whole-line requests (eight lanes per 128-byte
+// line; the next chunk's requests are in flight while this one is summed) into an LDS tile the lanes then walk row by row.
+// The wave then folds its 64 sums itself -- the first six levels of the neighbour tree: pairs (2i, 2i+1), an odd last one
+// carried up unchanged, which for an aligned group of 64 is the same within the wave as over the whole list -- and leaves
+// ONE value for k_sumsq32_fold (which, one workgroup walking every level through memory, took longer than the sums).
+// (One scalar load per value and lane, 4 KB apart from its neighbours', and the whole tree in the fold kernel: 0.8 ms for
+// 12.5 M x 8 values; `tools/operator_matrix.py`, Float32 `Normpower`.)
+constexpr int kSqBlocks = 64, kSqChunk = 64;
+__global__ __launch_bounds__(kSqBlocks) void k_sumsq32_blocks(const float* __restrict__ x, int64_t n, int nch,
+                                                              int64_t pitch, float* __restrict__ part, int64_t nb) {
+    __shared__ float tile[kSqBlocks][kSqChunk + 1];
+    const int t = threadIdx.x;
     const int64_t total = n * nch;
-    const int64_t e = (b + 1) * 1024 < total ? (b + 1) * 1024 : total;
-    int64_t i = b * 1024;
-    int64_t ch = i / n, f = i - ch * n;
+    const int64_t b0 = (int64_t)blockIdx.x * kSqBlocks;
+    constexpr int LPB = kSqChunk / 4;  // lanes (float4 requests) per block and chunk
+    constexpr int NQ = LPB;            // requests per lane and chunk: 64 blocks x LPB requests / 64 lanes
+    // request q = j * 64 + t of a chunk: block q / LPB of the wave, values (q % LPB) * 4 ... + 3 of its chunk
+    int64_t qi[NQ], qf[NQ];
+    int qc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = j * kSqBlocks + t;
+        qi[j] = (b0 + q / LPB) * 1024 + (q % LPB) * 4;
+        qc[j] = (int)(qi[j] < total ? qi[j] / n : nch);
+        qf[j] = qi[j] - (int64_t)qc[j] * n;
+    }
+    float v[NQ][4];
+    // a wave whose 64 blocks lie inside one channel (all but a handful) issues a chunk's requests back to back; behind a
+    // per-request edge test every load waited for the one before it
+    const int64_t wlast = (b0 + kSqBlocks) * 1024 - 1;
+    const bool interior = wlast < total && (b0 * 1024) / n == wlast / n;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u* src[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) src[j] = (const f4u*)(x + (interior ? (int64_t)qc[j] * pitch + qf[j] : 0));
+    auto request_interior = [&]() {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const f4u w = *src[j];
+            v[j][0] = w.x, v[j][1] = w.y, v[j][2] = w.z, v[j][3] = w.w;
+            src[j] += kSqChunk / 4;
+        }
+    };
+    // a wave that holds the signal's end or a channel boundary (rows of n >= 64 frames: at most one boundary per step):
+    // every value its own predicated load, no branches, so that a chunk's loads are still in flight together -- the
+    // handful of such waves otherwise ends long after all the others
+    auto request_edges = [&]() {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int64_t f = qf[j] + e;
+                int ch = qc[j];
+                if (f >= n) f -= n, ++ch;
+                const bool ok = qi[j] + e < total;
+                const float w = x[ok ? (int64_t)ch * pitch + f : 0];
+                v[j][e] = ok ? w : 0.f;
+            }
+            qi[j] += kSqChunk;
+            qf[j] += kSqChunk;
+            if (qf[j] >= n) qf[j] -= n, ++qc[j];
+        }
+    };
+    auto request_short_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (qi[j] + 3 < total && qf[j] + 3 < n) {
+                // (a 16-byte request from any 4-byte address: rows of arrays start where the caller put them)
+                const f4u w = *(const f4u*)(x + (int64_t)qc[j] * pitch + qf[j]);
+                v[j][0] = w.x, v[j][1] = w.y, v[j][2] = w.z, v[j][3] = w.w;
+            } else {  // the signal's end (zeros add nothing to a sum of squares) or a channel boundary inside the four
+                int64_t f = qf[j];
+                int ch = qc[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    while (f >= n && ch < nch) {
+                        f -= n;
+                        ++ch;
+                    }
+                    v[j][e] = (qi[j] + e < total) ? x[(int64_t)ch * pitch + f] : 0.f;
+                    ++f;
+                }
+            }
+            qi[j] += kSqChunk;
+            qf[j] += kSqChunk;
+            while (qf[j] >= n && qc[j] < nch) {
+                qf[j] -= n;
+                ++qc[j];
+            }
+        }
+    };
     float acc = 0.f;
-    for (; i < e; ++i) {
-        const float v = x[ch * pitch + f];
-        // the square is rounded on its own (Julia's x^2, then +): __fmul_rn / __fadd_rn are plain * and + to
-        // the compiler, which fuses them into v_fmac_f32 under its default contraction -- 1 ulp of the rms off
-        // on two of twelve long signals
-        float sq;
-        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(v));
-        acc = acc + sq;
-        if (++f == n) {
-            f = 0;
-            ++ch;
+    auto run = [&](auto request) {  // (the whole loop once per kind of wave: with the choice inside it the loads went back to waiting)
+    request();
+    for (int c = 0; c < 1024; c += kSqChunk) {
+        __syncthreads();  // (the previous chunk has been read)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = j * kSqBlocks + t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[q / LPB][(q % LPB) * 4 + e] = v[j][e];
+        }
+        __syncthreads();
+        if (c + kSqChunk < 1024) request();
+#pragma unroll
+        for (int k0 = 0; k0 < kSqChunk; k0 += 32) {
+            float w[32];  // (read as a batch: behind a `volatile` asm every LDS read was waited for on its own)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k] = tile[t][k0 + k];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                // the square is rounded on its own (Julia's x^2, then +): __fmul_rn / __fadd_rn are plain * and + to
+                // the compiler, which fuses them into v_fmac_f32 under its default contraction -- 1 ulp of the rms off
+                // on two of twelve long signals
+                float sq;
+                asm("v_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(w[k]));
+                acc = acc + sq;
+            }
         }
     }
-    part[b] = acc;
+    };
+    if (interior) run(request_interior);
+    else if (n >= kSqChunk) run(request_edges);
+    else run(request_short_rows);
+    // six levels of the neighbour tree inside the wave
+    int valid = b0 + t < nb;
+#pragma unroll
+    for (int d = 1; d < kSqBlocks; d <<= 1) {
+        const float other = __shfl_down(acc, d, 64);
+        const int ov = __shfl_down(valid, d, 64);
+        if ((t & (2 * d - 1)) == 0 && ov) acc = __fadd_rn(acc, other);
+    }
+    if (t == 0) part[blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, float* __restrict__ b, int64_t nb,
                                                          float count, double* __restrict__ rms) {
@@ -400,10 +535,10 @@ void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, dou
                 int nparts, double* rms, hipStream_t st) {
     if (dtype == SO_F32) {
         const int64_t nb = (n * nch + 1023) / 1024;
+        const int64_t nw = (nb + kSqBlocks - 1) / kSqBlocks;  // one value per wave of 64 blocks goes on to the fold kernel
         float* pa = (float*)partial;
-        hipLaunchKernelGGL(k_sumsq32_blocks, dim3((unsigned)((nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const float*)x, n, nch, pitch, pa, nb);
-        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nb, nb, (float)((double)n * (double)nch), rms);
+        hipLaunchKernelGGL(k_sumsq32_blocks, dim3((unsigned)nw), dim3(kSqBlocks), 0, st, (const float*)x, n, nch, pitch, pa, nb);
+        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nw, nw, (float)((double)n * (double)nch), rms);
         return;
     }
     if (dtype == SO_F32)

@@ -108,6 +108,7 @@ struct Stage {
     int64_t in_base = 0;  // first frame of the child the stage consumes
     bool processed = false;
     bool norm_alias = false;  // Normpower whose `vals` is its child stage's output buffer (no copy)
+    bool norm_direct = false; // Normpower of a plain array leaf: the rms is taken over the array where it lies, readers divide its loads
     bool under_norm = false;  // a Normpower consumes this stage (directly or through further stages)
     int out_buf = -1, in_buf = -1, aux_buf = -1;
     int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)

@@ -615,9 +615,36 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
                 if (stages[cs].out_buf < 0) stages[cs].out_buf = new_buf(0, Cn.nch, Cn.dtype);
                 stages[sid].out_buf = stages[cs].out_buf;
                 stages[sid].norm_alias = true;
-            } else
+            } else {
                 stages[sid].out_buf = new_buf(0, N.nch, N.dtype);  // sized in finalize()
+                // ... and of a plain array (through `Until` / `After`): the sum of squares is taken over the array where it
+                // lies and whoever reads `vals` divides the array's own frames (three passes over the signal -> two)
+                int k = N.kids[0];
+                while (nodes[k].nd.kind == SO_NODE_UNTIL || (nodes[k].nd.kind == SO_NODE_AFTER && !nodes[k].short_skip)) k = nodes[k].kids[0];
+                const so_node_t& a = nodes[k].nd;
+                if (kind == ST_NORM && a.kind == SO_NODE_ARRAY && a.s0 == 1 && a.l1 == 0 && (a.s1 > 0 || a.nch == 1) && nodes[k].dtype == N.dtype &&
+                    nodes[k].nch == N.nch && !std::getenv("SIGOPS_NORM_COPY"))
+                    stages[sid].norm_direct = true;
+            }
             if (kind == ST_NORM) stages[sid].rms_buf = raw_buf(8);
+        }
+        if (kind == ST_NORM && stages[sid].norm_direct) {  // the child's own pieces ./ rms
+            Expr s;
+            s.op = E_SCALAR;
+            s.dtype = SO_F64;
+            s.leaf.buf = stages[sid].rms_buf;
+            const int se = add_expr(s);
+            auto ps = lower(N.kids[0], r, m);
+            for (auto& p : ps) {
+                Expr d;
+                d.op = E_DIV;
+                d.dtype = N.dtype;
+                d.a = p.e;
+                d.b = se;
+                d.mono = exprs[p.e].mono;
+                p.e = add_expr(d);
+            }
+            return ps;
         }
         Expr e;
         e.op = E_LOAD;

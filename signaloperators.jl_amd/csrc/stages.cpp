@@ -1050,7 +1050,7 @@ void Plan::process_stage(int sid) {
     if (S.kind != ST_NORM && C.dtype == SO_I64) in_dtype = SO_F64;
     // direct source: a single plain contiguous load of the right type
     bool direct = false;
-    if (S.kind != ST_NORM && ps.size() == 1) {
+    if ((S.kind != ST_NORM || S.norm_direct) && ps.size() == 1) {
         const Expr& e = exprs[ps[0].e];
         if (e.op == E_LOAD && e.leaf.mode == LM_PLAIN && e.leaf.sf == 1 && e.leaf.sc == 1 &&
             e.leaf.fstride == 1 && e.leaf.dtype == in_dtype && e.leaf.df >= 0 && e.leaf.dc >= 0 &&
@@ -1107,6 +1107,9 @@ void Plan::process_stage(int sid) {
             fail(SO_ERR_RUNTIME, "internal: Normpower over a stage buffer expected that buffer");
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
+    } else if (S.kind == ST_NORM && S.norm_direct) {
+        // the array itself is `vals` (planner.cpp): K4 reads it in place
+        if (!direct || S.in_array_node < 0) fail(SO_ERR_RUNTIME, "internal: Normpower over an array expected one plain load");
     } else if (S.kind == ST_NORM) {
         // materialise the child straight into `vals` (the stage's own output buffer)
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);

@@ -73,6 +73,14 @@ for name, mk in cases.items():
         names = "+".join(s_["name"].replace("k_resample_", "rs_").replace("k_", "") for s_ in plan.steps())
         plan.close()
         print(f"{name:28s} {ms:8.3f} ms  {stt['algorithmic_bytes'] / ms / 1e9:6.2f} TB/s  [{names}]", flush=True)
+        if os.environ.get("STEPS"):  # per-step device time of one profiled execute
+            plan = so.Plan(so.ToChannels(tree, co), (nout, co), odt, (out.stride(0), out.stride(1)), True)
+            plan.execute(out.data_ptr(), st)
+            plan.set_profiling(1)
+            plan.execute(out.data_ptr(), st)
+            torch.cuda.synchronize()
+            print("    " + "  ".join(f"{s_['name']} {s_['ms']:.3f}" for s_ in plan.steps()), flush=True)
+            plan.close()
         del out
     except Exception as exc:  # (a case the mirror does not spell this way)
         print(f"{name:28s} skipped: {type(exc).__name__}: {str(exc)[:80]}", flush=True)
