@@ -547,7 +547,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         const Stage& S3 = P->stages[S.rsos_src];
                         RsSos rs = S.rs;
                         rs.out_pitch = ob.pitch;
-                        rs.out_f32 = g.out_dtype == SO_F32 && N.dtype == SO_F64;
+                        rs.out_f32 = g.out_dtype == SO_F32 || N.dtype == SO_F32;
                         // the kernel's output m is frame m - store_lo of this stage's buffer (a window: the resampler's warm
                         // start lies store_lo frames before the cascade's); the sink's own skipped frames come on top
                         char* const yk = (char*)ob.d - (size_t)S.rs.store_lo * (rs.out_f32 ? 4 : 8);

@@ -630,6 +630,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const SO_LDS DCarrier& C0 = sh->ctl.car[0];
     const int64_t cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const bool src32 = uni(g.src32) != 0;
+    const bool x32 = sizeof(TO) == 4 && uni(g.x32) != 0;
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && uni(g.fuse) >= -1 &&
                         (!src32 || uni(g.chunk) == 128);
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
@@ -786,6 +787,14 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         v4d ax = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
+        if constexpr (sizeof(TO) == 4) {
+            // a Float32 signal all the way: the reference's resampler hands the filter Float32 samples (K3's store rounds the
+            // same accumulators the same way); the Float64-result instantiations -- the headline's -- do not carry the test
+            if (x32) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ax[v] = (double)(float)ax[v];
+            }
+        }
         // next block of this wave: its window start is what this wave still needs of the ring
         int pi2 = pi, gi2 = gi + NY;
         while (gi2 >= ngroups) {

@@ -355,7 +355,8 @@ struct RsSos {
     int32_t out_f32;
     int32_t src32;        // carrier 0 is a Float32 array: its chunks land as Float32 in the upper half of their ring slots and the
                           // loader widens them in place (together with the fused step)
-    int32_t pad32_;
+    int32_t x32;          // a Float32 pipeline: the resampled values are rounded to Float32 before the cascade reads them (the
+                          // reference's Float32 resampler output; Float32 result instantiations only)
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space
     int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
     int64_t out_pitch;

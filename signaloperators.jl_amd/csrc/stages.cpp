@@ -1566,9 +1566,14 @@ void Plan::fuse_resample_sos() {
         Stage& S2 = stages[i2];
         if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 ||
             S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != S2.base || S2.pw_step >= 0 || S2.sg.exact || S2.xscan ||
-            S2.under_norm || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 || nodes[S2.node].dtype != SO_F64 ||
-            S2.in_frames != S2.need - S2.base)
+            S2.under_norm || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 ||
+            (nodes[S2.node].dtype != SO_F64 && nodes[S2.node].dtype != SO_F32) || S2.in_frames != S2.need - S2.base)
             continue;
+        // A Float32 signal all the way (Float32 source, resampler and filter stages): the kernel rounds the resampled values to
+        // Float32 where the reference's resampler stores them (RsSos::x32) and stores a Float32 result; its sources are plain
+        // Float32 arrays or buffers (a Float32 x Float32 step rounds too: K1 materialises it)
+        const bool pure32 = nodes[S2.node].dtype == SO_F32;
+        if (pure32 && std::getenv("SIGOPS_RSOS_NO32")) continue;
         if (S2.base > 0 && std::getenv("SIGOPS_RSOS_NOWINDOWS")) continue;
         int i3 = -1;
         for (size_t j = 0; j < stages.size(); ++j)
@@ -1581,8 +1586,14 @@ void Plan::fuse_resample_sos() {
         // kernel's coordinates are the resampler stage's: its output 0 is frame S3.base, the cascade starts from rest
         // there (earlier than the cascade stage alone would: a longer warm-up), and nothing below S2.base is stored.
         if (S3.base > S2.base) continue;
-        if (rp.nstate || nodes[S3.node].dtype != SO_F64 || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
+        if (rp.nstate || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
             continue;
+        if (pure32) {
+            bool plain = nodes[nodes[S3.node].kids[0]].dtype == SO_F32 && rp.ga == 0;
+            for (auto& c : S3.carriers)
+                if (c.nsteps != 0 || c.pad_ != 0 || c.dtype != SO_F32) plain = false;
+            if (!plain) continue;
+        }
         // (a stage that does not run the periodic kernel -- long super-periods: x 2 of eight channels -- has no carriers:
         //  its plain source, an array or a stage buffer, becomes one below)
         const bool plain_src = S3.carriers.empty() && (S3.in_buf >= 0 || S3.in_array_node >= 0);
@@ -1811,6 +1822,7 @@ void Plan::fuse_resample_sos() {
             g.src32 = 1;
         } else
             g.src32 = S3.carriers[0].dtype == SO_F32 && S3.carriers[0].nsteps == 0 ? 1 : 0;
+        g.x32 = pure32 ? 1 : 0;
         // carrier 0's step on the fast path
         {
             const DCarrier& c0 = S3.carriers[0];

@@ -348,3 +348,54 @@ def test_consecutive_filters_run_as_one_cascade(n):
     x32 = so.Signal(F(rng.standard_normal((n, 2)).astype(np.float32)), 44.1 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) | so.Filt(so.Highpass, 200 * so.Hz)
     assert sum(nm.startswith("k_sos") for nm in steps_of(x32, np.float32)) == 2   # (Float32: the reference rounds in between)
     assert relerr(so.sink(x32)[0], oracle_sink(x32)) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["array", "until", "window", "mix32", "append", "device"])
+@pytest.mark.parametrize("nch", [8, 2, 1, 3])
+def test_float32_pipelines(kind, nch):
+    """a Float32 signal all the way -- Float32 array, resampler, filter, result (round 4, last item): the reference's resampler
+    hands the filter Float32 samples, so the fused kernel rounds its `X` accumulators to Float32 (`RsSos::x32`; K3's Float32
+    store rounds the same values) before the cascade reads them and stores a Float32 result.  Against the oracle (1e-6, the
+    suite's Float32 tolerance) and against K3 + K2 (`SIGOPS_NO_RSOS=1`): the same resampled samples bit for bit, the
+    cascade's block association instead of the sequential recurrence -- Float32 results that differ only where a value sits
+    within 1e-13 of a rounding boundary."""
+    rng = np.random.default_rng(70 + nch)
+    n = 300_000
+    x32 = F((rng.standard_normal((n, nch)) * 0.5).astype(np.float32))
+    sig = so.Signal(x32, 44.1 * so.kHz)
+    if kind == "device":
+        torch = pytest.importorskip("torch")
+        dev = torch.from_numpy(np.ascontiguousarray(x32.T)).cuda()
+        sig = so.Signal(dev.t(), 44.1 * so.kHz)
+    src = {
+        "array": lambda: sig,
+        "device": lambda: sig,
+        "until": lambda: sig | so.Until(250_001 * so.frames),
+        "window": lambda: sig | so.After(10_000 * so.frames) | so.Until(200_000 * so.frames),
+        "mix32": lambda: so.Mix(sig, so.Signal(F((rng.standard_normal((n, nch)) * 0.1).astype(np.float32)), 44.1 * so.kHz)),
+        "append": lambda: so.Append(sig | so.Until(100_000 * so.frames), so.Signal(F(rng.standard_normal((150_000, nch)).astype(np.float32)), 44.1 * so.kHz)),
+    }[kind]()
+    x = pipeline(src)
+    a, b, fused = both(x)
+    assert fused or nch == 3 or kind == "append", kind
+    assert a.dtype == np.float32 and b.dtype == np.float32
+    assert relerr(a, b) < 1e-7 and np.mean(a == b) > 0.999
+    want = oracle_sink(pipeline(src if kind != "device" else so.Signal(x32, 44.1 * so.kHz)))
+    assert want.dtype == np.float32 and relerr(a, want) < 1e-6
+
+
+def test_float32_pipeline_windows_and_streams():
+    """a window of a Float32 pipeline (`After` above it: warm starts of both stages) and its blocks through `so.stream`"""
+    rng = np.random.default_rng(75)
+    n = 600_000
+    x32 = F((rng.standard_normal((n, 2)) * 0.5).astype(np.float32))
+    x = pipeline(so.Signal(x32, 44.1 * so.kHz))
+    want = oracle_sink(x)
+    win = x | so.After(300_000 * so.frames) | so.Until(200_000 * so.frames)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        got = so.sink(win)[0]
+    assert got.dtype == np.float32 and relerr(got, want[300_000:500_000]) < 1e-6
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        blocks = [blk for blk, _ in so.stream(x, 150_000)]
+    cat = np.concatenate(blocks, axis=0)
+    assert cat.dtype == np.float32 and cat.shape == want.shape and relerr(cat, want) < 1e-6
