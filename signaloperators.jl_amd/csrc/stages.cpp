@@ -495,7 +495,7 @@ void Plan::process_stage(int sid) {
                 int c = std::atoi(ev);
                 if ((c == 1 || c == 2 || c == 4 || c == 8) && N.nch % c == 0) ct = c;
             }
-            if (rows_try == 16 && (N.dtype != SO_F64 || (ct != 8 && ct != 4))) continue;  // (the Q = 1 instantiations)
+            if (rows_try == 16 && ((N.dtype != SO_F64 && N.dtype != SO_F32) || (ct != 8 && ct != 4))) continue;  // (the Q = 1 instantiations)
             const int pt = rows_try / ct;  // tile = 32 or 16 rows (k_resample_periodic's Q)
             // super-period: t periods so that (a) L*t is a multiple of 16 where possible and
             // (b) a tile (pt super-periods) covers ~1100 input frames per channel

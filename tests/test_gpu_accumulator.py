@@ -233,3 +233,33 @@ def test_persistent_form_of_the_arbitrary_rate_resampler(fs_in, fs_out, nch, n, 
     monkeypatch.setenv("SIGOPS_ARB_NO", "4")   # four outputs per lane (opt-in; eight-channel groups at rates near 1)
     four = so.sink(tree)[0]
     assert relerr(four, ref) < 1e-14
+
+
+@pytest.mark.parametrize("nch", [8, 4])
+@pytest.mark.parametrize("kind", ["44.1 -> 16 kHz", "fir 101 taps", "fir + gain"])
+def test_float32_long_windows_run_the_periodic_kernel(kind, nch):
+    """16-row tiles of K3 (windows of 28 / 36 k-steps) for Float32 signals too: a 101-tap `Filt(x, h)` or 44.1 -> 16 kHz on
+    Float32 data used to go to the row-tiled kernel (1.04 ms where Float64 took 0.66: `profiles/r04/operator_matrix_f32.txt`).
+    Same arithmetic as the Float64 instantiation (Float64 MFMAs over the widened tile), a Float32 store."""
+    rng = np.random.default_rng(900 + nch)
+    n = 400_000
+    x32 = np.asfortranarray((rng.standard_normal((n, nch)) * 0.5).astype(np.float32))
+    sig = so.Signal(x32, 44.1 * so.kHz)
+    tree = {"44.1 -> 16 kHz": lambda: sig | so.ToFramerate(16 * so.kHz),
+            "fir 101 taps": lambda: so.Filt(sig, np.hanning(101) / 50.0),
+            "fir + gain": lambda: so.Filt(sig | so.Amplify(so.Signal(so.sin, ω=3 * so.Hz)) | so.Until(n * so.frames) | so.ToEltype(np.float32), np.hanning(120) / 60.0)}[kind]()
+    nout = so.nframes(tree)
+    p = so.Plan(so.ToChannels(tree, nch), (nout, nch), np.float32, (1, nout), False)
+    names = [s["name"] for s in p.steps()]
+    p.close()
+    assert "k_resample_periodic" in names and "k_resample_rows" not in names, names
+    got = so.sink(tree)[0]
+    want = oracle_sink(tree)
+    assert got.dtype == want.dtype == np.float32 and got.shape == want.shape
+    assert relerr(got, want) < 1e-6
+    os.environ["SIGOPS_RS_NOQ1"] = "1"  # the row-tiled kernel on the same data
+    try:
+        rows = so.sink(tree)[0]
+    finally:
+        del os.environ["SIGOPS_RS_NOQ1"]
+    assert relerr(got, rows) < 1e-6
