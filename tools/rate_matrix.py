@@ -11,17 +11,18 @@ import sigops_amd as so
 
 rates = [8.0, 11.025, 16.0, 22.05, 24.0, 32.0, 44.1, 48.0, 88.2, 96.0, 192.0]
 secs = float(os.environ.get("SECS", "120"))
+TDT, NDT, ESZ = (torch.float32, np.float32, 4) if os.environ.get("F32") else (torch.float64, np.float64, 8)
 for nch in (8, 2):
     for fi in rates:
         for fo in rates:
             if fi == fo:
                 continue
             n = int(fi * 1000 * secs)
-            x = torch.randn((nch, n), dtype=torch.float64, device="cuda").t()
+            x = torch.randn((nch, n), dtype=TDT, device="cuda").t()
             tree = so.Signal(x, fi * so.kHz) | so.ToFramerate(fo * so.kHz)
             n_out = so.nframes(tree)
-            out = torch.empty((nch, n_out), dtype=torch.float64, device="cuda").t()
-            plan = so.Plan(so.ToChannels(tree, nch), (n_out, nch), np.float64, (out.stride(0), out.stride(1)), True)
+            out = torch.empty((nch, n_out), dtype=TDT, device="cuda").t()
+            plan = so.Plan(so.ToChannels(tree, nch), (n_out, nch), NDT, (out.stride(0), out.stride(1)), True)
             st = torch.cuda.current_stream().cuda_stream
             for _ in range(3):
                 plan.execute(out.data_ptr(), st)
@@ -35,6 +36,6 @@ for nch in (8, 2):
             ms = e0.elapsed_time(e1) / 10
             names = [s_["name"] for s_ in plan.steps()]
             plan.close()
-            tb = 8 * nch * (n + n_out) / ms / 1e9
+            tb = ESZ * nch * (n + n_out) / ms / 1e9
             print(f"{nch} ch {fi:7.3f} -> {fo:7.3f}  {ms:8.3f} ms  {tb:6.2f} TB/s  {names}", flush=True)
             del x, out
