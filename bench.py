@@ -128,27 +128,51 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-def self_launch(n):
+def self_launch(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: N children of this script, one rank each (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set), started BEFORE this process imports torch or touches a device; rank 0's JSON line is
-    relayed, a failing child fails the run."""
+    relayed.  The children are polled: the first one that exits non-zero (an import error, a rendezvous port taken
+    between the bind below and the child's own bind, a rank that failed) ends the others -- they would otherwise sit in
+    a barrier or a collective until the rendezvous / RCCL watchdog gives up --, and so does an overall time limit
+    (SIGOPS_BENCH_TIMEOUT seconds, default 3600).  No re-exec anywhere: fresh children, or a non-zero exit."""
     import socket
+    import tempfile
 
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SIGOPS_BENCH_TIMEOUT", "3600"))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()  # (a file, not a pipe: nobody has to drain it while the children are polled)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [p.wait() for p in procs]
-    for line in out0.splitlines():
-        if line.startswith("{"):
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t0 = time.monotonic()
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            why = "rank %d exited with %d" % bad[0]
+        elif time.monotonic() - t0 > timeout_s:
+            why = "no result after %.0f s (SIGOPS_BENCH_TIMEOUT)" % timeout_s
+        if why:
+            for p in procs:  # (exactly the children started above, by handle)
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    for line in out0.read().decode().splitlines():
+        if line.startswith("{") and not why:
             print(line, flush=True)
-    if any(codes):
-        raise SystemExit("bench.py: ranks exited with %s" % codes)
+    if why or any(codes):
+        raise SystemExit("bench.py: %s; ranks exited with %s" % (why or "a rank failed", codes))
 
 
 def launch_path_only(args, torch, dist, rank, world):
@@ -518,10 +542,10 @@ def main():
         a4 = argparse.Namespace(**vars(args))
         a4.workload = "config4"
         a4.steps, a4.warmup = max(5, args.steps // 4), max(2, args.warmup // 2)
-        try:
-            config4 = bench_multi.run(a4, so, torch, dist, rank, local_rank, world, dev, emit=False)
-        except Exception as exc:  # (the headline line must not depend on the secondary workload)
-            config4 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        # (the headline line must not depend on the secondary workload -- nor hang on it: bench_multi.run agrees over
+        #  all ranks, after its local set-up and after a first local execute, that every rank is still there before it
+        #  enters its barriers and all-gathers; a rank that failed makes all of them skip the workload)
+        config4 = bench_multi.run(a4, so, torch, dist, rank, local_rank, world, dev, emit=False)
 
     # ---- correctness gate (rank 0, same device noise, a prefix); the whole length: parity_full below ----
     gate = None

@@ -192,10 +192,19 @@ void Plan::finalize() {
         if (S.fused_away) continue;  // (runs inside its consumer's launch)
         const char* nm = S.kind == ST_SOS ? (S.rsos_src >= 0 ? "k_rsos" : S.sg.exact ? "k_sos_exact" : "k_sos") : S.kind == ST_RESAMPLE ? (S.periodic ? "k_resample_periodic" : S.rows ? "k_resample_rows" : S.tiled ? (S.arbk ? "k_resample_arb" : S.rt.pair ? "k_resample_tiled2" : "k_resample_tiled") : "k_resample") : "k_sumsq";
         Step st{1, sid, nm, 0};
-        int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
-        if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in + S.rs.n_out) * S.rs.nch * esz;
-        else if (S.kind == ST_SOS) st.bytes = 2 * (S.need - S.base) * S.sg.nch * esz;
-        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in + S.rg.n_out) * S.rg.nch * esz;
+        // algorithmic bytes of a stage: the samples it reads in the type they have WHERE THEY LIE (a Float32 array under a
+        // Float64 map is 4 bytes a sample, whatever the node's promoted type) plus the samples it writes in the type of
+        // the buffer they go to (a Float64 stage that rounds into the Float32 result itself writes 4)
+        const int64_t esz = (int64_t)dsize(nodes[S.node].dtype);
+        const int64_t osz = (sid == alias_stage && alias_narrow) ? (int64_t)dsize(out.dtype) : esz;
+        auto src_esz = [&](const Stage& R) -> int64_t {  // a resampler's source: carrier 0's array / buffer, else its child
+            if (!R.carriers.empty()) return (int64_t)dsize(R.carriers[0].dtype);
+            const std::vector<int>& kids = nodes[R.node].kids;
+            return !kids.empty() && kids[0] >= 0 ? (int64_t)dsize(nodes[kids[0]].dtype) : esz;
+        };
+        if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in * src_esz(stages[S.rsos_src]) + S.rs.n_out * osz) * S.rs.nch;
+        else if (S.kind == ST_SOS) st.bytes = (S.need - S.base) * S.sg.nch * (esz + osz);
+        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * src_esz(S) + S.rg.n_out * osz) * S.rg.nch;
         else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
         steps.push_back(st);
     }
@@ -579,6 +588,18 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             long long t0 = 0;
                             for (size_t i = 0; i < rtrace_n; ++i)
                                 if (tr[i] && (!t0 || tr[i] < t0)) t0 = tr[i];
+                            if (std::atoi(std::getenv("SIGOPS_RSOS_TRACE")) == 2) {  // a -DSO_RSOS_COUNT=1 build: poll counters, raw
+                                for (int w = 0; w < rs.nwaves; ++w)
+                                    for (int it = 0; it < 5; ++it) {
+                                        const long long* q = &tr[((size_t)w * kRsosTraceIters + it) * 8];
+                                        bool any = false;
+                                        for (int k = 0; k < 8; ++k) any = any || q[k];
+                                        if (!any) continue;
+                                        std::fprintf(stderr, "[rsos-count] w%02d row%d", w, it);
+                                        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld", q[k] - 1);
+                                        std::fprintf(stderr, "\n");
+                                    }
+                            } else
                             for (int w = 0; w < rs.nwaves; ++w)
                                 for (int it = 0; it < kRsosTraceIters; ++it) {
                                     const long long* q = &tr[((size_t)w * kRsosTraceIters + it) * 8];

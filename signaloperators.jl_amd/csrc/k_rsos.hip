@@ -132,6 +132,17 @@ __device__ __forceinline__ void rsos_add(uint32_t la, uint32_t row_bytes, v2d gn
     }
 }
 
+// ... with the rows' distance known at compile time (RB bytes; the ring geometries of the common shapes): one address register
+// and immediate offsets -- no vector instruction per row (every one of them waits for a gap in the MFMA stream of the
+// chain wave and the y wave this wave shares its SIMD with: ~30 of them per chunk were 0.13 ms of the headline's 1.08)
+template <int RB, int C, int RU>
+__device__ __forceinline__ void rsos_add_imm(uint32_t la, double g0, double g1) {
+    if constexpr (C < RU) {
+        asm volatile("ds_add_f64 %0, %1 offset:%3\n\tds_add_f64 %0, %2 offset:%4" ::"v"(la), "v"(g0), "v"(g1), "n"(C * RB), "n"(C * RB + 8) : "memory");
+        rsos_add_imm<RB, C + 1, RU>(la, g0, g1);
+    }
+}
+
 // A landed chunk of a Float32 array: 128 floats in the upper half of each row's 1 KB slot.  Widened in place -- lane l
 // owns frames l and 64 + l of every row; all reads (the upper half) are back before the first write, so the lower
 // half's doubles may overwrite what the upper half's were read from -- with the fused step applied on the way
@@ -200,14 +211,23 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 #ifndef SO_RSOS_TRACE
 #define SO_RSOS_TRACE 0  // (build with -DSO_RSOS_TRACE=1: the stamps cost the y waves ~70 instructions per block even when off)
 #endif
-__device__ __forceinline__ void rsos_stamp(long long* trace, int wave, int it, int k) {
-    constexpr int it0 = 400;
+__device__ __forceinline__ void rsos_stamp(long long* trace, int wave, int it, int k, int it0 = 400) {
     if constexpr (!SO_RSOS_TRACE) return;
     if (trace != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it >= it0 && it < it0 + kRsosTraceIters)
         ((long long SO_GLB*)trace)[(wave * kRsosTraceIters + (it - it0)) * 8 + k] = clock64();
 }
 
-// dynamic LDS: [ngroups][KS][64] taps | [16][rpitch] ring | [NX][3][64] D.x blocks | [NX][3][64] states | [16][16][2] sine bases
+// who waits for whom (tuning aid, a -DSO_RSOS_COUNT=1 build with SIGOPS_RSOS_TRACE=2): every wave of workgroup 0 counts the
+// polls of each of its waits -- in the spin paths only, nothing in the common path -- and leaves them in its first trace row
+#ifndef SO_RSOS_COUNT
+#define SO_RSOS_COUNT 0
+#endif
+__device__ __forceinline__ void rsos_count_out(long long* trace, int wave, int row, int k, long long v) {
+    if constexpr (!SO_RSOS_COUNT) return;
+    if (trace != nullptr && blockIdx.x == 0) ((long long SO_GLB*)trace)[((wave * kRsosTraceIters) + row) * 8 + k] = v + 1;
+}
+
+// dynamic LDS: [ngroups][KS][64] taps | [16][rpitch] ring | [NX][3][64] D.x blocks | [NS][3][64] states | [16][16][2] sine bases
 struct RsosLds {
     SO_LDS double *taps, *ring, *gtab;
     volatile SO_LDS double *xs, *ss;  // what the waves hand each other
@@ -217,14 +237,20 @@ struct RsosLds {
 __device__ __forceinline__ SO_LDS double* rsos_lds_ptr(const void* p) {
     return (SO_LDS double*)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const SO_LDS void*)p);
 }
-__device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch, int nx) {  // tapd: doubles of the tap table in LDS
+// state slots: the state entering block b is written at the chain's step b and read by the back part of block b, which its
+// y wave runs right behind the front part of its block b + NY -- the chain cannot pass b + NY before that front part has
+// delivered its D . x, so a state is dead NY + 1 steps after it was written; NY + 4 slots (b modulo that) leave three
+// chain steps (> 700 cycles) for the three reads behind the flag.  (Round 4 kept 2 NY + 1 like the D . x slots: 13.8 KB
+// that the input ring can use -- 768 frames instead of 640 for the headline's geometry.)
+__host__ __device__ constexpr int rsos_nss(int ny) { return ny + 4; }
+__device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch, int nx, int ns) {  // tapd: doubles of the tap table in LDS
     RsosLds l;
     SO_LDS double* dyn = rsos_lds_ptr(dyn_);
     l.taps = dyn;
     l.ring = l.taps + tapd;
     l.xs = l.ring + (size_t)16 * rpitch;
     l.ss = l.xs + (size_t)nx * 192;
-    l.gtab = (SO_LDS double*)l.ss + (size_t)nx * 192;
+    l.gtab = (SO_LDS double*)l.ss + (size_t)ns * 192;
     return l;
 }
 
@@ -268,7 +294,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
     const SO_LDS RsSos& g = sh->g;
     const int ngroups = uni(g.ngroups);
-    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, uni(g.rpitch), NX);
+    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, uni(g.rpitch), NX, rsos_nss(NY));
     const int NB = (uni(g.wp) + (int)rfl64(g.pr)) * ngroups;
     const double SO_GLB* mats = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)g.mats);
     long long* trace = (long long*)rfl64((int64_t)(uintptr_t)g.trace);
@@ -284,6 +310,8 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     // carries in registers for all 16 rows.  D . X arrives from the y waves (they have X in registers); the block after
     // the next is already on its way from LDS, its counter polled behind the MFMAs.
     int spins = 0;
+    [[maybe_unused]] int cnt_wait = 0, cnt_blocks = 0;  // (SO_RSOS_COUNT: per lane = the y wave whose D.x was late)
+    [[maybe_unused]] const long long cyc0 = SO_RSOS_COUNT ? clock64() : 0;
     while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1 && !(debug & 4)) spin_pause(spins, 1);
     // Two steps per loop iteration with the roles of the register sets swapped: the state a step leaves is the next
     // step's B operand where it is, the operand set a step has consumed is refilled (under its first MFMA) with the
@@ -300,7 +328,9 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     //                         Addresses, the counter's readfirstlane and the counter value therefore go into the gap
     //                         in front of the first MFMA; under it are scalar and LDS instructions only.
     v4d sA = v4d{0.0, 0.0, 0.0, 0.0}, sB = v4d{0.0, 0.0, 0.0, 0.0};  // state entering the even / odd block
-    double dA[3], dB[3] = {0.0, 0.0, 0.0};                            // D . x of the even / odd block
+    // D . x of the even / odd block, each in the four register pairs an MFMA takes as its C operand (rows 12 .. 15 of the
+    // state do not exist: the fourth pair is never read back and may hold anything -- it is never written either)
+    v4d dA = v4d{0.0, 0.0, 0.0, 0.0}, dB = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int v = 0; v < 3; ++v) dA[v] = l.xs[v * 64 + lane];
     if (NB > 1) {
@@ -312,25 +342,28 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     const uint32_t xs0 = (uint32_t)(uintptr_t)l.xs + (uint32_t)lane * 8u, ss0 = (uint32_t)(uintptr_t)l.ss + (uint32_t)lane * 8u;
     int fA = NB > 2 ? flag_ld(fl_base + 4 * (kRsosFlagXseq + 2 % NX)) : 0x7fffffff;  // counters of blocks 2 and 3
     int fB = NB > 3 ? flag_ld(fl_base + 4 * (kRsosFlagXseq + 3 % NX)) : 0x7fffffff;
-    int slot = 0;  // of block b
-    auto step = [&](int b, v4d& sin, v4d& sout, double (&din)[3], int& fpend) __attribute__((always_inline)) {
+    int slot = 0;   // of block b (D . x slots: b modulo NX)
+    int sslot = 0;  // ... and its state slot (b modulo NS)
+    constexpr int NS = rsos_nss(NY);
+    auto step = [&](int b, v4d& sin, v4d& sout, v4d& din, int& fpend) __attribute__((always_inline)) {
         // ---- the gap in front of the first MFMA: vector instructions ----
         int f = uni(fpend);  // counter of block b + 2's slot, requested two steps ago
         const int s2 = slot + 2 >= NX ? slot + 2 - NX : slot + 2, s4 = s2 + 2 >= NX ? s2 + 2 - NX : s2 + 2;
-        uint32_t ax = xs0 + (uint32_t)s2 * 1536u, as = ss0 + (uint32_t)slot * 1536u;
+        uint32_t ax = xs0 + (uint32_t)s2 * 1536u, as = ss0 + (uint32_t)sslot * 1536u;
         uint32_t af = fl_base + 4u * (uint32_t)(kRsosFlagXseq + s4), ag = fl_base + 4u * (uint32_t)kRsosFlagSseq;
         int bv = b;
         asm volatile("" : "+v"(ax), "+v"(as), "+v"(af), "+v"(ag), "+v"(bv));  // (in vector registers NOW)
-        v4d acc = v4d{din[0], din[1], din[2], 0.0};
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[0], sin[0], acc, 0, 0, 0);
+        v4d acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[0], sin[0], din, 0, 0, 0);  // (C = D . x where the LDS reads left it: no copy)
         __builtin_amdgcn_sched_barrier(0);
         // ---- under it: scalar and LDS instructions ----
         if (b + 2 < NB && !(debug & 512)) {
             if (f < b + 3 && !(debug & 4)) {  // (the y waves are behind: wait here -- everybody waits for this wave anyway)
                 spins = 0;
+                if constexpr (SO_RSOS_COUNT) cnt_blocks += lane == (b + 2) % NY ? 1 : 0;
                 do {
                     spin_pause(spins, 1);
+                    if constexpr (SO_RSOS_COUNT) cnt_wait += lane == (b + 2) % NY ? 1 : 0;
                     f = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
                 } while (f < b + 3);
             }
@@ -349,14 +382,22 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
         __builtin_amdgcn_sched_barrier(0);
         sout = acc;
         slot = slot + 1 == NX ? 0 : slot + 1;
+        sslot = sslot + 1 == NS ? 0 : sslot + 1;
     };
     for (int b = 0; b < NB; b += 2) {
-        rsos_stamp(trace, 0, b, 0);
+        rsos_stamp(trace, 0, b >> 1, 0, 200);
         step(b, sA, sB, dA, fA);
         if (b + 1 < NB) step(b + 1, sB, sA, dB, fB);
-        rsos_stamp(trace, 0, b, 3);
+        rsos_stamp(trace, 0, b >> 1, 3, 200);
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (SO_RSOS_COUNT) {
+        if (lane < 8) rsos_count_out(trace, 0, 0, lane, cnt_wait);
+        else if (lane < 16) rsos_count_out(trace, 0, 1, lane - 8, cnt_wait);
+        if (lane < 8) rsos_count_out(trace, 0, 2, lane, cnt_blocks);
+        else if (lane < 16) rsos_count_out(trace, 0, 3, lane - 8, cnt_blocks);
+        if (lane == 0) rsos_count_out(trace, 0, 4, 0, clock64() - cyc0);
+    }
     // A filter never recovers from a non-finite sample: the reference's recurrence carries a NaN or Inf on in its state
     // to the end of the channel (k_sos_poison).  Here the next range starts from rest wp periods early and
     // would be finite again: a range whose walk ends in a non-finite state is noted per channel (the smallest such
@@ -378,7 +419,13 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
 }
 
 // =========================== loader waves ===========================
-template <int NY, int NL, int RU, bool SRC32>
+// vmcnt of this wave, read without waiting (HW_REG_IB_STS: VM_CNT in bits 3:0 and 23:22)
+__device__ __forceinline__ int vmcnt_now() {
+    const uint32_t v = __builtin_amdgcn_s_getreg(7 | (0 << 6) | (31 << 11));
+    return (int)((v & 0xfu) | ((v >> 18) & 0x30u));
+}
+
+template <int NY, int NL, int RU, bool SRC32, int RB = 0>
 __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
@@ -388,7 +435,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int q = uni(q_);
     const SO_LDS RsSos& g = sh->g;
     const int ngroups = uni(g.ngroups), rpitch = uni(g.rpitch), RING = uni(g.ring), CH = uni(g.chunk);
-    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, rpitch, NX);
+    const RsosLds l = rsos_carve(dyn, uni(g.cyc) > 0 ? 0 : ngroups * uni(g.ks) * 64, rpitch, NX, rsos_nss(NY));
     const int ct = uni(g.ct);
     const int M = (int)rfl64(g.M);
     const int NP = uni(g.wp) + (int)rfl64(g.pr);
@@ -422,14 +469,20 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int kind0 = uni(C0.slot_kind[0]);
     const DLeaf leaf0 = leaf_uniform(sh_->ctl.leaves[min(kCtlLeaves - 1, max(0, uni(C0.slot_leaf[0])))]);
     double2 d0 = double2{0.0, 1.0}, d1 = double2{0.0, 1.0};
+    double2 d16 = double2{0.0, 1.0};  // (sin, cos) of the phase 16 chunks add: the share bases' step from refresh to refresh
     double gconst = 0.0;
     if (fuse >= 0) {
         if (fuse_sine) {  // (the lane's two frames of a chunk: 2 l and 2 l + 1, or l and 64 + l where it widens Float32)
             d0 = rsos_sine_at(src32 ? lane : 2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
             d1 = rsos_sine_at(src32 ? 64 + lane : 2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+            d16 = rsos_sine_at(16 * CH, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
         } else
             gconst = slot_eval(kind0, leaf0, 0);
     }
+    // share bases of this lane's (unit slot, chunk of sixteen): evaluated in full every eighth refresh, turned by d16 in between
+    // (4 multiply-adds instead of the ~150 vector instructions of a sincospi next to the chain wave's MFMAs; seven
+    // rotations add < 1e-15 to a base)
+    double2 rbase[4] = {double2{0.0, 1.0}, double2{0.0, 1.0}, double2{0.0, 1.0}, double2{0.0, 1.0}};
     // unit u: rows [u RU, (u + 1) RU) of the group = RU channels of range ri.  What the loop needs of this wave's units
     // (u = q + j NL) sits in lane j: first staged frame (ring position 0), its address in channel ch0's row, the unit's
     // first ring row in LDS, and the chunks [klo, khi) that lie inside carrier 0 and the signal -- the LDS-DMA ones.
@@ -509,30 +562,48 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         return n;
     };
     auto retire = [&](int k, int rho0, int allowed) __attribute__((always_inline)) {
-        rsos_stamp(trace, wave, k, 2);
-        wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
-        rsos_stamp(trace, wave, k, 3);
-        if ((fuse >= 0 || src32) && !(debug & 2)) {
-            if (fuse >= 0 && fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // share bases of chunks k .. k+15: lane = (unit slot, chunk)
-                for (int j4 = 0; j4 < MU; j4 += 4) {
-                    const int j = j4 + (lane >> 4);
+        rsos_stamp(trace, wave, k, 2, 40);
+        const bool gain = (fuse >= 0 || src32) && !(debug & 2);
+        // what does not depend on the chunk's samples comes BEFORE the wait for them: the share bases of the next sixteen
+        // chunks (every sixteenth chunk) and this chunk's own, read back from LDS
+        if (gain && fuse >= 0 && fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // lane = (unit slot, chunk)
+#pragma unroll
+            for (int j4 = 0; j4 < 16; j4 += 4) {
+                if (j4 >= MU) break;
+                const int j = j4 + (lane >> 4);
+                double2 bs;
+                if ((k & 127) == 0 || (debug & 65536)) {
                     const int64_t Au = (int64_t)(((uint64_t)(uint32_t)__shfl((int)((uint64_t)Au_l >> 32), j, 64) << 32) |
                                                  (uint32_t)__shfl((int)(uint32_t)Au_l, j, 64));
-                    if (j < MU) {
-                        const double2 bs = rsos_sine_at(Au + ((int64_t)(k + (lane & 15)) << shift) + leaf0.df + 1, leaf0.v0, leaf0.v1, leaf0.v2,
-                                                        leaf0.flag);
-                        const int u = q + j * NL;
-                        l.gtab[(u * 16 + (lane & 15)) * 2] = bs.x;
-                        l.gtab[(u * 16 + (lane & 15)) * 2 + 1] = bs.y;
-                    }
+                    bs = rsos_sine_at(Au + ((int64_t)(k + (lane & 15)) << shift) + leaf0.df + 1, leaf0.v0, leaf0.v1, leaf0.v2, leaf0.flag);
+                } else {
+                    const double2 o = rbase[j4 >> 2];
+                    bs.x = fma(o.x, d16.y, o.y * d16.x);
+                    bs.y = fma(o.y, d16.y, -(o.x * d16.x));
+                }
+                rbase[j4 >> 2] = bs;
+                if (j < MU) {
+                    const int u = q + j * NL;
+                    l.gtab[(u * 16 + (lane & 15)) * 2] = bs.x;
+                    l.gtab[(u * 16 + (lane & 15)) * 2 + 1] = bs.y;
                 }
             }
+        }
+        double2 bs0 = double2{0.0, 0.0}, bs1 = double2{0.0, 0.0};  // the first two units' bases (the others read theirs below)
+        if (gain && fuse >= 0 && fuse_sine) {
+            const int u0 = q, u1 = q + NL;
+            bs0 = double2{l.gtab[(u0 * 16 + (k & 15)) * 2], l.gtab[(u0 * 16 + (k & 15)) * 2 + 1]};
+            if (MU > 1) bs1 = double2{l.gtab[(u1 * 16 + (k & 15)) * 2], l.gtab[(u1 * 16 + (k & 15)) * 2 + 1]};
+        }
+        wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
+        rsos_stamp(trace, wave, k, 3, 40);
+        if (gain) {
             for (int j = 0; j < MU; ++j) {
                 if (!(k >= u_klo(j) && k < u_khi(j))) continue;
                 const int u = q + j * NL;
                 v2d gn;
                 if (fuse_sine) {
-                    const double2 bs = double2{l.gtab[(u * 16 + (k & 15)) * 2], l.gtab[(u * 16 + (k & 15)) * 2 + 1]};
+                    const double2 bs = j == 0 ? bs0 : j == 1 ? bs1 : double2{l.gtab[(u * 16 + (k & 15)) * 2], l.gtab[(u * 16 + (k & 15)) * 2 + 1]};
                     gn[0] = fma(bs.x, d0.y, bs.y * d0.x);
                     gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
                 } else
@@ -550,15 +621,21 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
                     switch (fuse) {
                     case 0: rsos_rmw<RU, 0>(la, row_bytes, gn); break;
-                    case 1: rsos_add<RU>(la, row_bytes, gn); break;         // v + m: the LDS adds (no fp64 vector instruction)
-                    case 2: rsos_add<RU>(la, row_bytes, -gn); break;        // v - m
+                    case 1:  // v + m: the LDS adds (no fp64 vector instruction)
+                        if constexpr (RB > 0) rsos_add_imm<RB, 0, RU>(la, gn[0], gn[1]);
+                        else rsos_add<RU>(la, row_bytes, gn);
+                        break;
+                    case 2:  // v - m
+                        if constexpr (RB > 0) rsos_add_imm<RB, 0, RU>(la, -gn[0], -gn[1]);
+                        else rsos_add<RU>(la, row_bytes, -gn);
+                        break;
                     default: rsos_rmw<RU, 3>(la, row_bytes, gn); break;
                     }
                 }
             }
         }
         flag_st(fl_base + 4 * (kRsosFlagLdp + q), (k + 1) * CH);
-        rsos_stamp(trace, wave, k, 4);
+        rsos_stamp(trace, wave, k, 4, 40);
     };
     int issued = 0, retired = 0;
     int rho_i = 0, rho_r = 0;       // ring positions of the next chunk to issue / to retire
@@ -566,7 +643,23 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int depth = uni(g.depth);
     int minrd = 0;  // what the y waves no longer need (cached)
     int spins = 0;
+    [[maybe_unused]] int cnt_idle = 0;
+    [[maybe_unused]] const long long cyc0 = SO_RSOS_COUNT ? clock64() : 0;
     for (;;) {
+        // a chunk that has landed is published before anything else is issued (vmcnt read without waiting): with "issue
+        // while there is room, then retire" a landed chunk waited for up to `depth` chunk issues of 16 LDS-DMA instructions
+        // each -- and the y waves for it (SIGOPS_RSOS_DEPTH=2 was 7 % faster than 4)
+        if (retired < issued && !(debug & 16384)) {
+            const int inflight = issued - retired;
+            const int allowed = (inflight > 1 ? c0n : 0) + (inflight > 2 ? c1n : 0) + (inflight > 3 ? c2n : 0);
+            if (vmcnt_now() <= allowed) {
+                retire(retired, rho_r, allowed);
+                rho_r = rho_r + CH == RING ? 0 : rho_r + CH;
+                ++retired;
+                spins = 0;
+                continue;
+            }
+        }
         bool can = issued < NK && issued - retired < depth;
         if (can && (issued + 1) * CH > RING) {  // ring space: the chunk overwrites positions rho - ring
             const int needrd = (issued + 1) * CH - RING;
@@ -578,9 +671,9 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         }
         if (can) {
             spins = 0;
-            rsos_stamp(trace, wave, issued, 0);
+            rsos_stamp(trace, wave, issued, 0, 40);
             const int n = issue(issued, rho_i);
-            rsos_stamp(trace, wave, issued, 1);
+            rsos_stamp(trace, wave, issued, 1, 40);
             rho_i = rho_i + CH == RING ? 0 : rho_i + CH;
             c2n = c1n;
             c1n = c0n;
@@ -599,8 +692,15 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         }
         if (issued >= NK) break;
         spin_pause(spins, 2);
+        if constexpr (SO_RSOS_COUNT) ++cnt_idle;
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (SO_RSOS_COUNT) {
+        if (lane == 0) {
+            rsos_count_out(trace, wave, 0, 0, cnt_idle);
+            rsos_count_out(trace, wave, 0, 4, clock64() - cyc0);
+        }
+    }
 }
 
 // =========================== y waves ===========================
@@ -616,7 +716,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const int yi = uni(yi_);
     const SO_LDS RsSos& g = sh->g;
     const int ngroups = uni(g.ngroups), rpitch = uni(g.rpitch), RING = uni(g.ring);
-    const RsosLds l = rsos_carve(dyn, CYC > 0 ? 0 : ngroups * KS * 64, rpitch, NX);
+    const RsosLds l = rsos_carve(dyn, CYC > 0 ? 0 : ngroups * KS * 64, rpitch, NX, rsos_nss(NY));
     const int ct = uni(g.ct), wp = uni(g.wp), debug = uni(g.debug);
     const int M = (int)rfl64(g.M);
     const int NB = (wp + (int)rfl64(g.pr)) * ngroups;
@@ -709,7 +809,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     // of one block back to back all y waves ended up waiting for the chain together, and then the chain for all of
     // them: a convoy.)  An in-order wave does nothing while it waits, so what a block costs besides its 21 MFMAs is
     // one LDS round trip, the hazard gaps behind three MFMA groups and ~100 other instructions.
-    int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, exchange slot
+    constexpr int NS = rsos_nss(NY);
+    int sslot = yi % NS;                 // state slot of the block in hand (b modulo NS)
+    int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, STATE slot
+    [[maybe_unused]] int cnt_in = 0, cnt_in_b = 0, cnt_st = 0, cnt_st_b = 0;
+    [[maybe_unused]] const long long cyc0 = SO_RSOS_COUNT ? clock64() : 0;
     // ... and its X^T T^T: two register sets that swap roles from block to block (the set a block fills is the one the
     // next block's back part accumulates into and stores from: no copy between them)
     v4d payA = v4d{0.0, 0.0, 0.0, 0.0}, payB = v4d{0.0, 0.0, 0.0, 0.0};
@@ -719,15 +823,17 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         int spins = 0;
         sq = uni(sq);
         if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
+            if constexpr (SO_RSOS_COUNT) ++cnt_st_b;
             do {
                 spin_pause(spins, 1);
+                if constexpr (SO_RSOS_COUNT) ++cnt_st;
                 sq = uni(flag_ld(f_sseq));
             } while (sq < pb_);
 #pragma unroll
             for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
         }
         if (ppi_ < wp) return;  // (a warm-up block: nothing to store)
-        rsos_stamp(trace, wave, pb_ / NY, 4);
+        rsos_stamp(trace, wave, pb_ / NY, 4, 40);
         v4d ay = pay_;
 #pragma unroll
         for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
@@ -748,19 +854,25 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
                     if (pb_ < nbs[v]) yp[v][t0] = (TO)ay[v];
             }
         }
-        rsos_stamp(trace, wave, pb_ / NY, 5);
+        rsos_stamp(trace, wave, pb_ / NY, 5, 40);
     };
-    auto block = [&](int b, const double (&at)[KS], v4d& pin, v4d& pout) __attribute__((always_inline)) {
-        const int wb = pi * M + uni(sh->jend[gi]) - ulo_kw;
+    // (je / jn: the window ends of this block's phase group and of the wave's next block's -- loop constants of a wave whose
+    //  blocks cycle through CYC groups, read from LDS otherwise)
+    auto block = [&](int b, const double (&at)[KS], v4d& pin, v4d& pout, int je, int jn) __attribute__((always_inline)) {
+        const int wb = pi * M + je - ulo_kw;
         const int need = wb + kw + 16;
-        rsos_stamp(trace, wave, b / NY, 0);
+        rsos_stamp(trace, wave, b / NY, 0, 40);
         int spins = 0;
+        if constexpr (SO_RSOS_COUNT) cnt_in_b += avail < need ? 1 : 0;
         while (avail < need && !(debug & 16)) {
             const int v = lane < NL ? flag_ld(fl_base + 4 * (kRsosFlagLdp + lane)) : 0x7fffffff;
             avail = wave_min(v, NL);
-            if (avail < need) spin_pause(spins, 2);
+            if (avail < need) {
+                spin_pause(spins, 2);
+                if constexpr (SO_RSOS_COUNT) ++cnt_in;
+            }
         }
-        rsos_stamp(trace, wave, b / NY, 1);
+        rsos_stamp(trace, wave, b / NY, 1, 40);
         // ---- the block's LDS reads, all at once ----
         int sq = 0;
         double sv[3] = {0.0, 0.0, 0.0};
@@ -801,7 +913,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             gi2 -= ngroups;
             ++pi2;
         }
-        const int wb2 = b + NY < NB ? pi2 * M + uni(sh->jend[gi2]) - ulo_kw : 0x7fffffff;
+        const int wb2 = b + NY < NB ? pi2 * M + jn - ulo_kw : 0x7fffffff;
         flag_st(fl_base + 4 * (kRsosFlagYrd + yi), wb2);
         if (b + NY < NB) {
             wbm += wb2 - wb;
@@ -813,7 +925,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             if (b < nb0) ax = v4d{0.0, 0.0, 0.0, 0.0};
             asm volatile("" : "+v"(ax));
         }
-        rsos_stamp(trace, wave, b / NY, 2);
+        rsos_stamp(trace, wave, b / NY, 2, 40);
         // ---- D . X for the chain wave (its share of the recurrence that does not depend on the state) ----
         v4d dx = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -830,10 +942,12 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
         // ---- the previous block's result ----
         if (pb_ >= 0) back(sq, sv, pin);
-        rsos_stamp(trace, wave, b / NY, 3);
+        rsos_stamp(trace, wave, b / NY, 3, 40);
         pb_ = b;
         ppi_ = pi;
-        pslot_ = slot;
+        pslot_ = sslot;
+        sslot += NY % NS;
+        if (sslot >= NS) sslot -= NS;
         pi = pi2;
         gi = gi2;
         slot += NY;  // (b + NY) mod (2 NY + 1)
@@ -852,9 +966,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     if constexpr (CYC > 0) {
         const double SO_GLB* tab = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)sh->tab);
         double treg[CYC][KS];
+        int jec[CYC];
 #pragma unroll
         for (int c = 0; c < CYC; ++c) {
             const int gc = (yi + c * NY) % ngroups;
+            jec[c] = uni(sh->jend[gc]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) treg[c][s] = tab[((size_t)gc * KS + s) * 64 + lane];
         }
@@ -862,22 +978,34 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #pragma unroll
             for (int k = 0; k < 2 * CYC; ++k) {
                 if (b < NB) {
-                    if ((k & 1) == 0) block(b, treg[k % CYC], payA, payB);
-                    else block(b, treg[k % CYC], payB, payA);
+                    if ((k & 1) == 0) block(b, treg[k % CYC], payA, payB, jec[k % CYC], jec[(k + 1) % CYC]);
+                    else block(b, treg[k % CYC], payB, payA, jec[k % CYC], jec[(k + 1) % CYC]);
                     cur = (k & 1) ^ 1;
                 }
                 b += NY;
             }
         }
         last_back();
+        if constexpr (SO_RSOS_COUNT) {
+            if (lane == 0) {
+                rsos_count_out(trace, wave, 0, 0, cnt_in);
+                rsos_count_out(trace, wave, 0, 1, cnt_in_b);
+                rsos_count_out(trace, wave, 0, 2, cnt_st);
+                rsos_count_out(trace, wave, 0, 3, cnt_st_b);
+                rsos_count_out(trace, wave, 0, 4, clock64() - cyc0);
+            }
+        }
     } else {
         for (int b = yi; b < NB; b += NY) {
             double at[KS];
             const SO_LDS double* tp = l.taps + gi * KS * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) at[s] = tp[s * 64];
-            if (cur == 0) block(b, at, payA, payB);
-            else block(b, at, payB, payA);
+            int gn = gi + NY;
+            while (gn >= ngroups) gn -= ngroups;
+            const int je = uni(sh->jend[gi]), jn = uni(sh->jend[gn]);
+            if (cur == 0) block(b, at, payA, payB, je, jn);
+            else block(b, at, payB, payA, je, jn);
             cur ^= 1;
         }
         last_back();
@@ -915,7 +1043,7 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
     }
     const int64_t ncg = g.nch / g.ct;
     const int64_t ngrp = ncg * ((g.nranges + g.rgs - 1) / g.rgs);
-    double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 192;
+    double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 192;  // (state slot 0)
     const int ru = g.ct < 8 ? g.ct : 8;
     for (int64_t G = blockIdx.x; G < ngrp; G += gridDim.x) {
         __syncthreads();  // (the previous group's LDS traffic is over; the first time: the tables are in place)
@@ -930,6 +1058,8 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
             switch (ru) {
             case 8:
                 if (g.src32) rsos_loader<NY, NL, 8, true>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 770) rsos_loader<NY, NL, 8, false, 770 * 8>(&sh, lds_raw, G, q);  // (rings of 768 / 640 frames:
+                else if (g.rpitch == 642) rsos_loader<NY, NL, 8, false, 642 * 8>(&sh, lds_raw, G, q);  //  row offsets as immediates)
                 else rsos_loader<NY, NL, 8, false>(&sh, lds_raw, G, q);
                 break;
             case 4:
@@ -967,7 +1097,7 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
     const int ny = nwaves == 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
-    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)nx * 192 + 16 * 16 * 2) * 8;
+    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)rsos_nss(ny) * 192 + 16 * 16 * 2) * 8;
 }
 size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 
@@ -1021,7 +1151,7 @@ int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, con
     if (g.ngroups > kRsosMaxGroups) return -1;
 #define SO_RS(KS_) \
     if (g.ks == KS_) return g.out_f32 ? launch_rsos_t<KS_, float>(tab, jend, g, y, gsrc, grid, st) : launch_rsos_t<KS_, double>(tab, jend, g, y, gsrc, grid, st);
-    SO_RS(12) SO_RS(14) SO_RS(16) SO_RS(20)
+    SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
 #undef SO_RS
     return -1;
 }

@@ -1668,8 +1668,42 @@ void Plan::fuse_resample_sos() {
         }
         if (!own_tab && (!blocks_ok || !S3.periodic)) continue;
         if (S3.base % Lp != 0 || Mp >= (1 << 20)) continue;
+        // The resampler stage's table has the k-steps of K3's instantiations (12, 14, 16 ...); its windows end at the
+        // group's newest input, so what a group does not need are its OLDEST slots.  Where every group's first slots are
+        // zero the fused kernel takes a shorter window from the same table -- 44.1 -> 48 kHz: 38 taps + a span of 14
+        // inputs are 52 = 13 k-steps, not 14: 27 MFMAs per block instead of 28 (same products, same order: the dropped
+        // ones were multiplications by zero).  The staged range (ulo) stays the stage's.
+        if (!own_tab && !std::getenv("SIGOPS_RSOS_NOTRIM") && !S3.tab_host.empty() && (size_t)ngp * kwp * 16 == S3.tab_host.size()) {
+            int lead = kwp;  // leading all-zero slots common to all groups
+            for (int gi = 0; gi < ngp && lead > 0; ++gi)
+                for (int kk = 0; kk < lead; ++kk) {
+                    bool z = true;
+                    for (int rr = 0; rr < 16 && z; ++rr) z = S3.tab_host[((size_t)gi * kwp + kk) * 16 + rr] == 0.0;
+                    if (!z) {
+                        lead = kk;
+                        break;
+                    }
+                }
+            int ksc = 0;
+            for (int k : {12, 13, 14, 16, 20})
+                if (!ksc && 4 * k >= kwp - lead) ksc = k;
+            if (ksc && 4 * ksc < kwp) {
+                const int drop = kwp - 4 * ksc, kw = 4 * ksc;
+                own_taps.assign((size_t)ngp * kw * 16, 0.0);
+                for (int gi = 0; gi < ngp; ++gi)
+                    for (int kk = 0; kk < kw; ++kk)
+                        for (int rr = 0; rr < 16; ++rr)
+                            own_taps[((size_t)gi * kw + kk) * 16 + rr] = S3.tab_host[((size_t)gi * kwp + kk + drop) * 16 + rr];
+                own_jend = S3.jend_host;
+                kwp = kw;
+                own_tab = true;
+                if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                    std::fprintf(stderr, "[sigops] k_rsos: %d leading zero slots in every group's window: %d k-steps instead of %d\n", lead, ksc,
+                                 (kw + drop) / 4);
+            }
+        }
         const int ks = kwp / 4;
-        if (!(ks == 12 || ks == 14 || ks == 16 || ks == 20)) continue;
+        if (!(ks == 12 || ks == 13 || ks == 14 || ks == 16 || ks == 20)) continue;
         bool ok = true;
         // GA carriers (a Float32 array whose Float64 gain or summand K3's compute waves apply at the MFMA operand): this
         // kernel's loader widens the landed Float32 chunk in place and applies the step on the way, so the carriers go
@@ -1693,10 +1727,10 @@ void Plan::fuse_resample_sos() {
         const int64_t need = S2.need - S3.base, L = Lp;
         const int64_t store_lo = S2.base - S3.base;
         const int64_t nperiods = (need + L - 1) / L;
-        // warm-up: the first wp with ||A^(wp L)|| < 2^-70
+        // warm-up: the first wp with ||A^(wp L)|| < 2^-70 (SIGOPS_RSOS_WTOL: another exponent, a measurement aid)
         int64_t wp = 1;
         {
-            const double tol = std::ldexp(1.0, -70);
+            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 70)));
             const Mat P = matpow(sos_state_matrix(cf), L, D);
             Mat cur = P;
             while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {

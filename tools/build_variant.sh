@@ -6,8 +6,10 @@ set -eu
 name=$1; unit=$2; shift 2
 here=$(cd "$(dirname "$0")/../signaloperators.jl_amd/csrc" && pwd)
 obj=$here/${unit%.hip}_$name.o
+if [ -n "${RELINK_ONLY:-}" ] && [ -f "$obj" ]; then :; else
 /opt/rocm/bin/hipcc -mllvm -disable-machine-licm --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall \
     -Wno-unused-function "$@" -x hip -c "$here/$unit" -o "$obj"
+fi
 objs=""
 for s in k_pointwise k_sos k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
     if [ "$s.hip" = "$unit" ]; then objs="$objs $obj"; else objs="$objs $here/$s.o"; fi
