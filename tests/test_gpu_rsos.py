@@ -316,10 +316,14 @@ def test_device_tensor_with_an_odd_number_of_frames():
         with env(SIGOPS_RSOS_MINGROUPS=1):
             so.sink_into(out, x)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            so.sink_into(out, x)
-            torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+            best = None  # (the best of three: one call in a few hundred stalls for tens of milliseconds behind freed buffers)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                so.sink_into(out, x)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+        times.append(best)
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert times[0] < 3 * times[1] + 0.005, times
