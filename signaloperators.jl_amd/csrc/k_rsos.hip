@@ -238,11 +238,17 @@ __device__ __forceinline__ SO_LDS double* rsos_lds_ptr(const void* p) {
     return (SO_LDS double*)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const SO_LDS void*)p);
 }
 // state slots: the state entering block b is written at the chain's step b and read by the back part of block b, which its
-// y wave runs right behind the front part of its block b + NY -- the chain cannot pass b + NY before that front part has
-// delivered its D . x, so a state is dead NY + 1 steps after it was written; NY + 4 slots (b modulo that) leave three
-// chain steps (> 700 cycles) for the three reads behind the flag.  (Round 4 kept 2 NY + 1 like the D . x slots: 13.8 KB
-// that the input ring can use -- 768 frames instead of 640 for the headline's geometry.)
-__host__ __device__ constexpr int rsos_nss(int ny) { return ny + 4; }
+// y wave runs BEHIND the front part of its block b + NY -- i.e. after it has handed over that block's D . x, when the chain is
+// free to run on.  What holds the chain back for good is the same wave's NEXT hand-over: D . x of block b + 2 NY comes behind
+// the back part of block b in program order, and the chain reads D . x two steps ahead, so it cannot begin step b + 2 NY - 1
+// before the state of block b has been read: 2 NY - 1 slots are safe by construction, fewer are a race that a faster chain
+// wins (NY + 4 slots, tried for a larger input ring: one bad block in a million, the re-read of a low-priority wave whose
+// vector instructions wait behind its neighbours' MFMAs while the chain runs six steps; waiting for the state BEFORE the
+// hand-over instead makes the y waves and the chain wait for each other: 0.955 -> 1.007 ms).
+#ifndef SO_NSS_EXTRA
+#define SO_NSS_EXTRA (ny + 1)  // (-DSO_NSS_EXTRA=4: the racy NY + 4 of the measurement above)
+#endif
+__host__ __device__ constexpr int rsos_nss(int ny) { return ny + SO_NSS_EXTRA; }
 __device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch, int nx, int ns) {  // tapd: doubles of the tap table in LDS
     RsosLds l;
     SO_LDS double* dyn = rsos_lds_ptr(dyn_);
@@ -356,9 +362,24 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
         __builtin_amdgcn_sched_barrier(0);
         v4d acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[0], sin[0], din, 0, 0, 0);  // (C = D . x where the LDS reads left it: no copy)
         __builtin_amdgcn_sched_barrier(0);
-        // ---- under it: scalar and LDS instructions ----
-        if (b + 2 < NB && !(debug & 512)) {
-            if (f < b + 3 && !(debug & 4)) {  // (the y waves are behind: wait here -- everybody waits for this wave anyway)
+        // ---- under the MFMAs: scalar and LDS instructions, a few per MFMA (eight LDS instructions under the first one took
+        //      longer to issue than its 64 cycles and pushed the second back: 0.74 ms for the chain alone, 0.53 without them).
+        //      Under the first: the state entering block b (the registers the MFMAs are reading) for its y wave -- the
+        //      earliest it can go.  Under the second: D . x of block b + 2 into the registers the FIRST MFMA took its C
+        //      operand from (issued 64 cycles behind it: that read is over).  ... and the counter of block b + 4.  Nothing under the third: the next step's first wait would count its requests.
+#ifndef SO_CHAIN_ORDER
+#define SO_CHAIN_ORDER 1
+#endif
+        auto put_state = [&]() __attribute__((always_inline)) {
+            if (!(debug & 1024)) {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) *(volatile SO_LDS double*)(uintptr_t)(as + (uint32_t)v * 512u) = sin[v];
+                *(volatile SO_LDS int*)(uintptr_t)ag = bv;
+            }
+        };
+        const bool more = b + 2 < NB && !(debug & 512);
+        auto wait_dx = [&]() __attribute__((always_inline)) {
+            if (more && f < b + 3 && !(debug & 4)) {  // (the y waves are behind: wait here -- everybody waits for this wave anyway)
                 spins = 0;
                 if constexpr (SO_RSOS_COUNT) cnt_blocks += lane == (b + 2) % NY ? 1 : 0;
                 do {
@@ -367,18 +388,35 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
                     f = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
                 } while (f < b + 3);
             }
+        };
+        auto get_dx = [&]() __attribute__((always_inline)) {
+            if (more) {
 #pragma unroll
-            for (int v = 0; v < 3; ++v) din[v] = *(volatile SO_LDS double*)(uintptr_t)(ax + (uint32_t)v * 512u);
-            if (b + 4 < NB) fpend = *(volatile SO_LDS int*)(uintptr_t)af;
+                for (int v = 0; v < 3; ++v) din[v] = *(volatile SO_LDS double*)(uintptr_t)(ax + (uint32_t)v * 512u);
+            }
+        };
+        auto get_flag = [&]() __attribute__((always_inline)) {
+            if (more && b + 4 < NB) fpend = *(volatile SO_LDS int*)(uintptr_t)af;
+        };
+        if constexpr (SO_CHAIN_ORDER == 0) {
+            wait_dx();
+            get_dx();
+            get_flag();
+            put_state();
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[1], sin[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[2], sin[2], acc, 0, 0, 0);
+        } else {
+            put_state();
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[1], sin[1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_dx();
+            get_dx();
+            get_flag();
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[2], sin[2], acc, 0, 0, 0);
         }
-        if (!(debug & 1024)) {  // the state entering block b (the registers the MFMAs are reading) for its y wave
-#pragma unroll
-            for (int v = 0; v < 3; ++v) *(volatile SO_LDS double*)(uintptr_t)(as + (uint32_t)v * 512u) = sin[v];
-            *(volatile SO_LDS int*)(uintptr_t)ag = bv;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[1], sin[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[2], sin[2], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         sout = acc;
         slot = slot + 1 == NX ? 0 : slot + 1;
@@ -754,7 +792,15 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     }
     const SO_LDS char* const ringc = (const SO_LDS char*)l.ring + (uint32_t)n16 * (uint32_t)rpitch * 8u;
     // ... and the four result rows it stores: row gq + 4v, time n16
-    TO SO_GLB* yp[4];
+    // ... as byte offsets from the group's first result element (row 0, output 0 of its first range): the stores take a
+    // scalar base, advanced per block by scalar adds, and a 32-bit lane offset -- no 64-bit vector add per store.  (A group
+    // whose rows lie more than 4 GB apart -- long results of many channels -- rebuilds the address per store.)
+    uint32_t yo[4];
+    const int64_t ybase_e = (int64_t)(grp.cg * ct) * out_pitch + grp.ob0;
+#ifndef SO_Y_SADDR
+#define SO_Y_SADDR 1
+#endif
+    const bool yfits = SO_Y_SADDR && uni((int)((((int64_t)(ct - 1) * out_pitch + (int64_t)(16 / ct) * grp.prL + 16) * (int64_t)sizeof(TO)) < ((int64_t)1 << 32)));
     int nbs[4];      // block b of row gq + 4v is stored (by this lane: time n16 of the block) while b < nbs[v]
     int nbs_all;     // ... and by every lane of the wave while b < nbs_all (no predicates then)
     {
@@ -764,7 +810,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             const int row = gq + 4 * v;
             const int ri = row / ct, cv = row % ct;
             const int64_t ob = grp.ob0 + ri * grp.prL;
-            yp[v] = y + ((int64_t)(grp.cg * ct + cv) * out_pitch + ob + n16);
+            yo[v] = (uint32_t)(((int64_t)cv * out_pitch + (int64_t)ri * grp.prL + n16) * (int64_t)sizeof(TO));
             const int64_t tl = n_out - ob - n16;  // 16 b < tl
             const int64_t nb = tl <= 0 ? 0 : (tl + 15) / 16;
             nbs[v] = (int)(nb > 0x3fffffff ? 0x3fffffff : nb);
@@ -798,7 +844,10 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     int avail = 0;
     int wbm = -1;  // the block's window start modulo the ring
     if (yi >= NB) flag_st(fl_base + 4 * (kRsosFlagYrd + yi), 0x7fffffff);  // (no block for this wave: it needs nothing of the ring)
-    const uint32_t f_sseq = fl_base + 4 * kRsosFlagSseq;
+    // (two LDS addresses that never change, in vector registers the compiler cannot rematerialise from their scalars: a
+    //  v_mov per use is a vector instruction that waits for a gap between the SIMD's MFMAs)
+    uint32_t f_sseq = fl_base + 4 * kRsosFlagSseq, f_yrd = fl_base + 4 * (kRsosFlagYrd + yi);
+    asm volatile("" : "+v"(f_sseq), "+v"(f_yrd));
     // Per block of this wave, in this order:
     //   front(b)    one batch of LDS reads (the previous block's state counter and -- speculatively -- its state, then
     //               the 4 KS window samples), KS MFMAs -> X, X to the chain wave;
@@ -812,6 +861,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     constexpr int NS = rsos_nss(NY);
     int sslot = yi % NS;                 // state slot of the block in hand (b modulo NS)
     int pb_ = -1, ppi_ = 0, pslot_ = 0;  // the block whose back part is due: index, period, STATE slot
+    // ... and the address of its first result element in the group's row 0 (bytes; a running scalar: blocks are NY apart)
+    uint64_t ycur = (uint64_t)rfl64((int64_t)(uintptr_t)(y + (ybase_e + (int64_t)16 * yi))), ypend = 0;
     [[maybe_unused]] int cnt_in = 0, cnt_in_b = 0, cnt_st = 0, cnt_st_b = 0;
     [[maybe_unused]] const long long cyc0 = SO_RSOS_COUNT ? clock64() : 0;
     // ... and its X^T T^T: two register sets that swap roles from block to block (the set a block fills is the one the
@@ -839,19 +890,34 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
         if (!(debug & 1)) {
             const int64_t t0 = (int64_t)16 * pb_;
+            // (a scalar register pair + the lanes' 32-bit offsets: the store's own address form -- written out, the compiler
+            //  widens the offsets once and adds 64-bit lane pointers per store again.  It does not see the MFMA result a
+            //  Float64 store reads behind the asm either: the 18 wait states such a read needs are in front of the first store)
+            const uint64_t yb = (uint64_t)rfl64((int64_t)ypend);
+            // (tied to the accumulators: the MFMAs that write them stay in front of it, the stores that read them behind)
+            if (yfits && sizeof(TO) == 8) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3])::"memory");
+            auto put = [&](int v, TO val) __attribute__((always_inline)) {
+                if (yfits) {
+                    if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
+                    else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
+                } else {
+                    const int row = gq + 4 * v;
+                    y[(int64_t)(grp.cg * ct + row % ct) * out_pitch + grp.ob0 + (int64_t)(row / ct) * grp.prL + n16 + t0] = val;
+                }
+            };
             if (pb_ < nbl_max) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int64_t m = grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16;
-                    if (pb_ < nbs[v] && m >= slo) yp[v][t0] = (TO)ay[v];
+                    if (pb_ < nbs[v] && m >= slo) put(v, (TO)ay[v]);
                 }
             } else if (pb_ < nbs_all) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) yp[v][t0] = (TO)ay[v];
+                for (int v = 0; v < 4; ++v) put(v, (TO)ay[v]);
             } else {
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (pb_ < nbs[v]) yp[v][t0] = (TO)ay[v];
+                    if (pb_ < nbs[v]) put(v, (TO)ay[v]);
             }
         }
         rsos_stamp(trace, wave, pb_ / NY, 5, 40);
@@ -914,7 +980,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             ++pi2;
         }
         const int wb2 = b + NY < NB ? pi2 * M + jn - ulo_kw : 0x7fffffff;
-        flag_st(fl_base + 4 * (kRsosFlagYrd + yi), wb2);
+        flag_st(f_yrd, wb2);
         if (b + NY < NB) {
             wbm += wb2 - wb;
             while (wbm >= RING) wbm -= RING;
@@ -946,6 +1012,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         pb_ = b;
         ppi_ = pi;
         pslot_ = sslot;
+        ypend = ycur;
+        ycur += (uint64_t)(16 * NY) * sizeof(TO);
         sslot += NY % NS;
         if (sslot >= NS) sslot -= NS;
         pi = pi2;

@@ -1727,10 +1727,14 @@ void Plan::fuse_resample_sos() {
         const int64_t need = S2.need - S3.base, L = Lp;
         const int64_t store_lo = S2.base - S3.base;
         const int64_t nperiods = (need + L - 1) / L;
-        // warm-up: the first wp with ||A^(wp L)|| < 2^-70 (SIGOPS_RSOS_WTOL: another exponent, a measurement aid)
+        // warm-up: the first wp with ||A^(wp L)|| < 2^-56: what the frames in front of the warm-up leave in the state is an
+        // eighth of the state's own rounding unit (2^-53) by the time the range's first output is stored -- below anything
+        // the 50-term MFMA sums of a block can resolve.  (Round 4 cut at 2^-70 like the warm starts of windows, whose
+        // results are compared with cold starts at 1e-13: 27 periods instead of 22 for the headline's band-stop, 1.3 % of
+        // all blocks.  SIGOPS_RSOS_WTOL: another exponent.)
         int64_t wp = 1;
         {
-            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 70)));
+            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 56)));
             const Mat P = matpow(sos_state_matrix(cf), L, D);
             Mat cur = P;
             while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {
