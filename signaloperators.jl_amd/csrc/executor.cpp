@@ -568,7 +568,11 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             HIPCHECK(hipMemsetAsync(rs.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite range yet"
                         }
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
-                        const bool rtracing = std::getenv("SIGOPS_RSOS_TRACE") != nullptr;
+                        // (SIGOPS_RSOS_TRACE_SKIP=n: not the first n launches of the process -- a traced launch synchronises, and a run
+                        //  of traced launches never leaves the chip's power-management transient)
+                        static int rtrace_seen = 0;
+                        const char* const rtrace_skip = std::getenv("SIGOPS_RSOS_TRACE_SKIP");
+                        const bool rtracing = std::getenv("SIGOPS_RSOS_TRACE") != nullptr && rtrace_seen++ >= (rtrace_skip ? std::atoi(rtrace_skip) : 0);
                         const size_t rtrace_n = (size_t)16 * kRsosTraceIters * 8;
                         if (rtracing) {
                             if (!d_rtrace) HIPCHECK(hipMalloc(&d_rtrace, rtrace_n * 8));

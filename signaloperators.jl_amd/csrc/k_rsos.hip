@@ -797,6 +797,9 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     // whose rows lie more than 4 GB apart -- long results of many channels -- rebuilds the address per store.)
     uint32_t yo[4];
     const int64_t ybase_e = (int64_t)(grp.cg * ct) * out_pitch + grp.ob0;
+#ifndef SO_Y_EARLY
+#define SO_Y_EARLY 0  // (see block(): the pending block's state-dependent MFMAs in front of D . X -- measured, slower)
+#endif
 #ifndef SO_Y_SADDR
 #define SO_Y_SADDR 1
 #endif
@@ -868,9 +871,10 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     // ... and its X^T T^T: two register sets that swap roles from block to block (the set a block fills is the one the
     // next block's back part accumulates into and stores from: no copy between them)
     v4d payA = v4d{0.0, 0.0, 0.0, 0.0}, payB = v4d{0.0, 0.0, 0.0, 0.0};
-    auto back = [&](int sq, double (&sv)[3], v4d& pay_) __attribute__((always_inline)) {
-        // (the wait below is also what keeps this wave from running away from the chain wave: the exchange slots are
-        //  reused on the strength of it, so it stays for warm-up blocks, whose result is not computed)
+    // The back part of the pending block pb_ in three pieces: the wait for its state (also what keeps this wave from running
+    // away from the chain wave: the exchange slots are reused on the strength of it, so it stays for warm-up blocks, whose
+    // result is not computed), Y = X^T T^T + S^T C^T, the stores.
+    auto back_wait = [&](int sq, double (&sv)[3]) __attribute__((always_inline)) {
         int spins = 0;
         sq = uni(sq);
         if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
@@ -883,43 +887,51 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #pragma unroll
             for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
         }
-        if (ppi_ < wp) return;  // (a warm-up block: nothing to store)
-        rsos_stamp(trace, wave, pb_ / NY, 4, 40);
-        v4d ay = pay_;
+    };
+    auto back_mfma = [&](const double (&sv)[3], v4d ay) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
-        if (!(debug & 1)) {
-            const int64_t t0 = (int64_t)16 * pb_;
-            // (a scalar register pair + the lanes' 32-bit offsets: the store's own address form -- written out, the compiler
-            //  widens the offsets once and adds 64-bit lane pointers per store again.  It does not see the MFMA result a
-            //  Float64 store reads behind the asm either: the 18 wait states such a read needs are in front of the first store)
-            const uint64_t yb = (uint64_t)rfl64((int64_t)ypend);
-            // (tied to the accumulators: the MFMAs that write them stay in front of it, the stores that read them behind)
-            if (yfits && sizeof(TO) == 8) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3])::"memory");
-            auto put = [&](int v, TO val) __attribute__((always_inline)) {
-                if (yfits) {
-                    if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
-                    else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
-                } else {
-                    const int row = gq + 4 * v;
-                    y[(int64_t)(grp.cg * ct + row % ct) * out_pitch + grp.ob0 + (int64_t)(row / ct) * grp.prL + n16 + t0] = val;
-                }
-            };
-            if (pb_ < nbl_max) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int64_t m = grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16;
-                    if (pb_ < nbs[v] && m >= slo) put(v, (TO)ay[v]);
-                }
-            } else if (pb_ < nbs_all) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) put(v, (TO)ay[v]);
+        return ay;
+    };
+    // (fresh: the MFMAs that wrote ay are the last instructions in front of this -- the 18 wait states a Float64 store needs
+    //  behind them are inserted here, tied to the accumulators; not fresh: at least eight MFMAs lie in between)
+    auto back_store = [&](v4d ay, bool fresh) __attribute__((always_inline)) {
+        if (debug & 1) return;
+        const int64_t t0 = (int64_t)16 * pb_;
+        // (a scalar register pair + the lanes' 32-bit offsets: the store's own address form -- written out, the compiler
+        //  widens the offsets once and adds 64-bit lane pointers per store again.  It does not see the MFMA result a
+        //  Float64 store reads behind the asm either: hence `fresh`)
+        const uint64_t yb = (uint64_t)rfl64((int64_t)ypend);
+        if (fresh && yfits && sizeof(TO) == 8) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3])::"memory");
+        auto put = [&](int v, TO val) __attribute__((always_inline)) {
+            if (yfits) {
+                if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
+                else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
             } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (pb_ < nbs[v]) put(v, (TO)ay[v]);
+                const int row = gq + 4 * v;
+                y[(int64_t)(grp.cg * ct + row % ct) * out_pitch + grp.ob0 + (int64_t)(row / ct) * grp.prL + n16 + t0] = val;
             }
+        };
+        if (pb_ < nbl_max) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t m = grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16;
+                if (pb_ < nbs[v] && m >= slo) put(v, (TO)ay[v]);
+            }
+        } else if (pb_ < nbs_all) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) put(v, (TO)ay[v]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (pb_ < nbs[v]) put(v, (TO)ay[v]);
         }
+    };
+    auto back = [&](int sq, double (&sv)[3], v4d& pay_) __attribute__((always_inline)) {
+        back_wait(sq, sv);
+        if (ppi_ < wp) return;  // (a warm-up block: nothing to store)
+        rsos_stamp(trace, wave, pb_ / NY, 4, 40);
+        back_store(back_mfma(sv, pay_), true);
         rsos_stamp(trace, wave, pb_ / NY, 5, 40);
     };
     // (je / jn: the window ends of this block's phase group and of the wave's next block's -- loop constants of a wave whose
@@ -973,6 +985,16 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
                 for (int v = 0; v < 4; ++v) ax[v] = (double)(float)ax[v];
             }
         }
+        // ---- (-DSO_Y_EARLY=1) the pending block's state-dependent product HERE where its state has arrived: D . X and
+        //      X^T T^T below read the resampler's accumulators as A / B operands and cannot issue until the last of its MFMAs
+        //      has left the pipe; these three depend on nothing in flight, and the stores then need no wait states.  Measured:
+        //      the y waves alone 0.899 -> 0.896 ms, the whole kernel 0.964 -> 0.978 -- D . x reaches the chain three MFMAs later.
+        bool early = false;
+        v4d ay_early = pin;
+        if (SO_Y_EARLY && pb_ >= 0 && ppi_ >= wp && (uni(sq) >= pb_ || (debug & 8))) {
+            ay_early = back_mfma(sv, pin);
+            early = true;
+        }
         // next block of this wave: its window start is what this wave still needs of the ring
         int pi2 = pi, gi2 = gi + NY;
         while (gi2 >= ngroups) {
@@ -1007,7 +1029,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
         flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
         // ---- the previous block's result ----
-        if (pb_ >= 0) back(sq, sv, pin);
+        if (early) back_store(ay_early, false);
+        else if (pb_ >= 0) back(sq, sv, pin);
         rsos_stamp(trace, wave, b / NY, 3, 40);
         pb_ = b;
         ppi_ = pi;
