@@ -1242,7 +1242,7 @@ int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, con
     if (g.ngroups > kRsosMaxGroups) return -1;
 #define SO_RS(KS_) \
     if (g.ks == KS_) return g.out_f32 ? launch_rsos_t<KS_, float>(tab, jend, g, y, gsrc, grid, st) : launch_rsos_t<KS_, double>(tab, jend, g, y, gsrc, grid, st);
-    SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
+    SO_RS(4) SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
 #undef SO_RS
     return -1;
 }

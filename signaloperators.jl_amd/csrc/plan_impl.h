@@ -399,6 +399,7 @@ struct Plan {
     void count_array(int ni);
     void fuse_state_passes();
     void fuse_resample_sos();
+    void fuse_plain_sos();
     void batch_sos_stages();
     void sos_chunking(int sid, int64_t need, int nch, int dtype, const std::vector<SosCoefs>& groups, bool exact, int64_t target);
     void finalize();

@@ -1219,6 +1219,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
         P->fuse_state_passes();
         P->fuse_resample_sos();
+        P->fuse_plain_sos();
         P->batch_sos_stages();
         const auto t_lowered = std::chrono::steady_clock::now();
         P->finalize();

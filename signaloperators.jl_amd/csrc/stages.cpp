@@ -1101,6 +1101,16 @@ void Plan::process_stage(int sid) {
             }
         }
     }
+    // A filter over a plain source (an array, a stage buffer, either one plus / times a sine) may run as ONE pass of the
+    // block-state-space kernel (Plan::fuse_plain_sos: k_rsos with an identity resampler) instead of the three-pass chunked
+    // scan: its source as a carrier, like a periodic resampler's.  The direct view above stays -- what the three passes
+    // read if the fused form is not taken.
+    if (direct && S.kind == ST_SOS && S.groups.size() == 1 && S.groups[0].nsec <= 6 && !S.sg.exact && !S.onepass && !S.under_norm &&
+        S.base == 0 && in_base == 0 && in_frames == need && N.dtype == SO_F64 &&
+        need * N.nch >= (std::getenv("SIGOPS_RSOS_MINGROUPS") ? (int64_t)4096 : ((int64_t)1 << 22)) && !std::getenv("SIGOPS_NO_RSOS") && !std::getenv("SIGOPS_NO_PLAIN_RSOS")) {
+        std::vector<DCarrier> cs;
+        if (build_carriers(ps, N.nch, cs, false) && cs.size() == 1) S.carriers = cs;
+    }
     if (S.kind == ST_NORM && S.norm_alias) {
         // `vals` is the child stage's buffer (planner.cpp): lowering the child above registered the frames it needs
         if (ps.size() != 1 || exprs[ps[0].e].op != E_LOAD || exprs[ps[0].e].leaf.buf != S.out_buf)
@@ -1471,7 +1481,7 @@ void Plan::batch_sos_stages() {
         // (not below a Normpower: such a filter keeps every chunk in its scan, or the exact block scan, by its OWN
         //  chunk count -- sos_chunking -- which the batch would change)
         if (S.kind != ST_SOS || S.onepass || S.sg.exact || S.xscan || S.under_norm || S.pre_stage >= 0 || S.groups.size() != 1 ||
-            S.in_array_node < 0 || S.pw_step >= 0 || S.sg.nchunks < 1)
+            S.in_array_node < 0 || S.pw_step >= 0 || S.sg.nchunks < 1 || S.rsos_src >= 0)
             continue;
         kinds[{S.groups[0].nsec, nodes[S.node].dtype}].push_back(sid);
     }
@@ -1717,8 +1727,9 @@ void Plan::fuse_resample_sos() {
             if (L.buf == S2.in_buf) ok = false;
         for (size_t j = 0; j < stages.size(); ++j) {
             if (j != i2 && stages[j].in_buf == S2.in_buf) ok = false;
-            for (auto& c : stages[j].carriers)
-                if (c.buf == S2.in_buf) ok = false;
+            if (j != i2)  // (the filter's own carrier over that buffer, a candidate of fuse_plain_sos, goes with it below)
+                for (auto& c : stages[j].carriers)
+                    if (c.buf == S2.in_buf) ok = false;
         }
         if (!ok) continue;
         const SosCoefs& cf = S2.groups[0];
@@ -1878,6 +1889,7 @@ void Plan::fuse_resample_sos() {
         }
         S2.rs = g;
         S2.rsos_src = i3;
+        S2.carriers.clear();  // (what process_stage prepared for the single-pass form of a plain filter: the resampler's serve now)
         if (own_tab) {
             S2.rsos_tab_host.swap(own_taps);
             S2.rsos_jend_host.swap(own_jend);
@@ -1895,6 +1907,147 @@ void Plan::fuse_resample_sos() {
                          "ks=%d ring=%d chunk=%d waves=%d cyc=%d fuse=%d/%d\n",
                          (long long)nranges, (long long)pr, (long long)wp, (long long)ngrp, ct, rgs, ks, g.ring, g.chunk, g.nwaves, g.cyc,
                          g.fuse, g.fuse_sine);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A plain `Filt` in one pass over HBM: the fused kernel's roles with an identity resampler (reference: the IIR's
+// nextblock filters every block of its child once, src/filters.jl:240-255; K2's chunked scan reads its input twice).
+// Period = ten blocks of 16 frames, every block's [16 x 16] tap operand the identity over the block's own 16 inputs
+// (4 k-steps: X = I . Win, exact), so a block costs 4 + 4 + 4 + 3 MFMAs on its y wave and 3 on the chain wave against 27
+// for the headline -- and the input is read once.  Conditions: process_stage built a carrier for the source (whole-signal
+// filters over an array / a buffer, optionally plus or times one sine; one group of at most 6 sections; not the
+// sequential / exact-scan / under-Normpower variants), and the estimate below.
+void Plan::fuse_plain_sos() {
+    if (std::getenv("SIGOPS_NO_RSOS") || std::getenv("SIGOPS_NO_PLAIN_RSOS")) return;
+    auto env_int = [](const char* name, int dflt) {
+        const char* ev = std::getenv(name);
+        return ev ? std::atoi(ev) : dflt;
+    };
+    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+        Stage& S2 = stages[i2];
+        if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || S2.xscan ||
+            S2.under_norm || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
+            continue;
+        const int dt = nodes[S2.node].dtype;
+        if (dt != SO_F64 && dt != SO_F32) continue;
+        const DCarrier& c0 = S2.carriers[0];
+        const bool pure32 = dt == SO_F32;  // (not taken today, see the estimate below; the kernel has the instantiations)
+        if (pure32 && (c0.nsteps != 0 || c0.dtype != SO_F32)) continue;
+        if (!pure32 && c0.dtype != SO_F64) continue;
+        const SosCoefs& cf = S2.groups[0];
+        const int D = 2 * cf.nsec;
+        const int nch = nodes[S2.node].nch;
+        const int64_t need = S2.need, L = 160;
+        const int ngp = 10, ks = 4, kw = 16;
+        const int64_t nperiods = (need + L - 1) / L;
+        int64_t wp = 1;
+        {
+            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 56)));
+            const Mat P = matpow(sos_state_matrix(cf), L, D);
+            Mat cur = P;
+            while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {
+                cur = matmul(cur, P, D);
+                ++wp;
+            }
+            if (!(maxabs(cur) < tol)) continue;
+        }
+        int ct = 1;
+        for (int c : {16, 8, 4, 2})
+            if (nch % c == 0) {
+                ct = c;
+                break;
+            }
+        const int rgs = 16 / ct;
+        const int64_t ncg = nch / ct;
+        const int cus = env_int("SIGOPS_RSOS_GRID", 256);
+        int64_t rgroups = std::max<int64_t>(1, cus / ncg);
+        int64_t nranges = rgroups * rgs;
+        const int64_t min_pr = std::max<int64_t>(1, 4 * wp);  // (a range at least four warm-ups long: <= 25 % of the blocks)
+        if (nperiods / nranges < min_pr) nranges = std::max<int64_t>(rgs, nperiods / min_pr / rgs * rgs);
+        if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES")) nranges = std::max<int64_t>(1, std::atoll(ev));
+        const int64_t pr = (nperiods + nranges - 1) / nranges;
+        nranges = (nperiods + pr - 1) / pr;
+        const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
+        if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * L >= ((int64_t)1 << 30)) continue;
+        if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
+            if (ngrp < std::atoll(ev)) continue;
+        } else {
+            // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
+            // channels, eight loader units per chunk: 1.7 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
+            // 2.5 ps + 195 us beyond (tools/r05/iir_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
+            // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals keep the three passes: their
+            // chunks would have to be widened by the one loader wave (12.5 M x 8: 0.47 against 0.39 ms).
+            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.25 : ct == 2 ? 1.7 : 3.4;
+            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
+            const double nsamp = (double)need * nch;
+            const double t_three = nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 2.5e-6 * nsamp + 195.0;
+            if (std::getenv("SIGOPS_DEBUG_PLAN"))
+                std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
+                             (long long)ngrp, (long long)pr, (long long)wp, t_three);
+            if (t_fused > t_three) continue;
+        }
+        RsSos g{};
+        g.n_in = S2.in_frames;
+        g.n_out = need;
+        g.store_lo = 0;
+        g.L = L;
+        g.M = L;
+        g.pr = pr;
+        g.wp = (int32_t)wp;
+        g.nranges = (int32_t)nranges;
+        g.ngroups = ngp;
+        g.ks = ks;
+        g.ulo = 0;
+        g.ct = ct;
+        g.rgs = rgs;
+        g.nch = nch;
+        g.chunk = 128;
+        g.depth = std::max(1, std::min(4, env_int("SIGOPS_RSOS_DEPTH", 4)));
+        g.nsec = cf.nsec;
+        g.debug = env_int("SIGOPS_RSOS_DEBUG", 0);
+        g.nwaves = 12;
+        g.cyc = 1;
+        {
+            const int ny = 10;
+            const int64_t span = (int64_t)(2 * ny - 1) * 17 + kw + 16 + 2 * g.chunk;
+            int ring = 4096;
+            while (ring >= 128 && rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc) > rsos_lds_budget()) ring -= 128;
+            if (const char* ev = std::getenv("SIGOPS_RSOS_RING")) ring = std::min(ring, std::max(128, std::atoi(ev) / 128 * 128));
+            if (ring < 128 || ring < span) continue;
+            g.ring = ring;
+            g.rpitch = ring + 2;
+        }
+        g.src32 = pure32 ? 1 : 0;
+        g.x32 = pure32 ? 1 : 0;
+        g.fuse = -1;
+        if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 && (c0.op[0] == OP_MUL || c0.op[0] == OP_ADD || c0.op[0] == OP_SUB)) {
+            g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);
+            const DLeaf& L0 = leaves[c0.slot_leaf[0]];
+            const int kind = c0.slot_kind[0];
+            if (kind == OP_FUNC && L0.mode == SO_FN_SIN && L0.sf == 1) g.fuse_sine = 1;
+            else if (kind == OP_CONST || kind == OP_SCALAR) g.fuse_sine = 0;
+            else g.fuse = -2;
+        } else if (c0.nsteps > 0)
+            g.fuse = -2;
+        // identity taps: block gi of the period reads inputs [16 gi, 16 gi + 16)
+        S2.rsos_tab_host.assign((size_t)ngp * kw * 16, 0.0);
+        S2.rsos_jend_host.assign((size_t)ngp, 0);
+        for (int gi = 0; gi < ngp; ++gi) {
+            S2.rsos_jend_host[(size_t)gi] = 16 * gi + 15;
+            for (int kk = 0; kk < kw; ++kk) S2.rsos_tab_host[((size_t)gi * kw + kk) * 16 + kk] = 1.0;
+        }
+        S2.rsos_tab_buf = raw_buf(S2.rsos_tab_host.size() * 8);
+        S2.rsos_jend_buf = raw_buf(S2.rsos_jend_host.size() * 4);
+        S2.rs = g;
+        S2.rsos_src = (int)i2;  // (its own carriers, control block and tables)
+        S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);
+        rsos_block_matrices(cf, S2.rsos_mats_host);
+        S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);
+        if (S2.bad_buf < 0) S2.bad_buf = raw_buf((size_t)nch * 4);
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr, "[sigops] IIR in one pass (k_rsos, identity resampler): %lld ranges of %lld periods (+%lld warm-up), %lld groups of %d ch x %d ranges, ring=%d fuse=%d/%d\n",
+                         (long long)nranges, (long long)pr, (long long)wp, (long long)ngrp, ct, rgs, g.ring, g.fuse, g.fuse_sine);
     }
 }
 

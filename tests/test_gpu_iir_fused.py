@@ -1,0 +1,155 @@
+"""A plain `Filt` as ONE pass of the block-state-space kernel (k_rsos with an identity resampler, Plan::fuse_plain_sos;
+reference: the IIR's nextblock filters each block of its child once, src/filters.jl:240-255) against the CPU oracle and
+against the engine's three-pass chunked scan (K2, `SIGOPS_NO_PLAIN_RSOS=1` at plan creation) on identical inputs.
+
+`SIGOPS_RSOS_MINGROUPS=1` lets short signals take the one-pass form (by default the planner's estimate decides: from a few
+million samples on).  Tolerances: Float64 1e-10 against the oracle (another association of the same sums), 1e-11 between the
+two engine paths; Float32 1e-6 / results that differ in single rounding steps."""
+import os
+
+import numpy as np
+import pytest
+
+import sigops_amd as so
+from oracle_bridge import oracle_sink, relerr
+from test_gpu_rsos import F, env, steps_of
+
+pytestmark = pytest.mark.gpu
+
+
+def both(x, to=None):
+    """(one-pass result, three-pass result, one pass taken?)"""
+    with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_PLAIN_RSOS=None, SIGOPS_NO_RSOS=None):
+        fused = "k_rsos" in steps_of(x, np.float32 if to is np.float32 else np.float64)
+        a = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
+    with env(SIGOPS_NO_PLAIN_RSOS=1):
+        b = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
+    return a, b, fused
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4, 8, 16, 24])
+def test_channel_counts(nch):
+    rng = np.random.default_rng(70 + nch)
+    n = 300000 if nch <= 8 else 150000
+    x = so.Signal(F(rng.standard_normal((n, nch))), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    a, b, fused = both(x)
+    assert fused
+    assert a.shape == b.shape and relerr(a, b) < 1e-11
+    assert relerr(a, oracle_sink(x)) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["lowpass", "highpass", "bandpass", "order1", "order12"])
+def test_filters(kind):
+    rng = np.random.default_rng(5)
+    src = so.Signal(F(rng.standard_normal((400000, 8))), 44.1 * so.kHz)
+    x = {"lowpass": src | so.Filt(so.Lowpass, 4 * so.kHz), "highpass": src | so.Filt(so.Highpass, 300 * so.Hz),
+         "bandpass": src | so.Filt(so.Bandpass, 1 * so.kHz, 3 * so.kHz), "order1": src | so.Filt(so.Lowpass, 2 * so.kHz, order=1),
+         "order12": src | so.Filt(so.Lowpass, 5 * so.kHz, order=12)}[kind]
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-11 and relerr(a, oracle_sink(x)) < 1e-10
+
+
+def test_config2_shape_mix_with_a_sine():
+    """BASELINE config 2: Mix(sin 1 kHz, noise) |> Filt(Bandstop): the sum is formed where the chunks land in LDS"""
+    rng = np.random.default_rng(1983)
+    n = 600000
+    noise = F(rng.standard_normal((n, 2)))
+    x = so.Mix(so.Signal(so.sin, ω=1 * so.kHz) | so.Until(n * so.frames), so.Signal(noise, 44.1 * so.kHz)) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-10 and relerr(a, oracle_sink(x)) < 1e-10
+
+
+def test_amplify_with_a_sine_and_device_tensors():
+    import torch
+
+    n = 500001  # (odd: every second row of the [channels x frames] tensor is 8 bytes off a 16-byte boundary)
+    xt = torch.randn((8, n), dtype=torch.float64, device="cuda")
+    x = so.Amplify(so.Signal(xt.t(), 44.1 * so.kHz), so.Signal(so.sin, ω=7 * so.Hz)) | so.Until(n * so.frames) | so.Filt(so.Lowpass, 3 * so.kHz)
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-11
+    xh = so.Amplify(so.Signal(F(xt.t().cpu().numpy()), 44.1 * so.kHz), so.Signal(so.sin, ω=7 * so.Hz)) | so.Until(n * so.frames) | so.Filt(so.Lowpass, 3 * so.kHz)
+    assert relerr(a, oracle_sink(xh)) < 1e-10
+
+
+def test_float32_signals_keep_the_three_pass_form():
+    """Float32 arrays would have to be widened by the one loader wave (0.47 against 0.39 ms for 12.5 M x 8): K2 stays"""
+    rng = np.random.default_rng(8)
+    x = so.Signal(F(rng.standard_normal((400000, 8)).astype(np.float32)), 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz)
+    a, b, fused = both(x)
+    assert not fused and a.dtype == np.float32
+    assert relerr(a, oracle_sink(x)) < 1e-6 and np.array_equal(a, b)
+
+
+def test_float64_filter_into_a_float32_result():
+    """sink! converts on the store (reference src/sink.jl:262-266): the kernel's own narrowing store"""
+    rng = np.random.default_rng(9)
+    x = so.Signal(F(rng.standard_normal((300000, 4))), 44.1 * so.kHz) | so.Filt(so.Highpass, 1 * so.kHz)
+    want = oracle_sink(x).astype(np.float32)
+    outs = []
+    for e in (dict(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_PLAIN_RSOS=None), dict(SIGOPS_NO_PLAIN_RSOS=1)):
+        with env(**e):
+            got = np.empty(want.shape, dtype=np.float32, order="F")
+            so.sink_into(got, x)
+            outs.append(got)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        assert "k_rsos" in steps_of(x, np.float32)
+    assert relerr(outs[0], want) < 1e-6 and relerr(outs[0], outs[1]) < 1e-7
+
+
+def test_non_finite_samples():
+    """A filter never recovers from a non-finite sample (the reference's recurrence carries it on in its state).  The
+    block form multiplies whole blocks of 16 frames -- 0 * NaN is NaN -- so the one-pass result is non-finite from the
+    START of the 16-frame block (frames 16 k ... 16 k + 15 of the signal) that holds a channel's first non-finite sample:
+    up to 15 frames earlier than the reference, never later, never in another channel.  The exact set, stated:"""
+    rng = np.random.default_rng(10)
+    d = rng.standard_normal((400000, 8))
+    first = {3: 123457, 5: 300000}
+    d[first[3], 3] = np.nan
+    d[first[5], 5] = np.inf
+    x = so.Signal(F(d), 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz)
+    a, b, fused = both(x)
+    want = oracle_sink(x)
+    assert fused
+    assert np.array_equal(np.isfinite(b), np.isfinite(want))  # (the three-pass form: exactly the reference's set)
+    expect = np.ones(d.shape, dtype=bool)
+    for c, i in first.items():
+        assert not np.isfinite(want[i:, c]).any() and np.isfinite(want[:i, c]).all()
+        expect[i // 16 * 16:, c] = False
+    assert np.array_equal(np.isfinite(a), expect)
+    assert relerr(a[expect], want[expect]) < 1e-10
+
+
+def test_under_append_and_with_a_ramp_behind_it():
+    """window aliasing: the filtered scenes write their windows of the result themselves"""
+    rng = np.random.default_rng(11)
+    scenes = [so.Signal(F(rng.standard_normal((200000, 2))), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.Ramp(10 * so.ms)
+              for _ in range(3)]
+    x = so.Append(*scenes)
+    a, b, fused = both(x)
+    assert fused
+    assert relerr(a, b) < 1e-11 and relerr(a, oracle_sink(x)) < 1e-10
+
+
+def test_default_policy_takes_one_pass_for_long_signals_only():
+    rng = np.random.default_rng(12)
+    short = so.Signal(F(rng.standard_normal((100000, 8))), 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz)
+    long_ = so.Signal(F(rng.standard_normal((3000000, 8))), 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz)
+    with env(SIGOPS_RSOS_MINGROUPS=None, SIGOPS_NO_RSOS=None, SIGOPS_NO_PLAIN_RSOS=None):
+        assert "k_rsos" not in steps_of(short)
+        assert steps_of(long_) == ["k_rsos"]
+        got = so.sink(long_)[0]
+    with env(SIGOPS_NO_PLAIN_RSOS=1):
+        ref = so.sink(long_)[0]
+    assert relerr(got, ref) < 1e-11
+
+
+def test_run_to_run_identity():
+    rng = np.random.default_rng(13)
+    x = so.Signal(F(rng.standard_normal((500000, 8))), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        a = so.sink(x)[0]
+        for _ in range(4):
+            assert np.array_equal(a, so.sink(x)[0])
