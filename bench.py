@@ -316,6 +316,34 @@ def mfma_roofline_of(stage, n_out, nch, plan_steps):
             "note": "issued fp64 MFMA flops of the stored outputs (28 MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure"}
 
 
+def one_shot_probe():
+    """tools/oneshot_probe.py in fresh child processes (this process has every cache warm by now): once without a cache
+    directory, twice with a new one (the second of those finds the accumulator replay on disk).  Never fails the bench."""
+    import tempfile
+
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SIGOPS_CACHE_DIR")}
+        env.update(env_extra)
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "oneshot_probe.py")], env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=180)
+            for line in out.stdout.decode().splitlines():
+                if line.startswith("{"):
+                    return json.loads(line)["calls"]
+        except Exception:
+            pass
+        return None
+
+    cold = run({})
+    with tempfile.TemporaryDirectory() as d:
+        run({"SIGOPS_CACHE_DIR": d})
+        warm = run({"SIGOPS_CACHE_DIR": d})
+    return {"what": "the headline sink once, in a fresh process: plan create + first execute + destroy, host clock (ms); "
+                    "device-resident leaf and result; `again`: the same call repeated in that process",
+            "no_cache_dir": cold[0] if cold else None, "warm_cache_dir": warm[0] if warm else None,
+            "again_in_process": cold[-1] if cold else None}
+
+
 def parity_gate(so, tree_fn, noise_host, tol=1e-6):
     """engine vs oracle on a prefix of the same input (BASELINE.md §2's correctness gate).  Runs AFTER the
     timed loops: freeing this one-shot plan's device buffers right before them stalled the device for
@@ -413,6 +441,7 @@ def main():
                     help="signal seconds for the CPU-oracle sample (0 = skip); the full 600 s x 8 ch pipeline "
                          "is ~10-20 s of CPU work on one core")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 object")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the one-shot latency probe (three child processes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -602,6 +631,8 @@ def main():
             "config3": secondary,
             "config4": config4,
         }
+        if world == 1 and args.workload == "ns" and not args.no_one_shot and not args.no_secondary:
+            res["one_shot"] = one_shot_probe()
         if args.cpu_seconds > 0 and world == 1:
             noise_host = np.asfortranarray(noise_t.t().cpu().numpy())
             full, res["cpu_baseline"] = cpu_baseline(so, headline_fn, args.cpu_seconds, nch, ndt, noise_host, gpu_result)

@@ -15,6 +15,20 @@ static inline int carrier_vec_ok(const DCarrier& c, int64_t V) {
 }
 
 // ---------------------------------------------------------------------------
+// Plan tables go up in pieces of 16 KB: the runtime sets its staging path for pageable copies of 32 KB and more up on the
+// first such copy of the PROCESS -- 6 ms, measured, which the 66 KB tap table of a first one-shot sink paid (a host that has
+// already copied its signal to the device has paid it; one whose data was produced on the device has not).  Small copies go
+// another way.  Tables of more than a megabyte are not chopped up.
+static hipError_t h2d_small(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kPiece = 16 * 1024;
+    if (bytes < 2 * kPiece || bytes > (1u << 20)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    for (size_t off = 0; off < bytes; off += kPiece) {
+        const hipError_t e = hipMemcpy((char*)dst + off, (const char*)src + off, std::min(kPiece, bytes - off), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 void Plan::finalize() {
     // size stage output buffers now that every need is known
     for (size_t si = 0; si < stages.size(); ++si) {
@@ -64,13 +78,20 @@ void Plan::finalize() {
         out_stage_buf = (int)bufs.size() - 1;
     }
     // allocate
+    const bool dbg_t = std::getenv("SIGOPS_DEBUG_PLAN") != nullptr;
+    const auto tf0 = std::chrono::steady_clock::now();
     int64_t scratch = 0;
+    int nalloc = 0;
     for (auto& b : bufs) {
         if (b.external) continue;
         HIPCHECK(hipMalloc(&b.d, std::max<size_t>(b.bytes, 64)));
         scratch += (int64_t)b.bytes;
+        ++nalloc;
     }
     stats.scratch_bytes = scratch;
+    if (dbg_t)
+        std::fprintf(stderr, "[sigops] finalize: %d hipMalloc calls, %lld bytes: %.3f ms\n", nalloc, (long long)scratch,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
     if (out_alias_buf >= 0 && !out.is_device) {
         bufs[out_alias_buf].d = bufs[out_stage_buf].d;
         bufs[out_alias_buf].pitch = bufs[out_stage_buf].pitch;
@@ -109,68 +130,74 @@ void Plan::finalize() {
             for (auto& c : S.carriers)
                 std::fprintf(stderr, "[sigops] carrier [%lld,%lld) base=%p cstride=%lld df=%lld dtype=%d vec_ok=%d nsteps=%d frame_len=%d depth=%d\n",
                              (long long)c.a, (long long)c.b, c.base, (long long)c.cstride, (long long)c.df, c.dtype, c.vec_ok, c.nsteps, c.frame_len, c.depth);
-        HIPCHECK(hipMemcpy(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice));
+        HIPCHECK(h2d_small(bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier)));
         {
             const RsCtl ctl = make_ctl(S);
-            HIPCHECK(hipMemcpy(bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl), hipMemcpyHostToDevice));
+            HIPCHECK(h2d_small(bufs[S.ctl_buf].d, &ctl, sizeof(RsCtl)));
         }
     }
+    if (dbg_t)
+        std::fprintf(stderr, "[sigops] finalize: leaves and carriers patched, carrier blocks uploaded: %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
     // upload tables
     if (!pieces.empty()) {
         HIPCHECK(hipMalloc(&d_pieces, pieces.size() * sizeof(DPiece)));
-        HIPCHECK(hipMemcpy(d_pieces, pieces.data(), pieces.size() * sizeof(DPiece), hipMemcpyHostToDevice));
+        HIPCHECK(h2d_small(d_pieces, pieces.data(), pieces.size() * sizeof(DPiece)));
     }
     if (!ops.empty()) {
         HIPCHECK(hipMalloc(&d_ops, ops.size() * sizeof(DOp)));
-        HIPCHECK(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DOp), hipMemcpyHostToDevice));
+        HIPCHECK(h2d_small(d_ops, ops.data(), ops.size() * sizeof(DOp)));
     }
     if (!leaves.empty()) {
         HIPCHECK(hipMalloc(&d_leaves, leaves.size() * sizeof(DLeaf)));
-        HIPCHECK(hipMemcpy(d_leaves, leaves.data(), leaves.size() * sizeof(DLeaf), hipMemcpyHostToDevice));
+        HIPCHECK(h2d_small(d_leaves, leaves.data(), leaves.size() * sizeof(DLeaf)));
     }
     for (auto& S : stages) {
         if (S.need <= 0) continue;
         if (S.kind == ST_SOS && S.qmat_buf >= 0)
-            HIPCHECK(hipMemcpy(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(h2d_small(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8));
         if (S.kind == ST_SOS && S.rsos_src >= 0) {
-            HIPCHECK(hipMemcpy(bufs[S.rsos_mats_buf].d, S.rsos_mats_host.data(), S.rsos_mats_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(h2d_small(bufs[S.rsos_mats_buf].d, S.rsos_mats_host.data(), S.rsos_mats_host.size() * 8));
             if (S.rsos_tab_buf >= 0) {
-                HIPCHECK(hipMemcpy(bufs[S.rsos_tab_buf].d, S.rsos_tab_host.data(), S.rsos_tab_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.rsos_jend_buf].d, S.rsos_jend_host.data(), S.rsos_jend_host.size() * 4, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.rsos_tab_buf].d, S.rsos_tab_host.data(), S.rsos_tab_host.size() * 8));
+                HIPCHECK(h2d_small(bufs[S.rsos_jend_buf].d, S.rsos_jend_host.data(), S.rsos_jend_host.size() * 4));
             }
         }
         if (S.kind == ST_SOS && S.onepass)
-            HIPCHECK(hipMemcpy(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(h2d_small(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8));
         if (S.kind == ST_RESAMPLE) {
-            HIPCHECK(hipMemcpy(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8, hipMemcpyHostToDevice));
-            HIPCHECK(hipMemcpy(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8, hipMemcpyHostToDevice));
+            HIPCHECK(h2d_small(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8));
+            HIPCHECK(h2d_small(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8));
             if (S.wtab_buf >= 0)
-                HIPCHECK(hipMemcpy(bufs[S.wtab_buf].d, S.wtab_host.data(), S.wtab_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.wtab_buf].d, S.wtab_host.data(), S.wtab_host.size() * 8));
             if (S.tiled) {
-                HIPCHECK(hipMemcpy(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.pfbt_buf].d, S.pfbt_host.data(), S.pfbt_host.size() * 8));
+                HIPCHECK(h2d_small(bufs[S.dpfbt_buf].d, S.dpfbt_host.data(), S.dpfbt_host.size() * 8));
             }
             if (S.fix_buf >= 0)
-                HIPCHECK(hipMemcpy(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix), hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.fix_buf].d, S.fix_host.data(), S.fix_host.size() * sizeof(RsFix)));
             if (S.periodic || S.rows) {
-                HIPCHECK(hipMemcpy(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.tab_buf].d, S.tab_host.data(), S.tab_host.size() * 8));
+                HIPCHECK(h2d_small(bufs[S.jend_buf].d, S.jend_host.data(), S.jend_host.size() * 4));
             }
             if (S.rows && !S.mtab_host.empty()) {
-                HIPCHECK(hipMemcpy(bufs[S.mtab_buf].d, S.mtab_host.data(), S.mtab_host.size() * 8, hipMemcpyHostToDevice));
-                HIPCHECK(hipMemcpy(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small(bufs[S.mtab_buf].d, S.mtab_host.data(), S.mtab_host.size() * 8));
+                HIPCHECK(h2d_small(bufs[S.mjend_buf].d, S.mjend_host.data(), S.mjend_host.size() * 4));
             }
         } else if (S.kind == ST_SOS && S.mpow_buf >= 0) {
             for (size_t gi = 0; gi < S.xs_mats_host.size() && S.xs_mats_buf >= 0; ++gi)
-                HIPCHECK(hipMemcpy((char*)bufs[S.xs_mats_buf].d + gi * 2 * 16 * 16 * 8, S.xs_mats_host[gi].data(),
-                                   S.xs_mats_host[gi].size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small((char*)bufs[S.xs_mats_buf].d + gi * 2 * 16 * 16 * 8, S.xs_mats_host[gi].data(),
+                                   S.xs_mats_host[gi].size() * 8));
             size_t msz = 0;
             for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
             for (size_t gi = 0; gi < S.mpow_host.size(); ++gi)
-                HIPCHECK(hipMemcpy((char*)bufs[S.mpow_buf].d + gi * msz * 8, S.mpow_host[gi].data(),
-                                   S.mpow_host[gi].size() * 8, hipMemcpyHostToDevice));
+                HIPCHECK(h2d_small((char*)bufs[S.mpow_buf].d + gi * msz * 8, S.mpow_host[gi].data(),
+                                   S.mpow_host[gi].size() * 8));
         }
     }
+    if (dbg_t)
+        std::fprintf(stderr, "[sigops] finalize: tables uploaded: %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
     // step list: stages in increasing node order (children first), then the root program
     std::vector<int> order;
     for (size_t i = 0; i < stages.size(); ++i)

@@ -28,6 +28,14 @@
 #include "kcommon.h"
 #include "kstage.h"
 
+// One translation unit per window length (build.py: -DSO_RSOS_ONLY_KS=4 | 12 | 13 | 14 | 16 | 20, and 0 for the dispatcher):
+// the runtime loads a code object the first time one of ITS kernels is launched, and all instantiations in one object
+// were 8 ms of a first sink's 9 ms execute; the units also compile side by side.  -1 (the default, tools/build_variant.sh):
+// everything in this one.
+#ifndef SO_RSOS_ONLY_KS
+#define SO_RSOS_ONLY_KS -1
+#endif
+
 namespace so {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -1176,6 +1184,7 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
 
 constexpr size_t kRsosStaticLds = sizeof(RsosShared) + 64;
 
+#if SO_RSOS_ONLY_KS != 0
 template <int KS, int NW, typename TO, int CYC>
 static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
     const size_t lds = rsos_lds_bytes(g.ngroups, KS, g.rpitch, NW, CYC);
@@ -1184,13 +1193,6 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
         (void)hipFuncSetAttribute((const void*)k_rsos<KS, NW, TO, CYC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsos_lds_budget());
     hipLaunchKernelGGL((k_rsos<KS, NW, TO, CYC>), dim3((unsigned)grid), dim3(NW * 64), lds, st, tab, jend, g, (TO*)y, gsrc);
 }
-
-// LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
-size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
-    const int ny = nwaves == 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
-    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)rsos_nss(ny) * 192 + 16 * 16 * 2) * 8;
-}
-size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 
 // returns 0 when launched, -1 if no instantiation fits
 template <int KS, typename TO>
@@ -1237,14 +1239,47 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
     }
     return -1;
 }
-int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
+#endif  // SO_RSOS_ONLY_KS != 0
+
+#define SO_RSOS_ARGS const double *tab, const int *jend, const RsSos &g, void *y, const RsGlobalTables &gsrc, int grid, hipStream_t st
+#if SO_RSOS_ONLY_KS > 0
+// this unit's window length: launch_rsos_ks<N>, called by the dispatcher's unit
+#define SO_RSOS_CAT2(a, b) a##b
+#define SO_RSOS_CAT(a, b) SO_RSOS_CAT2(a, b)
+int SO_RSOS_CAT(launch_rsos_ks, SO_RSOS_ONLY_KS)(SO_RSOS_ARGS) {
+    return g.out_f32 ? launch_rsos_t<SO_RSOS_ONLY_KS, float>(tab, jend, g, y, gsrc, grid, st)
+                     : launch_rsos_t<SO_RSOS_ONLY_KS, double>(tab, jend, g, y, gsrc, grid, st);
+}
+#else
+// LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
+size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
+    const int ny = nwaves == 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
+    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)rsos_nss(ny) * 192 + 16 * 16 * 2) * 8;
+}
+size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
+
+#if SO_RSOS_ONLY_KS == 0
+int launch_rsos_ks4(SO_RSOS_ARGS);
+int launch_rsos_ks12(SO_RSOS_ARGS);
+int launch_rsos_ks13(SO_RSOS_ARGS);
+int launch_rsos_ks14(SO_RSOS_ARGS);
+int launch_rsos_ks16(SO_RSOS_ARGS);
+int launch_rsos_ks20(SO_RSOS_ARGS);
+#endif
+int launch_rsos(SO_RSOS_ARGS) {
     if (g.n_out <= 0) return 0;
     if (g.ngroups > kRsosMaxGroups) return -1;
+#if SO_RSOS_ONLY_KS == 0
+#define SO_RS(KS_) \
+    if (g.ks == KS_) return launch_rsos_ks##KS_(tab, jend, g, y, gsrc, grid, st);
+#else
 #define SO_RS(KS_) \
     if (g.ks == KS_) return g.out_f32 ? launch_rsos_t<KS_, float>(tab, jend, g, y, gsrc, grid, st) : launch_rsos_t<KS_, double>(tab, jend, g, y, gsrc, grid, st);
+#endif
     SO_RS(4) SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
 #undef SO_RS
     return -1;
 }
+#endif
 
 }  // namespace so
