@@ -96,22 +96,24 @@ def lib_sha16():
 
 
 def pmc_traffic(stage_name):
-    """HBM bytes per execute of a stage from the committed rocprofv3 PMC passes of this command
-    (profiles/r04/bench_pmc_hbm.json, written by tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    """HBM bytes per execute of a stage from the committed rocprofv3 PMC passes of this command (the newest
+    profiles/rNN/bench_pmc_hbm.json, written by tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
     corrected as MI355X_MICROARCH.md prescribes).  A file read, NOT a measurement of this run -- and only quoted while
-    the kernel sources it was collected on are the ones in the tree (their hash is recorded next to the counters): after
-    any change to them the line carries null and says so, instead of a number gone stale."""
-    path = os.path.join(ROOT, "profiles", "r04", "bench_pmc_hbm.json")
-    if not os.path.exists(path):
+    the kernel sources it was collected on (their hash is taken BEFORE the passes and kept next to the counters) are the
+    ones in the tree: after any change to them the line carries null and says so, instead of a number gone stale."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "bench_pmc_hbm.json")), reverse=True)
+    if not paths:
         return None, None
-    with open(path) as f:
+    rel = os.path.relpath(paths[0], ROOT)
+    with open(paths[0]) as f:
         d = json.load(f)
     if d.get("kernel_sources_sha16") != kernel_sources_sha16():
-        return None, "profiles/r04/bench_pmc_hbm.json is from other kernel sources (%s, now %s): not quoted" % (
-            d.get("kernel_sources_sha16"), kernel_sources_sha16())
+        return None, "%s is from other kernel sources (%s, now %s): not quoted" % (rel, d.get("kernel_sources_sha16"), kernel_sources_sha16())
     for key, val in d.get("stages", {}).items():
         if stage_name.startswith(key):
-            return val.get("corrected_bytes_per_execute"), "profiles/r04/bench_pmc_hbm.json (rocprofv3 --pmc passes of this command on these kernel sources; not this run)"
+            return val.get("corrected_bytes_per_execute"), rel + " (rocprofv3 --pmc passes of this command on these kernel sources; not this run)"
     return None, None
 
 
@@ -301,19 +303,20 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD's FP64 matrix figure for MI355X (256 CUs x 4
                                # /opt/skills has no fp64 row.  tools/micro/mfma64.hip reaches 64-69 on a loaded chip (profiles/r04/mfma64.txt)
 
 
-def mfma_roofline_of(stage, n_out, nch, plan_steps):
+def mfma_roofline_of(stage, n_out, nch, mfmas_per_block):
     """The fused resampler + IIR kernel is bound by the fp64 matrix pipe, not by HBM: the MFMA
-    flops its launch issues for the outputs it stores -- 28 v_mfma_f64_16x16x4 (2 048 flops each) per block of 16 outputs x
-    16 rows for the headline's 14 k-step windows, warm-up blocks not counted -- over the kernel's measured time.  Reported
-    NEXT TO `roofline` (which stays the HBM one the contract's per-unit figure is stated in)."""
-    if not stage["name"].startswith("k_rsos"):
+    flops its launch issues for the outputs it stores -- `mfmas_per_block` v_mfma_f64_16x16x4 (2 048 flops each; the
+    plan's own count, so_plan_counter: window k-steps + 14) per block of 16 outputs x 16 rows, warm-up blocks not
+    counted -- over the kernel's measured time.  Reported NEXT TO `roofline` (which stays the HBM one the contract's
+    per-unit figure is stated in)."""
+    if not stage["name"].startswith("k_rsos") or not mfmas_per_block or mfmas_per_block <= 0:
         return None
-    ks = 14  # (the headline's and config-3-rate windows; other rates: 12 / 16 / 20, DESIGN.md)
     blocks = n_out * nch / 256.0
-    tflops = blocks * (ks + 14) * 2048 / (stage["ms"] * 1e-3) / 1e12
+    tflops = blocks * mfmas_per_block * 2048 / (stage["ms"] * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS,
-            "kernel": stage["name"], "kernel_ms": stage["ms"],
-            "note": "issued fp64 MFMA flops of the stored outputs (28 MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure"}
+            "kernel": stage["name"], "kernel_ms": stage["ms"], "mfmas_per_block": mfmas_per_block,
+            "note": "issued fp64 MFMA flops of the stored outputs (%d MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure"
+                    % mfmas_per_block}
 
 
 def one_shot_probe():
@@ -611,7 +614,7 @@ def main():
                        "note": "warm-up is exactly --warmup steps; the first ~15 launches after an idle gap run up to 20% slower"},
             "algorithmic_bytes_per_step": algo,
             "roofline": roofline_of(dom, traffic, tsrc),
-            "roofline_mfma": mfma_roofline_of(dom, n_out, nch, stages),
+            "roofline_mfma": mfma_roofline_of(dom, n_out, nch, issue.get("fused_mfmas_per_block")),
             "roofline_sink": {"bound": "hbm", "achieved": sink_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": sink_gbps / HBM_PEAK_GBS, "frac_of_copy_ceiling": sink_gbps / HBM_COPY_GBS,
                               "from": "timed loop: algorithmic bytes of the sink (leaf read + result written) / ms_per_step"},

@@ -268,7 +268,9 @@ int32_t so_plan_step_info(const so_plan_t* plan, int32_t index, so_step_info_t* 
 typedef enum so_counter {
     SO_COUNTER_GRAPH_REPLAYS = 0,   /* executes replayed from the captured launch graph            */
     SO_COUNTER_GRAPH_CAPTURES = 1,  /* times the launch sequence was captured                      */
-    SO_COUNTER_DIRECT_EXECUTES = 2  /* executes issued launch by launch                            */
+    SO_COUNTER_DIRECT_EXECUTES = 2, /* executes issued launch by launch                            */
+    SO_COUNTER_FUSED_MFMAS_PER_BLOCK = 3 /* fp64 MFMAs the fused resampler + IIR kernel issues per block of 16 outputs x 16
+                                          * rows (0: the plan has no such launch): what a matrix-pipe roofline is priced with */
 } so_counter_t;
 int64_t so_plan_counter(const so_plan_t* plan, int32_t which);
 

@@ -1030,6 +1030,11 @@ int64_t plan_counter(const Plan* P, int which) {
     case SO_COUNTER_GRAPH_REPLAYS: return P->n_replays;
     case SO_COUNTER_GRAPH_CAPTURES: return P->n_captures;
     case SO_COUNTER_DIRECT_EXECUTES: return P->n_direct;
+    case SO_COUNTER_FUSED_MFMAS_PER_BLOCK: {  // k_rsos: window k-steps + 14 (D . X, X^T T^T, the chain's A^16 . S, S^T C^T)
+        for (const Stage& S : P->stages)
+            if (S.kind == ST_SOS && S.rsos_src >= 0 && S.need > 0) return S.rs.ks + 14;
+        return 0;
+    }
     default: return -1;
     }
 }

@@ -121,7 +121,7 @@ class Plan:
         """so_plan_counter: how the executes so far were issued (graph replays / captures / direct)"""
         L = K.lib()
         return {"graph_replays": L.so_plan_counter(self.handle, 0), "graph_captures": L.so_plan_counter(self.handle, 1),
-                "direct_executes": L.so_plan_counter(self.handle, 2)}
+                "direct_executes": L.so_plan_counter(self.handle, 2), "fused_mfmas_per_block": L.so_plan_counter(self.handle, 3)}
 
     def steps(self):
         """per-step statistics of the last (profiled) execute: so_plan_step_info"""

@@ -9,6 +9,8 @@ OUT=$R/gpurun_out/prof
 SUM=$R/gpurun_out/prof_summary
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
 cd $R
+# (the hash of the kernel sources the counters belong to: taken HERE, before the passes, not when they are summarised)
+python3 -c "import bench; print(bench.kernel_sources_sha16())" > $OUT/kernel_sources_sha16.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --cpu-seconds 0 > $OUT/trace.log 2>&1
 for W in ns config3; do
   ARGS="--workload $W --no-secondary --steps 100 --warmup 10 --cpu-seconds 0"

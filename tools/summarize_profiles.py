@@ -25,7 +25,10 @@ res = {"note": ("separate --pmc passes of `python3 bench.py --workload W --no-se
                 "--cpu-seconds 0`.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and "
                 "WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950, WRITE_SIZE is "
                 "exact; corrected HBM traffic = 2*FETCH + WRITE.  Per execute = summed over the stage's kernels / number of "
-                "executes."), "kernel_sources_sha16": bench.kernel_sources_sha16(), "stages": {}}
+                "executes."), "kernel_sources_sha16": None, "stages": {}}
+_h = os.path.join(src, "kernel_sources_sha16.txt")  # (written by collect_profiles.sh before the passes)
+res["kernel_sources_sha16"] = open(_h).read().strip() if os.path.exists(_h) else bench.kernel_sources_sha16()
+res["kernel_sources_sha16_taken"] = "before the PMC passes (collect_profiles.sh)" if os.path.exists(_h) else "when summarised"
 for wl in ("ns", "config3"):
     per = {}
     for name, sub in (("FETCH_SIZE", f"fetch_{wl}"), ("WRITE_SIZE", f"write_{wl}")):
