@@ -483,7 +483,14 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // rates whose period is long (44.1 -> 16 kHz: 441 inputs per period, 36 k-steps): two 32-row slots of it do not fit
 // LDS, two 16-row slots do, and the ring, the edge handling and the fused sources of this kernel then serve
 // what used to go to the row-tiled kernel without any overlap of loads and MFMAs (config 5).
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2>
+// F32M: a Float32 signal all the way (T = TO = float, plain source): operands, taps and accumulators in Float32 on
+// v_mfma_f32_16x16x4_f32 -- 32 cycles per instruction and SIMD where the Float64 one takes 64 (this kernel is bound by its
+// MFMAs on Float32 data: half the bytes, the same matrix cycles).  Same A / B operand maps; the RESULT map differs: row =
+// 4 (lane >> 4) + register, not (lane >> 4) + 4 register.  A k-ordered chain of Float32 fmas per output: within the
+// reference's 1e-6 for Float32 results (measured: profiles/r05/relerr_maxima_f32mfma.json), not bit-equal to the Float64
+// products rounded once -- SIGOPS_RS_NO_F32MFMA keeps those.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -964,14 +971,16 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const int kq = lane >> 4, n16 = lane & 15;
     const int ptmask = g.pt - 1, ptshift = g.ptshift;  // pt is a power of two
     const int gbeg = wave * G;
-    double breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
+    using AT = typename std::conditional<F32M, float, double>::type;  // MFMA operand / accumulator element
+    using ACC = typename std::conditional<F32M, v4f, v4d>::type;
+    AT breg[G][KS];  // taps of this wave's G groups: registers for the whole kernel
     int rowoff[Q];
     int goff[Q];  // GA: the same offset without the channel row (gains depend on the frame only)
 #pragma unroll
     for (int gg = 0; gg < G; ++gg)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            breg[gg][s] = gbeg + gg < g.ngroups ? tab[((size_t)(gbeg + gg) * KS + s) * 64 + lane] : 0.0;
+            breg[gg][s] = gbeg + gg < g.ngroups ? (AT)tab[((size_t)(gbeg + gg) * KS + s) * 64 + lane] : (AT)0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int rho = 16 * q + n16;  // A operand: row m = lane & 15 of row-tile q
@@ -988,7 +997,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     for (int q = 0; q < Q; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
+            const int rho = F32M ? 16 * q + 4 * kq + i : 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg (Float32 MFMA: 4*(lane>>4) + reg)
             yoff[q][i] = (int64_t)(rho >> ptshift) * g.out_pitch + (int64_t)(rho & ptmask) * g.L + n16;
         }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // taps loaded
@@ -1008,9 +1017,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             const int gi = gbeg + gg;
             if (gi < g.ngroups && !(g.pad & 1)) {
                 const int je = jeg[gg];
-                v4d acc[Q];
+                ACC acc[Q];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < Q; ++q) acc[q] = ACC{0, 0, 0, 0};
                 // A operands are software-pipelined one k-step ahead (double-buffered
                 // registers) so the LDS latency hides under the previous step's MFMAs; the
                 // per-step address is an immediate offset from fixed row pointers.
@@ -1021,10 +1030,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     ap[q] = cur + (rowoff[q] + je);
                     gp[q] = fbase + (size_t)fbr(it) * g.fslots * g.fpitch + (sh + goff[q] + je);
                 }
-                double abuf[2][Q];
+                AT abuf[2][Q];
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    abuf[0][q] = (double)ap[q][0];
+                    abuf[0][q] = (AT)ap[q][0];
                     if constexpr (GA && GADD) abuf[0][q] += gp[q][0];
                     else if constexpr (GA) abuf[0][q] *= gp[q][0];
                 }
@@ -1033,14 +1042,16 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     if (s + 1 < KS) {
 #pragma unroll
                         for (int q = 0; q < Q; ++q) {
-                            abuf[(s + 1) & 1][q] = (double)ap[q][4 * (s + 1)];
+                            abuf[(s + 1) & 1][q] = (AT)ap[q][4 * (s + 1)];
                             if constexpr (GA && GADD) abuf[(s + 1) & 1][q] += gp[q][4 * (s + 1)];
                             else if constexpr (GA) abuf[(s + 1) & 1][q] *= gp[q][4 * (s + 1)];
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < Q; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
+                    for (int q = 0; q < Q; ++q) {
+                        if constexpr (F32M) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
+                        else acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[s & 1][q], breg[gg][s], acc[q], 0, 0, 0);
+                    }
                 }
                 const int r = gi * 16 + n16;  // output index inside the period
                 if (g.pad & 4) continue;
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     for (int q = 0; q < Q; ++q)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int rho = 16 * q + kq + 4 * i;
+                            const int rho = F32M ? 16 * q + 4 * kq + i : 16 * q + kq + 4 * i;
                             const int64_t period = P0 + (rho & ptmask);
                             const int64_t m = period * g.L + r;
                             if (period < g.nperiods && r < g.L && m < g.n_out)
@@ -1081,7 +1092,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
@@ -1090,10 +1101,10 @@ static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPer
                   (ST ? (size_t)4 * g.ksw * 10 : 0)) * 8;  // + static RsCtl
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
 }
 
@@ -1154,6 +1165,12 @@ static int launch_rp_ct(void* y, const double* tab, const int* jend, const RsPer
             }                                                                             \
         }                                                                                 \
         if (g.out_f32) return -1;                                                         \
+        if constexpr (sizeof(T) == 4 && G_ == 1 && CT >= 4 && KS_ <= 20) {                \
+            if (g.f32m) { /* Float32 all the way: the Float32 MFMA */                     \
+                launch_rp_k<T, CT, KS_, G_, false, T, false, false, false, 2, true>(y, tab, jend, g, gsrc, st); \
+                return 0;                                                                 \
+            }                                                                             \
+        }                                                                                 \
         launch_rp_k<T, CT, KS_, G_>(y, tab, jend, g, gsrc, st);                           \
         return 0;                                                                         \
     }

@@ -287,7 +287,8 @@ struct RsPeriodic {
     int64_t nperiods;
     int32_t pt, ct;     // periods x channels per workgroup tile, pt*ct == rows
     int32_t rows;       // 32 (two 16-row MFMA tiles) or 16 (one: long periods, see k_resample_periodic's Q)
-    int32_t pad0;
+    int32_t f32m;       // a Float32 signal all the way (Float32 tile, Float32 result): the products on v_mfma_f32_16x16x4_f32 with
+                        // Float32-rounded taps -- half the matrix cycles of the Float64 instruction (k_resample_periodic F32M)
     int32_t ngroups;    // groups of 16 consecutive outputs per period
     int32_t kw;         // inputs in a group's window (multiple of 4)
     int32_t tile_len;   // inputs per channel staged in LDS

@@ -625,6 +625,10 @@ void Plan::process_stage(int sid) {
                 if (const char* ev = std::getenv("SIGOPS_RS_GRID")) rp.grid = std::max(1, std::atoi(ev));
                 if (const char* ev = std::getenv("SIGOPS_RS_DEBUG")) rp.pad = std::atoi(ev);  // ablation knob
                 if (const char* ev = std::getenv("SIGOPS_RS_NLOAD")) rp.nload = std::max(1, std::atoi(ev));  // tuning knob
+                // A Float32 signal all the way (the stage's own type: its source tile and its output are Float32): the products
+                // on the Float32 MFMA where an instantiation exists (32-row tiles, one group per compute wave, windows of up to
+                // 20 k-steps, 4 or 8 channels per tile); SIGOPS_RS_NO_F32MFMA keeps the Float64 products rounded once.
+                rp.f32m = (N.dtype == SO_F32 && rows_try == 32 && gper == 1 && kw <= 80 && ct >= 4 && !std::getenv("SIGOPS_RS_NO_F32MFMA")) ? 1 : 0;
                 stages[sid].periodic = true;
                 stages[sid].per_j = jr;
                 stages[sid].per_p = pr;
