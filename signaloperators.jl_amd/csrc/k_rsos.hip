@@ -51,8 +51,10 @@ __device__ __forceinline__ int flag_ld(uint32_t a) { return *(const volatile SO_
 __device__ __forceinline__ void flag_st(uint32_t a, int v) { *(volatile SO_LDS int*)(uintptr_t)a = v; }
 // every wait of this kernel is for another wave of the same workgroup and lasts microseconds: a wait that does not end
 // is a bug of the protocol, and a trap (the launch fails) is better than a hung device
-__device__ __forceinline__ void spin_pause(int& spins, int sleep) {
-    if (++spins > (1 << 22)) __builtin_trap();
+// (SIGOPS_RSOS_DEBUG bit 32768 lowers the limit of the y waves' wait for a state to 4 096 polls: with bit 64 -- no chain wave --
+//  that wait never ends, and the test of the host's report of such a failure need not hold a GPU for seconds)
+__device__ __forceinline__ void spin_pause(int& spins, int sleep, int limit = 1 << 22) {
+    if (++spins > limit) __builtin_trap();
     if (sleep == 1) __builtin_amdgcn_s_sleep(1);
     else __builtin_amdgcn_s_sleep(2);
 }
@@ -888,7 +890,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
             if constexpr (SO_RSOS_COUNT) ++cnt_st_b;
             do {
-                spin_pause(spins, 1);
+                spin_pause(spins, 1, (debug & 32768) ? 4096 : (1 << 22));
                 if constexpr (SO_RSOS_COUNT) ++cnt_st;
                 sq = uni(flag_ld(f_sseq));
             } while (sq < pb_);

@@ -403,3 +403,33 @@ def test_float32_pipeline_windows_and_streams():
         blocks = [blk for blk, _ in so.stream(x, 150_000)]
     cat = np.concatenate(blocks, axis=0)
     assert cat.dtype == np.float32 and cat.shape == want.shape and relerr(cat, want) < 1e-6
+
+
+def test_a_wait_that_does_not_end_ends_the_process_not_the_device():
+    """k_rsos ends a wait between its waves that never ends with a trap: the ROCm runtime then aborts the PROCESS (its queue
+    callback, "HSA_STATUS_ERROR_EXCEPTION ... hardware exception": nothing the library's host side could turn into an
+    SO_ERR_* return) -- a dead process instead of a hung device.  Forced in a child: no chain wave (ablation bit 64), the
+    y waves' wait for a state cut to 4 096 polls (bit 32768)."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+os.environ["SIGOPS_RSOS_DEBUG"] = str(64 + 32768)
+os.environ["SIGOPS_RSOS_MINGROUPS"] = "1"
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import sigops_amd as so
+rng = np.random.default_rng(1)
+x = so.Signal(np.asfortranarray(rng.standard_normal((200000, 8))), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz)
+so.sink(x)
+print("RETURNED")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode != 0 and "RETURNED" not in out and "hardware exception" in out, (r.returncode, out[-1500:])
+    # ... and the device is fine afterwards: this process sinks the same tree
+    rng = np.random.default_rng(1)
+    x = pipeline(so.Signal(F(rng.standard_normal((200000, 8))), 44.1 * so.kHz))
+    with env(SIGOPS_RSOS_MINGROUPS=1):
+        assert relerr(so.sink(x)[0], oracle_sink(x)) < 1e-9
