@@ -1121,9 +1121,19 @@ void Plan::process_stage(int sid) {
             fail(SO_ERR_RUNTIME, "internal: Normpower over a stage buffer expected that buffer");
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
-    } else if (S.kind == ST_NORM && S.norm_direct) {
+    } else if (S.kind == ST_NORM && S.norm_direct && direct && S.in_array_node >= 0) {
         // the array itself is `vals` (planner.cpp): K4 reads it in place
-        if (!direct || S.in_array_node < 0) fail(SO_ERR_RUNTIME, "internal: Normpower over an array expected one plain load");
+    } else if (S.kind == ST_NORM && S.norm_direct) {
+        // planner.cpp took the in-place form from the node kinds (an array under Until / After), the lowered child is not
+        // ONE plain load after all (pieces split at a boundary, a view the leaf test does not take): the sum of squares
+        // is taken over a materialised copy as it used to be -- the readers, lowered as "the child's own pieces ./ rms",
+        // are unaffected -- instead of refusing the plan
+        S.norm_direct = false;
+        S.in_array_node = -1;
+        S.in_offset = 0;
+        S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
+        S.in_buf = S.out_buf;
+        S.in_pitch = -1;
     } else if (S.kind == ST_NORM) {
         // materialise the child straight into `vals` (the stage's own output buffer)
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
@@ -1717,7 +1727,7 @@ void Plan::fuse_resample_sos() {
             }
         }
         const int ks = kwp / 4;
-        if (!(ks == 12 || ks == 13 || ks == 14 || ks == 16 || ks == 20)) continue;
+        if (!(ks == 12 || ks == 13 || ks == 14 || ks == 16 || ks == 20)) continue;  // (the window lengths k_rsos is instantiated for)
         bool ok = true;
         // GA carriers (a Float32 array whose Float64 gain or summand K3's compute waves apply at the MFMA operand): this
         // kernel's loader widens the landed Float32 chunk in place and applies the step on the way, so the carriers go
@@ -1835,6 +1845,12 @@ void Plan::fuse_resample_sos() {
             if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : std::atoi(ev) == 16 && cyc_of(16) == 1 && ks <= 16 ? 16 : 12;
             g.nwaves = nw;
             g.cyc = (nw == 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
+            // (waves, groups per wave, window) as launch_rsos_t instantiates them -- a combination it has not (the 16-wave
+            //  geometry with its taps in LDS, SIGOPS_RSOS_LDSTAPS) keeps the two kernels HERE instead of failing the execute
+            const bool inst = nw == 12 ? (g.cyc == 0 || g.cyc == 1 || (g.cyc == 2 && ks <= 16))
+                            : nw == 16 ? g.cyc == 1
+                                       : (g.cyc == 0 || g.cyc == 1 || g.cyc == 2 || (g.cyc == 3 && ks <= 20) || (g.cyc == 5 && ks <= 16));
+            if (!inst) continue;
         }
         // input ring: as large as fits next to the tap table (if any) and the exchange slots
         {

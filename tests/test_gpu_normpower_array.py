@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import sigops_amd as so
-from oracle_bridge import oracle_sink
+from oracle_bridge import oracle_sink, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +133,24 @@ def test_float32_sum_of_squares_edges(nch):
         if n > 64:  # a copy with a pitch of its own (the filter's output buffer) and a window of the array
             t2 = so.Signal(x, 10 * so.kHz) | so.After(7 * so.frames) | so.Normpower
             assert np.array_equal(so.sink(t2)[0], oracle_sink(t2)), (n, nch, "after")
+
+
+def test_normpower_over_views_the_in_place_form_does_not_take():
+    """interleaved and strided device tensors, a channel subset: `vals` is a copy there (or the in-place form falls back to
+    one, stages.cpp) -- never a refused plan"""
+    import torch
+
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((50000, 6))
+    il = torch.tensor(base, device="cuda")                      # [frames x channels] row-major: interleaved
+    planar = torch.tensor(np.ascontiguousarray(base.T), device="cuda").t()
+    strided = torch.tensor(np.ascontiguousarray(np.repeat(base.T, 2, axis=1)), device="cuda").t()[::2]   # every second frame of a longer tensor
+    for leaf, ref in ((il, base), (planar, base), (strided, base)):
+        x = so.Signal(leaf, 10 * so.kHz) | so.Normpower
+        got = so.sink(x)[0]
+        want = ref / np.sqrt(np.mean(ref ** 2))
+        assert relerr(got, want) < 1e-12
+        y = so.Signal(leaf, 10 * so.kHz) | so.After(100 * so.frames) | so.Until(40000 * so.frames) | so.Normpower
+        goty = so.sink(y)[0]
+        w = ref[100:40100]
+        assert relerr(goty, w / np.sqrt(np.mean(w ** 2))) < 1e-12

@@ -56,7 +56,9 @@ def both(x, to=None):
     with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_RSOS=None):
         fused = "k_rsos" in steps_of(x)
         a = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
-    with env(SIGOPS_NO_RSOS=1):
+    # (the two-kernel reference with K3's Float64 products: on Float32 signals K3 alone takes the Float32 MFMA -- another
+    #  rounding, tests/test_gpu_f32_mfma.py -- while the fused kernel resamples in Float64 and rounds once, as K3 did)
+    with env(SIGOPS_NO_RSOS=1, SIGOPS_RS_NO_F32MFMA=1):
         b = so.sink(x, to)[0] if to is not None else so.sink(x)[0]
     return a, b, fused
 
@@ -433,3 +435,34 @@ print("RETURNED")
     x = pipeline(so.Signal(F(rng.standard_normal((200000, 8))), 44.1 * so.kHz))
     with env(SIGOPS_RSOS_MINGROUPS=1):
         assert relerr(so.sink(x)[0], oracle_sink(x)) < 1e-9
+
+
+@pytest.mark.parametrize("shape", ["odd rows", "odd base", "both"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_float32_device_tensors_off_their_16_byte_boundaries(shape, fused):
+    """Float32 rows that are only element-aligned -- an odd number of frames per row, a view that starts one sample into its
+    storage -- take the 16-byte LDS-DMA path (executor.cpp carrier_vec_ok: the memory pipeline takes any address aligned
+    for the element); SIGOPS_STRICT_ALIGN=1 sends them through the general staging path.  Same values, bit for bit, in
+    K3 (`ToFramerate`) and in the fused kernel (`ToFramerate |> Filt`)."""
+    import torch
+
+    n = 300001 if shape != "odd base" else 300000
+    store = torch.randn((8, n + 4), dtype=torch.float32, device="cuda")
+    view = store[:, 1:n + 1] if shape != "odd rows" else store[:, :n]
+    if shape == "odd rows":
+        view = torch.randn((8, n), dtype=torch.float32, device="cuda")
+    x = so.Signal(view.t(), 44.1 * so.kHz) | so.ToFramerate(48 * so.kHz)
+    if fused:
+        x = x | so.Filt(so.Lowpass, 6 * so.kHz)
+    outs = []
+    for strict in (None, 1):
+        with env(SIGOPS_STRICT_ALIGN=strict, SIGOPS_RSOS_MINGROUPS=1):
+            if fused:
+                assert "k_rsos" in steps_of(x, np.float32)
+            got, _ = so.sink(x, "torch")
+            outs.append(got.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    host = so.Signal(F(view.t().cpu().numpy()), 44.1 * so.kHz) | so.ToFramerate(48 * so.kHz)
+    if fused:
+        host = host | so.Filt(so.Lowpass, 6 * so.kHz)
+    assert relerr(outs[0], oracle_sink(host)) < 1e-6
