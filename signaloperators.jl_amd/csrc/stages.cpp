@@ -1995,7 +1995,7 @@ void Plan::fuse_plain_sos() {
         } else {
             // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
             // channels, eight loader units per chunk: 1.7 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
-            // 2.5 ps + 195 us beyond (tools/r05/iir_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
+            // 2.5 ps + 195 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
             // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals keep the three passes: their
             // chunks would have to be widened by the one loader wave (12.5 M x 8: 0.47 against 0.39 ms).
             const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.25 : ct == 2 ? 1.7 : 3.4;

@@ -2,7 +2,7 @@
 time on 8 ch x 600 s at 44.1 -> 48 kHz, accuracy of both against the oracle on a prefix, and a sweep of signal kinds
 (noise, a loud low tone, a sum of tones, a DC offset with small noise) whose cancellation behaviour differs."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import sigops_amd as so

@@ -1,7 +1,7 @@
 """Repeated full-length check of the fused kernel against the two-kernel path on the headline pipeline: the reference result
 is computed once, the fused plan is executed N times and every result compared (a rare bad block shows as n_bad > 0)."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import sigops_amd as so

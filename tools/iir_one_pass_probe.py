@@ -1,6 +1,6 @@
 """plain Filt: one pass (k_rsos, identity resampler) against the three-pass K2 on device-resident data"""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import sigops_amd as so
