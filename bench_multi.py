@@ -175,7 +175,7 @@ def run(args, so, torch, dist, rank, local_rank, world, dev, emit=True):
         def with_gather():
             compute()
             if world > 1:
-                dist.all_gather_into_tensor(outs, slab)
+                dist.all_gather_into_tensor(outs.view(world * nch, width), slab)  # (the concatenated form: what RCCL and gloo both take)
                 pos = 0
                 for r in range(world):  # planar [nch x total] result on every rank
                     full[:, pos:pos + counts[r]] = outs[r, :, :counts[r]]

@@ -39,3 +39,20 @@ def test_gpus_2_on_a_one_gpu_box_is_labelled_oversubscribed():
     res = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "20", "--cpu-seconds", "0", "--no-secondary")
     assert res["n_gpus"] == 2 and res["value"] > 0
     assert "OVERSUBSCRIBED" in res["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config4", "config5"])
+def test_gpus_2_on_a_one_gpu_box_runs_the_sharded_workloads_too(workload):
+    """the N > 1 branches of bench_multi.py (shares, agreement over the ranks, the gather or the channel slabs) on one GPU,
+    two ranks sharing it over gloo: not a measurement -- the first run of these branches must not be the driver's 8-GPU run"""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU: a real two-rank run")
+    res = run_bench("--gpus", "2", "--workload", workload, "--steps", "2", "--warmup", "1", "--seconds", "20")
+    assert res["n_gpus"] == 2 and res["value"] > 0
+    if workload == "config4":
+        assert res["scaling"] == "strong" and res["config"]["scenes_per_rank"] == 32 and res["parity_gate"]["relerr"] < 1e-8
+    else:
+        assert res["scaling"] == "weak" and res["config"]["channels"] == 256 and res["config"]["finite"]
