@@ -522,7 +522,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 }
                 for (int q = 0; q < 3; ++q) B.total[q] = first[q];
                 const bool poison = B.bad_buf >= 0 && !std::getenv("SIGOPS_SOS_NOPOISON");
-                if (poison) HIPCHECK(hipMemsetAsync(P->bufs[B.bad_buf].d, 0x7f, P->bufs[B.bad_buf].bytes, st));  // "no non-finite chunk yet"
+                if (poison) launch_fill_u32(P->bufs[B.bad_buf].d, P->bufs[B.bad_buf].bytes / 4, 0x7f7f7f7fu, st);  // "no non-finite chunk yet"
                 int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
                 if (poison) nl += launch_sos_poison_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.dtype, st);
                 s.launches = nl;
@@ -574,7 +574,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     if (S.bad_buf >= 0 && S.pre_stage < 0 && S.rsos_src < 0 && !S.onepass && !S.xscan && !g.exact &&
                         !std::getenv("SIGOPS_SOS_NOPOISON")) {
                         g.bad = (int32_t*)P->bufs[S.bad_buf].d;
-                        HIPCHECK(hipMemsetAsync(g.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite chunk yet"
+                        launch_fill_u32(g.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite chunk yet"
                     }
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
@@ -592,7 +592,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rs.bad = nullptr;
                         if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
                             rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
-                            HIPCHECK(hipMemsetAsync(rs.bad, 0x7f, (size_t)N.nch * 4, st));  // "no non-finite range yet"
+                            launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite range yet"
                         }
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
                         // (SIGOPS_RSOS_TRACE_SKIP=n: not the first n launches of the process -- a traced launch synchronises, and a run
@@ -714,7 +714,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                          S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
                                          gg, S.groups[gi], st);
                         nl += launch_sos_poison(ob.d, gg, st);  // (behind a NaN the reference stays NaN: SosGeom::bad)
-                        if (gg.bad && gi + 1 < S.groups.size()) HIPCHECK(hipMemsetAsync(gg.bad, 0x7f, (size_t)N.nch * 4, st));
+                        if (gg.bad && gi + 1 < S.groups.size()) launch_fill_u32(gg.bad, (size_t)N.nch, 0x7f7f7f7fu, st);
                     }
                     s.launches = nl;
                     launches += nl;

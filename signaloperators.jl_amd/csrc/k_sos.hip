@@ -238,6 +238,20 @@ __device__ __forceinline__ void sos_tiled_body(const T* __restrict__ x, T* __res
 // NaN over the frames behind a channel's first non-finite chunk (SosGeom::bad): the reference's sequential recurrence
 // never recovers from a NaN or Inf (reference src/filters.jl:252-255 -> DSP.jl filt!: the state carries it on), the
 // chunked form does after K chunks.  A few workgroups per channel; channels without a bad chunk return at once.
+// "no non-finite chunk yet" into a filter's per-channel words, as a kernel of our own: hipMemsetAsync becomes a memset NODE
+// when the launch sequence is captured into a HIP graph, and a replayed graph of a single-stream plan whose stages write
+// windows of the result left those words in a state that made k_sos_poison fill whole windows with NaN (ROCm 7.0; direct
+// launches and multi-stream graphs were fine: tests/test_gpu_window_alias.py under SIGOPS_SINGLE_STREAM=1).  A kernel node
+// carries its arguments by value.
+__global__ void k_fill_u32(uint32_t* __restrict__ p, int n, uint32_t v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_u32(void* p, size_t n, uint32_t v, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, (int)n, v);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sos_poison(T* __restrict__ y, SosGeom g) {
     const int ch = blockIdx.y;

@@ -107,13 +107,18 @@ def test_device_result_repointed_between_executes():
     plan.close()
 
 
+@pytest.mark.parametrize("single_stream", [False, True])
 @pytest.mark.parametrize("orders", [(2, 4, 6), (5, 5, 5)])
-def test_graph_replay_after_the_result_moved_away_and_back(orders):
+def test_graph_replay_after_the_result_moved_away_and_back(orders, single_stream, monkeypatch):
     """in-place root pieces (ramp edges of window-aliased stages) read the RESULT
     through leaves that are re-pointed at every new result pointer.  With device leaves the plan is
     graph-eligible: A, A (captured for A), B (direct, leaves now point at B), A -- replaying A's graph
     while the device leaf table still pointed at B applied the ramp to B's already ramped values."""
     torch = pytest.importorskip("torch")
+    if single_stream:
+        # (round 5: the replayed graph of a ONE-stream plan left whole windows NaN -- the filters' "no non-finite chunk yet"
+        #  words were reset by hipMemsetAsync, a memset node in the graph; they are reset by a kernel of the library's now)
+        monkeypatch.setenv("SIGOPS_SINGLE_STREAM", "1")
     rng = np.random.default_rng(18)
     host = [_noise(rng, n, 2) for n in (9999, 12001, 8000)]
     dev = [torch.from_numpy(np.ascontiguousarray(h.T)).cuda() for h in host]  # [nch][n]: planar, time fastest
@@ -135,7 +140,7 @@ def test_graph_replay_after_the_result_moved_away_and_back(orders):
     c = plan.counters()
     # filters of three different orders keep their own launches: four steps, replayed as a graph; filters of one
     # order share their launches (test_gpu_sos_batch.py): two steps, launched directly -- same sequence either way
-    if len(set(orders)) == 3:
+    if len(set(orders)) == 3 and not os.environ.get("SIGOPS_NO_GRAPH"):
         assert c["graph_replays"] >= 2 and c["graph_captures"] >= 1, c  # (the graph path really ran)
     assert c["graph_replays"] + c["direct_executes"] + c["graph_captures"] == len(order), c
     plan.close()
