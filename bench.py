@@ -332,19 +332,23 @@ def one_shot_probe():
                                  stderr=subprocess.DEVNULL, timeout=180)
             for line in out.stdout.decode().splitlines():
                 if line.startswith("{"):
-                    return json.loads(line)["calls"]
+                    d = json.loads(line)
+                    imp[0] = d.get("import_ms")
+                    return d["calls"]
         except Exception:
             pass
         return None
 
+    imp = [None]
     cold = run({})
     with tempfile.TemporaryDirectory() as d:
         run({"SIGOPS_CACHE_DIR": d})
         warm = run({"SIGOPS_CACHE_DIR": d})
     return {"what": "the headline sink once, in a fresh process: plan create + first execute + destroy, host clock (ms); "
-                    "device-resident leaf and result; `again`: the same call repeated in that process",
+                    "device-resident leaf and result; `again`: the same call repeated in that process; `import_ms`: the "
+                    "package import in front of it (torch already imported), which opens the engine library -- not in one_shot_ms",
             "no_cache_dir": cold[0] if cold else None, "warm_cache_dir": warm[0] if warm else None,
-            "again_in_process": cold[-1] if cold else None}
+            "again_in_process": cold[-1] if cold else None, "import_ms": imp[0]}
 
 
 def parity_gate(so, tree_fn, noise_host, tol=1e-6):

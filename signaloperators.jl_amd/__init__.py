@@ -37,3 +37,17 @@ toframerate = _eager(ToFramerate)
 tochannels = _eager(ToChannels)
 toeltype = _eager(ToEltype)
 format = _eager(Format)
+
+# The engine library is opened when the package is imported (as a Julia package opens its library in `__init__`, before the
+# first `ccall`): dlopen + the registration of its code objects take ~5 ms, which the first sink of a process does not pay.
+# Without the library the package's host half still imports -- trees, units, the WAV layer -- and the first call that needs
+# the engine raises EngineMissing as before.  SIGOPS_LAZY_LOAD=1 keeps the load for that first call.
+import os as _os
+
+if not _os.environ.get("SIGOPS_LAZY_LOAD"):
+    try:
+        from . import _capi as _capi_mod
+
+        _capi_mod.lib()
+    except Exception:  # (missing or unloadable library: reported by the call that needs it)
+        pass

@@ -28,12 +28,19 @@
 #include "kcommon.h"
 #include "kstage.h"
 
-// One translation unit per window length (build.py: -DSO_RSOS_ONLY_KS=4 | 12 | 13 | 14 | 16 | 20, and 0 for the dispatcher):
+// One translation unit per window length, result type and workgroup size (build.py: -DSO_RSOS_ONLY_KS=4 | 12 | 13 | 14 |
+// 16 | 20 with -DSO_RSOS_ONLY_F32=0 | 1 and -DSO_RSOS_ONLY_NW=12 | 16 | 8, and -DSO_RSOS_ONLY_KS=0 for the dispatcher):
 // the runtime loads a code object the first time one of ITS kernels is launched, and all instantiations in one object
 // were 8 ms of a first sink's 9 ms execute; the units also compile side by side.  -1 (the default, tools/build_variant.sh):
 // everything in this one.
 #ifndef SO_RSOS_ONLY_KS
 #define SO_RSOS_ONLY_KS -1
+#endif
+#ifndef SO_RSOS_ONLY_F32
+#define SO_RSOS_ONLY_F32 0
+#endif
+#ifndef SO_RSOS_ONLY_NW
+#define SO_RSOS_ONLY_NW 0  // (0: every workgroup size in this unit)
 #endif
 
 namespace so {
@@ -1201,7 +1208,7 @@ template <int KS, typename TO>
 static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st) {
     // (register taps: cyc * KS doubles per y wave -- up to 32 of them at 12 waves per workgroup (168 registers each), up
     //  to 80 at 8 waves (256 registers))
-    if (g.nwaves == 12) {
+    if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 12) if (g.nwaves == 12) {
         switch (g.cyc) {
         case 0: launch_rsos_k<KS, 12, TO, 0>(tab, jend, g, y, gsrc, grid, st); return 0;
         case 1: launch_rsos_k<KS, 12, TO, 1>(tab, jend, g, y, gsrc, grid, st); return 0;
@@ -1214,12 +1221,12 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
         default: return -1;
         }
     }
-    if (g.nwaves == 16) {
+    if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 16) if (g.nwaves == 16) {
         if (g.cyc != 1) return -1;
         launch_rsos_k<KS, 16, TO, 1>(tab, jend, g, y, gsrc, grid, st);
         return 0;
     }
-    if (g.nwaves == 8) {
+    if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 8) if (g.nwaves == 8) {
         switch (g.cyc) {
         case 0: launch_rsos_k<KS, 8, TO, 0>(tab, jend, g, y, gsrc, grid, st); return 0;
         case 1: launch_rsos_k<KS, 8, TO, 1>(tab, jend, g, y, gsrc, grid, st); return 0;
@@ -1248,9 +1255,17 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
 // this unit's window length: launch_rsos_ks<N>, called by the dispatcher's unit
 #define SO_RSOS_CAT2(a, b) a##b
 #define SO_RSOS_CAT(a, b) SO_RSOS_CAT2(a, b)
-int SO_RSOS_CAT(launch_rsos_ks, SO_RSOS_ONLY_KS)(SO_RSOS_ARGS) {
-    return g.out_f32 ? launch_rsos_t<SO_RSOS_ONLY_KS, float>(tab, jend, g, y, gsrc, grid, st)
-                     : launch_rsos_t<SO_RSOS_ONLY_KS, double>(tab, jend, g, y, gsrc, grid, st);
+// (... and result type: -DSO_RSOS_ONLY_F32=0 the Float64 results of this window length, =1 the Float32 ones)
+// (... and workgroup size: launch_rsos_ks<N><d|f><12|16|8>)
+#if SO_RSOS_ONLY_F32
+#define SO_RSOS_TAG f
+#define SO_RSOS_TO float
+#else
+#define SO_RSOS_TAG d
+#define SO_RSOS_TO double
+#endif
+int SO_RSOS_CAT(SO_RSOS_CAT(SO_RSOS_CAT(launch_rsos_ks, SO_RSOS_ONLY_KS), SO_RSOS_TAG), SO_RSOS_ONLY_NW)(SO_RSOS_ARGS) {
+    return launch_rsos_t<SO_RSOS_ONLY_KS, SO_RSOS_TO>(tab, jend, g, y, gsrc, grid, st);
 }
 #else
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
@@ -1261,19 +1276,23 @@ size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
 size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 
 #if SO_RSOS_ONLY_KS == 0
-int launch_rsos_ks4(SO_RSOS_ARGS);
-int launch_rsos_ks12(SO_RSOS_ARGS);
-int launch_rsos_ks13(SO_RSOS_ARGS);
-int launch_rsos_ks14(SO_RSOS_ARGS);
-int launch_rsos_ks16(SO_RSOS_ARGS);
-int launch_rsos_ks20(SO_RSOS_ARGS);
+#define SO_RS(KS_) \
+    int launch_rsos_ks##KS_##d12(SO_RSOS_ARGS); int launch_rsos_ks##KS_##d16(SO_RSOS_ARGS); int launch_rsos_ks##KS_##d8(SO_RSOS_ARGS); \
+    int launch_rsos_ks##KS_##f12(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f16(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f8(SO_RSOS_ARGS);
+SO_RS(4) SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
+#undef SO_RS
 #endif
 int launch_rsos(SO_RSOS_ARGS) {
     if (g.n_out <= 0) return 0;
     if (g.ngroups > kRsosMaxGroups) return -1;
 #if SO_RSOS_ONLY_KS == 0
 #define SO_RS(KS_) \
-    if (g.ks == KS_) return launch_rsos_ks##KS_(tab, jend, g, y, gsrc, grid, st);
+    if (g.ks == KS_) {                                                                                                             \
+        if (g.nwaves == 12) return g.out_f32 ? launch_rsos_ks##KS_##f12(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d12(tab, jend, g, y, gsrc, grid, st); \
+        if (g.nwaves == 16) return g.out_f32 ? launch_rsos_ks##KS_##f16(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d16(tab, jend, g, y, gsrc, grid, st); \
+        if (g.nwaves == 8) return g.out_f32 ? launch_rsos_ks##KS_##f8(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d8(tab, jend, g, y, gsrc, grid, st);    \
+        return -1;                                                                                                                 \
+    }
 #else
 #define SO_RS(KS_) \
     if (g.ks == KS_) return g.out_f32 ? launch_rsos_t<KS_, float>(tab, jend, g, y, gsrc, grid, st) : launch_rsos_t<KS_, double>(tab, jend, g, y, gsrc, grid, st);

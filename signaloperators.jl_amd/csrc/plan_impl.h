@@ -436,6 +436,11 @@ int rtc_launch(const void* fn, int64_t nblocks, const DPiece* d_pieces, int npie
                hipStream_t st);
 
 // ---- accumulator.cpp ----
+// One double per key between processes (SIGOPS_CACHE_DIR; accumulator.cpp): host-side analyses that depend on nothing but
+// their key -- a cascade's rounding sensitivity -- and cost a first sink a millisecond each.  The file carries the key in
+// full; false / no-op without a cache directory.
+bool disk_value_get(const char* kind, const std::vector<double>& key, double& val);
+void disk_value_put(const char* kind, const std::vector<double>& key, double val);
 void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
                               std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from = 0);
 void rs_detect_exact(RsGeom& g, double fo, double fi, double rate);

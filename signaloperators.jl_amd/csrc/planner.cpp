@@ -1153,6 +1153,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         if (device < 0 || device >= ndev) fail(SO_ERR_INVALID, "bad device ordinal");
         P->device = device;
         HIPCHECK(hipSetDevice(device));
+        const auto t_dev = std::chrono::steady_clock::now();
         P->out = *out;
         P->root = root;
         P->build_nodes(nodes, n_nodes);
@@ -1166,6 +1167,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
             fail(SO_ERR_LENGTH, "Signal is too short to skip " + std::to_string(R.short_skip) + " frames");
         std::vector<Piece> rootp;
         if (out->nframes > 0) rootp = P->lower(root, Rect{0, out->nframes, 0, out->nch}, Map{1, 0, 1, 0});
+        const auto t_low = std::chrono::steady_clock::now();
         // stages: largest node index first (all users of a stage have larger indices)
         for (;;) {
             int best = -1;
@@ -1214,6 +1216,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
                         if (S.in_buf == e.leaf.buf) P->alias_stage = -1;
             }
         }
+        const auto t_stg = std::chrono::steady_clock::now();
         int rootstep = -1;
         if (P->alias_stage < 0) P->try_window_alias(rootp);
         if (P->alias_stage < 0) rootstep = P->emit_pointwise(rootp, -1, out->dtype);
@@ -1228,8 +1231,9 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
         P->plan_lanes();
         if (std::getenv("SIGOPS_DEBUG_PLAN")) {
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[sigops] plan_create: lowering and stage setup %.3f ms, allocation and uploads %.3f ms, lanes %.3f ms\n",
-                         ms(t_create0, t_lowered), ms(t_lowered, t_final), ms(t_final, std::chrono::steady_clock::now()));
+            std::fprintf(stderr, "[sigops] plan_create: lowering and stage setup %.3f ms (device %.3f, tree %.3f, stages %.3f, fusion %.3f), allocation and uploads %.3f ms, lanes %.3f ms\n",
+                         ms(t_create0, t_lowered), ms(t_create0, t_dev), ms(t_dev, t_low), ms(t_low, t_stg), ms(t_stg, t_lowered), ms(t_lowered, t_final),
+                         ms(t_final, std::chrono::steady_clock::now()));
         }
     } catch (const PlanError& e) {
         status = e.status;

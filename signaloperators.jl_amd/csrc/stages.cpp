@@ -82,6 +82,8 @@ static double sos_rounding_sensitivity(const double* sos, int nsec, double gain)
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
+        double dv;
+        if (disk_value_get("sens", key, dv)) return cache[key] = dv;
     }
     std::vector<double> s(2 * (size_t)nsec, 0.0);
     std::vector<long double> sl(2 * (size_t)nsec, 0.0L);
@@ -112,6 +114,7 @@ static double sos_rounding_sensitivity(const double* sos, int nsec, double gain)
     }
     double r = den > 0 ? (double)std::sqrt((double)(num / den)) : 0.0;
     if (!std::isfinite(r)) r = 0.0;  // (an unstable design: nothing to protect)
+    disk_value_put("sens", key, r);
     std::lock_guard<std::mutex> lk(mu);
     cache[key] = r;
     return r;
@@ -137,13 +140,16 @@ static double sos_chunk_sensitivity(const std::vector<SosCoefs>& groups, int64_t
         key.push_back(cf.gain);
     }
     key.push_back((double)L);
+    const int64_t nchunks = std::min<int64_t>(std::max<int64_t>(8, std::min<int64_t>(48, 65536 / L)), (need + L - 1) / L);
+    const int64_t n = std::min<int64_t>(need, nchunks * L);
+    key.push_back((double)n);  // (the probe's length: a short signal is probed over its own length)
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
+        double dv;
+        if (disk_value_get("chunk", key, dv)) return cache[key] = dv;
     }
-    const int64_t nchunks = std::min<int64_t>(std::max<int64_t>(8, std::min<int64_t>(48, 65536 / L)), (need + L - 1) / L);
-    const int64_t n = std::min<int64_t>(need, nchunks * L);
     double worst = 0.0;
     if (nchunks >= 2) {
         std::vector<double> x((size_t)n), yseq((size_t)n), ychk((size_t)n);
@@ -195,6 +201,7 @@ static double sos_chunk_sensitivity(const std::vector<SosCoefs>& groups, int64_t
             x = yseq;  // the next group filters this group's output
         }
     }
+    disk_value_put("chunk", key, worst);
     std::lock_guard<std::mutex> lk(mu);
     cache[key] = worst;
     return worst;

@@ -12,7 +12,7 @@ if [ -n "${RELINK_ONLY:-}" ] && [ -f "$obj" ]; then :; else
 fi
 objs=""
 # (k_rsos.hip is built as one unit per window length, k_rsos_ks*.o; as a variant it is ONE unit with everything in it)
-for s in k_pointwise k_sos k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
+for s in k_pointwise k_sos k_small k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
     if [ "$s.hip" = "$unit" ]; then objs="$objs $obj"
     elif [ "$s" = k_rsos ]; then objs="$objs $(ls $here/k_rsos_ks*.o | tr '\n' ' ')"
     else objs="$objs $here/$s.o"; fi

@@ -6,7 +6,9 @@ import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-import sigops_amd as so
+_t_imp = time.perf_counter()
+import sigops_amd as so  # (opens the engine library: dlopen + code-object registration, reported as import_ms, not part of a sink)
+import_ms = round((time.perf_counter() - _t_imp) * 1e3, 3)
 dev = torch.device("cuda:0")
 nch, n_in = 8, int(round(600 * 44100))
 gen = torch.Generator(device=dev); gen.manual_seed(1983)
@@ -32,4 +34,4 @@ for i in range(3):
     t3 = time.perf_counter()
     res.append({"create_ms": round((t1 - t0) * 1e3, 3), "execute_ms": round((t2 - t1) * 1e3, 3), "destroy_ms": round((t3 - t2) * 1e3, 3),
                 "one_shot_ms": round((t3 - t0) * 1e3, 3)})
-print(json.dumps({"cache_dir": os.environ.get("SIGOPS_CACHE_DIR"), "calls": res}), flush=True)
+print(json.dumps({"cache_dir": os.environ.get("SIGOPS_CACHE_DIR"), "import_ms": import_ms, "calls": res}), flush=True)
