@@ -1,5 +1,6 @@
 // DSP.jl phase accumulator replay for the arbitrary-rate resampler (see the comment below) and the
 // host-only position diagnostics of the C-ABI (so_resample_positions).
+#include <chrono>
 #include <thread>
 #include <string>
 #include <unistd.h>
@@ -220,6 +221,8 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     prev.clear();
     fix.clear();
     if (!g.arbitrary || need <= 0) return;
+    const auto t_r0 = std::chrono::steady_clock::now();
+    auto t_r1 = t_r0, t_r2 = t_r0, t_r3 = t_r0;
     const int nphi = g.nphi, taps = g.taps;
     const double dnphi = (double)nphi;
     const bool pow2 = (nphi & (nphi - 1)) == 0;
@@ -375,6 +378,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                     seg[t].xb0 = xb + ka * dxb;
                     seg[t].acc0 = acc + (double)ka * dacc;
                 }
+                t_r1 = std::chrono::steady_clock::now();
                 std::vector<std::thread> th;
                 int started = 0;
                 try {
@@ -392,6 +396,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                 } catch (...) {  // (no more threads to be had: the ranges that did start still count)
                 }
                 for (auto& t : th) t.join();
+                t_r2 = std::chrono::steady_clock::now();
                 int good = 0;  // ranges whose start state has been confirmed
                 for (int t = 0; t < started; ++t) {
                     const bool ok = t == 0 ? (seg[0].xb0 == xb && std::memcmp(&seg[0].acc0, &acc, 8) == 0)
@@ -424,6 +429,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
         if (mcur < need) made.push_back(AccCheckpoint{mcur, xb, acc});
     }
     made.push_back(AccCheckpoint{need, xb, acc});
+    t_r3 = std::chrono::steady_clock::now();
     {
         std::lock_guard<std::mutex> lock(g_acc_mu);
         std::vector<AccCheckpoint>* store = nullptr;
@@ -487,6 +493,11 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
             f.m -= from;
             f.j -= jin;
         }
+    }
+    if (std::getenv("SIGOPS_DEBUG_PLAN")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[sigops] accumulator replay of %lld outputs: head %.3f ms, ranges in threads %.3f, rest in order %.3f, lists %.3f (%zu deviations, %zu fix-ups)\n",
+                     (long long)(need - from), ms(t_r0, t_r1), ms(t_r1, t_r2), ms(t_r2, t_r3), ms(t_r3, std::chrono::steady_clock::now()), rec.size(), fix.size());
     }
 }
 
