@@ -255,6 +255,31 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     const int64_t L = g.L, dq = exact ? ((int64_t)nphi * g.M) / L : 0, dfr = exact ? ((int64_t)nphi * g.M) % L : 0;
     struct Rec { int64_t m, qa; double alpha; };
     std::vector<Rec> rec;
+    // The deviations in pieces, in output order: what ran before the threaded ranges, each confirmed range (its list moved,
+    // not copied: 360 000 records for ten minutes of 44.1 -> 48 kHz), the rest.  Each piece with the counts the lists below
+    // are decided by -- per period position: records, records of the baked form -- made by the thread that made the piece.
+    struct Part {
+        std::vector<Rec> rec;
+        int64_t ma = 0, mb = 0;       // outputs [ma, mb) (records only of outputs >= from)
+        std::vector<int64_t> ca, cb;  // per period position: records / of the baked form (empty: no period, or not counted)
+    };
+    std::vector<Part> parts;
+    const bool periodic = exact && L >= 1 && L <= 65536;
+    auto exact_q = [&](int64_t m) {
+        const int64_t Nn = m * ((int64_t)nphi * g.M);
+        return g.c0i + Nn / L;
+    };
+    auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
+    auto count_part = [&](Part& pa) {
+        if (!periodic) return;
+        pa.ca.assign((size_t)L, 0);
+        pa.cb.assign((size_t)L, 0);
+        for (const Rec& r : pa.rec) {
+            const size_t pos = (size_t)(r.m % L);
+            pa.ca[pos]++;
+            if (baked(r)) pa.cb[pos]++;
+        }
+    };
     int64_t m0 = 0;
     const AccKey ckey = acc_key(g, h, hlen);
     std::vector<AccCheckpoint> made;
@@ -342,7 +367,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     //      started from -- so the concatenation is the sequential replay.  A range that fails the check
     //      (and everything after it) is replayed sequentially from the true state. ----
     const unsigned hw = std::thread::hardware_concurrency();
-    int nthreads = (int)std::min<unsigned>(64, hw ? hw : 1);  // (16 until round 3: 13 ms for 28.8 M outputs; ranges stay >= 4096 periods)
+    int nthreads = (int)std::min<unsigned>(64, hw ? hw : 1);  // (16 until round 3: 13 ms for 28.8 M outputs)
     if (const char* ev = std::getenv("SIGOPS_REPLAY_THREADS")) nthreads = std::max(1, std::atoi(ev));  // tuning knob
     if (exact && nthreads > 1 && need - mcur >= ((int64_t)1 << 21) && L >= 2 && L <= 65536) {
         // a phase that is not a tie of the closed form (its position is >= 1/L away from an integer:
@@ -362,12 +387,12 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
             const int64_t dxb = xb - xb1;
             mcur = mref + L;
             const int64_t periods = (need - mcur) / L;
-            const int nseg = (int)std::min<int64_t>(nthreads, periods / 4096);
+            const int nseg = (int)std::min<int64_t>(nthreads, periods / 1024);  // (ranges of >= 1024 periods: a thread's start costs ~30 us)
             if (nseg >= 2 && dxb == (int64_t)g.M * nphi) {
                 struct Seg {
                     int64_t ma, mb, xb0, xb1;
                     double acc0, acc1;
-                    std::vector<Rec> rec;
+                    Part part;
                 };
                 std::vector<Seg> seg(nseg);
                 for (int t = 0; t < nseg; ++t) {
@@ -387,9 +412,13 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                             std::vector<int8_t> memo((size_t)nphi * 4, -1);
                             int64_t x = seg[t].xb0;
                             double a = seg[t].acc0;
-                            run(seg[t].ma, seg[t].mb, x, a, seg[t].rec, memo);
+                            seg[t].part.rec.reserve((size_t)((seg[t].mb - seg[t].ma) / L) * 2 + 64);
+                            run(seg[t].ma, seg[t].mb, x, a, seg[t].part.rec, memo);
                             seg[t].xb1 = x;
                             seg[t].acc1 = a;
+                            seg[t].part.ma = seg[t].ma;
+                            seg[t].part.mb = seg[t].mb;
+                            count_part(seg[t].part);
                         });
                         ++started;
                     }
@@ -404,8 +433,16 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
                     if (!ok) break;
                     ++good;
                 }
+                if (good > 0) {  // (what ran in order so far is a piece of its own)
+                    Part head;
+                    head.rec.swap(rec);
+                    head.ma = m0;
+                    head.mb = mcur;
+                    count_part(head);
+                    parts.push_back(std::move(head));
+                }
                 for (int t = 0; t < good; ++t) {
-                    rec.insert(rec.end(), seg[t].rec.begin(), seg[t].rec.end());
+                    parts.push_back(std::move(seg[t].part));
                     made.push_back(AccCheckpoint{seg[t].ma, seg[t].xb0, seg[t].acc0});
                     xb = seg[t].xb1;
                     acc = seg[t].acc1;
@@ -447,16 +484,21 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
         }
         if (store->size() > 256) store->erase(store->begin(), store->begin() + (store->size() - 256));
     }
-    auto exact_q = [&](int64_t m) {
-        const int64_t Nn = m * ((int64_t)nphi * g.M);
-        return g.c0i + Nn / L;
-    };
-    auto baked = [&](const Rec& r) { return r.qa == exact_q(r.m) - 1 && r.alpha > 0.5; };
-    if (bake && exact && L <= 65536) {
+    {  // the rest in order: the last piece
+        Part tail;
+        tail.rec.swap(rec);
+        tail.ma = parts.empty() ? m0 : parts.back().mb;
+        tail.mb = need;
+        count_part(tail);
+        parts.push_back(std::move(tail));
+    }
+    size_t nrec = 0;
+    for (const Part& pa : parts) nrec += pa.rec.size();
+    if (bake && periodic) {
         // majority per period position among the deviations of the form (fine position - 1, α ≈ 1)
         std::vector<int64_t> cnt(L, 0);
-        for (const Rec& r : rec)
-            if (baked(r)) cnt[r.m % L]++;
+        for (const Part& pa : parts)
+            for (int64_t r = 0; r < L; ++r) cnt[r] += pa.cb[(size_t)r];
         prev.assign(L, 0);
         bool any = false;
         for (int64_t r = 0; r < L; ++r) {
@@ -468,23 +510,37 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     }
     // fix-up list: deviations the tables do not already contain + outputs at baked positions
     // where the accumulator agreed with the closed form after all
+    auto fdiv = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };  // floor(a / b), b > 0
     if (!prev.empty()) {
-        for (int64_t r = 0; r < L; ++r) {
-            if (!prev[r]) continue;
-            size_t k = 0;
-            for (int64_t m = from + r; m < need; m += L) {  // outputs at a baked position
-                while (k < rec.size() && rec[k].m < m) ++k;
-                if (k < rec.size() && rec[k].m == m) continue;  // deviates: baked, or listed below
-                const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
-                fix.push_back(RsFix{m, q / nphi, (int32_t)(q % nphi), 0, (double)(Nn % L) / (double)L});
+        for (const Part& pa : parts) {
+            const int64_t a = std::max(pa.ma, from), b = pa.mb;
+            if (a >= b) continue;
+            size_t in_tables = 0;  // records of this piece that are what the tables contain
+            for (int64_t r = 0; r < L; ++r) {
+                if (!prev[r]) continue;
+                in_tables += (size_t)pa.cb[(size_t)r];
+                // outputs of this piece at baked position r: every one with a record of its own?  (The usual case, decided by
+                // the counts; otherwise the ones without are looked up.)
+                const int64_t occ = fdiv(b - 1 - r, L) - fdiv(a - 1 - r, L);
+                if (pa.ca[(size_t)r] == occ) continue;
+                size_t k = 0;
+                int64_t m = a + ((r - a % L) % L + L) % L;
+                for (; m < b; m += L) {
+                    while (k < pa.rec.size() && pa.rec[k].m < m) ++k;
+                    if (k < pa.rec.size() && pa.rec[k].m == m) continue;  // deviates: baked, or listed below
+                    const int64_t q = exact_q(m), Nn = m * ((int64_t)nphi * g.M);
+                    fix.push_back(RsFix{m, q / nphi, (int32_t)(q % nphi), 0, (double)(Nn % L) / (double)L});
+                }
+            }
+            if (in_tables == pa.rec.size()) continue;
+            for (const Rec& r : pa.rec) {
+                if (prev[r.m % L] && baked(r)) continue;  // what the tables contain
+                fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
             }
         }
-        for (const Rec& r : rec) {
-            if (prev[r.m % L] && baked(r)) continue;  // what the tables contain
-            fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
-        }
     } else {
-        for (const Rec& r : rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
+        for (const Part& pa : parts)
+            for (const Rec& r : pa.rec) fix.push_back(RsFix{r.m, r.qa / nphi, (int32_t)(r.qa % nphi), 0, r.alpha});
     }
     std::sort(fix.begin(), fix.end(), [](const RsFix& a, const RsFix& b) { return a.m < b.m; });
     if (from > 0) {
@@ -497,7 +553,7 @@ static void replay_phase_accumulator_impl(const RsGeom& g, const double* h, int 
     if (std::getenv("SIGOPS_DEBUG_PLAN")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::fprintf(stderr, "[sigops] accumulator replay of %lld outputs: head %.3f ms, ranges in threads %.3f, rest in order %.3f, lists %.3f (%zu deviations, %zu fix-ups)\n",
-                     (long long)(need - from), ms(t_r0, t_r1), ms(t_r1, t_r2), ms(t_r2, t_r3), ms(t_r3, std::chrono::steady_clock::now()), rec.size(), fix.size());
+                     (long long)(need - from), ms(t_r0, t_r1), ms(t_r1, t_r2), ms(t_r2, t_r3), ms(t_r3, std::chrono::steady_clock::now()), nrec, fix.size());
     }
 }
 
