@@ -64,7 +64,10 @@ void Plan::finalize() {
     };
     for (size_t i = 0; i < leaves.size(); ++i) stage_host_array(leaf_array_node[i]);
     for (auto& S : stages) {
-        for (auto& c : S.carriers) stage_host_array(c.array_node);
+        for (auto& c : S.carriers) {
+            stage_host_array(c.array_node);
+            if (car_has_arr2(c)) stage_host_array(c.array_node2);
+        }
         stage_host_array(S.in_array_node);
     }
     if (!out.is_device && out.nframes > 0) {
@@ -125,6 +128,15 @@ void Plan::finalize() {
             }
             const int64_t V = 16 / (int64_t)dsize(c.dtype);
             c.vec_ok = carrier_vec_ok(c, V);
+            if (car_has_arr2(c)) {  // the step's second array (a caller's: match_carrier)
+                const so_node_t& nd = nodes[c.array_node2].nd;
+                if (!nd.i0 && !array_buf.count(c.array_node2)) fail(SO_ERR_RUNTIME, "internal: carrier array without device copy");
+                c.base2 = nd.i0 ? array_ptr[c.array_node2] : bufs[array_buf[c.array_node2]].d;
+                c.vec_ok2 = (uintptr_t)c.base2 % 8 == 0;
+            } else {
+                c.base2 = nullptr;
+                c.array_node2 = c.buf2 = -1;
+            }
         }
         if (std::getenv("SIGOPS_DEBUG_PLAN"))
             for (auto& c : S.carriers)
@@ -231,7 +243,7 @@ void Plan::finalize() {
         };
         if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in * src_esz(stages[S.rsos_src]) + S.rs.n_out * osz) * S.rs.nch;
         else if (S.kind == ST_SOS) st.bytes = (S.need - S.base) * S.sg.nch * (esz + osz);
-        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * src_esz(S) + S.rg.n_out * osz) * S.rg.nch;
+        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * (src_esz(S) + (S.rp.arr2 ? 8 : 0)) + S.rg.n_out * osz) * S.rg.nch;  // (arr2: a second Float64 array read)
         else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
         steps.push_back(st);
     }
@@ -996,13 +1008,19 @@ int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& e
         // carriers of fused resampler stages (by value at launch + a device copy for the slow path)
         for (auto& S : P->stages) {
             bool touched = false;
-            for (auto& c : S.carriers)
+            for (auto& c : S.carriers) {
                 if (c.array_node == node_index) {
                     c.base = data;
                     const int64_t V = 16 / (int64_t)dsize(c.dtype);
                     c.vec_ok = carrier_vec_ok(c, V);
                     touched = true;
                 }
+                if (car_has_arr2(c) && c.array_node2 == node_index) {
+                    c.base2 = data;
+                    c.vec_ok2 = (uintptr_t)c.base2 % 8 == 0;
+                    touched = true;
+                }
+            }
             if (touched) {
                 const RsCtl ctl = P->make_ctl(S);
                 if (hipMemcpy(P->bufs[S.car_buf].d, S.carriers.data(), S.carriers.size() * sizeof(DCarrier), hipMemcpyHostToDevice) != hipSuccess ||

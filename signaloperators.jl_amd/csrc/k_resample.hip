@@ -365,8 +365,9 @@ __device__ __forceinline__ bool rs_dma_chunk(const RsStageGeom& g, const RsCtl& 
     cu = 0;
     while (cu + 1 < ncar && car[cu].b <= gf) ++cu;  // carriers are sorted
     const DCarrier& C = car[cu];
+    // (a carrier whose step takes a second array: the general path loads both)
     return !(g.pad & 8) && C.base != nullptr && C.vec_ok && C.dtype == SO_F64 && gf >= C.a &&
-           gl <= C.b && gf >= 0 && gl <= g.n_in && (((gf + C.df) & 1) == 0);
+           gl <= C.b && gf >= 0 && gl <= g.n_in && (((gf + C.df) & 1) == 0) && !(C.nsteps > 0 && (C.arg[0] & kCarArr2));
 }
 
 // Stage one input tile (CT channels x nfr frames from global frame xbase) into an LDS slot
@@ -377,7 +378,7 @@ __device__ __forceinline__ bool rs_dma_chunk(const RsStageGeom& g, const RsCtl& 
 //   PASS 1 (modify): after the wave's own DMA of this tile has landed (`allowed` = DMA
 //                    instructions it issued for younger tiles), apply the carrier steps in
 //                    place to exactly the chunks it copied.
-template <typename T, int CT, int PASS>
+template <typename T, int CT, int PASS, bool A2 = false>
 __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, int nfr, int c0,
                                           T* __restrict__ buf, const RsCtl& ctl,
                                           const RsGlobalTables& gsrc, int tid, int nthr, int allowed) {
@@ -446,7 +447,7 @@ __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, i
             }
         }
         if constexpr (PASS == 0)
-            if (act) stage_generic_impl<T, CT>(g.n_in, g.lds_pitch, gsrc.car, ctl.ncar, gsrc.ops, gsrc.leaves, gi, iv, ci, c0, buf);
+            if (act) stage_generic_impl<T, CT, A2>(g.n_in, g.lds_pitch, gsrc.car, ctl.ncar, gsrc.ops, gsrc.leaves, gi, iv, ci, c0, buf);
     }
     if constexpr (PASS == 1) {
         if (!waited) wait_vmcnt_le(allowed);
@@ -458,7 +459,7 @@ __device__ __forceinline__ int stage_tile(const RsStageGeom& g, int64_t xbase, i
 // blocks, and inlined next to the loader's fast path it pushes that past the 128-register
 // budget -- spills there are scratch reloads with s_waitcnt vmcnt(0) in the middle of the
 // LDS-DMA ring.  Only tiles at a signal/carrier edge and non-fp64 sources come here.
-template <typename T, int CT, int PASS>
+template <typename T, int CT, int PASS, bool A2 = false>
 __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pitch, int pad, int64_t xbase,
                                                         int nfr, int c0, T* __restrict__ buf,
                                                         const RsCtl* ctl, const DCarrier* gcar,
@@ -466,7 +467,7 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
                                                         int nthr, int allowed) {
     const RsStageGeom g{n_in, lds_pitch, pad};
     const RsGlobalTables gsrc{nullptr, gcar, gops, gleaves};
-    return stage_tile<T, CT, PASS>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
+    return stage_tile<T, CT, PASS, A2>(g, xbase, nfr, c0, buf, *ctl, gsrc, tid, nthr, allowed);
 }
 
 // GA (gain at the A operand): a Float32 array times ONE Float64 per-frame gain (`Amplify(x32,
@@ -483,6 +484,13 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // rates whose period is long (44.1 -> 16 kHz: 441 inputs per period, 36 k-steps): two 32-row slots of it do not fit
 // LDS, two 16-row slots do, and the ring, the edge handling and the fused sources of this kernel then serve
 // what used to go to the row-tiled kernel without any overlap of loads and MFMAs (config 5).
+// A2: carrier 0's one step takes a SECOND Float64 array as its operand (`Mix(x, y)` / `Amplify(x, y)` of two arrays: DCarrier::base2,
+// arg bit kCarArr2).  Both arrays go by LDS-DMA: the first into the tile ring as ever, the loader wave's own chunk of the second
+// (CT rows x 1 KB) into a staging area of that wave behind a ring of TWO tiles (the planner's choice for this instantiation: one
+// tile of look-ahead for either array); retiring the tile, the wave applies the step in place -- two LDS reads, one operation,
+// one LDS write per 16 bytes, the operations K1 would have done on the way to a materialised sum.  (The chunk in registers
+// instead -- 4 CT of them, fetched an iteration ahead or at retire time -- was spilled right behind its loads in a kernel that
+// has 128: each spill a wait for its load.)  A separate instantiation: nothing of this in the other kernels' loader loops.
 // F32M: a Float32 signal all the way (T = TO = float, plain source): operands, taps and accumulators in Float32 on
 // v_mfma_f32_16x16x4_f32 -- 32 cycles per instruction and SIMD where the Float64 one takes 64 (this kernel is bound by its
 // MFMAs on Float32 data: half the bytes, the same matrix cycles).  Same A / B operand maps; the RESULT map differs: row =
@@ -490,7 +498,7 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // reference's 1e-6 for Float32 results (measured: profiles/r05/relerr_maxima_f32mfma.json), not bit-equal to the Float64
 // products rounded once -- SIGOPS_RS_NO_F32MFMA keeps those.
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false>
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false, bool A2 = false>
 __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     const double* __restrict__ tab, const int* __restrict__ jend, RsPeriodic g, TO* __restrict__ y,
     RsGlobalTables gsrc) {
@@ -588,6 +596,23 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
     const int64_t lo_ok = a0 > 0 ? a0 : 0;
     const int64_t hi_ok = b0 < g.n_in ? b0 : g.n_in;
+    // A2: the second array of carrier 0's one step; one2: 0 v*m, 1 v+m, 2 v-m, 3 m-v
+    int one2 = -1;
+    const char* base2 = nullptr;
+    int64_t cs2 = 0, df2 = 0;
+    int a2_lanes = 0;  // vectors per row the active loader lanes take in one round (a fast tile: one round)
+    if constexpr (A2) {
+        if (nsteps0 == 1 && (st0.arg[0] & kCarArr2) && !(st0.arg[0] & 0x200) && sizeof(T) == 8 &&
+            __builtin_amdgcn_readfirstlane((int)(C0.base2 != nullptr && C0.vec_ok2 && C0.dtype2 == SO_F64))) {
+            one2 = st0.op[0] == OP_MUL ? 0 : st0.op[0] == OP_ADD ? 1 : st0.op[0] == OP_SUB ? ((st0.arg[0] & 0x100) ? 3 : 2) : -1;
+            base2 = (const char*)rfl64((int64_t)(uintptr_t)C0.base2);
+            cs2 = rfl64(C0.cstride2);
+            df2 = rfl64(C0.df2);
+            if (df2 & 1) one2 = -1;
+        }
+        const int nldr_ = nwaves - (ST ? g.nstate : 0);
+        a2_lanes = 64 * (g.nload > 0 && g.nload < nldr_ - nc ? g.nload : nldr_ - nc);
+    }
     // GADD: frames the fused pieces cover (carriers are sorted and adjacent): the gain is added there only
     int64_t ga_lo = 0, ga_hi = 0;
     if constexpr (GADD) {
@@ -600,8 +625,11 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         xa = p.xb - sh;
         nfr = g.tile_len + sh;
         // (in-place steps of the fast path are fp64-only; fused fp32 sources take the general path)
-        return single && nodiv0 && (sizeof(T) == 8 || nsteps0 == 0) && xa >= lo_ok &&
-               xa + ((nfr + V - 1) & ~(V - 1)) <= hi_ok;
+        bool ok = single && nodiv0 && (sizeof(T) == 8 || nsteps0 == 0) && xa >= lo_ok &&
+                  xa + ((nfr + V - 1) & ~(V - 1)) <= hi_ok;
+        if constexpr (A2)  // (a step on a second array: the fast form, or the general path for the whole tile)
+            if (nsteps0 > 0 && (st0.arg[0] & kCarArr2)) ok = ok && one2 >= 0 && S == 2 && (nfr + V - 1) / V <= a2_lanes;
+        return ok;
     };
     // Gain ring (g.fslots > 0): the per-frame slot values of a fused source -- sin generators,
     // ramps: ~150 fp64 instructions per frame -- are evaluated by ALL sixteen waves, two tiles
@@ -791,7 +819,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         const int lw64 = __builtin_amdgcn_readfirstlane(ltid - llane);  // first vector of this wave
         // one step `v (op) slot0`, no Float32 rounding: 0 mul, 1 add, 2 v-m, 3 m-v; -1: step interpreter
         int one0 = -1;
-        if (nsteps0 == 1 && (st0.arg[0] & 0x2ff) == 0 && !(g.pad & 128))
+        if (nsteps0 == 1 && (st0.arg[0] & (0x2ff | kCarArr2)) == 0 && !(g.pad & 128))
             one0 = st0.op[0] == OP_MUL ? 0 : st0.op[0] == OP_ADD ? 1 : st0.op[0] == OP_SUB ? ((st0.arg[0] & 0x100) ? 3 : 2) : -1;
         // Loader waves issue a handful of instructions and then sleep on memory; without a
         // raised priority the MFMA-issuing compute waves on the same SIMD win arbitration
@@ -799,6 +827,9 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         if (!(g.pad & 16)) __builtin_amdgcn_s_setprio(3);
         const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));  // byte address of the ring
         const uint32_t lane16 = (uint32_t)llane * 16u;                            // per-lane byte offset in a chunk
+        // A2: this wave's staging rows of the second array (CT x 1 KB, behind the tile ring -- there is no gain ring here)
+        [[maybe_unused]] const uint32_t a2_stage =
+            __builtin_amdgcn_readfirstlane(lds_addr(fbase) + (uint32_t)(lidx < nactive ? lidx : 0) * (uint32_t)CT * 1024u);
         // state waves: row offsets of the A operands, first slot of this wave's half of the window
         constexpr int kSwK = 24;  // k-steps per state wave (planner: 2 * kSwK * 4 >= staged span of a row)
         int srow[Q];
@@ -830,9 +861,16 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                         dma_rows<CT>(mask, lane16, row + (int64_t)ivb * 16, cs0 * (int64_t)sizeof(T),
                                      lbase + (uint32_t)ivb * 16u, (uint32_t)g.lds_pitch * (uint32_t)sizeof(T));
                         n += CT;
+                        if constexpr (A2) {
+                            if (one2 >= 0) {  // (one round per tile: is_fast) the same chunk of the second array -> this wave's staging rows
+                                const char* rowb = base2 + ((int64_t)c0 * cs2 + df2 + xa) * 8;
+                                dma_rows<CT>(mask, lane16, rowb + (int64_t)ivb * 16, cs2 * 8, a2_stage, 1024u);
+                                n += CT;
+                            }
+                        }
                     }
                 } else {
-                    n = stage_tile_ool<T, CT, 0>(g.n_in, g.lds_pitch, g.pad, xa, nfr, c0, lds + slot * bufsz, &sctl,
+                    n = stage_tile_ool<T, CT, 0, A2>(g.n_in, g.lds_pitch, g.pad, xa, nfr, c0, lds + slot * bufsz, &sctl,
                                                  gsrc.car, gsrc.ops, gsrc.leaves, ltid, lthr, 0);
                 }
             }
@@ -857,8 +895,29 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             const bool fast = is_fast(pr, xa, nfr);
             // (a fused source without a gain ring -- it did not fit in LDS -- takes the general
             //  in-place path: same chunk ownership as the fast issue)
-            if (live && !((g.pad & 2) && it > 0) && (!fast || (fused0 && !fring))) {
-                stage_tile_ool<T, CT, 1>(g.n_in, g.lds_pitch, g.pad, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz,
+            bool a2tile = false;
+            if constexpr (A2) a2tile = live && fast && one2 >= 0 && !((g.pad & 2) && it > 0);
+            if (a2tile) {
+                if constexpr (A2) {
+                    const int nvec = (nfr + 1) >> 1;
+                    const uint32_t lbase = lds_addr(lds + sr * bufsz);
+                    rs_stamp(g, wave, it, 5);
+                    wait_vmcnt_le(allowed);  // this tile's DMAs -- both arrays' -- have landed
+                    rs_stamp(g, wave, it, 6);
+                    const int iv = lw64 + llane;
+                    if (iv < nvec) {
+                        const uint32_t la = lbase + (uint32_t)iv * 16u, sa = a2_stage + lane16;
+                        switch (one2) {
+                        case 0: rmw_arr2<CT, 0>(la, g.lds_pitch, sa); break;
+                        case 1: rmw_arr2<CT, 1>(la, g.lds_pitch, sa); break;
+                        case 2: rmw_arr2<CT, 2>(la, g.lds_pitch, sa); break;
+                        default: rmw_arr2<CT, 3>(la, g.lds_pitch, sa); break;
+                        }
+                    }
+                    rs_stamp(g, wave, it, 7);
+                }
+            } else if (live && !((g.pad & 2) && it > 0) && (!fast || (fused0 && !fring))) {
+                stage_tile_ool<T, CT, 1, A2>(g.n_in, g.lds_pitch, g.pad, xa, nfr, (int)pr.tc * CT, lds + sr * bufsz,
                                          &sctl, gsrc.car, gsrc.ops, gsrc.leaves, ltid, lthr, allowed);
             } else if (live && fast && fring && !GA) {
                 // carrier 0's steps in place on the chunks this wave copied, gains from the ring
@@ -1092,19 +1151,25 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     }
 }
 
-template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false>
+// loader waves that copy (RsPeriodic::nload, or all of them): the A2 instantiation's staging areas
+static int rs_a2_loaders(const RsPeriodic& g) {
+    const int nl = g.nwaves - g.ncompute;
+    return g.nload > 0 && g.nload < nl ? g.nload : nl;
+}
+template <typename T, int CT, int KS, int G, bool TWO = false, typename TO = T, bool GA = false, bool ST = false, bool GADD = false, int Q = 2, bool F32M = false, bool A2 = false>
 static void launch_rp_k(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                         const RsGlobalTables& gsrc, hipStream_t st) {
     const int64_t ntiles = ((g.nperiods + g.pt - 1) / g.pt) * (g.nch / CT);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, g.grid));
     size_t lds = (((size_t)g.nslots * CT * g.lds_pitch * sizeof(T) + 7) / 8 + (size_t)(GA ? 3 : 2) * g.fslots * g.fpitch + (g.ftwo ? kRsTwoDoubles : 0) +
                   (ST ? (size_t)4 * g.ksw * 10 : 0)) * 8;  // + static RsCtl
+    if constexpr (A2) lds += (size_t)rs_a2_loaders(g) * CT * 1024;  // the loader waves' staging rows of the second array
     static bool seen[64];
     if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M>,
+        (void)hipFuncSetAttribute((const void*)k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M, A2>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (int)sizeof(RsCtl) - 64);  // static: the control block
-    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M>), grid, dim3(64 * g.nwaves), lds, st, tab,
+    hipLaunchKernelGGL((k_resample_periodic<T, CT, KS, G, TWO, TO, GA, ST, GADD, Q, F32M, A2>), grid, dim3(64 * g.nwaves), lds, st, tab,
                        jend, g, (TO*)y, gsrc);
 }
 
@@ -1207,6 +1272,15 @@ static int launch_rp_q1(void* y, const double* tab, const int* jend, const RsPer
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
+    if (g.arr2) {  // a step on a second Float64 array: the A2 instantiations (Float64, 14 k-steps, one group per compute wave)
+        const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+        if (dtype != SO_F64 || g.rows != 32 || g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
+        switch (g.ct) {
+        case 8: launch_rp_k<double, 8, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;
+        case 4: launch_rp_k<double, 4, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;
+        default: return -1;
+        }
+    }
     if (g.rows == 16) {
         if (dtype == SO_F32) {
             switch (g.ct) {
@@ -1292,7 +1366,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_fix(RsFixArgs a) {
                             val[0][0] = C.dtype == SO_F32 ? (double)SO_GLOBAL_PTR(float, C.base)[off]
                                                           : SO_GLOBAL_PTR(double, C.base)[off];
                         }
-                        if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
+                        if (C.nsteps == 1 && (C.arg[0] & kCarArr2) && C.base != nullptr) carrier_arr2<1, 1>(C, c, n, false, val);
+                        else if (C.nsteps > 0) carrier_apply<1, 1>(C, F, val, st32);
                         if (C.pad_ >= 3) val[0][0] += F[0][0];     // GA carrier, add: Float32 sample plus its Float64 operand
                         else if (C.pad_) val[0][0] *= F[0][0];  // GA carrier: Float32 sample times its Float64 gain
                         xv = st32 ? (double)(float)val[0][0] : val[0][0];

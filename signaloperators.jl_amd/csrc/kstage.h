@@ -81,6 +81,12 @@ __device__ __forceinline__ v2d lds_ld16(uint32_t a) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+template <int OFF>  // ... at a + OFF (the instruction's own offset field: no address register per row)
+__device__ __forceinline__ v2d lds_ld16_off(uint32_t a) {
+    v2d v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ void lds_st16(uint32_t a, v2d v) {
     asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
@@ -220,9 +226,61 @@ __device__ __forceinline__ void rmw_one_chunk(uint32_t la, int lds_pitch, uint32
     for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
 }
 
+// ... and the in-place step whose operand is a second ARRAY's samples, staged by LDS-DMA as rows of 1 KB at `sa` (this lane's
+// 16 bytes of row c at sa + 1024 c: k_resample_periodic A2).  OP: 0 v*m, 1 v+m, 2 v-m, 3 m-v -- the operations K1 would have
+// done on the way to a materialised sum, on the same values.
+template <int CT, int OP, int R0 = 0>
+__device__ __forceinline__ void rmw_arr2(uint32_t la, int lds_pitch, uint32_t sa) {
+    if constexpr (CT > 4) {  // four rows at a time (registers)
+        rmw_arr2<4, OP, R0>(la, lds_pitch, sa);
+        rmw_arr2<CT - 4, OP, R0 + 4>(la + (uint32_t)(4 * lds_pitch) * 8u, lds_pitch, sa);
+        return;
+    } else {
+        v2d raw[CT], m[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * 8u);
+        m[0] = lds_ld16_off<R0 * 1024>(sa);
+        if constexpr (CT > 1) m[1] = lds_ld16_off<(R0 + 1) * 1024>(sa);
+        if constexpr (CT > 2) m[2] = lds_ld16_off<(R0 + 2) * 1024>(sa);
+        if constexpr (CT > 3) m[3] = lds_ld16_off<(R0 + 3) * 1024>(sa);
+        lds_wait(raw);
+        lds_wait(m);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) raw[c] = OP == 0 ? raw[c] * m[c] : OP == 1 ? raw[c] + m[c] : OP == 2 ? raw[c] - m[c] : m[c] - raw[c];
+        lds_pin(raw);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
+    }
+}
+
+// The one step of a carrier whose operand is a SECOND array (DCarrier::base2, arg bit kCarArr2): `v (op) y[c][n]` on a
+// CT x V register block of frames g0 (+ e where `vec`) -- the general path's form (scalar loads, row by row: the block of
+// the first array's samples is already in registers, a second one next to it would not fit the 128 the kernel has).
+template <int CT, int V, typename CarT>
+__device__ __forceinline__ void carrier_arr2(const CarT& C, int c0, int64_t g0, bool vec, double (&val)[CT][V]) {
+    const int op = C.op[0];
+    const bool flip = C.arg[0] & 0x100, r32 = C.arg[0] & 0x200;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        double b[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int64_t off = (int64_t)(c0 + c) * C.cstride2 + g0 + (vec ? e : 0) + C.df2;
+            b[e] = C.dtype2 == SO_F32 ? (double)SO_GLOBAL_PTR(float, C.base2)[off] : SO_GLOBAL_PTR(double, C.base2)[off];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const double v = val[c][e], m = b[e];
+            double r = op == OP_ADD ? v + m : op == OP_SUB ? (flip ? m - v : v - m) : v * m;
+            if (r32) r = (double)(float)r;
+            val[c][e] = r;
+        }
+    }
+}
+
 // Slow path of the staging (tile edges, f32 sources, generated pieces, unaligned arrays): one
 // 16-byte vector per lane, load -> carrier steps -> LDS store, synchronously.
-template <typename T, int CT>
+template <typename T, int CT, bool A2 = false>
 __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
                                                         const DCarrier* __restrict__ car, int ncar,
                                                         const DOp* __restrict__ ops,
@@ -294,7 +352,10 @@ __device__ __forceinline__ void stage_generic_impl(int64_t n_in, int lds_pitch,
             }
         }
         // ---- steps ----
-        if (steps) carrier_apply<CT, V>(C, F, val, sizeof(T) == 4);
+        bool two_arrays = false;
+        if constexpr (A2) two_arrays = steps && C.nsteps == 1 && (C.arg[0] & kCarArr2) && C.base != nullptr;
+        if (two_arrays) carrier_arr2<CT, V>(C, c0, g0, vec, val);
+        else if (steps) carrier_apply<CT, V>(C, F, val, sizeof(T) == 4);
         // ---- LDS stores ----
         if (vec) {
 #pragma unroll

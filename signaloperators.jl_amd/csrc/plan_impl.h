@@ -385,7 +385,8 @@ struct Plan {
     std::vector<int>* rtc_loads = nullptr;  // rtc_source: the array leaves of the piece being written, read as frame pairs
     std::string rtc_source(const std::vector<Piece>& ps);
     bool match_carrier(int ei, DCarrier& C, std::vector<int>& monos);
-    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false);
+    bool build_carriers(const std::vector<Piece>& ps, int nch, std::vector<DCarrier>& out, bool allow_ga = false, bool allow_arr2 = false);
+    bool carrier_arr2_ok = false;  // (match_carrier: a step on a second array may be formed -- set by build_carriers for its matches)
     RsCtl make_ctl(const Stage& S) const;
     void gen(int e, std::vector<DOp>& code, std::map<int, int>& hoisted, std::vector<DOp>& fcode,
              bool allow_hoist);

@@ -1200,7 +1200,7 @@ Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const s
                                             !P->stages[i].onepass && out->frame_stride == 1 &&
                                             e.leaf.df >= P->stages[i].base && !std::getenv("SIGOPS_NO_WINDOW_ALIAS"))) &&
                         (e.leaf.dtype == out->dtype || (P->stages[i].kind == ST_RESAMPLE && P->stages[i].periodic &&
-                                                        P->stages[i].rp.ct >= 4 && P->stages[i].rp.rows == 32 &&
+                                                        P->stages[i].rp.ct >= 4 && P->stages[i].rp.rows == 32 && !P->stages[i].rp.arr2 &&
                                                         (P->stages[i].rp.ngroups + P->stages[i].rp.ncompute - 1) / P->stages[i].rp.ncompute == 1) ||
                          // (one group: later groups of a cascade filter the result buffer in place)
                          (P->stages[i].kind == ST_SOS && P->stages[i].groups.size() == 1 && !P->stages[i].onepass &&

@@ -91,7 +91,20 @@ struct DCarrier {
     int32_t pad_;  // 1: GA carrier (k_resample_periodic GA): Float32 array, its single multiply by slot 0
                    //    is applied by the compute waves (nsteps is 0 for the staging code); 2: a generated
                    //    piece of such a source (staged as 1.0f); 3 / 4: the same with an ADD (staged as 0.0f)
+    // A SECOND planar array as the operand of one step (arg bit 0x400 instead of a slot): `v (op) base2[c*cstride2 + n + df2]`
+    // -- `Mix(x, y)` / `Amplify(x, y)` of two arrays in front of a resampler, which the reference evaluates block by block
+    // inside the resampler's pull (src/mapsignal.jl:54-57, src/filters.jl:240-244) and K1 used to materialise.  Patched
+    // like `base`.  array_node2 < 0 and buf2 < 0: none.
+    const void* base2;
+    int64_t cstride2, df2;
+    int32_t dtype2, buf2, array_node2, vec_ok2;
 };
+constexpr int kCarArr2 = 0x400;  // DCarrier::arg bit: the step's operand is the second array's sample
+inline bool car_has_arr2(const DCarrier& c) {  // (host code)
+    for (int i = 0; i < c.nsteps && i < 4; ++i)
+        if (c.arg[i] & kCarArr2) return true;
+    return false;
+}
 
 // Control block of the periodic resampler's fused source.  Every workgroup copies it into LDS
 // at kernel start, so the loader waves read carriers / slot leaves with ds_reads instead of
@@ -308,6 +321,7 @@ struct RsPeriodic {
     int32_t ftwo;       // gain ring: LDS reserved for the two-level sin evaluation (kRsTwoDoubles more doubles)
     int32_t out_f32;    // fp64 kernel storing into a Float32 result (`sink` of a Float64 signal into Float32)
     int32_t ga;         // GA instantiation: Float32 tiles, the gain multiplied (1) or added (2) at the A operand; lds_pitch in floats
+    int32_t arr2;       // A2 instantiation: some carrier's step takes a second array (DCarrier::base2)
     // Fused IIR state pass (the stage's only consumer is an SOS filter): the last nstate (= 2) loader
     // waves multiply every row's staged window [jlo, jlo + 4*ksw) by wtab = (G . Tap), the filter's
     // zero-state end-of-period state as a linear function of the resampler's INPUT, and write

@@ -1146,11 +1146,21 @@ void Plan::process_stage(int sid) {
         S.pw_step = emit_pointwise(ps, S.out_buf, N.dtype);
         S.in_buf = S.out_buf;
         S.in_pitch = -1;
-    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic && build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype))) {
+    } else if (!direct && S.kind == ST_RESAMPLE && S.periodic &&
+               build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype),
+                              // (the A2 instantiations: Float64, 32-row tiles of 4 or 8 channels, 14 k-steps, one group per compute wave)
+                              // ... and two tile slots + the loader waves' staging rows of the second array fit LDS)
+                              N.dtype == SO_F64 && S.rp.rows == 32 && (S.rp.ct == 8 || S.rp.ct == 4) && S.rp.kw == 56 &&
+                                  (S.rp.ngroups + S.rp.ncompute - 1) / S.rp.ncompute == 1 &&
+                                  (size_t)2 * S.rp.ct * S.rp.lds_pitch * 8 + (size_t)(S.rp.nwaves - S.rp.ncompute) * S.rp.ct * 1024 <=
+                                      160 * 1024 - sizeof(RsCtl) - 64)) {
         // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
         // staging, no intermediate in HBM
         S.in_buf = -1;
         S.in_array_node = -1;
+        for (auto& c : S.carriers)
+            if (car_has_arr2(c)) S.rp.arr2 = 1;
+        if (S.rp.arr2) S.rp.nslots = 2;  // (the A2 instantiation: one tile of look-ahead, the rest of LDS for the second array's staging rows)
         if (S.carriers[0].pad_) {
             // GA instantiation: Float32 tiles (pitch in floats, 16-byte rows, 128-byte aligned start),
             // three gain arrays, no in-place work for the loaders
@@ -1298,13 +1308,45 @@ bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
                 return add_step(oc, e.a, true, r32);
             }
         }
+        // `x (op) y` of two Float64 arrays (`Mix(x, y)`, `Amplify(x, y)`): x the carrier, y its one step's operand (the
+        // resampler's A2 instantiation; the caller says whether its geometry has one)
+        if (carrier_arr2_ok && oc != OP_DIV && !r32 && e.dtype == SO_F64 && C.nsteps == 0 && monos.empty()) {
+            auto plain_array = [&](int ei2, DCarrier& c) {
+                const Expr* x = &exprs[ei2];
+                if (x->op != E_LOAD || x->array_node < 0) return false;  // (a caller's array; stage buffers stay with K1)
+                const DLeaf& L = x->leaf;
+                if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1 || L.dc < 0 || L.dtype != SO_F64) return false;
+                c.dtype2 = L.dtype;
+                c.array_node2 = x->array_node;
+                c.buf2 = -1;
+                c.cstride2 = L.cstride;
+                c.df2 = L.df + L.dc * L.cstride;
+                return true;
+            };
+            DCarrier c2 = C;
+            std::vector<int> m2;
+            if (exprs[e.a].op == E_LOAD && match_carrier(e.a, c2, m2) && c2.nsteps == 0 && c2.dtype == SO_F64 && m2.empty() && plain_array(e.b, c2)) {
+                C = c2;
+                C.op[0] = oc;
+                C.arg[0] = kCarArr2;
+                C.nsteps = 1;
+                count_array(C.array_node2);
+                return true;
+            }
+        }
         return false;
     }
     default: return false;
     }
 }
 
-bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out, bool allow_ga) {
+bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<DCarrier>& out, bool allow_ga, bool allow_arr2) {
+    struct Arr2Scope {  // (match_carrier's permission to form a step on a second array: for this call only)
+        bool& flag;
+        bool old;
+        ~Arr2Scope() { flag = old; }
+    } arr2_scope{carrier_arr2_ok, carrier_arr2_ok};
+    carrier_arr2_ok = allow_arr2 && !std::getenv("SIGOPS_NO_ARR2");
     std::vector<Piece> ps = ps_in;
     for (auto& p : ps)
         if (p.r.c0 != 0 || p.r.c1 != nch) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 1); return false; }
@@ -1322,6 +1364,9 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         cs.push_back(c);
         monos_all.push_back(monos);
     }
+    // a step on a second array: carrier 0's (the kernel's fast path is carrier 0's), and nothing else in that carrier
+    for (size_t i = 0; i < cs.size(); ++i)
+        if (car_has_arr2(cs[i]) && (cs[i].nsteps != 1 || !car_has_arr2(cs[0]))) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 8); return false; }
     // compile the per-frame programs; everything must fit the kernel-argument control block
     if (cs.size() > (size_t)kCtlCar) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 3); return false; }
     // fp32 stages: the kernel's in-place steps are fp64-only (fp32 tiles go through the general
@@ -1617,8 +1662,8 @@ void Plan::fuse_resample_sos() {
         // kernel's coordinates are the resampler stage's: its output 0 is frame S3.base, the cascade starts from rest
         // there (earlier than the cascade stage alone would: a longer warm-up), and nothing below S2.base is stored.
         if (S3.base > S2.base) continue;
-        if (rp.nstate || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
-            continue;
+        if (rp.nstate || rp.arr2 || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
+            continue;  // (arr2: a source of two arrays is K3's A2 instantiation's; this kernel's loader takes one)
         if (pure32) {
             bool plain = nodes[nodes[S3.node].kids[0]].dtype == SO_F32 && rp.ga == 0;
             for (auto& c : S3.carriers)
@@ -2091,7 +2136,7 @@ void Plan::fuse_state_passes() {
         if (i3 < 0 || i3 == alias_stage || stages[i3].win_off >= 0) continue;
         Stage& S3 = stages[i3];
         const RsPeriodic& rp0 = S3.rp;
-        if (!S3.periodic || S2.sg.exact || S2.xscan || S2.src_op || rp0.ga || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
+        if (!S3.periodic || S2.sg.exact || S2.xscan || S2.src_op || rp0.ga || rp0.arr2 || rp0.nstate || nodes[S3.node].dtype != SO_F64 || nodes[S2.node].dtype != SO_F64 ||
             rp0.rows != 32 || rp0.nwaves - rp0.ncompute < 4 || S3.need < S2.in_frames || S3.per_j.empty() || rp0.kw != 56 ||
             (rp0.ngroups + rp0.ncompute - 1) / rp0.ncompute != 1 || !(rp0.ct == 8 || rp0.ct == 4))
             continue;  // (the instantiations with state waves: k_resample.hip launch_rp_st)
