@@ -45,6 +45,8 @@ cases = {
     "ToFramerate 48k": lambda: X | so.ToFramerate(48 * so.kHz),
     "ToFramerate 48k | Filt": lambda: X | so.ToFramerate(48 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz),
     "Mix(x, y) | ToFramerate": lambda: so.Mix(X, Y) | so.ToFramerate(48 * so.kHz),
+    "Amplify(x, y) | ToFramerate": lambda: so.Amplify(X, Y) | so.ToFramerate(48 * so.kHz),
+    "Mix(x, y) | Filt | ToFramerate": lambda: so.Mix(X, Y) | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz),
     "ToEltype(Float32)": lambda: so.ToEltype(X, np.float32),
 }
 only = os.environ.get("ONLY")
