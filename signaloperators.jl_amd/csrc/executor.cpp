@@ -132,7 +132,7 @@ void Plan::finalize() {
                 const so_node_t& nd = nodes[c.array_node2].nd;
                 if (!nd.i0 && !array_buf.count(c.array_node2)) fail(SO_ERR_RUNTIME, "internal: carrier array without device copy");
                 c.base2 = nd.i0 ? array_ptr[c.array_node2] : bufs[array_buf[c.array_node2]].d;
-                c.vec_ok2 = (uintptr_t)c.base2 % 8 == 0;
+                c.vec_ok2 = (uintptr_t)c.base2 % (c.dtype2 == SO_F64 ? 8 : 4) == 0;
             } else {
                 c.base2 = nullptr;
                 c.array_node2 = c.buf2 = -1;
@@ -243,7 +243,7 @@ void Plan::finalize() {
         };
         if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in * src_esz(stages[S.rsos_src]) + S.rs.n_out * osz) * S.rs.nch;
         else if (S.kind == ST_SOS) st.bytes = (S.need - S.base) * S.sg.nch * (esz + osz);
-        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * (src_esz(S) + (S.rp.arr2 ? 8 : 0)) + S.rg.n_out * osz) * S.rg.nch;  // (arr2: a second Float64 array read)
+        else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * (src_esz(S) + (S.rp.arr2 ? src_esz(S) : 0)) + S.rg.n_out * osz) * S.rg.nch;  // (arr2: a second array of the source's type read)
         else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;
         steps.push_back(st);
     }
@@ -1017,7 +1017,7 @@ int plan_set_array(Plan* P, int32_t node_index, const void* data, std::string& e
                 }
                 if (car_has_arr2(c) && c.array_node2 == node_index) {
                     c.base2 = data;
-                    c.vec_ok2 = (uintptr_t)c.base2 % 8 == 0;
+                    c.vec_ok2 = (uintptr_t)c.base2 % (c.dtype2 == SO_F64 ? 8 : 4) == 0;
                     touched = true;
                 }
             }

@@ -491,6 +491,8 @@ __device__ __attribute__((noinline)) int stage_tile_ool(int64_t n_in, int lds_pi
 // one LDS write per 16 bytes, the operations K1 would have done on the way to a materialised sum.  (The chunk in registers
 // instead -- 4 CT of them, fetched an iteration ahead or at retire time -- was spilled right behind its loads in a kernel that
 // has 128: each spill a wait for its load.)  A separate instantiation: nothing of this in the other kernels' loader loops.
+// With F32M: two Float32 arrays of a Float32 signal -- Float32 tile and staging rows, the step in Float32 (Julia's arithmetic on
+// Float32 operands, what K1's materialised map computes), the products on the Float32 MFMA.
 // F32M: a Float32 signal all the way (T = TO = float, plain source): operands, taps and accumulators in Float32 on
 // v_mfma_f32_16x16x4_f32 -- 32 cycles per instruction and SIMD where the Float64 one takes 64 (this kernel is bound by its
 // MFMAs on Float32 data: half the bytes, the same matrix cycles).  Same A / B operand maps; the RESULT map differs: row =
@@ -602,13 +604,15 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
     int64_t cs2 = 0, df2 = 0;
     int a2_lanes = 0;  // vectors per row the active loader lanes take in one round (a fast tile: one round)
     if constexpr (A2) {
-        if (nsteps0 == 1 && (st0.arg[0] & kCarArr2) && !(st0.arg[0] & 0x200) && sizeof(T) == 8 &&
-            __builtin_amdgcn_readfirstlane((int)(C0.base2 != nullptr && C0.vec_ok2 && C0.dtype2 == SO_F64))) {
+        // (Float64 arrays, or -- a Float32 signal all the way, F32M -- two Float32 arrays whose step rounds to Float32: the
+        //  tile's own arithmetic)
+        if (nsteps0 == 1 && (st0.arg[0] & kCarArr2) && (sizeof(T) == 8 ? !(st0.arg[0] & 0x200) : (F32M && (st0.arg[0] & 0x200) != 0)) &&
+            __builtin_amdgcn_readfirstlane((int)(C0.base2 != nullptr && C0.vec_ok2 && C0.dtype2 == (sizeof(T) == 8 ? SO_F64 : SO_F32)))) {
             one2 = st0.op[0] == OP_MUL ? 0 : st0.op[0] == OP_ADD ? 1 : st0.op[0] == OP_SUB ? ((st0.arg[0] & 0x100) ? 3 : 2) : -1;
             base2 = (const char*)rfl64((int64_t)(uintptr_t)C0.base2);
             cs2 = rfl64(C0.cstride2);
             df2 = rfl64(C0.df2);
-            if (df2 & 1) one2 = -1;
+            if (df2 & (V - 1)) one2 = -1;
         }
         const int nldr_ = nwaves - (ST ? g.nstate : 0);
         a2_lanes = 64 * (g.nload > 0 && g.nload < nldr_ - nc ? g.nload : nldr_ - nc);
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
         xa = p.xb - sh;
         nfr = g.tile_len + sh;
         // (in-place steps of the fast path are fp64-only; fused fp32 sources take the general path)
-        bool ok = single && nodiv0 && (sizeof(T) == 8 || nsteps0 == 0) && xa >= lo_ok &&
+        bool ok = single && nodiv0 && (sizeof(T) == 8 || nsteps0 == 0 || (A2 && one2 >= 0)) && xa >= lo_ok &&
                   xa + ((nfr + V - 1) & ~(V - 1)) <= hi_ok;
         if constexpr (A2)  // (a step on a second array: the fast form, or the general path for the whole tile)
             if (nsteps0 > 0 && (st0.arg[0] & kCarArr2)) ok = ok && one2 >= 0 && S == 2 && (nfr + V - 1) / V <= a2_lanes;
@@ -863,8 +867,8 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                         n += CT;
                         if constexpr (A2) {
                             if (one2 >= 0) {  // (one round per tile: is_fast) the same chunk of the second array -> this wave's staging rows
-                                const char* rowb = base2 + ((int64_t)c0 * cs2 + df2 + xa) * 8;
-                                dma_rows<CT>(mask, lane16, rowb + (int64_t)ivb * 16, cs2 * 8, a2_stage, 1024u);
+                                const char* rowb = base2 + ((int64_t)c0 * cs2 + df2 + xa) * (int64_t)sizeof(T);
+                                dma_rows<CT>(mask, lane16, rowb + (int64_t)ivb * 16, cs2 * (int64_t)sizeof(T), a2_stage, 1024u);
                                 n += CT;
                             }
                         }
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
             if constexpr (A2) a2tile = live && fast && one2 >= 0 && !((g.pad & 2) && it > 0);
             if (a2tile) {
                 if constexpr (A2) {
-                    const int nvec = (nfr + 1) >> 1;
+                    const int nvec = (nfr + V - 1) / V;
                     const uint32_t lbase = lds_addr(lds + sr * bufsz);
                     rs_stamp(g, wave, it, 5);
                     wait_vmcnt_le(allowed);  // this tile's DMAs -- both arrays' -- have landed
@@ -908,10 +912,10 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     if (iv < nvec) {
                         const uint32_t la = lbase + (uint32_t)iv * 16u, sa = a2_stage + lane16;
                         switch (one2) {
-                        case 0: rmw_arr2<CT, 0>(la, g.lds_pitch, sa); break;
-                        case 1: rmw_arr2<CT, 1>(la, g.lds_pitch, sa); break;
-                        case 2: rmw_arr2<CT, 2>(la, g.lds_pitch, sa); break;
-                        default: rmw_arr2<CT, 3>(la, g.lds_pitch, sa); break;
+                        case 0: rmw_arr2<T, CT, 0>(la, g.lds_pitch, sa); break;
+                        case 1: rmw_arr2<T, CT, 1>(la, g.lds_pitch, sa); break;
+                        case 2: rmw_arr2<T, CT, 2>(la, g.lds_pitch, sa); break;
+                        default: rmw_arr2<T, CT, 3>(la, g.lds_pitch, sa); break;
                         }
                     }
                     rs_stamp(g, wave, it, 7);
@@ -1274,7 +1278,16 @@ int launch_resample_periodic(void* y, const double* tab, const int* jend, const 
     if (g.n_out <= 0) return 0;
     if (g.arr2) {  // a step on a second Float64 array: the A2 instantiations (Float64, 14 k-steps, one group per compute wave)
         const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
-        if (dtype != SO_F64 || g.rows != 32 || g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
+        if (g.rows != 32 || g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
+        if (dtype == SO_F32) {  // (two Float32 arrays, a Float32 signal all the way: the Float32 MFMA's instantiation)
+            if (!g.f32m) return -1;
+            switch (g.ct) {
+            case 8: launch_rp_k<float, 8, 14, 1, false, float, false, false, false, 2, true, true>(y, tab, jend, g, gsrc, st); return 0;
+            case 4: launch_rp_k<float, 4, 14, 1, false, float, false, false, false, 2, true, true>(y, tab, jend, g, gsrc, st); return 0;
+            default: return -1;
+            }
+        }
+        if (dtype != SO_F64) return -1;
         switch (g.ct) {
         case 8: launch_rp_k<double, 8, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;
         case 4: launch_rp_k<double, 4, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;

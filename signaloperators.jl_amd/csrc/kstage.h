@@ -229,16 +229,19 @@ __device__ __forceinline__ void rmw_one_chunk(uint32_t la, int lds_pitch, uint32
 // ... and the in-place step whose operand is a second ARRAY's samples, staged by LDS-DMA as rows of 1 KB at `sa` (this lane's
 // 16 bytes of row c at sa + 1024 c: k_resample_periodic A2).  OP: 0 v*m, 1 v+m, 2 v-m, 3 m-v -- the operations K1 would have
 // done on the way to a materialised sum, on the same values.
-template <int CT, int OP, int R0 = 0>
+// (T = float: the tile and the staging rows hold Float32 samples, four to the 16 bytes, and the operation is Float32's --
+//  Julia's `+` / `*` on Float32 operands, what K1's materialised map computes)
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+template <typename T, int CT, int OP, int R0 = 0>
 __device__ __forceinline__ void rmw_arr2(uint32_t la, int lds_pitch, uint32_t sa) {
     if constexpr (CT > 4) {  // four rows at a time (registers)
-        rmw_arr2<4, OP, R0>(la, lds_pitch, sa);
-        rmw_arr2<CT - 4, OP, R0 + 4>(la + (uint32_t)(4 * lds_pitch) * 8u, lds_pitch, sa);
+        rmw_arr2<T, 4, OP, R0>(la, lds_pitch, sa);
+        rmw_arr2<T, CT - 4, OP, R0 + 4>(la + (uint32_t)(4 * lds_pitch) * (uint32_t)sizeof(T), lds_pitch, sa);
         return;
     } else {
         v2d raw[CT], m[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * 8u);
+        for (int c = 0; c < CT; ++c) raw[c] = lds_ld16(la + (uint32_t)(c * lds_pitch) * (uint32_t)sizeof(T));
         m[0] = lds_ld16_off<R0 * 1024>(sa);
         if constexpr (CT > 1) m[1] = lds_ld16_off<(R0 + 1) * 1024>(sa);
         if constexpr (CT > 2) m[2] = lds_ld16_off<(R0 + 2) * 1024>(sa);
@@ -246,10 +249,18 @@ __device__ __forceinline__ void rmw_arr2(uint32_t la, int lds_pitch, uint32_t sa
         lds_wait(raw);
         lds_wait(m);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) raw[c] = OP == 0 ? raw[c] * m[c] : OP == 1 ? raw[c] + m[c] : OP == 2 ? raw[c] - m[c] : m[c] - raw[c];
+        for (int c = 0; c < CT; ++c) {
+            if constexpr (sizeof(T) == 8) {
+                raw[c] = OP == 0 ? raw[c] * m[c] : OP == 1 ? raw[c] + m[c] : OP == 2 ? raw[c] - m[c] : m[c] - raw[c];
+            } else {
+                const v4f_ a = __builtin_bit_cast(v4f_, raw[c]), b = __builtin_bit_cast(v4f_, m[c]);
+                const v4f_ r = OP == 0 ? a * b : OP == 1 ? a + b : OP == 2 ? a - b : b - a;
+                raw[c] = __builtin_bit_cast(v2d, r);
+            }
+        }
         lds_pin(raw);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * 8u, raw[c]);
+        for (int c = 0; c < CT; ++c) lds_st16(la + (uint32_t)(c * lds_pitch) * (uint32_t)sizeof(T), raw[c]);
     }
 }
 

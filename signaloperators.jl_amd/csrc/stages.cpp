@@ -1148,11 +1148,11 @@ void Plan::process_stage(int sid) {
         S.in_pitch = -1;
     } else if (!direct && S.kind == ST_RESAMPLE && S.periodic &&
                build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype),
-                              // (the A2 instantiations: Float64, 32-row tiles of 4 or 8 channels, 14 k-steps, one group per compute wave)
+                              // (the A2 instantiations: Float64 -- or Float32 all the way --, 32-row tiles of 4 or 8 channels, 14 k-steps, one group per compute wave)
                               // ... and two tile slots + the loader waves' staging rows of the second array fit LDS)
-                              N.dtype == SO_F64 && S.rp.rows == 32 && (S.rp.ct == 8 || S.rp.ct == 4) && S.rp.kw == 56 &&
+                              (N.dtype == SO_F64 || (N.dtype == SO_F32 && S.rp.f32m)) && S.rp.rows == 32 && (S.rp.ct == 8 || S.rp.ct == 4) && S.rp.kw == 56 &&
                                   (S.rp.ngroups + S.rp.ncompute - 1) / S.rp.ncompute == 1 &&
-                                  (size_t)2 * S.rp.ct * S.rp.lds_pitch * 8 + (size_t)(S.rp.nwaves - S.rp.ncompute) * S.rp.ct * 1024 <=
+                                  (size_t)2 * S.rp.ct * S.rp.lds_pitch * dsize(N.dtype) + (size_t)(S.rp.nwaves - S.rp.ncompute) * S.rp.ct * 1024 <=
                                       160 * 1024 - sizeof(RsCtl) - 64)) {
         // every piece is `array (op) per-frame values`: evaluated inside the kernel's LDS
         // staging, no intermediate in HBM
@@ -1310,12 +1310,14 @@ bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
         }
         // `x (op) y` of two Float64 arrays (`Mix(x, y)`, `Amplify(x, y)`): x the carrier, y its one step's operand (the
         // resampler's A2 instantiation; the caller says whether its geometry has one)
-        if (carrier_arr2_ok && oc != OP_DIV && !r32 && e.dtype == SO_F64 && C.nsteps == 0 && monos.empty()) {
+        // (... or of two Float32 arrays of a Float32 signal: the step rounds to Float32, the Float32 tile's own arithmetic)
+        const int adt = e.dtype == SO_F32 ? SO_F32 : SO_F64;
+        if (carrier_arr2_ok && oc != OP_DIV && (e.dtype == SO_F64 ? !r32 : (e.dtype == SO_F32 && r32)) && C.nsteps == 0 && monos.empty()) {
             auto plain_array = [&](int ei2, DCarrier& c) {
                 const Expr* x = &exprs[ei2];
                 if (x->op != E_LOAD || x->array_node < 0) return false;  // (a caller's array; stage buffers stay with K1)
                 const DLeaf& L = x->leaf;
-                if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1 || L.dc < 0 || L.dtype != SO_F64) return false;
+                if (L.mode != LM_PLAIN || L.sf != 1 || L.sc != 1 || L.fstride != 1 || L.dc < 0 || L.dtype != adt) return false;
                 c.dtype2 = L.dtype;
                 c.array_node2 = x->array_node;
                 c.buf2 = -1;
@@ -1325,10 +1327,10 @@ bool Plan::match_carrier(int ei, DCarrier& C, std::vector<int>& monos) {
             };
             DCarrier c2 = C;
             std::vector<int> m2;
-            if (exprs[e.a].op == E_LOAD && match_carrier(e.a, c2, m2) && c2.nsteps == 0 && c2.dtype == SO_F64 && m2.empty() && plain_array(e.b, c2)) {
+            if (exprs[e.a].op == E_LOAD && match_carrier(e.a, c2, m2) && c2.nsteps == 0 && c2.dtype == adt && m2.empty() && plain_array(e.b, c2)) {
                 C = c2;
                 C.op[0] = oc;
-                C.arg[0] = kCarArr2;
+                C.arg[0] = kCarArr2 | (r32 ? 0x200 : 0);
                 C.nsteps = 1;
                 count_array(C.array_node2);
                 return true;
@@ -1392,7 +1394,7 @@ bool Plan::build_carriers(const std::vector<Piece>& ps_in, int nch, std::vector<
         std::fprintf(stderr, "[sigops] carriers=%zu allow_ga=%d dtype=%d nsteps=%d op=%d arg=%#x monos=%zu -> ga=%d\n", cs.size(), (int)allow_ga,
                      cs[0].dtype, cs[0].nsteps, cs[0].op[0], cs[0].arg[0], monos_all[0].size(), (int)ga);
     for (auto& c : cs)
-        if (!ga && c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
+        if (!ga && c.dtype == SO_F32 && c.nsteps > 0 && (c.array_node >= 0 || c.buf >= 0) && !car_has_arr2(c)) { if (std::getenv("SIGOPS_DEBUG_PLAN")) std::fprintf(stderr, "[sigops] carrier fusion rejected (#%d)\n", 4); return false; }
     std::vector<std::vector<DOp>> fcodes(cs.size());
     size_t nops_total = 0;
     std::set<int> leafset;

@@ -383,9 +383,14 @@ def test_float32_pipelines(kind, nch):
     }[kind]()
     x = pipeline(src)
     a, b, fused = both(x)
-    assert fused or nch == 3 or kind == "append", kind
+    # (two Float32 arrays of 8 channels: K3's two-array instantiation resamples the sum in one launch and the filter follows
+    #  it -- 0.82 ms where K1 + the fused kernel took 1.05, tests/test_gpu_two_arrays.py)
+    assert fused or nch == 3 or kind == "append" or (kind == "mix32" and nch == 8), kind
     assert a.dtype == np.float32 and b.dtype == np.float32
-    assert relerr(a, b) < 1e-7 and np.mean(a == b) > 0.999
+    if kind == "mix32" and nch == 8 and not fused:  # (... on the Float32 MFMA: its own rounding against `b`'s Float64 products, test_gpu_f32_mfma.py)
+        assert relerr(a, b) < 3e-7
+    else:
+        assert relerr(a, b) < 1e-7 and np.mean(a == b) > 0.999
     want = oracle_sink(pipeline(src if kind != "device" else so.Signal(x32, 44.1 * so.kHz)))
     assert want.dtype == np.float32 and relerr(a, want) < 1e-6
 

@@ -79,6 +79,28 @@ def test_two_arrays_in_front_of_the_resampler_one_launch_bit_equal_to_the_materi
     assert relerr(a, oracle_sink(tree)) <= 1e-9
 
 
+@pytest.mark.parametrize("nch", [8, 4])
+@pytest.mark.parametrize("op", sorted(OPS))
+def test_two_float32_arrays_of_a_float32_signal(op, nch):
+    """Float32 operands: the step rounds to Float32 (Julia's Float32 arithmetic, what K1's map computes) in the Float32
+    tile, the products run on the Float32 MFMA as for one Float32 array -- bit-equal to the materialised path again"""
+    n = 98_765
+    x, y = arrays(n, nch, 21, np.float32)
+    tree = OPS[op](so.Signal(x, 44.1 * so.kHz), so.Signal(y, 44.1 * so.kHz)) | so.ToFramerate(48 * so.kHz)
+    with env(SIGOPS_NO_ARR2=None):
+        names = steps_of(tree, np.float32)
+        a = so.sink(tree)[0]
+    with env(SIGOPS_NO_ARR2=1):
+        names0 = steps_of(tree, np.float32)
+        b = so.sink(tree)[0]
+    assert a.dtype == np.float32 and names == ["k_resample_periodic"] and len(names0) == 2, (names, names0)
+    assert np.array_equal(a, b)
+    assert relerr(a, oracle_sink(tree)) <= 1e-6
+    with env(SIGOPS_RS_NO_F32MFMA=1):  # (without the Float32 MFMA there is no such instantiation: K1 materialises)
+        assert len(steps_of(tree, np.float32)) == 2
+        assert relerr(so.sink(tree)[0], oracle_sink(tree)) <= 1e-6
+
+
 def test_rates_and_lengths():
     """other rate pairs of the 14-k-step family, lengths around tile and period boundaries, a one-frame signal"""
     for (fi, fo) in [(44.1, 48.0), (48.0, 44.1), (32.0, 48.0), (22.05, 24.0)]:
@@ -111,7 +133,7 @@ def test_what_the_instantiation_does_not_take_stays_right():
     x32, y32 = x.astype(np.float32), y.astype(np.float32)
     X, Y = so.Signal(x, 44.1 * so.kHz), so.Signal(y, 44.1 * so.kHz)
     trees = {
-        "Float32 operands": so.Mix(so.Signal(x32, 44.1 * so.kHz), so.Signal(y32, 44.1 * so.kHz)) | so.ToFramerate(48 * so.kHz),
+        "Float32 and Float64 operands": so.Mix(so.Signal(x32, 44.1 * so.kHz), Y) | so.ToFramerate(48 * so.kHz),
         "three operands": so.Mix(X, Y, so.Signal(so.sin, ω=1 * so.kHz)) | so.Until(n * so.frames) | so.ToFramerate(48 * so.kHz),
         "a gain on top": so.Amplify(so.Mix(X, Y), 0.5) | so.ToFramerate(48 * so.kHz),
         "another rate's window": so.Mix(X, Y) | so.ToFramerate(16 * so.kHz),
