@@ -22,13 +22,13 @@ OPS = ["mix", "amp", "sub", "rsub"]
 
 def steps_of(x):
     n, nch = so.nframes(x), so.nchannels(x)
-    p = so.Plan(so.ToChannels(x, nch), (n, nch), np.float64, (1, n), False)
+    p = so.Plan(so.ToChannels(x, nch), (n, nch), np.float32 if so.sampletype(x) == np.float32 else np.float64, (1, n), False)
     names = [s["name"] for s in p.steps()]
     p.close()
     return names
 
 
-bad, fused, worst = [], 0, 0.0
+bad, fused, worst, worst32 = [], 0, 0.0, 0.0
 for case in range(ncases):
     fi, fo = rng.choice(RATES, 2, replace=False)
     if rng.random() < 0.6:  # (the 14-k-step family the instantiation takes, up-sampling: the lazy map is resampled as a whole)
@@ -36,8 +36,9 @@ for case in range(ncases):
     nch = int(rng.choice([1, 2, 3, 4, 8, 16]))
     nx = int(rng.integers(1, 60000))
     ny = nx if rng.random() < 0.5 else int(rng.integers(1, 60000))
-    x = np.asfortranarray(rng.standard_normal((nx, nch)))
-    y = np.asfortranarray(rng.standard_normal((ny, nch)))
+    dt = np.float32 if rng.random() < 0.35 else np.float64  # (both operands: a Float32 signal all the way, or Float64)
+    x = np.asfortranarray(rng.standard_normal((nx, nch)).astype(dt))
+    y = np.asfortranarray(rng.standard_normal((ny, nch)).astype(dt))
     X, Y = so.Signal(x, fi * so.kHz), so.Signal(y, fi * so.kHz)
     if rng.random() < 0.3:
         X = so.After(X, int(rng.integers(0, max(1, nx // 2))) * so.frames)
@@ -64,8 +65,11 @@ for case in range(ncases):
     one = names == ["k_resample_periodic"]
     fused += one
     e = float(relerr(a, w)) if a.size else 0.0
-    worst = max(worst, e)
-    if not np.array_equal(a, b) or not (e <= 1e-8):
-        bad.append({"case": case, "fi": fi, "fo": fo, "nch": nch, "nx": nx, "ny": ny, "op": op, "names": names, "relerr": e,
+    if dt == np.float64:
+        worst = max(worst, e)
+    else:
+        worst32 = max(worst32, e)
+    if not np.array_equal(a, b) or not (e <= (1e-6 if dt == np.float32 else 1e-8)):
+        bad.append({"case": case, "fi": fi, "fo": fo, "nch": nch, "nx": nx, "ny": ny, "op": op, "dtype": np.dtype(dt).name, "names": names, "relerr": e,
                     "equal": bool(np.array_equal(a, b))})
-print(json.dumps({"cases": ncases, "seed": seed, "one_launch": int(fused), "worst_relerr": worst, "bad": bad[:10], "n_bad": len(bad)}))
+print(json.dumps({"cases": ncases, "seed": seed, "one_launch": int(fused), "worst_relerr": worst, "worst_relerr_f32": worst32, "bad": bad[:10], "n_bad": len(bad)}))
