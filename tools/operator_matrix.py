@@ -1,4 +1,6 @@
-"""One operator at a time over 1.25e7 frames x 8 channels (Float64): looking for cliffs outside the benches' shapes."""
+"""One operator at a time over 1.25e7 frames x 8 channels (Float64): looking for cliffs outside the benches' shapes.
+Per row: WARM untimed executes (default 20: the chip raises its clock over the first ~25 ms of a kernel after an idle gap, and
+with 3 the matrix-heavy rows read 10 - 25 % above their steady state), then the mean of REPS (default 30) between two events."""
 import os
 import sys
 
@@ -50,6 +52,7 @@ cases = {
     "ToEltype(Float32)": lambda: so.ToEltype(X, np.float32),
 }
 only = os.environ.get("ONLY")
+WARM, REPS = int(os.environ.get("WARM", "20")), int(os.environ.get("REPS", "30"))
 for name, mk in cases.items():
     if only and only not in name:
         continue
@@ -61,16 +64,16 @@ for name, mk in cases.items():
         out = torch.empty((co, nout), dtype=tdt, device="cuda").t()
         plan = so.Plan(so.ToChannels(tree, co), (nout, co), odt, (out.stride(0), out.stride(1)), True)
         st = torch.cuda.current_stream().cuda_stream
-        for _ in range(3):
+        for _ in range(WARM):
             plan.execute(out.data_ptr(), st)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(REPS):
             plan.execute(out.data_ptr(), st)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / REPS
         stt = plan.stats()
         names = "+".join(s_["name"].replace("k_resample_", "rs_").replace("k_", "") for s_ in plan.steps())
         plan.close()
