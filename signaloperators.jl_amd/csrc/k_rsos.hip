@@ -820,6 +820,9 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #ifndef SO_Y_SADDR
 #define SO_Y_SADDR 1
 #endif
+#ifndef SO_ST_NT
+#define SO_ST_NT ""  // (cache-policy bits of the result stores: measured and not set, see kstage.h SO_LD_NT)
+#endif
     const bool yfits = SO_Y_SADDR && uni((int)((((int64_t)(ct - 1) * out_pitch + (int64_t)(16 / ct) * grp.prL + 16) * (int64_t)sizeof(TO)) < ((int64_t)1 << 32)));
     int nbs[4];      // block b of row gq + 4v is stored (by this lane: time n16 of the block) while b < nbs[v]
     int nbs_all;     // ... and by every lane of the wave while b < nbs_all (no predicates then)
@@ -922,7 +925,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         if (fresh && yfits && sizeof(TO) == 8) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3])::"memory");
         auto put = [&](int v, TO val) __attribute__((always_inline)) {
             if (yfits) {
-                if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
+                if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" SO_ST_NT ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
                 else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
             } else {
                 const int row = gq + 4 * v;

@@ -109,6 +109,13 @@ __device__ __forceinline__ void lds_wait(v2d (&v)[N]) {  // results of lds_ld16 
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
 }
 
+// (cache-policy bits of the staging loads, e.g. -DSO_LD_NT='" nt"'.  Measured with the same hint on the fused kernel's result
+//  stores, k_rsos.hip SO_ST_NT: the headline's 3.5 GB stream 0.961 -> 0.947 ms, but the same kernel on 12.5 M x 8 frames 0.457
+//  -> 0.59 and K3's two-array instantiation 0.545 -> 0.60 -- what a loop of executes over 1 - 2 GB keeps in the 256 MB
+//  memory-side cache is worth more than the hint.  Not set.)
+#ifndef SO_LD_NT
+#define SO_LD_NT ""
+#endif
 // 16-byte-per-lane asynchronous global -> LDS copy (global_load_lds_dwordx4): the wave
 // writes 1 KiB contiguously at the wave-uniform LDS address `l`; no VGPR staging, so a few
 // loader waves keep whole tiles in flight.
@@ -118,7 +125,7 @@ __device__ __forceinline__ void lds_wait(v2d (&v)[N]) {  // results of lds_ld16 
 // tiles in flight.  Hidden from the compiler, the only waits are the counted ones below; its
 // own vmcnt(N) for ordinary loads only get stricter (in-order return), never wrong.
 __device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SO_LD_NT
                  :
                  : "s"(lds_byte_addr), "v"(g)
                  : "memory");  // (m0 is reserved: hipcc keeps nothing live in it, and warns if it is listed)
@@ -129,7 +136,7 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_byte_addr) {
 // mask built by scalar code.  While the compute waves of the SIMD run their MFMA burst a loader
 // wave gets a vector-ALU issue slot only every ~64+ cycles (fp64 MFMA and VALU share the ALUs),
 // so per-DMA address arithmetic on the VALU costs more than the copy itself.
-#define SO_DMA_ROW(I) "s_mov_b32 m0, %[l" #I "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[voff], %[b" #I "]\n\t"
+#define SO_DMA_ROW(I) "s_mov_b32 m0, %[l" #I "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[voff], %[b" #I "]" SO_LD_NT "\n\t"
 template <int CT>
 __device__ __forceinline__ void dma_rows(uint64_t mask, uint32_t voff, const char* base, int64_t row_stride,
                                          uint32_t lds, uint32_t lds_stride) {  // strides in bytes
