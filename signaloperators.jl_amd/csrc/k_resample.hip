@@ -4,7 +4,20 @@
 #include "krespos.h"
 #include "kstage.h"
 
+// One translation unit per (tile type, channels per tile) of the periodic kernel (build.py: -DSO_RP_UNIT=1 .. 8 = Float64 tiles
+// of 8 / 4 / 2 / 1 channels, Float32 tiles of 8 / 4 / 2 / 1), and -DSO_RP_UNIT=0 for everything else in this file (the other
+// resampler kernels, the fix-up kernel, the dispatcher): the runtime loads a code object the first time one of ITS kernels is
+// launched (~1.1 ms per MB; all 150 instantiations in one object were 5.4 MB in front of a first resampling sink), and the
+// units compile side by side.  -1 (the default, tools/build_variant.sh): everything in this one.
+#ifndef SO_RP_UNIT
+#define SO_RP_UNIT -1
+#endif
+
 namespace so {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#if SO_RP_UNIT <= 0
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_resample(const T* __restrict__ x,
@@ -162,7 +175,6 @@ void launch_resample_tiled(const void* x, void* y, const double* pfbt, const dou
     else launch_resample_tiled_t<double>(x, y, pfbt, dpfbt, g, st);
 }
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
 // K3r: row-tiled polyphase resampler for rational rates with LONG periods / filters (e.g.
@@ -331,6 +343,9 @@ int launch_resample_rows(const void* x, void* y, const double* ctab, const int* 
 // block is the product  Y[32 x 16] = X[32 x kw] * Tap[kw x 16]  (X = the rows' input
 // windows, Tap = the group's combined taps h + alpha*dh, zero outside each output's
 // support).  It is evaluated with v_mfma_f64_16x16x4_f64 used purely as a register-blocking
+#endif  // SO_RP_UNIT <= 0
+
+#if SO_RP_UNIT != 0
 // device: each lane supplies ONE input sample (one ds_read_b64) and ONE tap (a register,
 // loaded once per kernel) per 1024 multiply-adds, so neither LDS bandwidth nor tap
 // delivery limits the kernel (a scalar-operand VALU formulation measured ~700 clk per
@@ -1272,70 +1287,110 @@ static int launch_rp_q1(void* y, const double* tab, const int* jend, const RsPer
     return -1;
 }
 
+// everything the periodic kernel has for one tile type and channel count: this unit's instantiations
+template <typename T, int CT>
+static int launch_rp_unit(void* y, const double* tab, const int* jend, const RsPeriodic& g, const RsGlobalTables& gsrc, hipStream_t st) {
+    constexpr bool F = sizeof(T) == 4;
+    constexpr bool wide = CT == 8 || CT == 4;
+    if (g.arr2) {  // a step on a second array: the A2 instantiations (14 k-steps, one group per compute wave; Float64, or -- two
+                   // Float32 arrays of a Float32 signal -- the Float32 MFMA's)
+        const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
+        if (g.rows != 32 || g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
+        if constexpr (wide && F) {
+            if (!g.f32m) return -1;
+            launch_rp_k<float, CT, 14, 1, false, float, false, false, false, 2, true, true>(y, tab, jend, g, gsrc, st);
+            return 0;
+        } else if constexpr (wide) {
+            launch_rp_k<double, CT, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st);
+            return 0;
+        }
+        return -1;
+    }
+    if (g.rows == 16) {
+        if constexpr (wide) return launch_rp_q1<T, CT>(y, tab, jend, g, gsrc, st);
+        return -1;
+    }
+    if (g.nstate > 0) {
+        if constexpr (wide && !F) return launch_rp_st<CT>(y, tab, jend, g, gsrc, st);
+        return -1;
+    }
+    if (g.ga) {
+        if constexpr (wide && F) return launch_rp_ga<CT>(y, tab, jend, g, gsrc, st);
+        return -1;
+    }
+    return launch_rp_ct<T, CT>(y, tab, jend, g, gsrc, st);
+}
+#endif  // SO_RP_UNIT != 0
+
+#define SO_RP_ARGS void *y, const double *tab, const int *jend, const RsPeriodic &g, const RsGlobalTables &gsrc, hipStream_t st
+#define SO_RP_UNITS(X) X(1, d8, double, 8) X(2, d4, double, 4) X(3, d2, double, 2) X(4, d1, double, 1) X(5, f8, float, 8) X(6, f4, float, 4) X(7, f2, float, 2) X(8, f1, float, 1)
+#if SO_RP_UNIT == 0
+#define SO_RP_X(ID, TAG, T, CT) int launch_rp_unit_##TAG(SO_RP_ARGS);
+#elif SO_RP_UNIT < 0
+#define SO_RP_X(ID, TAG, T, CT) \
+    int launch_rp_unit_##TAG(SO_RP_ARGS) { return launch_rp_unit<T, CT>(y, tab, jend, g, gsrc, st); }
+#else
+#define SO_RP_X(ID, TAG, T, CT) SO_RP_X2(ID, TAG, T, CT)
+#define SO_RP_X2(ID, TAG, T, CT) SO_RP_IF_##ID(int launch_rp_unit_##TAG(SO_RP_ARGS) { return launch_rp_unit<T, CT>(y, tab, jend, g, gsrc, st); })
+#endif
+// (SO_RP_IF_<id>(code...): `code` in the unit with that id, nothing elsewhere)
+#define SO_RP_IF_1(...)
+#define SO_RP_IF_2(...)
+#define SO_RP_IF_3(...)
+#define SO_RP_IF_4(...)
+#define SO_RP_IF_5(...)
+#define SO_RP_IF_6(...)
+#define SO_RP_IF_7(...)
+#define SO_RP_IF_8(...)
+#if SO_RP_UNIT == 1
+#undef SO_RP_IF_1
+#define SO_RP_IF_1(...) __VA_ARGS__
+#elif SO_RP_UNIT == 2
+#undef SO_RP_IF_2
+#define SO_RP_IF_2(...) __VA_ARGS__
+#elif SO_RP_UNIT == 3
+#undef SO_RP_IF_3
+#define SO_RP_IF_3(...) __VA_ARGS__
+#elif SO_RP_UNIT == 4
+#undef SO_RP_IF_4
+#define SO_RP_IF_4(...) __VA_ARGS__
+#elif SO_RP_UNIT == 5
+#undef SO_RP_IF_5
+#define SO_RP_IF_5(...) __VA_ARGS__
+#elif SO_RP_UNIT == 6
+#undef SO_RP_IF_6
+#define SO_RP_IF_6(...) __VA_ARGS__
+#elif SO_RP_UNIT == 7
+#undef SO_RP_IF_7
+#define SO_RP_IF_7(...) __VA_ARGS__
+#elif SO_RP_UNIT == 8
+#undef SO_RP_IF_8
+#define SO_RP_IF_8(...) __VA_ARGS__
+#endif
+SO_RP_UNITS(SO_RP_X)
+#undef SO_RP_X
+
+#if SO_RP_UNIT <= 0
 // returns 0 when launched, -1 if no instantiation fits (caller falls back to k_resample)
 int launch_resample_periodic(void* y, const double* tab, const int* jend, const RsPeriodic& g,
                              int dtype, const RsGlobalTables& gsrc, hipStream_t st) {
     if (g.n_out <= 0) return 0;
-    if (g.arr2) {  // a step on a second Float64 array: the A2 instantiations (Float64, 14 k-steps, one group per compute wave)
-        const int gper = (g.ngroups + g.ncompute - 1) / g.ncompute;
-        if (g.rows != 32 || g.kw != 4 * 14 || gper != 1 || g.out_f32 || g.ga || g.nstate) return -1;
-        if (dtype == SO_F32) {  // (two Float32 arrays, a Float32 signal all the way: the Float32 MFMA's instantiation)
-            if (!g.f32m) return -1;
-            switch (g.ct) {
-            case 8: launch_rp_k<float, 8, 14, 1, false, float, false, false, false, 2, true, true>(y, tab, jend, g, gsrc, st); return 0;
-            case 4: launch_rp_k<float, 4, 14, 1, false, float, false, false, false, 2, true, true>(y, tab, jend, g, gsrc, st); return 0;
-            default: return -1;
-            }
-        }
-        if (dtype != SO_F64) return -1;
+    // the tile type: Float32 tiles for Float32 signals and for the GA instantiations (a Float32 array under a Float64 step)
+    const bool f32 = g.ga ? true : g.nstate > 0 ? false : dtype == SO_F32;
+    if (!f32 && !g.nstate && dtype != SO_F64) return -1;
+    if (f32) {
         switch (g.ct) {
-        case 8: launch_rp_k<double, 8, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;
-        case 4: launch_rp_k<double, 4, 14, 1, false, double, false, false, false, 2, false, true>(y, tab, jend, g, gsrc, st); return 0;
-        default: return -1;
-        }
-    }
-    if (g.rows == 16) {
-        if (dtype == SO_F32) {
-            switch (g.ct) {
-            case 8: return launch_rp_q1<float, 8>(y, tab, jend, g, gsrc, st);
-            case 4: return launch_rp_q1<float, 4>(y, tab, jend, g, gsrc, st);
-            default: return -1;
-            }
-        }
-        if (dtype != SO_F64) return -1;
-        switch (g.ct) {
-        case 8: return launch_rp_q1<double, 8>(y, tab, jend, g, gsrc, st);
-        case 4: return launch_rp_q1<double, 4>(y, tab, jend, g, gsrc, st);
-        default: return -1;
-        }
-    }
-    if (g.nstate > 0) {
-        switch (g.ct) {
-        case 8: return launch_rp_st<8>(y, tab, jend, g, gsrc, st);
-        case 4: return launch_rp_st<4>(y, tab, jend, g, gsrc, st);
-        default: return -1;
-        }
-    }
-    if (g.ga) {
-        switch (g.ct) {
-        case 8: return launch_rp_ga<8>(y, tab, jend, g, gsrc, st);
-        case 4: return launch_rp_ga<4>(y, tab, jend, g, gsrc, st);
-        default: return -1;
-        }
-    }
-    if (dtype == SO_F32) {
-        switch (g.ct) {
-        case 8: return launch_rp_ct<float, 8>(y, tab, jend, g, gsrc, st);
-        case 4: return launch_rp_ct<float, 4>(y, tab, jend, g, gsrc, st);
-        case 2: return launch_rp_ct<float, 2>(y, tab, jend, g, gsrc, st);
-        default: return launch_rp_ct<float, 1>(y, tab, jend, g, gsrc, st);
+        case 8: return launch_rp_unit_f8(y, tab, jend, g, gsrc, st);
+        case 4: return launch_rp_unit_f4(y, tab, jend, g, gsrc, st);
+        case 2: return launch_rp_unit_f2(y, tab, jend, g, gsrc, st);
+        default: return g.arr2 || g.rows == 16 || g.ga ? -1 : launch_rp_unit_f1(y, tab, jend, g, gsrc, st);
         }
     }
     switch (g.ct) {
-    case 8: return launch_rp_ct<double, 8>(y, tab, jend, g, gsrc, st);
-    case 4: return launch_rp_ct<double, 4>(y, tab, jend, g, gsrc, st);
-    case 2: return launch_rp_ct<double, 2>(y, tab, jend, g, gsrc, st);
-    default: return launch_rp_ct<double, 1>(y, tab, jend, g, gsrc, st);
+    case 8: return launch_rp_unit_d8(y, tab, jend, g, gsrc, st);
+    case 4: return launch_rp_unit_d4(y, tab, jend, g, gsrc, st);
+    case 2: return launch_rp_unit_d2(y, tab, jend, g, gsrc, st);
+    default: return g.arr2 || g.rows == 16 || g.nstate ? -1 : launch_rp_unit_d1(y, tab, jend, g, gsrc, st);
     }
 }
 
@@ -1413,5 +1468,7 @@ void launch_resample_fix(const RsFixArgs& a, hipStream_t st) {
     const int per = kBlock / 64;
     hipLaunchKernelGGL(k_resample_fix, dim3((unsigned)((a.nfix + per - 1) / per)), dim3(kBlock), 0, st, a);
 }
+
+#endif  // SO_RP_UNIT <= 0
 
 }  // namespace so

@@ -11,10 +11,11 @@ if [ -n "${RELINK_ONLY:-}" ] && [ -f "$obj" ]; then :; else
     -Wno-unused-function "$@" -x hip -c "$here/$unit" -o "$obj"
 fi
 objs=""
-# (k_rsos.hip is built as one unit per window length, k_rsos_ks*.o; as a variant it is ONE unit with everything in it)
+# (k_rsos.hip and k_resample.hip are built as several units, k_rsos_ks*.o / k_resample_u*.o; as a variant each is ONE unit with everything in it)
 for s in k_pointwise k_sos k_small k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
     if [ "$s.hip" = "$unit" ]; then objs="$objs $obj"
     elif [ "$s" = k_rsos ]; then objs="$objs $(ls $here/k_rsos_ks*.o | tr '\n' ' ')"
+    elif [ "$s" = k_resample ]; then objs="$objs $(ls $here/k_resample_u*.o | tr '\n' ' ')"
     else objs="$objs $here/$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$here/exports.map -o "$here/libsigops_$name.so" $objs -ldl
