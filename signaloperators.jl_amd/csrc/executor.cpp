@@ -365,6 +365,8 @@ void Plan::release() {
     if (d_pieces) (void)hipFree(d_pieces);
     if (d_ops) (void)hipFree(d_ops);
     if (d_leaves) (void)hipFree(d_leaves);
+    if (kerr) (void)hipHostFree(kerr);
+    kerr = nullptr;
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
 }
@@ -374,6 +376,15 @@ void Plan::release() {
 static size_t prof_cap(const Plan* P) {
     const size_t evset = 2 * std::max<size_t>(1, P->steps.size());
     return std::max<size_t>(1, std::min<size_t>(kProfExecs, 8192 / evset));
+}
+
+// a kernel gave up on a wait between its waves (k_rsos: a protocol that did not hold; its result and
+// everything computed from it is wrong): reported once: by the execute itself where it synchronises (a host result), else by the next call on the plan
+static bool kernel_gave_up(Plan* P, std::string& err) {
+    if (!P->kerr || !*(volatile uint32_t*)P->kerr) return false;
+    *(volatile uint32_t*)P->kerr = 0;
+    err = "k_rsos: a wait between its waves did not end (this plan's last result is invalid)";
+    return true;
 }
 
 static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& err) {
@@ -605,6 +616,16 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
                             rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
                             launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite range yet"
+                        }
+                        if (!P->kerr && !std::getenv("SIGOPS_RSOS_TRAP")) {  // (the word the kernel reports a wait that did not end in)
+                            if (hipHostMalloc((void**)&P->kerr, 64, hipHostMallocMapped) == hipSuccess) *P->kerr = 0;
+                            else P->kerr = nullptr, (void)hipGetLastError();
+                        }
+                        rs.err = nullptr;
+                        if (P->kerr) {
+                            void* dp = nullptr;
+                            if (hipHostGetDevicePointer(&dp, P->kerr, 0) == hipSuccess) rs.err = (uint32_t*)dp;
+                            else (void)hipGetLastError();
                         }
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
                         // (SIGOPS_RSOS_TRACE_SKIP=n: not the first n launches of the process -- a traced launch synchronises, and a run
@@ -879,6 +900,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
         } else if (!P->host_leaves.empty() || P->profiling == 1) {
             HIPCHECK(hipStreamSynchronize(st));
         }
+        if (!P->out.is_device && P->out.nframes > 0) {  // (synchronised above)
+            std::string why;
+            if (kernel_gave_up(P, why)) fail(SO_ERR_RUNTIME, why);
+        }
         if (P->profiling == 2) P->prof_execs++;
         if (P->profiling == 1) {
             HIPCHECK(hipStreamSynchronize(st));
@@ -909,6 +934,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
 // pointer on, the whole multi-stream launch sequence is replayed from a captured HIP graph.
 int plan_execute(Plan* P, void* outp, void* stream, std::string& err) {
     DeviceGuard guard(P->device);
+    if (kernel_gave_up(P, err)) return SO_ERR_RUNTIME;
     const bool eligible = P->steps.size() >= 4 && P->out.is_device && P->host_leaves.empty() && !P->profiling &&
                           !std::getenv("SIGOPS_NO_GRAPH") && !std::getenv("SIGOPS_RS_TRACE");
     if (!eligible) {

@@ -57,14 +57,19 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int flag_ld(uint32_t a) { return *(const volatile SO_LDS int*)(uintptr_t)a; }
 __device__ __forceinline__ void flag_st(uint32_t a, int v) { *(volatile SO_LDS int*)(uintptr_t)a = v; }
 // every wait of this kernel is for another wave of the same workgroup and lasts microseconds: a wait that does not end
-// is a bug of the protocol, and a trap (the launch fails) is better than a hung device
+// is a bug of the protocol.  The wave that finds one says so in the plan's host-mapped error word (RsSos::err) and ENDS; the
+// waves that wait for it in turn do the same, the launch finishes with a wrong result, and the host reports
+// "k_rsos: a wait between its waves did not end" with the next call on the plan (executor.cpp) -- an error return, not the
+// dead process a trap is (the ROCm runtime aborts on one) and not a hung device.  Without the word: a trap.
 // (SIGOPS_RSOS_DEBUG bit 32768 lowers the limit of the y waves' wait for a state to 4 096 polls: with bit 64 -- no chain wave --
-//  that wait never ends, and the test of the host's report of such a failure need not hold a GPU for seconds)
-__device__ __forceinline__ void spin_pause(int& spins, int sleep, int limit = 1 << 22) {
-    if (++spins > limit) __builtin_trap();
-    if (sleep == 1) __builtin_amdgcn_s_sleep(1);
-    else __builtin_amdgcn_s_sleep(2);
-}
+//  that wait never ends, and the test of the host's report need not hold a GPU for seconds)
+// (inline and without a call: as an out-of-line routine -- even a noreturn one -- the cold path cost the headline 1 %)
+#define SO_SPIN_PAUSE(spins, sleep, limit)                         \
+    do {                                                           \
+        if (++(spins) > (limit)) rsos_wait_failed(sh);             \
+        if ((sleep) == 1) __builtin_amdgcn_s_sleep(1);             \
+        else __builtin_amdgcn_s_sleep(2);                          \
+    } while (0)
 __device__ __forceinline__ int wave_min(int v, int n) {  // min of lanes [0, n), wave-uniform result
     int m = __builtin_amdgcn_readlane(v, 0);
 #pragma unroll
@@ -219,10 +224,21 @@ struct RsosShared {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+
 // Global-memory pointers rebuilt from values in LDS are GENERIC to the compiler: their loads and stores would be flat_
 // instructions, which count on lgkmcnt as well as vmcnt -- every wait for an LDS read would then also wait for the result
 // stores of the block before (a trip to HBM).  Typed as address space 1 they are global_ instructions.
 #define SO_GLB __attribute__((address_space(1)))
+
+// (see SO_SPIN_PAUSE above; never taken in a launch that works)
+__device__ __forceinline__ void rsos_wait_failed(SO_LDS RsosShared* sh) {
+    uint32_t SO_GLB* const e = (uint32_t SO_GLB*)rfl64((int64_t)(uintptr_t)sh->g.err);
+    if (e == nullptr) __builtin_trap();
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store((uint32_t*)e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_endpgm();
+}
 
 // cycle stamp of workgroup 0 (tuning aid, SIGOPS_RSOS_TRACE); iterations [it0, it0 + kRsosTraceIters) are recorded
 #ifndef SO_RSOS_TRACE
@@ -335,7 +351,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     int spins = 0;
     [[maybe_unused]] int cnt_wait = 0, cnt_blocks = 0;  // (SO_RSOS_COUNT: per lane = the y wave whose D.x was late)
     [[maybe_unused]] const long long cyc0 = SO_RSOS_COUNT ? clock64() : 0;
-    while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1 && !(debug & 4)) spin_pause(spins, 1);
+    while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 0))) < 1 && !(debug & 4)) SO_SPIN_PAUSE(spins, 1, 1 << 22);
     // Two steps per loop iteration with the roles of the register sets swapped: the state a step leaves is the next
     // step's B operand where it is, the operand set a step has consumed is refilled (under its first MFMA) with the
     // block two steps on, and the counter that guards that refill was requested two steps earlier still.
@@ -358,7 +374,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     for (int v = 0; v < 3; ++v) dA[v] = l.xs[v * 64 + lane];
     if (NB > 1) {
         spins = 0;
-        while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2 && !(debug & 4)) spin_pause(spins, 1);
+        while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2 && !(debug & 4)) SO_SPIN_PAUSE(spins, 1, 1 << 22);
 #pragma unroll
         for (int v = 0; v < 3; ++v) dB[v] = l.xs[192 + v * 64 + lane];
     }
@@ -400,7 +416,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
                 spins = 0;
                 if constexpr (SO_RSOS_COUNT) cnt_blocks += lane == (b + 2) % NY ? 1 : 0;
                 do {
-                    spin_pause(spins, 1);
+                    SO_SPIN_PAUSE(spins, 1, 1 << 22);
                     if constexpr (SO_RSOS_COUNT) cnt_wait += lane == (b + 2) % NY ? 1 : 0;
                     f = uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + s2)));
                 } while (f < b + 3);
@@ -746,7 +762,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             continue;
         }
         if (issued >= NK) break;
-        spin_pause(spins, 2);
+        SO_SPIN_PAUSE(spins, 2, 1 << 22);
         if constexpr (SO_RSOS_COUNT) ++cnt_idle;
     }
     __builtin_amdgcn_s_setprio(0);
@@ -900,7 +916,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         if (sq < pb_ && !(debug & 8)) {  // (the speculative read was early: wait, read again)
             if constexpr (SO_RSOS_COUNT) ++cnt_st_b;
             do {
-                spin_pause(spins, 1, (debug & 32768) ? 4096 : (1 << 22));
+                SO_SPIN_PAUSE(spins, 1, (debug & 32768) ? 4096 : (1 << 22));
                 if constexpr (SO_RSOS_COUNT) ++cnt_st;
                 sq = uni(flag_ld(f_sseq));
             } while (sq < pb_);
@@ -966,7 +982,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             const int v = lane < NL ? flag_ld(fl_base + 4 * (kRsosFlagLdp + lane)) : 0x7fffffff;
             avail = wave_min(v, NL);
             if (avail < need) {
-                spin_pause(spins, 2);
+                SO_SPIN_PAUSE(spins, 2, 1 << 22);
                 if constexpr (SO_RSOS_COUNT) ++cnt_in;
             }
         }

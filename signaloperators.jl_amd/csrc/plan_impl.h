@@ -255,6 +255,7 @@ struct Plan {
     DPiece* d_pieces = nullptr;
     DOp* d_ops = nullptr;
     DLeaf* d_leaves = nullptr;
+    uint32_t* kerr = nullptr;  // host-mapped word a kernel writes when it gives up on a wait between its waves (k_rsos: RsSos::err)
     int out_stage_buf = -1;  // device staging for a host result
     int out_alias_buf = -1;  // pseudo buffer standing for the result (leaves of in-place root pieces point at it)
     void try_window_alias(std::vector<Piece>& rootp);

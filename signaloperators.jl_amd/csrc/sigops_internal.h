@@ -380,6 +380,8 @@ struct RsSos {
     const double* mats;   // [14][64] MFMA operands: D k-steps 0..3, A^16 k-steps 0..2, T^T k-steps 0..3, C^T k-steps 0..2
     int32_t* bad;         // per channel: first range that ended in a non-finite state, or null
     long long* trace;     // SIGOPS_RSOS_TRACE: [16 waves][kRsosTraceIters][8] cycle stamps of workgroup 0, or null
+    uint32_t* err;        // host-mapped word of the plan: a wait between the kernel's waves that did not end writes 1 here and the
+                          // wave ends (the host reports it with the next call on the plan); null: such a wait traps
 };
 constexpr int kRsosTraceIters = 96;
 

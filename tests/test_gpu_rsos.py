@@ -412,11 +412,12 @@ def test_float32_pipeline_windows_and_streams():
     assert cat.dtype == np.float32 and cat.shape == want.shape and relerr(cat, want) < 1e-6
 
 
-def test_a_wait_that_does_not_end_ends_the_process_not_the_device():
-    """k_rsos ends a wait between its waves that never ends with a trap: the ROCm runtime then aborts the PROCESS (its queue
-    callback, "HSA_STATUS_ERROR_EXCEPTION ... hardware exception": nothing the library's host side could turn into an
-    SO_ERR_* return) -- a dead process instead of a hung device.  Forced in a child: no chain wave (ablation bit 64), the
-    y waves' wait for a state cut to 4 096 polls (bit 32768)."""
+def test_a_wait_that_does_not_end_is_an_error_return_not_a_dead_process():
+    """A wait between k_rsos's waves that never ends: the wave says so in the plan's host-mapped error word and ends, the
+    waves that wait for it in turn do the same, the launch finishes -- and the host reports it: `sink` into a host result
+    (it synchronises) raises, an execute into a device result returns and the NEXT call on the plan raises.  Neither a hung
+    device nor the dead process a trap is (SIGOPS_RSOS_TRAP=1 keeps the trap: the ROCm runtime aborts the process on one).
+    Forced in a child: no chain wave (ablation bit 64), the y waves' wait for a state cut to 4 096 polls (bit 32768)."""
     import subprocess
     import sys
 
@@ -425,17 +426,42 @@ import os, sys
 os.environ["SIGOPS_RSOS_DEBUG"] = str(64 + 32768)
 os.environ["SIGOPS_RSOS_MINGROUPS"] = "1"
 sys.path.insert(0, %r); sys.path.insert(0, %r)
-import numpy as np
+import numpy as np, torch
 import sigops_amd as so
 rng = np.random.default_rng(1)
 x = so.Signal(np.asfortranarray(rng.standard_normal((200000, 8))), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz)
-so.sink(x)
-print("RETURNED")
+try:
+    so.sink(x)
+    print("HOST RESULT RETURNED")
+except so.ErrorException as e:
+    print("HOST RESULT RAISED:", e)
+n = so.nframes(x)
+out = torch.empty((8, n), dtype=torch.float64, device="cuda").t()
+plan = so.Plan(so.ToChannels(x, 8), (n, 8), np.float64, (out.stride(0), out.stride(1)), True, device=0)
+plan.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+print("DEVICE RESULT RETURNED")
+try:
+    plan.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    print("SECOND EXECUTE RETURNED")
+except so.ErrorException as e:
+    print("SECOND EXECUTE RAISED:", e)
+torch.cuda.synchronize()
+plan.close()
+os.environ.pop("SIGOPS_RSOS_DEBUG")
+from oracle_bridge import oracle_sink, relerr
+print("AFTERWARDS", float(relerr(so.sink(x)[0], oracle_sink(x))) < 1e-9)
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode()
-    assert r.returncode != 0 and "RETURNED" not in out and "hardware exception" in out, (r.returncode, out[-1500:])
-    # ... and the device is fine afterwards: this process sinks the same tree
+    assert r.returncode == 0, (r.returncode, out[-1500:])
+    assert "HOST RESULT RAISED: k_rsos: a wait between its waves did not end" in out and "HOST RESULT RETURNED" not in out, out[-1500:]
+    assert "DEVICE RESULT RETURNED" in out and "SECOND EXECUTE RAISED: k_rsos: a wait between its waves did not end" in out, out[-1500:]
+    assert "AFTERWARDS True" in out, out[-1500:]
+    # ... with the trap instead (the opt-out): a dead process, the device fine afterwards
+    code_trap = "import os\nos.environ['SIGOPS_RSOS_TRAP'] = '1'\n" + code
+    r = subprocess.run([sys.executable, "-c", code_trap], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode != 0 and "RETURNED" not in r.stdout.decode(), (r.returncode, r.stdout.decode()[-800:])
     rng = np.random.default_rng(1)
     x = pipeline(so.Signal(F(rng.standard_normal((200000, 8))), 44.1 * so.kHz))
     with env(SIGOPS_RSOS_MINGROUPS=1):
