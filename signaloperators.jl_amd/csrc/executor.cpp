@@ -378,12 +378,33 @@ static size_t prof_cap(const Plan* P) {
     return std::max<size_t>(1, std::min<size_t>(kProfExecs, 8192 / evset));
 }
 
+// the plan's host-mapped word a kernel reports a wait between its waves in that did not end (device address, or null: the
+// kernel then traps -- also the choice of SIGOPS_RSOS_TRAP=1)
+static uint32_t* kernel_error_word(Plan* P) {
+    if (std::getenv("SIGOPS_RSOS_TRAP")) return nullptr;
+    if (!P->kerr) {
+        if (hipHostMalloc((void**)&P->kerr, 64, hipHostMallocMapped) == hipSuccess) *P->kerr = 0;
+        else {
+            P->kerr = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, P->kerr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (uint32_t*)dp;
+}
+
 // a kernel gave up on a wait between its waves (k_rsos: a protocol that did not hold; its result and
 // everything computed from it is wrong): reported once: by the execute itself where it synchronises (a host result), else by the next call on the plan
 static bool kernel_gave_up(Plan* P, std::string& err) {
     if (!P->kerr || !*(volatile uint32_t*)P->kerr) return false;
+    const uint32_t who = *(volatile uint32_t*)P->kerr;  // 1: k_rsos, 2: k_resample_arb
     *(volatile uint32_t*)P->kerr = 0;
-    err = "k_rsos: a wait between its waves did not end (this plan's last result is invalid)";
+    err = std::string(who == 2 ? "k_resample_arb" : "k_rsos") + ": a wait between its waves did not end (this plan's last result is invalid)";
     return true;
 }
 
@@ -617,16 +638,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
                             launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite range yet"
                         }
-                        if (!P->kerr && !std::getenv("SIGOPS_RSOS_TRAP")) {  // (the word the kernel reports a wait that did not end in)
-                            if (hipHostMalloc((void**)&P->kerr, 64, hipHostMallocMapped) == hipSuccess) *P->kerr = 0;
-                            else P->kerr = nullptr, (void)hipGetLastError();
-                        }
-                        rs.err = nullptr;
-                        if (P->kerr) {
-                            void* dp = nullptr;
-                            if (hipHostGetDevicePointer(&dp, P->kerr, 0) == hipSuccess) rs.err = (uint32_t*)dp;
-                            else (void)hipGetLastError();
-                        }
+                        rs.err = kernel_error_word(P);
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
                         // (SIGOPS_RSOS_TRACE_SKIP=n: not the first n launches of the process -- a traced launch synchronises, and a run
                         //  of traced launches never leaves the chip's power-management transient)
@@ -815,6 +827,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             RsArb ra = S.ra;
                             ra.g.in_pitch = in_pitch;
                             ra.g.out_pitch = ob.pitch;
+                            ra.err = kernel_error_word(P);
                             done = launch_resample_arb(inp, ob.d, (const double*)P->bufs[S.pfbt_buf].d,
                                                        (const double*)P->bufs[S.dpfbt_buf].d, ra, st) == 0;
                         }

@@ -50,8 +50,16 @@ __device__ __forceinline__ int64_t a_uni64(int64_t v) {
 }
 __device__ __forceinline__ int a_flag_ld(const SO_LDS int* p) { return *(const volatile SO_LDS int*)p; }
 __device__ __forceinline__ void a_flag_st(SO_LDS int* p, int v) { *(volatile SO_LDS int*)p = v; }
-__device__ __forceinline__ void a_pause(int& spins) {
-    if (++spins > (1 << 22)) __builtin_trap();  // (a wait for another wave of the workgroup that does not end is a bug: fail the launch)
+// (a wait for another wave of the workgroup that does not end is a bug of the protocol: said in the plan's host-mapped error
+//  word, the wave ends, the host reports it -- k_rsos.hip SO_SPIN_PAUSE; without the word a trap)
+__device__ __forceinline__ void a_pause(int& spins, uint32_t* err) {
+    if (++spins > (1 << 22)) {
+        if (err == nullptr) __builtin_trap();
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_endpgm();
+    }
     __builtin_amdgcn_s_sleep(2);
 }
 __device__ __forceinline__ int a_wave_max(int v) {
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const T* _
                 while (needrd > 0 && minrd < needrd && !(debug & 1)) {
                     int v = lane < NC ? a_flag_ld(f_rd + lane) : 0x7fffffff;
                     minrd = a_wave_min(v);
-                    if (minrd < needrd) a_pause(spins);
+                    if (minrd < needrd) a_pause(spins, a.err);
                 }
                 spins = 0;
                 const int64_t fa = F0 + (int64_t)k * CHF;  // absolute first frame of the chunk
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(NO == 4 ? 512 : 768) void k_resample_arb(const T* _
         const int smin = a_wave_min(sA);
         const int emax = a_wave_max(sA + 2 * npairs);
         if (lane == 0) a_flag_st(f_rd + wave, smin);
-        while (a_uni(a_flag_ld(f_ldp)) < min(emax, E) && !(a.debug & 1)) a_pause(spins);
+        while (a_uni(a_flag_ld(f_ldp)) < min(emax, E) && !(a.debug & 1)) a_pause(spins, a.err);
         spins = 0;
         asm volatile("" ::: "memory");
         // frame f of the walk is tap k = r - f of an output whose newest input is r: granule k + Z of its phase's row

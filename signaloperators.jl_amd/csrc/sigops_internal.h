@@ -253,6 +253,7 @@ struct RsArb {
     int32_t no, pad_;  // outputs per lane (2 or 4); a batch is 64 * no outputs
     int64_t bpr;       // batches per range
     int64_t nbatches;  // ceil(n_out / (64 no))
+    uint32_t* err;     // the plan's host-mapped error word (see RsSos::err), or null: a wait that does not end traps
 };
 
 // DSP.jl's FIRArbitrary positions its outputs with a floating-point phase accumulator
