@@ -121,6 +121,13 @@ __device__ __attribute__((noinline)) void rsos_stage_slow(int64_t n_in, int rpit
     const int lane = threadIdx.x & 63;
     if (lane < lanes) stage_generic_impl<double, RU>(n_in, rpitch, gcar, ncar, gops, gleaves, n0 + 2 * lane, lane, 0, ch0, buf);
 }
+// ... into a ring that keeps Float32 samples (RsSos::ring32): four frames per lane, rows 2 rpitch floats apart
+template <int RU>
+__device__ __attribute__((noinline)) void rsos_stage_slow32(int64_t n_in, int rpitch, const DCarrier* gcar, int ncar, const DOp* gops,
+                                                            const DLeaf* gleaves, int64_t n0, int lanes, int ch0, float* buf) {
+    const int lane = threadIdx.x & 63;
+    if (lane < lanes) stage_generic_impl<float, RU>(n_in, 2 * rpitch, gcar, ncar, gops, gleaves, n0 + 4 * lane, lane, 0, ch0, buf);
+}
 
 // in-place step of carrier 0 on one lane's 16 bytes of each of the RU rows of a landed chunk; OP: 0 v*m, 1 v+m, 2 v-m, 3 m-v
 template <int RU, int OP>
@@ -528,6 +535,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const int64_t a0 = rfl64(C0.a), b0 = rfl64(C0.b), cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const char* const base0 = (const char*)rfl64((int64_t)(uintptr_t)C0.base);
     const int fuse = uni(g.fuse), fuse_sine = uni(g.fuse_sine), debug = uni(g.debug);
+    const bool ring32 = SRC32 && uni(g.ring32) != 0;  // (the chunks stay Float32, at four bytes a frame: the y waves widen their operands)
     constexpr bool src32 = SRC32;  // (a Float32 array: 4-byte elements, 128 of them per chunk and LDS-DMA instruction; its own
                                    //  instantiation: the Float64 loader's per-chunk path stays what it was)
     constexpr int esh = src32 ? 2 : 3;
@@ -609,18 +617,26 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             if (fast && (debug & 8192)) continue;
             if (fast) {
                 const char* row = (const char*)(uintptr_t)(u_rowb(j) + ((int64_t)k << (shift + esh)));
-                if constexpr (src32) dma_rows<RU>(0xffffffffull, lane16, row, cs0 * 4, u_lds(j) + (uint32_t)rho0 * 8u + 512u, row_bytes);
+                if constexpr (src32) dma_rows<RU>(0xffffffffull, lane16, row, cs0 * 4, u_lds(j) + (ring32 ? (uint32_t)rho0 * 4u : (uint32_t)rho0 * 8u + 512u), row_bytes);
                 else dma_rows<RU>(dmask, lane16, row, cs0 * 8, u_lds(j) + (uint32_t)rho0 * 8u, row_bytes);
                 n += RU;
             } else if (k < __builtin_amdgcn_readlane(kzl_l, j) || k >= __builtin_amdgcn_readlane(kzh_l, j)) {
                 // wholly before the signal's first frame (the warm-up of the first range) or behind its last: zeros
                 // (Pad(x.signal, zero), reference src/filters.jl:240) -- the general path below costs ~30 000 cycles
                 // per chunk, and the workgroup that walks range 0 held the whole kernel up by 0.46 ms with it
-                if (lane < lanes) {
-                    const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
+                if (lane < (ring32 ? lanes >> 1 : lanes)) {
+                    const uint32_t la = u_lds(j) + (uint32_t)rho0 * (ring32 ? 4u : 8u) + lane16;
                     const v2d z = v2d{0.0, 0.0};
 #pragma unroll
                     for (int c = 0; c < RU; ++c) lds_st16(la + (uint32_t)c * row_bytes, z);
+                }
+            } else if (!(debug & 4096) && ring32) {
+                if constexpr (src32) {
+                    const int u = q + j * NL;
+                    rsos_stage_slow32<RU>(n_in, rpitch, (const DCarrier*)rfl64((int64_t)(uintptr_t)sh->gcar), uni(sh->ctl.ncar),
+                                          (const DOp*)rfl64((int64_t)(uintptr_t)sh->gops), (const DLeaf*)rfl64((int64_t)(uintptr_t)sh->gleaves),
+                                          u_Au(j) + ((int64_t)k << shift), lanes >> 1, u_ch0(j),
+                                          (float*)(l.ring + (size_t)(u * RU) * rpitch) + rho0);
                 }
             } else if (!(debug & 4096)) {
                 const int u = q + j * NL;
@@ -634,7 +650,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     };
     auto retire = [&](int k, int rho0, int allowed) __attribute__((always_inline)) {
         rsos_stamp(trace, wave, k, 2, 40);
-        const bool gain = (fuse >= 0 || src32) && !(debug & 2);
+        const bool gain = (fuse >= 0 || (src32 && !ring32)) && !(debug & 2);
         // what does not depend on the chunk's samples comes BEFORE the wait for them: the share bases of the next sixteen
         // chunks (every sixteenth chunk) and this chunk's own, read back from LDS
         if (gain && fuse >= 0 && fuse_sine && (k & 15) == 0 && !(debug & 2048)) {  // lane = (unit slot, chunk)
@@ -802,6 +818,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const int64_t cs0 = rfl64(C0.cstride), df0 = rfl64(C0.df);
     const bool src32 = uni(g.src32) != 0;
     const bool x32 = sizeof(TO) == 4 && uni(g.x32) != 0;
+    // (the ring keeps Float32 samples, four bytes a frame: RsSos::ring32 -- Float32-result instantiations only)
+    [[maybe_unused]] const bool ring32 = sizeof(TO) == 4 && uni(g.ring32) != 0;
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && uni(g.fuse) >= -1 &&
                         (!src32 || uni(g.chunk) == 128);
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
@@ -998,7 +1016,29 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         if (wbm < 0) wbm = wb % RING;
         const int pos = wbm + cl;  // < RING + 20: one conditional subtraction per read wraps it
         double bx[KS];
-        if (wbm + 20 + kw <= RING) {  // (no lane's window wraps: one address, immediate offsets)
+        bool have_bx = false;
+        if constexpr (sizeof(TO) == 4) {
+            if (ring32) {  // Float32 samples in the ring: widened here (KS conversions per block; the loader's widening pass of
+                           // every chunk, one wave next to the chain's MFMAs, was the slower place for them)
+                float bf[KS];
+                if (wbm + 20 + kw <= RING) {
+                    const SO_LDS float* p0 = (const SO_LDS float*)(ringc + (uint32_t)pos * 4u);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) bf[s] = p0[4 * s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const int p_ = pos + 4 * s;
+                        bf[s] = *(const SO_LDS float*)(ringc + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 4u);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) bx[s] = (double)bf[s];
+                have_bx = true;
+            }
+        }
+        if (have_bx) {
+        } else if (wbm + 20 + kw <= RING) {  // (no lane's window wraps: one address, immediate offsets)
             const SO_LDS double* p0 = (const SO_LDS double*)(ringc + (uint32_t)pos * 8u);
 #pragma unroll
             for (int s = 0; s < KS; ++s) bx[s] = p0[4 * s];

@@ -371,6 +371,8 @@ struct RsSos {
     int32_t out_f32;
     int32_t src32;        // carrier 0 is a Float32 array: its chunks land as Float32 in the upper half of their ring slots and the
                           // loader widens them in place (together with the fused step)
+    int32_t ring32;       // src32 without a step (a Float32 signal all the way): the ring KEEPS Float32 samples, four bytes a frame
+                          // in the first half of each row, and the y waves widen their window operands (no widening pass by the loader)
     int32_t x32;          // a Float32 pipeline: the resampled values are rounded to Float32 before the cascade reads them (the
                           // reference's Float32 resampler output; Float32 result instantiations only)
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space

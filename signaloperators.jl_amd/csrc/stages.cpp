@@ -1117,10 +1117,11 @@ void Plan::process_stage(int sid) {
     // scan: its source as a carrier, like a periodic resampler's.  The direct view above stays -- what the three passes
     // read if the fused form is not taken.
     if (direct && S.kind == ST_SOS && S.groups.size() == 1 && S.groups[0].nsec <= 6 && !S.sg.exact && !S.onepass && !S.under_norm &&
-        S.base == 0 && in_base == 0 && in_frames == need && N.dtype == SO_F64 &&
+        S.base == 0 && in_base == 0 && in_frames == need && (N.dtype == SO_F64 || (N.dtype == SO_F32 && !std::getenv("SIGOPS_RSOS_NO32"))) &&
         need * N.nch >= (std::getenv("SIGOPS_RSOS_MINGROUPS") ? (int64_t)4096 : ((int64_t)1 << 22)) && !std::getenv("SIGOPS_NO_RSOS") && !std::getenv("SIGOPS_NO_PLAIN_RSOS")) {
         std::vector<DCarrier> cs;
-        if (build_carriers(ps, N.nch, cs, false) && cs.size() == 1) S.carriers = cs;
+        // (a Float32 signal: a plain Float32 array or buffer only -- the kernel's ring then keeps the Float32 samples)
+        if (build_carriers(ps, N.nch, cs, false) && cs.size() == 1 && (N.dtype == SO_F64 || (cs[0].nsteps == 0 && cs[0].dtype == SO_F32))) S.carriers = cs;
     }
     if (S.kind == ST_NORM && S.norm_alias) {
         // `vals` is the child stage's buffer (planner.cpp): lowering the child above registered the frames it needs
@@ -1961,6 +1962,7 @@ void Plan::fuse_resample_sos() {
             } else if (c0.nsteps > 0)
                 g.fuse = -2;  // (every chunk takes the general staging path)
         }
+        g.ring32 = g.src32 && g.fuse == -1 && pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;  // (no step: the ring keeps the Float32 samples)
         S2.rs = g;
         S2.rsos_src = i3;
         S2.carriers.clear();  // (what process_stage prepared for the single-pass form of a plain filter: the resampler's serve now)
@@ -2006,7 +2008,7 @@ void Plan::fuse_plain_sos() {
         const int dt = nodes[S2.node].dtype;
         if (dt != SO_F64 && dt != SO_F32) continue;
         const DCarrier& c0 = S2.carriers[0];
-        const bool pure32 = dt == SO_F32;  // (not taken today, see the estimate below; the kernel has the instantiations)
+        const bool pure32 = dt == SO_F32;  // (a plain Float32 source: the ring keeps its samples, RsSos::ring32)
         if (pure32 && (c0.nsteps != 0 || c0.dtype != SO_F32)) continue;
         if (!pure32 && c0.dtype != SO_F64) continue;
         const SosCoefs& cf = S2.groups[0];
@@ -2050,12 +2052,13 @@ void Plan::fuse_plain_sos() {
             // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
             // channels, eight loader units per chunk: 1.7 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
             // 2.5 ps + 195 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
-            // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals keep the three passes: their
-            // chunks would have to be widened by the one loader wave (12.5 M x 8: 0.47 against 0.39 ms).
+            // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals: widened chunk by chunk by the one
+            // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
             const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.25 : ct == 2 ? 1.7 : 3.4;
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
             const double nsamp = (double)need * nch;
-            const double t_three = nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 2.5e-6 * nsamp + 195.0;
+            // (Float32 signals: the three passes move half the bytes and take 0.88 of the time; this kernel's pace is the chain's)
+            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 2.5e-6 * nsamp + 195.0) * (pure32 ? 0.88 : 1.0);
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
                              (long long)ngrp, (long long)pr, (long long)wp, t_three);
@@ -2094,6 +2097,7 @@ void Plan::fuse_plain_sos() {
         }
         g.src32 = pure32 ? 1 : 0;
         g.x32 = pure32 ? 1 : 0;
+        g.ring32 = pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;
         g.fuse = -1;
         if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 && (c0.op[0] == OP_MUL || c0.op[0] == OP_ADD || c0.op[0] == OP_SUB)) {
             g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);

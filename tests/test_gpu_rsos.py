@@ -387,7 +387,7 @@ def test_float32_pipelines(kind, nch):
     #  it -- 0.82 ms where K1 + the fused kernel took 1.05, tests/test_gpu_two_arrays.py)
     assert fused or nch == 3 or kind == "append" or (kind == "mix32" and nch == 8), kind
     assert a.dtype == np.float32 and b.dtype == np.float32
-    if kind == "mix32" and nch == 8 and not fused:  # (... on the Float32 MFMA: its own rounding against `b`'s Float64 products, test_gpu_f32_mfma.py)
+    if kind == "mix32" and nch == 8:  # (... on the Float32 MFMA: its own rounding against `b`'s Float64 products, test_gpu_f32_mfma.py)
         assert relerr(a, b) < 3e-7
     else:
         assert relerr(a, b) < 1e-7 and np.mean(a == b) > 0.999
