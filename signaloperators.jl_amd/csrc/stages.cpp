@@ -2051,14 +2051,15 @@ void Plan::fuse_plain_sos() {
         } else {
             // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
             // channels, eight loader units per chunk: 1.7 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
-            // 2.5 ps + 195 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
+            // 3.4 ps + 110 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
             // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals: widened chunk by chunk by the one
             // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
             const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.25 : ct == 2 ? 1.7 : 3.4;
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
             const double nsamp = (double)need * nch;
-            // (Float32 signals: the three passes move half the bytes and take 0.88 of the time; this kernel's pace is the chain's)
-            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 2.5e-6 * nsamp + 195.0) * (pure32 ? 0.88 : 1.0);
+            // (re-measured at the round's end: 12.5 M x 8 0.452 ms, 28.8 M x 8 0.891; Float32 signals: the three passes move half
+            //  the bytes and take 0.9 of the time -- 0.40 / 0.82 --, this kernel's pace is the chain's: 0.335 / 0.72)
+            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (pure32 ? 0.9 : 1.0);
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
                              (long long)ngrp, (long long)pr, (long long)wp, t_three);
