@@ -2000,11 +2000,18 @@ void Plan::fuse_plain_sos() {
         const char* ev = std::getenv(name);
         return ev ? std::atoi(ev) : dflt;
     };
+    // Several filters of this kind in one plan (config 4's 64 scenes) are ONE batched launch per pass of the three-pass form
+    // (batch_sos_stages, 26 us per scene); as launches of their own of this kernel they would be 42 us each.  Small ones stay
+    // for the batch.
+    int candidates = 0;
+    for (auto& S : stages)
+        if (S.kind == ST_SOS && S.rsos_src < 0 && S.carriers.size() == 1 && S.need > 0) ++candidates;
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {
         Stage& S2 = stages[i2];
         if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || S2.xscan ||
             S2.under_norm || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
             continue;
+        if (candidates > 1 && (int64_t)S2.need * nodes[S2.node].nch < ((int64_t)1 << 26) && !std::getenv("SIGOPS_RSOS_MINGROUPS")) continue;
         const int dt = nodes[S2.node].dtype;
         if (dt != SO_F64 && dt != SO_F32) continue;
         const DCarrier& c0 = S2.carriers[0];
@@ -2050,11 +2057,13 @@ void Plan::fuse_plain_sos() {
             if (ngrp < std::atoll(ev)) continue;
         } else {
             // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
-            // channels, eight loader units per chunk: 1.7 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
+            // channels, eight loader units per chunk: 1.3 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
             // 3.4 ps + 110 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
             // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals: widened chunk by chunk by the one
             // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
-            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.25 : ct == 2 ? 1.7 : 3.4;
+            // (unit costs re-measured with the loader's vectorised unit scan: 25 M x 4 0.417 against 0.444, 50 M x 2 0.452 / 0.465)
+            // (50 M x 2: the three passes read 0.406 - 0.465 by box, this form 0.452 - 0.458: 1.4 keeps the three passes there)
+            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.19 : ct == 2 ? 1.4 : 3.4;
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
             const double nsamp = (double)need * nch;
             // (re-measured at the round's end: 12.5 M x 8 0.452 ms, 28.8 M x 8 0.891; Float32 signals: the three passes move half

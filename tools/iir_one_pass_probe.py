@@ -24,7 +24,7 @@ def run(n, nch, dtype, env):
     ms = e0.elapsed_time(e1) / 60
     names = [s["name"] for s in plan.steps()]; st = plan.stats(); plan.close()
     return {"n": n, "nch": nch, "dtype": dtype, "ms": round(ms, 4), "steps": names, "TBps": round(st["algorithmic_bytes"] / (ms * 1e-3) / 1e12, 3)}
-for n, nch in ((12_500_000, 8), (28_800_000, 8), (2_646_000, 2), (50_000_000, 2), (6_000_000, 16)):
+for n, nch in ((12_500_000, 8), (28_800_000, 8), (2_646_000, 2), (50_000_000, 2), (25_000_000, 4), (6_000_000, 16)):
     for dt in ("f64", "f32"):
         print(json.dumps(run(n, nch, dt, {"SIGOPS_NO_PLAIN_RSOS": None})), flush=True)
         print(json.dumps(run(n, nch, dt, {"SIGOPS_NO_PLAIN_RSOS": "1"})), flush=True)
