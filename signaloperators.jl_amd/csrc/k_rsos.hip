@@ -730,7 +730,50 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         }
         wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
         rsos_stamp(trace, wave, k, 3, 40);
-        if (gain) {
+        bool gain_done = false;
+        if constexpr (RU < 8 && !SRC32) {
+            if (gain) {
+                // more than two units per chunk: which of them take the step from one vector compare and a ballot, their share
+                // bases four units at a time (ONE wait for four LDS reads), the units' ring rows from scalars -- unit by unit
+                // (two table reads, an LDS round trip for the base, one more table read each) the step cost a stereo
+                // chunk's eight units a third of the kernel (Mix(sin, x) of two channels: 1.75 ms against 1.39 without it)
+                const uint64_t fm = __ballot(lane < MU && k >= klo_l && k < khi_l);
+#pragma unroll 1
+                for (int jb = 0; jb < MU; jb += 4) {
+                    double2 bsr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        bsr[i] = double2{0.0, 0.0};
+                        if (fuse_sine && ((fm >> (jb + i)) & 1)) {
+                            const int u = q + (jb + i) * NL;
+                            bsr[i] = double2{l.gtab[(u * 16 + (k & 15)) * 2], l.gtab[(u * 16 + (k & 15)) * 2 + 1]};
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((fm >> (jb + i)) & 1)) continue;
+                        const int u = q + (jb + i) * NL;
+                        v2d gn;
+                        if (fuse_sine) {
+                            gn[0] = fma(bsr[i].x, d0.y, bsr[i].y * d0.x);
+                            gn[1] = fma(bsr[i].x, d1.y, bsr[i].y * d1.x);
+                        } else
+                            gn[0] = gn[1] = gconst;
+                        if (lane < lanes) {
+                            const uint32_t la = ring_b + (uint32_t)(u * RU) * row_bytes + (uint32_t)rho0 * 8u + lane16;
+                            switch (fuse) {
+                            case 0: rsos_rmw<RU, 0>(la, row_bytes, gn); break;
+                            case 1: rsos_add<RU>(la, row_bytes, gn); break;   // v + m: the LDS adds (no fp64 vector instruction)
+                            case 2: rsos_add<RU>(la, row_bytes, -gn); break;  // v - m
+                            default: rsos_rmw<RU, 3>(la, row_bytes, gn); break;
+                            }
+                        }
+                    }
+                }
+                gain_done = true;
+            }
+        }
+        if (gain && !gain_done) {
             for (int j = 0; j < MU; ++j) {
                 if (!(k >= u_klo(j) && k < u_khi(j))) continue;
                 const int u = q + j * NL;
