@@ -244,6 +244,16 @@ int64_t so_plan_nframes(const so_plan_t* plan);
  */
 int32_t so_plan_execute(so_plan_t* plan, void* out, void* hip_stream);
 
+/*
+ * Waits for what the plan has launched so far (`hip_stream`: the stream of its last execute) and returns what only
+ * shows once the kernels have run: SO_ERR_RUNTIME with "k_rsos: a wait between its waves did not end" if a kernel gave
+ * up on a wait between its waves (its result is invalid).  The call to make behind an execute into a DEVICE result
+ * before trusting it -- the reference's `sink!` (src/sink.jl:225-241) returns when the result is complete, and so does
+ * execute + check; an execute into a host result synchronises and reports by itself.  so_plan_destroy without it
+ * prints the failure to stderr (it has nobody to return it to).
+ */
+int32_t so_plan_check(so_plan_t* plan, void* hip_stream);
+
 /* Rebind the data pointer of ARRAY node `node_index` (same shape/strides/residency)
  * so a plan can be reused for a new input without re-planning. */
 int32_t so_plan_set_array(so_plan_t* plan, int32_t node_index, const void* data);

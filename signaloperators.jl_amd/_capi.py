@@ -55,7 +55,7 @@ class so_step_info_t(C.Structure):
 
 
 EXPORTS = ["so_abi_version", "so_last_error", "so_device_count", "so_plan_create",
-           "so_plan_nframes", "so_plan_execute", "so_plan_set_array", "so_plan_stats",
+           "so_plan_nframes", "so_plan_execute", "so_plan_check", "so_plan_set_array", "so_plan_stats",
            "so_plan_set_profiling", "so_plan_destroy", "so_design_iir",
            "so_design_resample_rational", "so_design_resample_arbitrary",
            "so_resample_positions", "so_plan_step_info", "so_design_iir_zpk", "so_zpk_to_sos", "so_tf_to_sos", "so_tf_zero_input", "so_plan_counter",
@@ -100,6 +100,8 @@ def lib():
     L.so_plan_nframes.argtypes = [C.c_void_p]
     L.so_plan_execute.restype = C.c_int32
     L.so_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.so_plan_check.restype = C.c_int32
+    L.so_plan_check.argtypes = [C.c_void_p, C.c_void_p]
     L.so_plan_set_array.restype = C.c_int32
     L.so_plan_set_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.so_plan_stats.restype = C.c_int32

@@ -34,8 +34,15 @@ struct AccCheckpoint {
     int64_t m, xb;
     double acc;
 };
+static uint64_t taps_fnv(const double* h, int hlen) {  // (hsum alone, a weighted sum, collides for permuted or compensating taps)
+    uint64_t f = 1469598103934665603ull;
+    const unsigned char* hb = reinterpret_cast<const unsigned char*>(h);
+    for (size_t i = 0; i < (size_t)hlen * sizeof(double); ++i) f = (f ^ hb[i]) * 1099511628211ull;
+    return f;
+}
 struct AccKey {
     double delta, c0, hsum;
+    uint64_t hfnv;  // FNV-1a over the taps' bytes
     int64_t c0i, L, M;
     int32_t nphi, taps, exact, hlen;
     bool operator==(const AccKey& o) const { return std::memcmp(this, &o, sizeof(AccKey)) == 0; }
@@ -55,6 +62,7 @@ static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
     k.exact = g.exact;
     k.hlen = hlen;
     for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    k.hfnv = taps_fnv(h, hlen);
     return k;
 }
 
@@ -64,12 +72,20 @@ static AccKey acc_key(const RsGeom& g, const double* h, int hlen) {
 // Outputs [from, need) (absolute); `from` is a whole number of periods of an exact rational rate (any output of a rate
 // without a period), and the fix-up list comes back in the window's own coordinates (output m - from, input
 // j - from/L*M, or j - g.j0).
+// Version of everything a cached replay or probe value depends on besides its key: the replay itself, RsFix and how the
+// fix-up list is generated, the cascade's sensitivity probes.  Part of the key (and so of the file name and of the
+// header that is compared byte for byte): a build that changes any of them bumps it, and the files of older builds are
+// simply never looked at again.
+constexpr int32_t kAccAlgoVersion = 6;
+
 void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_t need, bool bake,
                                      std::vector<uint8_t>& prev, std::vector<RsFix>& fix, int64_t from) {
     struct Key {
         double delta, c0, hsum;
+        uint64_t hfnv;  // FNV-1a over the taps' bytes (hsum alone, a weighted sum, collides for permuted or compensating taps)
         int64_t c0i, L, M, need, from, j0;
         int32_t nphi, taps, exact, hlen, bake;
+        int32_t version;  // kAccAlgoVersion: what a file was computed WITH, not only FOR
         bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
     };
     struct Entry {
@@ -95,6 +111,8 @@ void replay_phase_accumulator(const RsGeom& g, const double* h, int hlen, int64_
     k.hlen = hlen;
     k.bake = bake;
     for (int i = 0; i < hlen; ++i) k.hsum += h[i] * (1.0 + 1e-3 * (i % 97));
+    k.hfnv = taps_fnv(h, hlen);
+    k.version = kAccAlgoVersion;
     if (!g.arbitrary || need <= 0) {
         prev.clear();
         fix.clear();
@@ -183,7 +201,7 @@ static std::string disk_value_path(const char* kind, const std::vector<double>& 
     const unsigned char* kb = reinterpret_cast<const unsigned char*>(key.data());
     for (size_t i = 0; i < key.size() * sizeof(double); ++i) hsh = (hsh ^ kb[i]) * 1099511628211ull;
     char nm[96];
-    std::snprintf(nm, sizeof nm, "/sigops_%s_%016llx.bin", kind, (unsigned long long)hsh);
+    std::snprintf(nm, sizeof nm, "/sigops_%s_v%d_%016llx.bin", kind, (int)kAccAlgoVersion, (unsigned long long)hsh);
     return std::string(d) + nm;
 }
 bool disk_value_get(const char* kind, const std::vector<double>& key, double& val) {

@@ -56,6 +56,14 @@ int32_t so_plan_execute(so_plan_t* plan, void* out, void* hip_stream) {
     return SO_OK;
 }
 
+int32_t so_plan_check(so_plan_t* plan, void* hip_stream) {
+    if (!plan) return set_err(SO_ERR_INVALID, "so_plan_check: null plan");
+    std::string err;
+    int st = so::plan_check(plan->p, hip_stream, err);
+    if (st != SO_OK) return set_err(st, err);
+    return SO_OK;
+}
+
 int32_t so_plan_set_array(so_plan_t* plan, int32_t node_index, const void* data) {
     if (!plan) return set_err(SO_ERR_INVALID, "so_plan_set_array: null plan");
     std::string err;

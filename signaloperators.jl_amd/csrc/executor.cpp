@@ -365,7 +365,18 @@ void Plan::release() {
     if (d_pieces) (void)hipFree(d_pieces);
     if (d_ops) (void)hipFree(d_ops);
     if (d_leaves) (void)hipFree(d_leaves);
-    if (kerr) (void)hipHostFree(kerr);
+    if (kerr) {
+        // (the hipFree calls above synchronised the device: whatever the plan's last launch had to say is in the word now.  An
+        //  execute into a device result returns before its kernels have run, and the caller may never make another call on
+        //  this plan -- a one-shot sink: so_plan_check is the call that reports it; where the host destroys the plan without
+        //  it, the result it holds is invalid and nobody has been told: say so as loudly as a library can)
+        (void)hipDeviceSynchronize();
+        const uint32_t who = *(volatile uint32_t*)kerr;
+        if (who)
+            std::fprintf(stderr, "libsigops: %s: a wait between its waves did not end -- THE LAST RESULT OF THIS PLAN IS INVALID (so_plan_destroy "
+                                 "without so_plan_check)\n", who == 2 ? "k_resample_arb" : "k_rsos");
+        (void)hipHostFree(kerr);
+    }
     kerr = nullptr;
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -566,7 +577,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 }
                 for (int q = 0; q < 3; ++q) B.total[q] = first[q];
                 const bool poison = B.bad_buf >= 0 && !std::getenv("SIGOPS_SOS_NOPOISON");
-                if (poison) launch_fill_u32(P->bufs[B.bad_buf].d, P->bufs[B.bad_buf].bytes / 4, 0x7f7f7f7fu, st);  // "no non-finite chunk yet"
+                if (poison) HIPCHECK((hipError_t)launch_fill_u32(P->bufs[B.bad_buf].d, P->bufs[B.bad_buf].bytes / 4, 0x7f7f7f7fu, st));  // "no non-finite chunk yet"
                 int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
                 if (poison) nl += launch_sos_poison_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.dtype, st);
                 s.launches = nl;
@@ -618,7 +629,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                     if (S.bad_buf >= 0 && S.pre_stage < 0 && S.rsos_src < 0 && !S.onepass && !S.xscan && !g.exact &&
                         !std::getenv("SIGOPS_SOS_NOPOISON")) {
                         g.bad = (int32_t*)P->bufs[S.bad_buf].d;
-                        launch_fill_u32(g.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite chunk yet"
+                        HIPCHECK((hipError_t)launch_fill_u32(g.bad, (size_t)N.nch, 0x7f7f7f7fu, st));  // "no non-finite chunk yet"
                     }
                     size_t msz = 0;
                     for (auto& v : S.mpow_host) msz = std::max(msz, v.size());
@@ -628,6 +639,8 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         RsSos rs = S.rs;
                         rs.out_pitch = ob.pitch;
                         rs.out_f32 = g.out_dtype == SO_F32 || N.dtype == SO_F32;
+                        if (rs.f32m && rs.out_f32) rs.ring32 = 1;  // (a Float32 result: Float32 samples in the ring, the Float32 MFMA)
+                        else rs.f32m = 0;
                         // the kernel's output m is frame m - store_lo of this stage's buffer (a window: the resampler's warm
                         // start lies store_lo frames before the cascade's); the sink's own skipped frames come on top
                         char* const yk = (char*)ob.d - (size_t)S.rs.store_lo * (rs.out_f32 ? 4 : 8);
@@ -636,7 +649,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rs.bad = nullptr;
                         if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
                             rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
-                            launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st);  // "no non-finite range yet"
+                            HIPCHECK((hipError_t)launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st));  // "no non-finite range yet"
                         }
                         rs.err = kernel_error_word(P);
                         static long long* d_rtrace = nullptr;  // SIGOPS_RSOS_TRACE tuning aid
@@ -706,8 +719,15 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         o.vec_out = ((uintptr_t)ob.d % 16 == 0) && (o.out_pitch % al == 0);
                         Buf& sb = P->bufs[S.one_sync_buf];
                         Buf& vb = P->bufs[S.one_vpub_buf];
-                        HIPCHECK(hipMemsetAsync(sb.d, 0, sb.bytes, st));     // ticket counter
-                        HIPCHECK(hipMemsetAsync(vb.d, 0xff, vb.bytes, st));  // "not published yet"
+                        // (kernel nodes, not memset nodes, as for the poison words: this sequence is graph-capturable too, and a
+                        //  stale ticket counter would hang the kernel -- k_small.hip)
+                        if (sb.bytes % 4 == 0 && vb.bytes % 4 == 0) {
+                            HIPCHECK((hipError_t)launch_fill_u32(sb.d, sb.bytes / 4, 0u, st));           // ticket counter
+                            HIPCHECK((hipError_t)launch_fill_u32(vb.d, vb.bytes / 4, 0xffffffffu, st));  // "not published yet"
+                        } else {
+                            HIPCHECK(hipMemsetAsync(sb.d, 0, sb.bytes, st));
+                            HIPCHECK(hipMemsetAsync(vb.d, 0xff, vb.bytes, st));
+                        }
                         launch_sos_onepass(x, ob.d, o, S.groups[gi], (const double*)P->bufs[S.one_tabs_buf].d + S.one_tabs_off[gi],
                                            (int*)sb.d, (double*)P->bufs[S.one_vpub_buf].d, N.dtype, st);
                         nl += 1;
@@ -759,7 +779,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                          S.mpow_buf >= 0 ? (const double*)((char*)P->bufs[S.mpow_buf].d + gi * msz * 8) : nullptr,
                                          gg, S.groups[gi], st);
                         nl += launch_sos_poison(ob.d, gg, st);  // (behind a NaN the reference stays NaN: SosGeom::bad)
-                        if (gg.bad && gi + 1 < S.groups.size()) launch_fill_u32(gg.bad, (size_t)N.nch, 0x7f7f7f7fu, st);
+                        if (gg.bad && gi + 1 < S.groups.size()) HIPCHECK((hipError_t)launch_fill_u32(gg.bad, (size_t)N.nch, 0x7f7f7f7fu, st));
                     }
                     s.launches = nl;
                     launches += nl;
@@ -1122,6 +1142,23 @@ int plan_step_info(const Plan* P, int index, so_step_info_t* info) {
     }
     return (int)P->steps.size();
 }
+// so_plan_check: waits for everything the plan has launched so far (the stream its last execute ran on -- or the whole
+// device where the plan ran on lanes of its own) and reports what only shows once the kernels have run: a kernel that
+// gave up on a wait between its waves.  The call a host makes behind an execute into a DEVICE result before it trusts it
+// (a host result's execute synchronises and reports by itself).
+int plan_check(Plan* P, void* stream, std::string& err) {
+    DeviceGuard guard(P->device);
+    try {
+        if (P->nlanes > 1 || P->graph_exec) HIPCHECK(hipDeviceSynchronize());
+        else HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    } catch (const PlanError& e) {
+        err = e.msg;
+        return e.status;
+    }
+    if (kernel_gave_up(P, err)) return SO_ERR_RUNTIME;
+    return SO_OK;
+}
+
 void plan_destroy(Plan* P) {
     if (!P) return;
     {

@@ -46,6 +46,7 @@
 namespace so {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define SO_LDS __attribute__((address_space(3)))
 // LDS sequence counters (single writer each) and the data they announce: VOLATILE accesses -- the compiler keeps them in
@@ -169,6 +170,39 @@ __device__ __forceinline__ void rsos_add_imm(uint32_t la, double g0, double g1) 
     if constexpr (C < RU) {
         asm volatile("ds_add_f64 %0, %1 offset:%3\n\tds_add_f64 %0, %2 offset:%4" ::"v"(la), "v"(g0), "v"(g1), "n"(C * RB), "n"(C * RB + 8) : "memory");
         rsos_add_imm<RB, C + 1, RU>(la, g0, g1);
+    }
+}
+
+// The fused step on a ring that KEEPS Float32 samples (RsSos::f32m: a Float32 result resampled on the Float32 MFMA).  Lane l owns
+// frames 2 l and 2 l + 1 of every row of the landed chunk (four bytes a frame: eight bytes per lane and row).  v + m / v - m
+// with the LDS's own Float32 adder (ds_add_f32: nothing for the vector ALU next to the chain wave's MFMAs); v * m / m - v are
+// read, computed and written back.  The operand is the step's Float64 value rounded to Float32 once: the samples that enter
+// the resampler are Float32 on this path.  OP: 0 v*m, 1 v+m (v-m: with -m), 3 m-v
+template <int RU, int OP>
+__device__ __forceinline__ void rsos_step32(uint32_t la, uint32_t row_bytes, float g0, float g1) {
+    if constexpr (OP == 1) {
+#pragma unroll
+        for (int c = 0; c < RU; ++c) {
+            const uint32_t a = la + (uint32_t)c * row_bytes;
+            asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4" ::"v"(a), "v"(g0), "v"(g1) : "memory");
+        }
+    } else if constexpr (RU > 4) {
+        rsos_step32<4, OP>(la, row_bytes, g0, g1);
+        rsos_step32<RU - 4, OP>(la + 4 * row_bytes, row_bytes, g0, g1);
+    } else {
+        float2 raw[RU];
+#pragma unroll
+        for (int c = 0; c < RU; ++c) asm volatile("ds_read_b64 %0, %1" : "=v"(raw[c]) : "v"(la + (uint32_t)c * row_bytes) : "memory");
+        if constexpr (RU == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])::"memory");
+        else if constexpr (RU == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0])::"memory");
+#pragma unroll
+        for (int c = 0; c < RU; ++c) {
+            raw[c].x = OP == 0 ? raw[c].x * g0 : g0 - raw[c].x;
+            raw[c].y = OP == 0 ? raw[c].y * g1 : g1 - raw[c].y;
+        }
+#pragma unroll
+        for (int c = 0; c < RU; ++c) asm volatile("ds_write_b64 %0, %1" ::"v"(la + (uint32_t)c * row_bytes), "v"(raw[c]) : "memory");
     }
 }
 
@@ -552,8 +586,9 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     double gconst = 0.0;
     if (fuse >= 0) {
         if (fuse_sine) {  // (the lane's two frames of a chunk: 2 l and 2 l + 1, or l and 64 + l where it widens Float32)
-            d0 = rsos_sine_at(src32 ? lane : 2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
-            d1 = rsos_sine_at(src32 ? 64 + lane : 2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+            // (... or, where the ring keeps the Float32 samples and the step is done on them -- RsSos::f32m --, 2 l and 2 l + 1 again)
+            d0 = rsos_sine_at(src32 && !ring32 ? lane : 2 * lane, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
+            d1 = rsos_sine_at(src32 && !ring32 ? 64 + lane : 2 * lane + 1, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
             d16 = rsos_sine_at(16 * CH, leaf0.v0, 0.0, leaf0.v2, leaf0.flag);
         } else
             gconst = slot_eval(kind0, leaf0, 0);
@@ -784,7 +819,18 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
                 } else
                     gn[0] = gn[1] = gconst;
-                if constexpr (src32) {
+                if (src32 && ring32) {  // (the step on the Float32 samples where they lie: RsSos::f32m)
+                    if (lane < lanes) {
+                        const uint32_t la = u_lds(j) + (uint32_t)rho0 * 4u + (uint32_t)lane * 8u;
+                        const float g0 = (float)gn[0], g1 = (float)gn[1];
+                        switch (fuse) {
+                        case 0: rsos_step32<RU, 0>(la, row_bytes, g0, g1); break;
+                        case 1: rsos_step32<RU, 1>(la, row_bytes, g0, g1); break;
+                        case 2: rsos_step32<RU, 1>(la, row_bytes, -g0, -g1); break;
+                        default: rsos_step32<RU, 3>(la, row_bytes, g0, g1); break;
+                        }
+                    }
+                } else if constexpr (src32) {
                     const uint32_t slot = u_lds(j) + (uint32_t)rho0 * 8u;
                     switch (fuse) {
                     case 0: rsos_widen<RU, 0>(slot, row_bytes, lane, gn[0], gn[1]); break;
@@ -882,8 +928,15 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
 // =========================== y waves ===========================
 // CYC > 0: the wave's blocks cycle through CYC phase groups of the period (yi, yi + NY, ... modulo ngroups) and their
 // taps stay in registers for the whole kernel; CYC == 0: taps of any phase from the LDS table.
-template <int KS, int NY, int NL, typename TO, int CYC>
+// F32M (Float32 results over a ring of Float32 samples, RsSos::f32m): the resampling product X = Tap^T . Win on
+// v_mfma_f32_16x16x4_f32 -- taps rounded to Float32 once, Float32 window operands straight from the ring, Float32
+// accumulators: 32 cycles per instruction where the Float64 one takes 64, and no widening of the window.  Its RESULT map is
+// row = 4 (lane >> 4) + reg where the Float64 instruction's is (lane >> 4) + 4 reg: register v of X, widened, is still k-step v of
+// the products that follow (D . X, X^T T^T: all Float64, like the cascade) -- with the k index of THEIR other operand
+// permuted the same way (Dk, Tk below are read from the matrices' table in that order).
+template <int KS, int NY, int NL, typename TO, int CYC, bool F32M = false>
 __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dyn, int64_t G_, int yi_) {
+    static_assert(!F32M || (sizeof(TO) == 4 && CYC > 0), "the Float32 MFMA form: Float32 results, taps in registers");
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
@@ -914,10 +967,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
     const int gq = lane >> 4, n16 = lane & 15;
     double Dk[4], Tk[4], Ck[3];
+    // (k-step v, lane (gq, n16) holds index 4 v + gq of the contracted dimension; F32M: 4 gq + v -- see above)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) Dk[v] = mats[v * 64 + lane];
+    for (int v = 0; v < 4; ++v) Dk[v] = F32M ? mats[(lane >> 4) * 64 + v * 16 + (lane & 15)] : mats[v * 64 + lane];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) Tk[v] = mats[(7 + v) * 64 + lane];
+    for (int v = 0; v < 4; ++v) Tk[v] = F32M ? mats[(7 + (lane >> 4)) * 64 + v * 16 + (lane & 15)] : mats[(7 + v) * 64 + lane];
 #pragma unroll
     for (int v = 0; v < 3; ++v) Ck[v] = mats[(11 + v) * 64 + lane];
     // this lane's B-operand row ...
@@ -935,7 +989,13 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     // ... as byte offsets from the group's first result element (row 0, output 0 of its first range): the stores take a
     // scalar base, advanced per block by scalar adds, and a 32-bit lane offset -- no 64-bit vector add per store.  (A group
     // whose rows lie more than 4 GB apart -- long results of many channels -- rebuilds the address per store.)
-    uint32_t yo[4];
+    // ONE lane offset (row gq, time n16) and three wave-uniform steps: row gq + 4 v is (channel, range) = ((gq + 4 v) % ct,
+    // (gq + 4 v) / ct), and for every ct in {1, 2, 4, 8, 16} its distance from row gq is the same for all gq -- it goes onto the
+    // stores' SCALAR base.  (Four lane offsets and four per-lane block limits in registers were what the 128-register
+    // instantiation -- 16 waves: two-channel groups -- spilled: every store was preceded by a scratch reload and an
+    // `s_waitcnt vmcnt(0)`, i.e. by a wait for the PREVIOUS store's acknowledgement: the 0.3 ms "store cost" of stereo signals.)
+    uint32_t yo0;
+    int64_t ystep[4];
     const int64_t ybase_e = (int64_t)(grp.cg * ct) * out_pitch + grp.ob0;
 #ifndef SO_Y_EARLY
 #define SO_Y_EARLY 0  // (see block(): the pending block's state-dependent MFMAs in front of D . X -- measured, slower)
@@ -947,21 +1007,23 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 #define SO_ST_NT ""  // (cache-policy bits of the result stores: measured and not set, see kstage.h SO_LD_NT)
 #endif
     const bool yfits = SO_Y_SADDR && uni((int)((((int64_t)(ct - 1) * out_pitch + (int64_t)(16 / ct) * grp.prL + 16) * (int64_t)sizeof(TO)) < ((int64_t)1 << 32)));
-    int nbs[4];      // block b of row gq + 4v is stored (by this lane: time n16 of the block) while b < nbs[v]
-    int nbs_all;     // ... and by every lane of the wave while b < nbs_all (no predicates then)
+    int nbs_all;     // block b is stored by every lane of the wave while b < nbs_all (no predicates then)
     {
         int m = 0x7fffffff;
+        int64_t off0 = 0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int row = gq + 4 * v;
             const int ri = row / ct, cv = row % ct;
             const int64_t ob = grp.ob0 + ri * grp.prL;
-            yo[v] = (uint32_t)(((int64_t)cv * out_pitch + (int64_t)ri * grp.prL + n16) * (int64_t)sizeof(TO));
+            const int64_t off = ((int64_t)cv * out_pitch + (int64_t)ri * grp.prL + n16) * (int64_t)sizeof(TO);
+            if (v == 0) off0 = off;
+            ystep[v] = rfl64(off - off0);
             const int64_t tl = n_out - ob - n16;  // 16 b < tl
             const int64_t nb = tl <= 0 ? 0 : (tl + 15) / 16;
-            nbs[v] = (int)(nb > 0x3fffffff ? 0x3fffffff : nb);
-            m = min(m, nbs[v]);
+            m = min(m, (int)(nb > 0x3fffffff ? 0x3fffffff : nb));
         }
+        yo0 = (uint32_t)off0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
         nbs_all = uni(m);
@@ -1046,28 +1108,30 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         //  Float64 store reads behind the asm either: hence `fresh`)
         const uint64_t yb = (uint64_t)rfl64((int64_t)ypend);
         if (fresh && yfits && sizeof(TO) == 8) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3])::"memory");
+        // (the output this lane's register v holds: its row's first output + the block's offset + the lane's time)
+        auto out_index = [&](int v) __attribute__((always_inline)) { return grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16; };
         auto put = [&](int v, TO val) __attribute__((always_inline)) {
             if (yfits) {
-                if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" SO_ST_NT ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
-                else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo[v]), "v"(val), "s"(yb) : "memory");
+                const uint64_t ybv = yb + (uint64_t)ystep[v];  // (scalar)
+                if constexpr (sizeof(TO) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" SO_ST_NT ::"v"(yo0), "v"(val), "s"(ybv) : "memory");
+                else asm volatile("global_store_dword %0, %1, %2" ::"v"(yo0), "v"(val), "s"(ybv) : "memory");
             } else {
-                const int row = gq + 4 * v;
+                // (results whose rows lie more than 4 GB apart: the address per store, from a row index the compiler cannot see
+                //  through -- hoisted out of the loop, four 64-bit lane pointers are what gets spilled)
+                int row = gq + 4 * v;
+                asm volatile("" : "+v"(row));
                 y[(int64_t)(grp.cg * ct + row % ct) * out_pitch + grp.ob0 + (int64_t)(row / ct) * grp.prL + n16 + t0] = val;
             }
         };
-        if (pb_ < nbl_max) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int64_t m = grp.ob0 + (int64_t)((gq + 4 * v) / ct) * grp.prL + t0 + n16;
-                if (pb_ < nbs[v] && m >= slo) put(v, (TO)ay[v]);
-            }
-        } else if (pb_ < nbs_all) {
+        if (pb_ >= nbl_max && pb_ < nbs_all) {  // (the common path: every lane stores, no predicates)
 #pragma unroll
             for (int v = 0; v < 4; ++v) put(v, (TO)ay[v]);
-        } else {
+        } else {  // (the first blocks of a window's first ranges, the last blocks of the signal: output by output)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (pb_ < nbs[v]) put(v, (TO)ay[v]);
+            for (int v = 0; v < 4; ++v) {
+                const int64_t m = out_index(v);
+                if (m >= slo && m < n_out) put(v, (TO)ay[v]);
+            }
         }
     };
     auto back = [&](int sq, double (&sv)[3], v4d& pay_) __attribute__((always_inline)) {
@@ -1079,7 +1143,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     };
     // (je / jn: the window ends of this block's phase group and of the wave's next block's -- loop constants of a wave whose
     //  blocks cycle through CYC groups, read from LDS otherwise)
-    auto block = [&](int b, const double (&at)[KS], v4d& pin, v4d& pout, int je, int jn) __attribute__((always_inline)) {
+    using TapT = std::conditional_t<F32M, float, double>;
+    auto block = [&](int b, const TapT (&at)[KS], v4d& pin, v4d& pout, int je, int jn) __attribute__((always_inline)) {
         const int wb = pi * M + je - ulo_kw;
         const int need = wb + kw + 16;
         rsos_stamp(trace, wave, b / NY, 0, 40);
@@ -1106,7 +1171,21 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         const int pos = wbm + cl;  // < RING + 20: one conditional subtraction per read wraps it
         double bx[KS];
         bool have_bx = false;
-        if constexpr (sizeof(TO) == 4) {
+        [[maybe_unused]] float bf32[KS];
+        if constexpr (F32M) {  // (the ring keeps Float32 samples: they ARE the B operands)
+            if (wbm + 20 + kw <= RING) {
+                const SO_LDS float* p0 = (const SO_LDS float*)(ringc + (uint32_t)pos * 4u);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) bf32[s] = p0[4 * s];
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int p_ = pos + 4 * s;
+                    bf32[s] = *(const SO_LDS float*)(ringc + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 4u);
+                }
+            }
+            have_bx = true;
+        } else if constexpr (sizeof(TO) == 4) {
             if (ring32) {  // Float32 samples in the ring: widened here (KS conversions per block; the loader's widening pass of
                            // every chunk, one wave next to the chain's MFMAs, was the slower place for them)
                 float bf[KS];
@@ -1140,9 +1219,22 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         }
         // ---- resample: X[t][row] = sum_k Tap[t][k] Win[k][row] (LDS returns in order: counted lgkmcnt waits) ----
         v4d ax = v4d{0.0, 0.0, 0.0, 0.0};
+        if constexpr (F32M) {
+            // two accumulator chains (the instruction's dependent latency is 40 cycles against 32 of issue), added at the end
+            v4f a0 = v4f{0.f, 0.f, 0.f, 0.f}, a1 = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
-        if constexpr (sizeof(TO) == 4) {
+            for (int s = 0; s < KS; ++s) {
+                if (s & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[s], bf32[s], a1, 0, 0, 0);
+                else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[s], bf32[s], a0, 0, 0, 0);
+            }
+            const v4f af = a0 + a1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ax[v] = (double)af[v];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(at[s], bx[s], ax, 0, 0, 0);
+        }
+        if constexpr (sizeof(TO) == 4 && !F32M) {
             // a Float32 signal all the way: the reference's resampler hands the filter Float32 samples (K3's store rounds the
             // same accumulators the same way); the Float64-result instantiations -- the headline's -- do not carry the test
             if (x32) {
@@ -1221,14 +1313,14 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     };
     if constexpr (CYC > 0) {
         const double SO_GLB* tab = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)sh->tab);
-        double treg[CYC][KS];
+        TapT treg[CYC][KS];
         int jec[CYC];
 #pragma unroll
         for (int c = 0; c < CYC; ++c) {
             const int gc = (yi + c * NY) % ngroups;
             jec[c] = uni(sh->jend[gc]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) treg[c][s] = tab[((size_t)gc * KS + s) * 64 + lane];
+            for (int s = 0; s < KS; ++s) treg[c][s] = (TapT)tab[((size_t)gc * KS + s) * 64 + lane];
         }
         for (int b = yi; b < NB;) {
 #pragma unroll
@@ -1251,7 +1343,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
                 rsos_count_out(trace, wave, 0, 4, clock64() - cyc0);
             }
         }
-    } else {
+    } else if constexpr (!F32M) {
         for (int b = yi; b < NB; b += NY) {
             double at[KS];
             const SO_LDS double* tp = l.taps + gi * KS * 64 + lane;
@@ -1334,7 +1426,14 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
         } else if (!(g.debug & 128))
             {
             if (NW == 16 && wave > 12) continue;
-            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, NW == 16 ? (wave < 4 ? wave - 1 : wave < 8 ? wave - 2 : wave < 12 ? wave - 3 : 9) : wave - (wave > 4 ? 2 : 1));
+            const int yi = NW == 16 ? (wave < 4 ? wave - 1 : wave < 8 ? wave - 2 : wave < 12 ? wave - 3 : 9) : wave - (wave > 4 ? 2 : 1);
+            if constexpr (sizeof(TO) == 4 && CYC > 0) {
+                if (g.f32m) {
+                    rsos_ywave<KS, NY, NL, TO, CYC, true>(&sh, lds_raw, G, yi);
+                    continue;
+                }
+            }
+            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, yi);
         }
     }
 }

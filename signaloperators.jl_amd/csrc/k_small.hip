@@ -15,9 +15,12 @@ __global__ void k_fill_u32(uint32_t* __restrict__ p, int n, uint32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-void launch_fill_u32(void* p, size_t n, uint32_t v, hipStream_t st) {
-    if (n == 0) return;
+int launch_fill_u32(void* p, size_t n, uint32_t v, hipStream_t st) {  // returns the launch's hipError_t
+    if (n == 0) return 0;
     hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, (int)n, v);
+    // (the call this replaces was checked: a launch that did not happen leaves the words stale -- whole windows NaN, or a
+    //  one-pass filter waiting for a ticket that never comes)
+    return (int)hipGetLastError();
 }
 
 // NaN over the frames behind a channel's first non-finite chunk (SosGeom::bad): the reference's sequential recurrence

@@ -9,7 +9,7 @@ void launch_pointwise(const DPiece* d_pieces, int npieces, int64_t nblocks, cons
                       const DLeaf* d_leaves, OutView out, bool deep, hipStream_t st, bool chain = false, bool il = false);
 // returns number of kernel launches
 int launch_sos_poison(void* y, const SosGeom& g, hipStream_t st);
-void launch_fill_u32(void* p, size_t n, uint32_t v, hipStream_t st);  // (instead of hipMemsetAsync: see k_sos.hip)
+int launch_fill_u32(void* p, size_t n, uint32_t v, hipStream_t st);  // (returns the launch's hipError_t)  // (instead of hipMemsetAsync: see k_sos.hip)
 int launch_sos_poison_batch(const SosDesc* desc, int n, int dtype, hipStream_t st);
 int launch_sos_batch(const SosDesc* desc, int n, int nsec, int dtype, const int64_t* total, hipStream_t st);
 int launch_sos(const void* x, void* y, double* v, double* s0, const double* mpow,

@@ -32,6 +32,7 @@ struct Plan;
 Plan* plan_create(const so_node_t* nodes, int32_t n_nodes, int32_t root, const so_out_desc_t* out,
                   int32_t device, int& status, std::string& err);
 int plan_execute(Plan* p, void* out, void* stream, std::string& err);
+int plan_check(Plan* p, void* stream, std::string& err);
 int plan_set_array(Plan* p, int32_t node_index, const void* data, std::string& err);
 int64_t plan_nframes(const Plan* p);
 void plan_stats(const Plan* p, so_stats_t* st);

@@ -1963,6 +1963,14 @@ void Plan::fuse_resample_sos() {
                 g.fuse = -2;  // (every chunk takes the general staging path)
         }
         g.ring32 = g.src32 && g.fuse == -1 && pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;  // (no step: the ring keeps the Float32 samples)
+        // A Float32 array -- with or without the fast path's one step -- into a Float32 RESULT (known at execute time: the stage
+        // may turn out to write the sink's Float32 buffer itself, Plan::alias_narrow): the ring keeps Float32 samples, the step is
+        // done on them, and the resampling product runs on the Float32 MFMA (k_rsos.hip, F32M; taps in registers only).  What
+        // reaches the cascade is the Float32-rounded resampler output of a Float32 signal (reference src/filters.jl:105) -- for
+        // a Float64 signal made of a Float32 array and a Float64 generator it is that signal rounded to Float32 on its way INTO
+        // the resampler instead of on its way into the Float32 result: inside the 1e-6 contract (tools/soak_rsos_f32m.py,
+        // profiles/r06/relerr_maxima_rsos_f32m.json: worst 1.5e-7; gate 3e-7), SIGOPS_RSOS_NO_F32MFMA=1 keeps the Float64 products.
+        g.f32m = g.src32 && g.fuse >= -1 && g.cyc > 0 && !std::getenv("SIGOPS_RSOS_NO_F32MFMA") && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;
         S2.rs = g;
         S2.rsos_src = i3;
         S2.carriers.clear();  // (what process_stage prepared for the single-pass form of a plain filter: the resampler's serve now)
@@ -2024,9 +2032,12 @@ void Plan::fuse_plain_sos() {
         const int64_t need = S2.need, L = 160;
         const int ngp = 10, ks = 4, kw = 16;
         const int64_t nperiods = (need + L - 1) / L;
+        // warm-up cut of the PLAIN filter: 2^-70, as the warm starts of windows (its warm-up blocks are cheap -- 18 MFMAs, no
+        // resampling --, and this is the default path of any long Filt: a range that starts in near silence behind a loud passage
+        // must not see what the cut dropped; the fused resampler + IIR form above cuts at 2^-56)
         int64_t wp = 1;
         {
-            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 56)));
+            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_PLAIN_WTOL", 70)));
             const Mat P = matpow(sos_state_matrix(cf), L, D);
             Mat cur = P;
             while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {

@@ -91,6 +91,17 @@ class Plan:
         st = K.lib().so_plan_execute(self.handle, C.c_void_p(out_ptr), C.c_void_p(stream or 0))
         if st != 0:
             raise S.ErrorException(K.last_error())
+        # (an execute into a device result returns before its kernels have run: what they report is still to come)
+        self._unchecked = (stream or 0) if self.desc.is_device else None
+
+    def check(self, stream=None):
+        """so_plan_check: wait for what the plan has launched and raise what only shows once the kernels have run (a
+        kernel that gave up on a wait between its waves: the result is invalid).  `sink!` returns a complete result
+        (reference src/sink.jl:225-241): `sink_into` calls this behind an execute into a device result."""
+        self._unchecked = None
+        st = K.lib().so_plan_check(self.handle, C.c_void_p(stream or 0))
+        if st != 0:
+            raise S.ErrorException(K.last_error())
 
     def set_array(self, k, data):
         """so_plan_set_array: point the k-th array leaf of the tree (depth-first order) at new data
@@ -136,8 +147,15 @@ class Plan:
 
     def close(self):
         if self.handle:
+            err = None
+            if getattr(self, "_unchecked", None) is not None:  # a device result nobody has checked: do not lose its failure
+                if K.lib().so_plan_check(self.handle, C.c_void_p(self._unchecked)) != 0:
+                    err = K.last_error()
+                self._unchecked = None
             K.lib().so_plan_destroy(self.handle)
             self.handle = C.c_void_p()
+            if err is not None:
+                raise S.ErrorException(err)
 
     def __del__(self):
         try:
@@ -173,6 +191,8 @@ def sink_into(result, x, *, device=0, rng=None, stream=None):
     plan = Plan(x, shape, dt, strides, is_dev, device=device, rng=rng)
     try:
         plan.execute(ptr, stream)
+        if is_dev:
+            plan.check(stream)  # (a complete result or an exception, as the reference's sink!)
     finally:
         plan.close()
     return result

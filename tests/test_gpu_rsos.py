@@ -448,6 +448,27 @@ except so.ErrorException as e:
     print("SECOND EXECUTE RAISED:", e)
 torch.cuda.synchronize()
 plan.close()
+# a one-shot sink into a device tensor (execute, no second call on the plan): so_plan_check behind the execute raises
+try:
+    so.sink(x, "torch")
+    print("ONE-SHOT DEVICE SINK RETURNED")
+except so.ErrorException as e:
+    print("ONE-SHOT DEVICE SINK RAISED:", e)
+# ... and a plan somebody destroys without having checked it: Plan.close checks for them
+plan = so.Plan(so.ToChannels(x, 8), (n, 8), np.float64, (out.stride(0), out.stride(1)), True, device=0)
+plan.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+try:
+    plan.close()
+    print("CLOSE RETURNED")
+except so.ErrorException as e:
+    print("CLOSE RAISED:", e)
+# ... and the C-ABI's own last resort: so_plan_destroy without so_plan_check says it on stderr
+from sigops_amd import _capi
+plan = so.Plan(so.ToChannels(x, 8), (n, 8), np.float64, (out.stride(0), out.stride(1)), True, device=0)
+plan.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+plan._unchecked = None
+sys.stdout.flush()
+plan.close()
 os.environ.pop("SIGOPS_RSOS_DEBUG")
 from oracle_bridge import oracle_sink, relerr
 print("AFTERWARDS", float(relerr(so.sink(x)[0], oracle_sink(x))) < 1e-9)
@@ -457,6 +478,9 @@ print("AFTERWARDS", float(relerr(so.sink(x)[0], oracle_sink(x))) < 1e-9)
     assert r.returncode == 0, (r.returncode, out[-1500:])
     assert "HOST RESULT RAISED: k_rsos: a wait between its waves did not end" in out and "HOST RESULT RETURNED" not in out, out[-1500:]
     assert "DEVICE RESULT RETURNED" in out and "SECOND EXECUTE RAISED: k_rsos: a wait between its waves did not end" in out, out[-1500:]
+    assert "ONE-SHOT DEVICE SINK RAISED: k_rsos: a wait between its waves did not end" in out and "ONE-SHOT DEVICE SINK RETURNED" not in out, out[-2500:]
+    assert "CLOSE RAISED: k_rsos: a wait between its waves did not end" in out and "CLOSE RETURNED" not in out, out[-2500:]
+    assert "libsigops: k_rsos: a wait between its waves did not end -- THE LAST RESULT OF THIS PLAN IS INVALID" in out, out[-2500:]
     assert "AFTERWARDS True" in out, out[-1500:]
     # ... with the trap instead (the opt-out): a dead process, the device fine afterwards
     code_trap = "import os\nos.environ['SIGOPS_RSOS_TRAP'] = '1'\n" + code

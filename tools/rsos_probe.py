@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--oracle", type=int, default=150000)
     ap.add_argument("--plain", action="store_true", help="no Mix: the noise alone through the resampler and the filter")
     ap.add_argument("--only-fused", action="store_true")
+    ap.add_argument("--pad-out", type=int, default=0, help="extra elements between the result's channels (pitch = frames + pad)")
+    ap.add_argument("--pad-in", type=int, default=0, help="extra elements between the input's channels")
     ap.add_argument("--warm", type=int, default=3, help="untimed executes before the timed ones (the chip's power management settles after ~30)")
     args = ap.parse_args()
     import numpy as np
@@ -36,7 +38,7 @@ def main():
     n_in = int(round(args.seconds * 44100))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1983)
-    noise_t = torch.randn((nch, n_in), dtype=torch.float64, device=dev, generator=gen)
+    noise_t = torch.randn((nch, n_in + args.pad_in), dtype=torch.float64, device=dev, generator=gen)[:, :n_in]
     noise = noise_t.t()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -53,7 +55,7 @@ def main():
             os.environ["SIGOPS_NO_RSOS"] = "1"
         x = tree(noise, n_in)
         n_out = so.nframes(x)
-        out_t = torch.empty((nch, n_out), dtype=torch.float64, device=dev)
+        out_t = torch.empty((nch, n_out + args.pad_out), dtype=torch.float64, device=dev)[:, :n_out]
         out = out_t.t()
         plan = so.Plan(so.ToChannels(x, nch), (n_out, nch), np.float64, (out.stride(0), out.stride(1)), True, device=0)
         for _ in range(args.warm):
