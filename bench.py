@@ -300,7 +300,9 @@ def roofline_of(stage, traffic=None, source=None):
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD's FP64 matrix figure for MI355X (256 CUs x 4 SIMDs x 32 FMA / clock x 2.4 GHz); the guide under
-                               # /opt/skills has no fp64 row.  tools/micro/mfma64.hip reaches 64-69 on a loaded chip (profiles/r04/mfma64.txt)
+                               # /opt/skills has no fp64 row.
+FP64_MFMA_MEASURED_TFLOPS = 68.9  # what back-to-back v_mfma_f64_16x16x4_f64 reach chip-wide, operands in registers (the clock drops to
+                                  # 2.0 - 2.1 GHz under that load): tools/micro/mfma64_shapes.hip, profiles/r06/mfma64_shapes.txt (64.7 - 68.9)
 
 
 def mfma_roofline_of(stage, n_out, nch, mfmas_per_block):
@@ -314,8 +316,9 @@ def mfma_roofline_of(stage, n_out, nch, mfmas_per_block):
     blocks = n_out * nch / 256.0
     tflops = blocks * mfmas_per_block * 2048 / (stage["ms"] * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS,
+            "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": tflops / FP64_MFMA_MEASURED_TFLOPS,
             "kernel": stage["name"], "kernel_ms": stage["ms"], "mfmas_per_block": mfmas_per_block,
-            "note": "issued fp64 MFMA flops of the stored outputs (%d MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure"
+            "note": "issued fp64 MFMA flops of the stored outputs (%d MFMAs per 16 x 16 block) / kernel time; peak = AMD's FP64 matrix figure, peak_measured = a loop of nothing but these MFMAs on this chip (profiles/r06/mfma64_shapes.txt)"
                     % mfmas_per_block}
 
 

@@ -173,20 +173,45 @@ __device__ __forceinline__ void rsos_add_imm(uint32_t la, double g0, double g1) 
     }
 }
 
+// ... for the groups of fewer than eight channels (four, eight or sixteen units per chunk): rows [R, R + N) of the group from
+// two address registers (rows 0 .. 7 and 8 .. 15: the immediate holds 16 bits) ...
+template <int RB, int R, int N>
+__device__ __forceinline__ void rsos_add_rows(uint32_t la0, uint32_t la8, double g0, double g1) {
+    if constexpr (N > 0) {
+        asm volatile("ds_add_f64 %0, %1 offset:%3\n\tds_add_f64 %0, %2 offset:%4" ::"v"(R < 8 ? la0 : la8), "v"(g0), "v"(g1), "n"((R & 7) * RB), "n"((R & 7) * RB + 8) : "memory");
+        rsos_add_rows<RB, R + 1, N - 1>(la0, la8, g0, g1);
+    }
+}
+// ... and ALL units of this loader wave (u = q + J NL; q RU rows are in la0 / la8), every one of them on the fast path: the
+// operand from the unit's share base and the lane's own (sin, cos) pairs, the adds -- four vector instructions per unit, none
+// per row (unit by unit with its own address arithmetic and per-row adds the step cost a four-channel group 0.31 ms where an
+// eight-channel one pays 0.02)
+template <int RB, int RU, int NL, int J, int MUC>
+__device__ __forceinline__ void rsos_add_units(uint32_t la0, uint32_t la8, const double2 (&bs)[MUC], double2 d0, double2 d1, bool sine, double gc, bool neg) {
+    if constexpr (J < MUC) {
+        double g0 = gc, g1 = gc;
+        if (sine) {
+            g0 = fma(bs[J].x, d0.y, bs[J].y * d0.x);
+            g1 = fma(bs[J].x, d1.y, bs[J].y * d1.x);
+        }
+        if (neg) {
+            g0 = -g0;
+            g1 = -g1;
+        }
+        rsos_add_rows<RB, J * NL * RU, RU>(la0, la8, g0, g1);
+        rsos_add_units<RB, RU, NL, J + 1, MUC>(la0, la8, bs, d0, d1, sine, gc, neg);
+    }
+}
+
 // The fused step on a ring that KEEPS Float32 samples (RsSos::f32m: a Float32 result resampled on the Float32 MFMA).  Lane l owns
-// frames 2 l and 2 l + 1 of every row of the landed chunk (four bytes a frame: eight bytes per lane and row).  v + m / v - m
-// with the LDS's own Float32 adder (ds_add_f32: nothing for the vector ALU next to the chain wave's MFMAs); v * m / m - v are
-// read, computed and written back.  The operand is the step's Float64 value rounded to Float32 once: the samples that enter
-// the resampler are Float32 on this path.  OP: 0 v*m, 1 v+m (v-m: with -m), 3 m-v
+// frames 2 l and 2 l + 1 of every row of the landed chunk (four bytes a frame: one 8-byte LDS access per lane and row): read,
+// one Float32 operation per frame, written back.  (The LDS's own Float32 adder -- ds_add_f32, as the Float64 path uses
+// ds_add_f64 -- made the step cost 1.07 ms of 1.88, with either lane map: measured, not used.)  The operand is the step's
+// Float64 value rounded to Float32 once: the samples that enter the resampler are Float32 on this path.
+// OP: 0 v*m, 1 v+m (v-m: with -m), 3 m-v
 template <int RU, int OP>
 __device__ __forceinline__ void rsos_step32(uint32_t la, uint32_t row_bytes, float g0, float g1) {
-    if constexpr (OP == 1) {
-#pragma unroll
-        for (int c = 0; c < RU; ++c) {
-            const uint32_t a = la + (uint32_t)c * row_bytes;
-            asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4" ::"v"(a), "v"(g0), "v"(g1) : "memory");
-        }
-    } else if constexpr (RU > 4) {
+    if constexpr (RU > 4) {
         rsos_step32<4, OP>(la, row_bytes, g0, g1);
         rsos_step32<RU - 4, OP>(la + 4 * row_bytes, row_bytes, g0, g1);
     } else {
@@ -198,12 +223,34 @@ __device__ __forceinline__ void rsos_step32(uint32_t la, uint32_t row_bytes, flo
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0])::"memory");
 #pragma unroll
         for (int c = 0; c < RU; ++c) {
-            raw[c].x = OP == 0 ? raw[c].x * g0 : g0 - raw[c].x;
-            raw[c].y = OP == 0 ? raw[c].y * g1 : g1 - raw[c].y;
+            raw[c].x = OP == 0 ? raw[c].x * g0 : OP == 1 ? raw[c].x + g0 : g0 - raw[c].x;
+            raw[c].y = OP == 0 ? raw[c].y * g1 : OP == 1 ? raw[c].y + g1 : g1 - raw[c].y;
         }
 #pragma unroll
         for (int c = 0; c < RU; ++c) asm volatile("ds_write_b64 %0, %1" ::"v"(la + (uint32_t)c * row_bytes), "v"(raw[c]) : "memory");
     }
+}
+
+// ... with the rows' distance known at compile time (RB bytes): one address register, immediate offsets, all RU rows' reads in
+// flight behind ONE wait (per row an address add and per four rows a wait were half of the step's instructions)
+template <int RB, int RU, int OP>
+__device__ __forceinline__ void rsos_step32_imm(uint32_t la, float g0, float g1) {
+    float2 raw[RU];
+#define SO_RD(C) if constexpr (C < RU) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(raw[C < RU ? C : 0]) : "v"(la), "n"((C < RU ? C : 0) * RB) : "memory");
+    SO_RD(0) SO_RD(1) SO_RD(2) SO_RD(3) SO_RD(4) SO_RD(5) SO_RD(6) SO_RD(7)
+#undef SO_RD
+    if constexpr (RU == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7])::"memory");
+    else if constexpr (RU == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])::"memory");
+    else if constexpr (RU == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0])::"memory");
+#pragma unroll
+    for (int c = 0; c < RU; ++c) {
+        raw[c].x = OP == 0 ? raw[c].x * g0 : OP == 1 ? raw[c].x + g0 : g0 - raw[c].x;
+        raw[c].y = OP == 0 ? raw[c].y * g1 : OP == 1 ? raw[c].y + g1 : g1 - raw[c].y;
+    }
+#define SO_WR(C) if constexpr (C < RU) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(la), "v"(raw[C < RU ? C : 0]), "n"((C < RU ? C : 0) * RB) : "memory");
+    SO_WR(0) SO_WR(1) SO_WR(2) SO_WR(3) SO_WR(4) SO_WR(5) SO_WR(6) SO_WR(7)
+#undef SO_WR
 }
 
 // A landed chunk of a Float32 array: 128 floats in the upper half of each row's 1 KB slot.  Widened in place -- lane l
@@ -773,8 +820,27 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                 // (two table reads, an LDS round trip for the base, one more table read each) the step cost a stereo
                 // chunk's eight units a third of the kernel (Mix(sin, x) of two channels: 1.75 ms against 1.39 without it)
                 const uint64_t fm = __ballot(lane < MU && k >= klo_l && k < khi_l);
+                constexpr int MUC = nunits / NL;  // (units per loader wave: nunits is a power of two, NL 1 or 2)
+                bool all_done = false;
+                if constexpr (RB > 0 && MUC * NL == nunits) {
+                    // the common chunk: every unit of the wave inside the signal, v + m or v - m, whole chunks
+                    if ((fuse == 1 || fuse == 2) && MU == MUC && fm == ((1ull << MUC) - 1ull) && lanes == 64) {
+                        double2 bs[MUC];
+#pragma unroll
+                        for (int j = 0; j < MUC; ++j) {
+                            bs[j] = double2{0.0, 0.0};
+                            if (fuse_sine) {
+                                const int u = q + j * NL;
+                                bs[j] = double2{l.gtab[(u * 16 + (k & 15)) * 2], l.gtab[(u * 16 + (k & 15)) * 2 + 1]};
+                            }
+                        }
+                        const uint32_t la0 = ring_b + (uint32_t)(q * RU) * (uint32_t)RB + (uint32_t)rho0 * 8u + lane16;
+                        rsos_add_units<RB, RU, NL, 0, MUC>(la0, la0 + 8u * (uint32_t)RB, bs, d0, d1, fuse_sine != 0, gconst, fuse == 2);
+                        all_done = true;
+                    }
+                }
 #pragma unroll 1
-                for (int jb = 0; jb < MU; jb += 4) {
+                for (int jb = 0; jb < MU && !all_done; jb += 4) {
                     double2 bsr[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -823,11 +889,20 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     if (lane < lanes) {
                         const uint32_t la = u_lds(j) + (uint32_t)rho0 * 4u + (uint32_t)lane * 8u;
                         const float g0 = (float)gn[0], g1 = (float)gn[1];
-                        switch (fuse) {
-                        case 0: rsos_step32<RU, 0>(la, row_bytes, g0, g1); break;
-                        case 1: rsos_step32<RU, 1>(la, row_bytes, g0, g1); break;
-                        case 2: rsos_step32<RU, 1>(la, row_bytes, -g0, -g1); break;
-                        default: rsos_step32<RU, 3>(la, row_bytes, g0, g1); break;
+                        if constexpr (RB > 0) {
+                            switch (fuse) {
+                            case 0: rsos_step32_imm<RB, RU, 0>(la, g0, g1); break;
+                            case 1: rsos_step32_imm<RB, RU, 1>(la, g0, g1); break;
+                            case 2: rsos_step32_imm<RB, RU, 1>(la, -g0, -g1); break;
+                            default: rsos_step32_imm<RB, RU, 3>(la, g0, g1); break;
+                            }
+                        } else {
+                            switch (fuse) {
+                            case 0: rsos_step32<RU, 0>(la, row_bytes, g0, g1); break;
+                            case 1: rsos_step32<RU, 1>(la, row_bytes, g0, g1); break;
+                            case 2: rsos_step32<RU, 1>(la, row_bytes, -g0, -g1); break;
+                            default: rsos_step32<RU, 3>(la, row_bytes, g0, g1); break;
+                            }
                         }
                     }
                 } else if constexpr (src32) {
@@ -1405,17 +1480,23 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
             if (g.debug & 256) continue;
             switch (ru) {
             case 8:
-                if (g.src32) rsos_loader<NY, NL, 8, true>(&sh, lds_raw, G, q);
+                if (g.src32 && g.rpitch == 770) rsos_loader<NY, NL, 8, true, 770 * 8>(&sh, lds_raw, G, q);
+                else if (g.src32 && g.rpitch == 642) rsos_loader<NY, NL, 8, true, 642 * 8>(&sh, lds_raw, G, q);
+                else if (g.src32) rsos_loader<NY, NL, 8, true>(&sh, lds_raw, G, q);
                 else if (g.rpitch == 770) rsos_loader<NY, NL, 8, false, 770 * 8>(&sh, lds_raw, G, q);  // (rings of 768 / 640 frames:
                 else if (g.rpitch == 642) rsos_loader<NY, NL, 8, false, 642 * 8>(&sh, lds_raw, G, q);  //  row offsets as immediates)
                 else rsos_loader<NY, NL, 8, false>(&sh, lds_raw, G, q);
                 break;
             case 4:
                 if (g.src32) rsos_loader<NY, NL, 4, true>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 770) rsos_loader<NY, NL, 4, false, 770 * 8>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 642) rsos_loader<NY, NL, 4, false, 642 * 8>(&sh, lds_raw, G, q);
                 else rsos_loader<NY, NL, 4, false>(&sh, lds_raw, G, q);
                 break;
             case 2:
                 if (g.src32) rsos_loader<NY, NL, 2, true>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 642) rsos_loader<NY, NL, 2, false, 642 * 8>(&sh, lds_raw, G, q);
                 else rsos_loader<NY, NL, 2, false>(&sh, lds_raw, G, q);
                 break;
             default:

@@ -1896,7 +1896,12 @@ void Plan::fuse_resample_sos() {
             int nw = fits(12) ? 12 : fits(8) ? 8 : 12;
             // (groups of two channels: eight loader units per chunk -- a second loader wave pays: 1.22 -> 1.01 ms for 1e8
             //  samples, tools/rsos_nw16.sh; for four and more channels it costs what it saves)
-            if (ct == 2 && nw == 12 && cyc_of(16) == 1 && ks <= 16) nw = 16;
+            // (round 6: that was with the 128-register instantiation's store offsets spilled -- every result store behind a scratch
+            //  reload and a wait for the previous store: 0.3 ms of a stereo signal's 1.34, k_rsos.hip `ystep`.  Without the spills
+            //  12 waves win where the loader has no step to apply (2 ch x 2400 s: 1.07 against 1.10 ms); with the fused step
+            //  the second loader wave still pays, 1.46 against 1.72)
+            const bool stepped = was_ga || (!plain_src && !S3.carriers.empty() && S3.carriers[0].nsteps > 0);
+            if (ct == 2 && stepped && nw == 12 && cyc_of(16) == 1 && ks <= 16) nw = 16;
             if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : std::atoi(ev) == 16 && cyc_of(16) == 1 && ks <= 16 ? 16 : 12;
             g.nwaves = nw;
             g.cyc = (nw == 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;

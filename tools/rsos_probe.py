@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--oracle", type=int, default=150000)
     ap.add_argument("--plain", action="store_true", help="no Mix: the noise alone through the resampler and the filter")
     ap.add_argument("--only-fused", action="store_true")
+    ap.add_argument("--f32", action="store_true", help="a Float32 leaf and a Float32 result")
     ap.add_argument("--pad-out", type=int, default=0, help="extra elements between the result's channels (pitch = frames + pad)")
     ap.add_argument("--pad-in", type=int, default=0, help="extra elements between the input's channels")
     ap.add_argument("--warm", type=int, default=3, help="untimed executes before the timed ones (the chip's power management settles after ~30)")
@@ -38,7 +39,9 @@ def main():
     n_in = int(round(args.seconds * 44100))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1983)
-    noise_t = torch.randn((nch, n_in + args.pad_in), dtype=torch.float64, device=dev, generator=gen)[:, :n_in]
+    tdt = torch.float32 if args.f32 else torch.float64
+    ndt = np.float32 if args.f32 else np.float64
+    noise_t = torch.randn((nch, n_in + args.pad_in), dtype=tdt, device=dev, generator=gen)[:, :n_in]
     noise = noise_t.t()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -55,9 +58,9 @@ def main():
             os.environ["SIGOPS_NO_RSOS"] = "1"
         x = tree(noise, n_in)
         n_out = so.nframes(x)
-        out_t = torch.empty((nch, n_out + args.pad_out), dtype=torch.float64, device=dev)[:, :n_out]
+        out_t = torch.empty((nch, n_out + args.pad_out), dtype=tdt, device=dev)[:, :n_out]
         out = out_t.t()
-        plan = so.Plan(so.ToChannels(x, nch), (n_out, nch), np.float64, (out.stride(0), out.stride(1)), True, device=0)
+        plan = so.Plan(so.ToChannels(x, nch), (n_out, nch), ndt, (out.stride(0), out.stride(1)), True, device=0)
         for _ in range(args.warm):
             plan.execute(out.data_ptr(), stream)
         torch.cuda.synchronize()
