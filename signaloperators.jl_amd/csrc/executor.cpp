@@ -170,6 +170,7 @@ void Plan::finalize() {
             HIPCHECK(h2d_small(bufs[S.qmat_buf].d, S.qmat_host.data(), S.qmat_host.size() * 8));
         if (S.kind == ST_SOS && S.rsos_src >= 0) {
             HIPCHECK(h2d_small(bufs[S.rsos_mats_buf].d, S.rsos_mats_host.data(), S.rsos_mats_host.size() * 8));
+            if (S.rsos_jrel_buf >= 0) HIPCHECK(h2d_small(bufs[S.rsos_jrel_buf].d, S.rsos_jrel_host.data(), S.rsos_jrel_host.size() * 4));
             if (S.rsos_tab_buf >= 0) {
                 HIPCHECK(h2d_small(bufs[S.rsos_tab_buf].d, S.rsos_tab_host.data(), S.rsos_tab_host.size() * 8));
                 HIPCHECK(h2d_small(bufs[S.rsos_jend_buf].d, S.rsos_jend_host.data(), S.rsos_jend_host.size() * 4));
@@ -647,7 +648,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rs.store_lo = S.rs.store_lo + g.store_lo;
                         rs.mats = (const double*)P->bufs[S.rsos_mats_buf].d;
                         rs.bad = nullptr;
-                        if (S.bad_buf >= 0 && rs.nranges > 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
+                        if (S.bad_buf >= 0 && rs.nranges >= 1 && !std::getenv("SIGOPS_SOS_NOPOISON")) {
                             rs.bad = (int32_t*)P->bufs[S.bad_buf].d;
                             HIPCHECK((hipError_t)launch_fill_u32(rs.bad, (size_t)N.nch, 0x7f7f7f7fu, st));  // "no non-finite range yet"
                         }
@@ -699,7 +700,21 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                                 }
                         }
                         nl = 1;
-                        if (rs.bad) {  // behind a non-finite sample the reference stays NaN: everything after the first bad range
+                        if (rs.bad && S.rsos_jrel_buf >= 0 && !std::getenv("SIGOPS_RSOS_NO_FIXUP")) {
+                            // behind a non-finite sample the reference stays non-finite: NaN over everything after the first bad
+                            // range -- and INSIDE that range the block the sample fell into (the block form makes all 16 outputs
+                            // non-finite, and a group's window is wider than an output's) output by output the reference's way
+                            RsFixup fx{};
+                            fx.g = rs;
+                            fx.tab = rtab;
+                            fx.jend = rjend;
+                            fx.jrel = (const int*)P->bufs[S.rsos_jrel_buf].d;
+                            fx.taps = S.rsos_taps;
+                            fx.cf = S.groups[0];
+                            fx.gsrc = RsGlobalTables{(const RsCtl*)P->bufs[S3.ctl_buf].d, (const DCarrier*)P->bufs[S3.car_buf].d, P->d_ops, P->d_leaves};
+                            fx.y = yk;
+                            nl += launch_rsos_fixup(fx, st);
+                        } else if (rs.bad) {
                             SosGeom pg = g;
                             pg.n = rs.n_out;
                             pg.chunk = rs.pr * rs.L;

@@ -150,6 +150,10 @@ struct Stage {
     std::vector<double> rsos_tab_host;  // fused kernel: tap operands of a super-period of its own (small rational ratios)
     std::vector<int> rsos_jend_host;
     int rsos_tab_buf = -1, rsos_jend_buf = -1;
+    // ... for the exact recomputation behind a non-finite sample (k_rsos_fixup): newest input of every output of the period
+    // relative to its group's window end, and the taps per output the REFERENCE multiplies (its own zero padding included)
+    std::vector<int> rsos_jrel_host;
+    int rsos_jrel_buf = -1, rsos_taps = 0;
     bool arbk = false;   // ... its persistent form (k_resample_arb), geometry in ra
     RsArb ra{};
     int pfbt_buf = -1, dpfbt_buf = -1;

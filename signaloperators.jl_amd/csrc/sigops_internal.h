@@ -390,6 +390,19 @@ struct RsSos {
 };
 constexpr int kRsosTraceIters = 96;
 
+// k_rsos_fixup (k_exact.hip): the launch behind k_rsos that makes a channel's non-finite outputs the REFERENCE's set
+struct RsFixup {
+    RsSos g;            // the fused launch's geometry (bad, store_lo, out_pitch, out_f32, x32 as launched)
+    const double* tab;  // [ngroups][4 ks][16] taps of output rr of group gi at window slot kk
+    const int* jend;    // [ngroups] window end (newest input of the group's last output), relative to the period's first input
+    const int* jrel;    // [L] newest input of output r of the period, relative to its group's window end (<= 0)
+    int32_t taps;       // taps per output as the reference multiplies them
+    int32_t pad;
+    SosCoefs cf;        // the cascade's sections (the per-sample DF2T form)
+    RsGlobalTables gsrc;  // the kernel's source, for single frames
+    void* y;            // result, in the kernel's output coordinates
+};
+
 // Row-tiled variant for rational rates whose period does not fit the MFMA kernel's LDS ring or
 // tap registers (strong downsampling: many inputs per period, long filters), see k_resample_rows.
 struct RsRows {

@@ -1687,6 +1687,7 @@ void Plan::fuse_resample_sos() {
         bool own_tab = false;
         std::vector<double> own_taps;
         std::vector<int> own_jend;
+        std::vector<int64_t> own_jr;  // (newest input of every output of the own table's super-period)
         const bool blocks_ok = S3.periodic && Lp > 0 && Lp % 16 == 0 && (int64_t)ngp * 16 == Lp && ngp <= 256;
         if (!S3.rg.arbitrary && (!blocks_ok || ngp > 10) && !std::getenv("SIGOPS_RSOS_NOOWNTAB")) {
             const RsGeom& rg = S3.rg;
@@ -1740,6 +1741,7 @@ void Plan::fuse_resample_sos() {
                 jlop = jlo;
                 own_taps.swap(tab);
                 own_jend.swap(jend);
+                own_jr = jr;
                 own_tab = found = true;
                 break;
             }
@@ -1979,6 +1981,17 @@ void Plan::fuse_resample_sos() {
         S2.rs = g;
         S2.rsos_src = i3;
         S2.carriers.clear();  // (what process_stage prepared for the single-pass form of a plain filter: the resampler's serve now)
+        {  // what k_rsos_fixup needs to recompute single outputs the reference's way
+            const std::vector<int64_t>& jr = own_jr.empty() ? S3.per_j : own_jr;
+            const std::vector<int>& je = own_tab ? own_jend : S3.jend_host;
+            S2.rsos_jrel_host.clear();
+            if ((int64_t)jr.size() >= Lp && (int64_t)je.size() >= ngp) {
+                S2.rsos_jrel_host.resize((size_t)Lp);
+                for (int64_t r = 0; r < Lp; ++r) S2.rsos_jrel_host[(size_t)r] = (int)(jr[(size_t)r] - je[(size_t)(r / 16)]);
+                S2.rsos_jrel_buf = raw_buf(S2.rsos_jrel_host.size() * 4);
+                S2.rsos_taps = S3.rg.taps;
+            }
+        }
         if (own_tab) {
             S2.rsos_tab_host.swap(own_taps);
             S2.rsos_jend_host.swap(own_jend);
@@ -2143,6 +2156,10 @@ void Plan::fuse_plain_sos() {
         }
         S2.rsos_tab_buf = raw_buf(S2.rsos_tab_host.size() * 8);
         S2.rsos_jend_buf = raw_buf(S2.rsos_jend_host.size() * 4);
+        S2.rsos_jrel_host.resize((size_t)L);  // (identity: output r's one tap is its own input)
+        for (int64_t r = 0; r < L; ++r) S2.rsos_jrel_host[(size_t)r] = (int)(r % 16) - 15;
+        S2.rsos_jrel_buf = raw_buf(S2.rsos_jrel_host.size() * 4);
+        S2.rsos_taps = 1;
         S2.rs = g;
         S2.rsos_src = (int)i2;  // (its own carriers, control block and tables)
         S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);

@@ -106,11 +106,15 @@ def test_float32_edges_windows_and_pieces_with_the_float32_ring():
                  X | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz),
                  so.Append(X | so.Until(50_001 * so.frames), Y) | so.Filt(so.Lowpass, 3 * so.kHz) | so.ToFramerate(48 * so.kHz)):
         with env(SIGOPS_RSOS_MINGROUPS=1):
+            dflt = so.sink(tree)[0]  # (round 6: resampled Float32 signals take the Float32 MFMA -- tests/test_gpu_rsos_f32m.py)
+        with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_RSOS_NO_F32MFMA=1):
             got = so.sink(tree)[0]
         with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_RSOS_NO_RING32=1):
             old = so.sink(tree)[0]
-        assert got.dtype == np.float32 and relerr(got, oracle_sink(tree)) < 1e-6
+        want = oracle_sink(tree)
+        assert got.dtype == np.float32 and relerr(got, want) < 1e-6
         assert np.array_equal(got, old)
+        assert dflt.dtype == np.float32 and relerr(dflt, want) < 1e-6 and relerr(dflt, got) < 3e-7
 
 
 def test_float64_filter_into_a_float32_result():
@@ -130,15 +134,18 @@ def test_float64_filter_into_a_float32_result():
 
 
 def test_non_finite_samples():
-    """A filter never recovers from a non-finite sample (the reference's recurrence carries it on in its state).  The
-    block form multiplies whole blocks of 16 frames -- 0 * NaN is NaN -- so the one-pass result is non-finite from the
-    START of the 16-frame block (frames 16 k ... 16 k + 15 of the signal) that holds a channel's first non-finite sample:
-    up to 15 frames earlier than the reference, never later, never in another channel.  The exact set, stated:"""
+    """A filter never recovers from a non-finite sample (the reference's recurrence carries it on in its state).  The block
+    form multiplies whole blocks of 16 frames -- 0 * NaN is NaN --, so k_rsos alone is non-finite from the START of the
+    16-frame block that holds a channel's first non-finite sample: up to 15 frames earlier than the reference (rounds 4 - 5
+    stated that superset here).  Round 6: k_rsos_fixup recomputes that block sample by sample -- the set is the reference's,
+    and the frames in front of the sample carry the reference's values."""
     rng = np.random.default_rng(10)
     d = rng.standard_normal((400000, 8))
-    first = {3: 123457, 5: 300000}
+    first = {3: 123457, 5: 300000, 6: 16 * 777 + 15, 7: 16 * 999}   # (middle of a block, start of one, its last frame, its first)
     d[first[3], 3] = np.nan
     d[first[5], 5] = np.inf
+    d[first[6], 6] = -np.inf
+    d[first[7], 7] = np.nan
     x = so.Signal(F(d), 44.1 * so.kHz) | so.Filt(so.Lowpass, 4 * so.kHz)
     a, b, fused = both(x)
     want = oracle_sink(x)
@@ -147,9 +154,14 @@ def test_non_finite_samples():
     expect = np.ones(d.shape, dtype=bool)
     for c, i in first.items():
         assert not np.isfinite(want[i:, c]).any() and np.isfinite(want[:i, c]).all()
-        expect[i // 16 * 16:, c] = False
+        expect[i:, c] = False
     assert np.array_equal(np.isfinite(a), expect)
     assert relerr(a[expect], want[expect]) < 1e-10
+    with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_RSOS_NO_FIXUP=1):   # (the kernel's own set, as it was)
+        raw = so.sink(x)[0]
+    for c, i in first.items():
+        expect[i // 16 * 16:, c] = False
+    assert np.array_equal(np.isfinite(raw), expect)
 
 
 def test_under_append_and_with_a_ramp_behind_it():

@@ -12,7 +12,7 @@ if [ -n "${RELINK_ONLY:-}" ] && [ -f "$obj" ]; then :; else
 fi
 objs=""
 # (k_rsos.hip and k_resample.hip are built as several units, k_rsos_ks*.o / k_resample_u*.o; as a variant each is ONE unit with everything in it)
-for s in k_pointwise k_sos k_small k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
+for s in k_pointwise k_sos k_small k_exact k_resample k_rsos k_resample_arb kernels2 planner stages accumulator executor design capi comm rtc; do
     if [ "$s.hip" = "$unit" ]; then objs="$objs $obj"
     elif [ "$s" = k_rsos ]; then objs="$objs $(ls $here/k_rsos_ks*.o | tr '\n' ' ')"
     elif [ "$s" = k_resample ]; then objs="$objs $(ls $here/k_resample_u*.o | tr '\n' ' ')"
