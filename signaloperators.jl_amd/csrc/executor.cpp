@@ -111,6 +111,15 @@ void Plan::finalize() {
             L.df -= bufs[L.buf].frame0;  // (stage buffers that start at a later frame: once, here)
         }
     }
+    // scalar leaves of a Normpower's rms: patched on the device by the launch that computes it (RmsPatch)
+    for (auto& S : stages) {
+        if (S.kind != ST_NORM || S.rms_buf < 0 || std::getenv("SIGOPS_NO_RMSPATCH")) continue;
+        S.rms_leaves.clear();
+        for (size_t i = 0; i < leaves.size(); ++i)
+            if (leaves[i].buf == S.rms_buf && leaf_array_node[i] < 0) S.rms_leaves.push_back((int)i);
+        if (S.rms_leaves.size() > 8) S.rms_leaves.clear();
+        for (int i : S.rms_leaves) leaves[(size_t)i].flag = 1;
+    }
     for (auto& S : stages) {
         if (S.carriers.empty()) continue;
         for (auto& c : S.carriers) {
@@ -906,8 +915,10 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         launches++;
                     }
                 } else {
+                    RmsPatch patch{};
+                    for (int li : S.rms_leaves) patch.dst[patch.n++] = &P->d_leaves[li].v0;
                     launch_rms(S.norm_direct ? (const void*)inp : ob.d, N.dtype, S.need, N.nch, S.norm_direct ? in_pitch : ob.pitch,
-                               (double*)P->bufs[S.partial_buf].d, S.nparts, (double*)P->bufs[S.rms_buf].d, st);
+                               (double*)P->bufs[S.partial_buf].d, S.nparts, (double*)P->bufs[S.rms_buf].d, st, patch);
                     s.launches = 2;
                     launches += 2;
                 }

@@ -84,7 +84,10 @@ __global__ __launch_bounds__(kBlock) void k_pointwise(const DPiece* __restrict__
             for (int i = 0; i < 4; ++i) {
                 const DOp o = ops[P.samp_pc + 1 + 2 * (i < nst ? i : 0)];
                 sslot[i] = i < nst ? (o.code == OP_LOADF ? o.arg : 4) : 0;
-                cval[i] = i < nst && o.code == OP_CONST ? leaves[o.arg].v0 : 0.0;
+                // (a device scalar -- a Normpower's rms -- is a constant of the launch: read once here, from the leaf its
+                //  producer patched (RmsPatch) or through its pointer)
+                cval[i] = i < nst && o.code == OP_CONST ? leaves[o.arg].v0
+                          : i < nst && o.code == OP_SCALAR ? (leaves[o.arg].flag ? leaves[o.arg].v0 : scalar_leaf(leaves[o.arg].base)) : 0.0;
                 sop[i] = i < nst ? ops[P.samp_pc + 2 + 2 * i].code : -1;
             }
             const bool in64 = L.dtype == SO_F64, out64 = out.dtype == SO_F64;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_partial(const T* __restrict__ 
 
 __global__ __launch_bounds__(kBlock) void k_sumsq_final(const double* __restrict__ partial,
                                                         int nparts, double count,
-                                                        double* __restrict__ rms) {
+                                                        double* __restrict__ rms, RmsPatch patch) {
     __shared__ double red[kBlock];
     double acc = 0.0;
     for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partial[i];
@@ -366,7 +369,11 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_final(const double* __restrict
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) rms[0] = sqrt(red[0] / count);
+    if (threadIdx.x == 0) {
+        const double r = sqrt(red[0] / count);
+        rms[0] = r;
+        for (int i = 0; i < patch.n; ++i) *patch.dst[i] = r;  // (the scalar leaves that read it: RmsPatch)
+    }
 }
 
 // Float32 signals: Julia reduces `mean(x -> float(x)^2, vals)` in Float32 -- pairwise over blocks of
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(kSqBlocks) void k_sumsq32_blocks(const float* __res
     if (t == 0) part[blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, float* __restrict__ b, int64_t nb,
-                                                         float count, double* __restrict__ rms) {
+                                                         float count, double* __restrict__ rms, RmsPatch patch) {
     float* in = a;
     float* out = b;
     int64_t m = nb;
@@ -527,18 +534,20 @@ __global__ __launch_bounds__(kBlock) void k_sumsq32_fold(float* __restrict__ a, 
     //  single-precision sequences do -- v_sqrt_f32 alone is 1 ulp)
     if (threadIdx.x == 0) {
         const float mean = (float)((double)(nb ? in[0] : 0.f) / (double)count);
-        rms[0] = (double)(float)sqrt((double)mean);
+        const double r = (double)(float)sqrt((double)mean);
+        rms[0] = r;
+        for (int i = 0; i < patch.n; ++i) *patch.dst[i] = r;  // (the scalar leaves that read it: RmsPatch)
     }
 }
 
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
-                int nparts, double* rms, hipStream_t st) {
+                int nparts, double* rms, hipStream_t st, const RmsPatch& patch) {
     if (dtype == SO_F32) {
         const int64_t nb = (n * nch + 1023) / 1024;
         const int64_t nw = (nb + kSqBlocks - 1) / kSqBlocks;  // one value per wave of 64 blocks goes on to the fold kernel
         float* pa = (float*)partial;
         hipLaunchKernelGGL(k_sumsq32_blocks, dim3((unsigned)nw), dim3(kSqBlocks), 0, st, (const float*)x, n, nch, pitch, pa, nb);
-        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nw, nw, (float)((double)n * (double)nch), rms);
+        hipLaunchKernelGGL(k_sumsq32_fold, dim3(1), dim3(kBlock), 0, st, pa, pa + nw, nw, (float)((double)n * (double)nch), rms, patch);
         return;
     }
     if (dtype == SO_F32)
@@ -548,7 +557,7 @@ void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, dou
         hipLaunchKernelGGL((k_sumsq_partial<double>), dim3(nparts), dim3(kBlock), 0, st,
                            (const double*)x, n, nch, pitch, partial);
     hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(kBlock), 0, st, partial, nparts,
-                       (double)n * (double)nch, rms);
+                       (double)n * (double)nch, rms, patch);
 }
 
 }  // namespace so

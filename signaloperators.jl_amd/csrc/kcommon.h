@@ -23,7 +23,7 @@ __device__ __forceinline__ double slot_eval(int kind, const DLeaf& L, int64_t n)
     double v;
     switch (kind & 0xff) {
     case OP_CONST: v = L.v0; break;
-    case OP_SCALAR: v = *(const double*)L.base; break;
+    case OP_SCALAR: v = scalar_leaf(L.base); break;
     case OP_FUNC: v = func_eval(L, n); break;
     default: v = ramp_eval(L, n); break;
     }
@@ -48,8 +48,8 @@ __device__ __forceinline__ double rfl_f64(double v) {
 __device__ __forceinline__ DLeaf leaf_uniform(const DLeaf& L) {
     DLeaf U = L;
     const uint64_t b = (uint64_t)(uintptr_t)L.base;
-    U.base = (const void*)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                                      __builtin_amdgcn_readfirstlane((uint32_t)b));
+    U.base = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b));  // (the builtin returns a signed int)
     U.v0 = rfl_f64(L.v0);
     U.v1 = rfl_f64(L.v1);
     U.v2 = rfl_f64(L.v2);
@@ -66,7 +66,7 @@ __device__ __forceinline__ void slot_eval2(int kind, const DLeaf& L, int64_t n, 
     double v0, v1;
     switch (kind & 0xff) {
     case OP_CONST: v0 = v1 = L.v0; break;
-    case OP_SCALAR: v0 = v1 = *(const double*)L.base; break;
+    case OP_SCALAR: v0 = v1 = scalar_leaf(L.base); break;
     case OP_FUNC:
         v0 = func_eval(L, n);
         v1 = func_eval(L, n + 1);
@@ -174,7 +174,10 @@ __device__ __forceinline__ void run_program(const DOp* __restrict__ ops, int pc,
             break;
         }
         case OP_SCALAR: {
-            const double v = *(const double*)leaves[op.arg].base;
+            // (flag: the launch that computed the scalar also left it in this leaf's v0 -- RmsPatch; control-block copies of a
+            //  leaf never carry the flag, Plan::make_ctl)
+            const DLeaf& L = leaves[op.arg];
+            const double v = L.flag ? L.v0 : scalar_leaf(L.base);
             SO_PUSH(v);
             break;
         }

@@ -52,5 +52,5 @@ int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, con
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc);
 size_t rsos_lds_budget();
 void launch_rms(const void* x, int dtype, int64_t n, int nch, int64_t pitch, double* partial,
-                int nparts, double* rms, hipStream_t st);
+                int nparts, double* rms, hipStream_t st, const RmsPatch& patch = RmsPatch{});
 }  // namespace so

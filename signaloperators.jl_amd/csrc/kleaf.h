@@ -17,6 +17,20 @@ namespace so {
 // scalar load -- the interpreter's next program word, the next leaf's descriptor -- also waited for the samples just
 // requested: one memory round trip per operand, one after the other.
 #define SO_GLOBAL_PTR(T, p) ((const T __attribute__((address_space(1)))*)(p))
+
+// A device scalar (OP_SCALAR: the rms a Normpower's sum of squares left in its buffer one launch earlier): the same word for
+// every lane and every element of the launch -- read through the SCALAR cache from a wave-uniform address in the constant
+// address space (s_load_dwordx2), not as a flat load per element and lane (what `*(const double*)L.base` compiles to: a
+// vector-memory instruction in front of every division, counted on both wait counters -- the dividing pass of `Normpower`
+// ran at 3.2 TB/s where a multiplication by a constant runs at 5.0; tools/norm_probe.py).
+__device__ __forceinline__ double scalar_leaf(const void* base) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    // (the builtin returns a signed int: without the casts a low word with its top bit set sign-extends over the high word)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint64_t u = ((uint64_t)hi << 32) | lo;
+    return *(const double __attribute__((address_space(4)))*)(uintptr_t)u;
+}
+
 typedef double so_v2d __attribute__((ext_vector_type(2)));
 typedef float so_v2f __attribute__((ext_vector_type(2)));
 

@@ -191,6 +191,7 @@ struct Stage {
     int fix_buf = -1;
     // norm
     int partial_buf = -1, rms_buf = -1;
+    std::vector<int> rms_leaves;  // scalar leaves that read rms_buf: the sum-of-squares launch writes the value into their v0 too (RmsPatch)
     int nparts = 0;
 };
 

@@ -950,6 +950,9 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
         for (auto& o : code)
             if (o.code == OP_FUNC || o.code == OP_RAMP)
                 fail(SO_ERR_UNSUPPORTED, "more than 4 distinct generator/ramp sub-expressions in one fused piece");
+        // a Float32 operation at the root of a piece that is stored as Float32: its rounding IS the store's (the same value
+        // rounded twice) -- without the op the program of `x32 ./ rms` is `array (op) scalar` and takes the chain path below
+        if (out_dtype == SO_F32 && code.size() >= 2 && code.back().code == OP_ROUND32 && !std::getenv("SIGOPS_K1_KEEPROUND")) code.pop_back();
         DPiece d{};
         d.depth = std::max(2, depth(p.e));
         if (d.depth > 2) st.deep = true;
@@ -961,7 +964,7 @@ int Plan::emit_pointwise(const std::vector<Piece>& ps_in, int out_buf, int out_d
             const bool leaf_il = L.cstride == 1 && L.fstride > 1 && L.sc == 1;
             bool ok = L.mode == LM_PLAIN && L.sf == 1 && (L.fstride == 1 || leaf_il);
             for (size_t i = 1; ok && i + 1 < code.size(); i += 2)
-                ok = (code[i].code == OP_LOADF || code[i].code == OP_CONST) && code[i + 1].code >= OP_ADD && code[i + 1].code <= OP_DIV;
+                ok = (code[i].code == OP_LOADF || code[i].code == OP_CONST || code[i].code == OP_SCALAR) && code[i + 1].code >= OP_ADD && code[i + 1].code <= OP_DIV;
             if (ok) {
                 d.chain = 1;
                 st.chain = true;

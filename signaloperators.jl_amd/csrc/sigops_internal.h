@@ -139,6 +139,15 @@ struct OutView {
 // Second-order-sections IIR (DSP.jl DF2T `filt!`; call site
 // reference src/filters.jl:252-255).  Up to kMaxSec sections per launch.
 constexpr int kMaxSec = 8;
+// Where a Normpower's sum-of-squares launch leaves the rms besides its own buffer: the `v0` of the scalar leaves that read it
+// (DLeaf::flag = 1 marks such a leaf: the pointwise programs then take the value from the leaf they fetch anyway -- one
+// dependent scalar load less per program run than through the leaf's pointer: the dividing pass 0.50 -> 0.34 ms for 12.5 M x 8)
+struct RmsPatch {
+    double* dst[8];
+    int32_t n;
+    int32_t pad;
+};
+
 struct SosCoefs {
     double b0[kMaxSec], b1[kMaxSec], b2[kMaxSec], a1[kMaxSec], a2[kMaxSec];
     double gain;

@@ -1496,6 +1496,7 @@ RsCtl Plan::make_ctl(const Stage& S) const {
                 if (it == leafmap.end()) {
                     if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
                     ctl.leaves[ctl.nleaves] = leaves[o.arg];
+                    if (o.code == OP_SCALAR) ctl.leaves[ctl.nleaves].flag = 0;  // (a COPY of the leaf: nobody patches its v0, RmsPatch)
                     it = leafmap.emplace(o.arg, ctl.nleaves++).first;
                 }
                 o.arg = it->second;
@@ -1508,6 +1509,7 @@ RsCtl Plan::make_ctl(const Stage& S) const {
             if (it == leafmap.end()) {
                 if (ctl.nleaves >= kCtlLeaves) throw PlanError{SO_ERR_RUNTIME, "internal: leaf control block overflow"};
                 ctl.leaves[ctl.nleaves] = leaves[c0.slot_leaf[k]];
+                if ((c0.slot_kind[k] & 0xff) == OP_SCALAR) ctl.leaves[ctl.nleaves].flag = 0;
                 it = leafmap.emplace(c0.slot_leaf[k], ctl.nleaves++).first;
             }
             c.slot_leaf[k] = it->second;
