@@ -1844,7 +1844,14 @@ void Plan::fuse_resample_sos() {
         const int64_t min_pr = std::max<int64_t>(1, wp);
         if (nperiods / nranges < min_pr) nranges = std::max<int64_t>(rgs, nperiods / min_pr / rgs * rgs);
         if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES")) nranges = std::max<int64_t>(1, std::atoll(ev));
-        const int64_t pr = (nperiods + nranges - 1) / nranges;
+        int64_t pr = (nperiods + nranges - 1) / nranges;
+        // groups of fewer than eight channels walk several ranges side by side: where a range is a multiple of 16 input frames long
+        // all of them stage their chunks at the same alignment and the loader addresses its units by scalar additions
+        // (k_rsos.hip, the loader's `klo_all`): a few periods more per range, fewer ranges
+        if (ct < 8 && !std::getenv("SIGOPS_RSOS_NOALIGNPR")) {
+            const int64_t mlt = 16 / std::__gcd<int64_t>(Mp % 16 == 0 ? 16 : Mp % 16, 16);
+            if (pr % mlt != 0 && pr >= 8 * mlt) pr = (pr + mlt - 1) / mlt * mlt;
+        }
         nranges = (nperiods + pr - 1) / pr;
         const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
         if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * Mp >= ((int64_t)1 << 30)) continue;
