@@ -597,7 +597,10 @@ def main():
         algo = st["algorithmic_bytes"]
         ms_per_step = elapsed / args.steps * 1e3
         dom = max(stages, key=lambda s: s["ms"])
-        traffic, tsrc = pmc_traffic(args.workload + ":" + dom["name"])
+        # (the PMC file's tags: the workload, "_f32" for a Float32 leaf and result, "_<n>ch" for another channel count --
+        #  tools/collect_r06.sh)
+        pmc_tag = args.workload + ("_f32" if args.dtype == "f32" else "") + ("_%dch" % args.channels if args.workload == "ns" and args.channels != 8 else "")
+        traffic, tsrc = pmc_traffic(pmc_tag + ":" + dom["name"])
         sink_gbps = algo / (ms_per_step * 1e-3) / 1e9
         res = {
             "metric": METRIC,

@@ -48,3 +48,26 @@ def test_windows_and_float64_signals_are_untouched():
     x32 = so.Signal(F(d.astype(np.float32)), 44.1 * so.kHz) | so.ToFramerate(48 * so.kHz) | so.After(50000 * so.frames) | so.Until(60000 * so.frames)
     a, b = both(x32)
     assert relerr(a, oracle_sink(x32)) < 1e-6 and relerr(a, b) < 3e-7
+
+
+def test_local_error_on_sixty_decibels_of_dynamic_range():
+    """The maxima above are norm-wise: a loud passage hides what happens in a quiet one next to it.  One second loud, one second
+    60 dB down, and DC plus small detail (where the taps' partial sums cancel): BLOCKWISE relative error (1024 outputs) of the
+    Float32-MFMA form against the oracle -- a few Float32 rounding units of the LOCAL level -- and next to the Float64 products'
+    own (the same data rounded once): the Float32 accumulation costs local accuracy a factor, not orders of magnitude."""
+    rng = np.random.default_rng(33)
+    n = 88200
+    env_ = np.where((np.arange(4 * n) // n) % 2 == 0, 1.0, 1e-3)[:, None]
+    for d in ((rng.standard_normal((4 * n, 8)) * env_), 1.0 + 1e-3 * rng.standard_normal((4 * n, 8)) * env_):
+        x = so.Signal(F(d.astype(np.float32)), 44.1 * so.kHz) | so.ToFramerate(48 * so.kHz)
+        a, b = both(x)
+        want = oracle_sink(x).astype(np.float64)
+        nb = want.shape[0] // 1024
+        w = want[: nb * 1024].reshape(nb, 1024, -1)
+        errs = []
+        for got in (a, b):
+            e = np.linalg.norm(got[: nb * 1024].astype(np.float64).reshape(nb, 1024, -1) - w, axis=(1, 2)) / np.linalg.norm(w, axis=(1, 2))
+            errs.append(e)
+        assert errs[0].max() < 2e-6 and np.median(errs[0]) < 3e-7, (errs[0].max(), np.median(errs[0]))
+        assert errs[1].max() < 2e-6
+        assert errs[0].max() < 8 * max(errs[1].max(), 6e-8)

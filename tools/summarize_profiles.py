@@ -18,7 +18,7 @@ if stats:
             w.writerow(row)
 
 STAGES = {"k_rsos": ["k_rsos", "k_sos_poison"], "k_resample_periodic": ["k_resample_periodic"],
-          "k_sos": ["k_sos_tiled", "k_sos_scan", "k_sos_onepass"], "k_pointwise": ["k_pointwise"]}
+          "k_sos": ["k_sos_tiled", "k_sos_scan", "k_sos_onepass", "k_sos_batch", "k_sos_"], "k_pointwise": ["k_pointwise"]}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_sources_sha16: bench.py quotes these counters only while the kernel sources are the same)
 res = {"note": ("separate --pmc passes of `python3 bench.py --workload W --no-secondary --steps 100 --warmup 10 "
@@ -29,7 +29,9 @@ res = {"note": ("separate --pmc passes of `python3 bench.py --workload W --no-se
 _h = os.path.join(src, "kernel_sources_sha16.txt")  # (written by collect_profiles.sh before the passes)
 res["kernel_sources_sha16"] = open(_h).read().strip() if os.path.exists(_h) else bench.kernel_sources_sha16()
 res["kernel_sources_sha16_taken"] = "before the PMC passes (collect_profiles.sh)" if os.path.exists(_h) else "when summarised"
-for wl in ("ns", "config3"):
+# (workload tags: the sub-directories fetch_<tag> / write_<tag> that exist -- tools/collect_profiles.sh, tools/collect_r06.sh)
+_tags = sorted({os.path.basename(d)[len("fetch_"):] for d in glob.glob(os.path.join(src, "fetch_*")) if os.path.isdir(d)})
+for wl in (_tags or ["ns", "config3"]):
     per = {}
     for name, sub in (("FETCH_SIZE", f"fetch_{wl}"), ("WRITE_SIZE", f"write_{wl}")):
         p = find(f"{sub}/**/*counter_collection.csv")
