@@ -187,6 +187,10 @@ void Plan::finalize() {
         }
         if (S.kind == ST_SOS && S.onepass)
             HIPCHECK(h2d_small(bufs[S.one_tabs_buf].d, S.one_tabs_host.data(), S.one_tabs_host.size() * 8));
+        if (S.kind == ST_RESAMPLE && S.rs_jrel_buf >= 0 && S.rs_nf_buf >= 0) {
+            HIPCHECK(h2d_small(bufs[S.rs_jrel_buf].d, S.rs_jrel_host.data(), S.rs_jrel_host.size() * 4));
+            HIPCHECK(hipMemset(bufs[S.rs_nf_buf].d, 0, 64));  // (the list's count: k_rs_fixup leaves it at zero again)
+        }
         if (S.kind == ST_RESAMPLE) {
             HIPCHECK(h2d_small(bufs[S.pfb_buf].d, S.pfb_host.data(), S.pfb_host.size() * 8));
             HIPCHECK(h2d_small(bufs[S.dpfb_buf].d, S.dpfb_host.data(), S.dpfb_host.size() * 8));
@@ -830,11 +834,28 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                             HIPCHECK(hipMemsetAsync(d_trace, 0, trace_n * 8, st));
                             rp.trace = d_trace;
                         }
+                        // (the list of (tile, group)s a non-finite sample reached, and the launch that recomputes them the reference's
+                        //  way: plain sources only -- a gain applied at the MFMA operand, a second array, a state pass keep the kernel's set)
+                        const bool nf_fix = S.rs_nf_buf >= 0 && S.rs_jrel_buf >= 0 && rp.ga == 0 && rp.arr2 == 0 && rp.nstate == 0 && S.ctl_buf >= 0 &&
+                                            S.car_buf >= 0 && !S.carriers.empty() && rp.rows <= 32 && rp.kw <= 160;
+                        rp.nf = nf_fix ? (uint32_t*)P->bufs[S.rs_nf_buf].d : nullptr;
                         if (launch_resample_periodic(ob.d, (const double*)P->bufs[S.tab_buf].d,
                                                      (const int*)P->bufs[S.jend_buf].d, rp, N.dtype,
                                                      RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves},
                                                      st) != 0)
                             fail(SO_ERR_RUNTIME, "internal: no periodic resampler instantiation for this geometry");
+                        if (nf_fix) {
+                            RsPerFixup fx{};
+                            fx.g = rp;
+                            fx.tab = (const double*)P->bufs[S.tab_buf].d;
+                            fx.jend = (const int*)P->bufs[S.jend_buf].d;
+                            fx.jrel = (const int*)P->bufs[S.rs_jrel_buf].d;
+                            fx.taps = S.rg.taps;
+                            fx.out_f32 = (N.dtype == SO_F32 || rp.out_f32) ? 1 : 0;
+                            fx.gsrc = RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves};
+                            fx.y = ob.d;
+                            s.launches += launch_rs_fixup(fx, st);
+                        }
                         if (tracing) {
                             std::vector<long long> tr(trace_n);
                             HIPCHECK(hipStreamSynchronize(st));

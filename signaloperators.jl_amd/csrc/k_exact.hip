@@ -134,6 +134,67 @@ __global__ __launch_bounds__(kFixThreads) void k_rsos_fixup(RsFixup fx) {
     for (int64_t m = max(bs, lo) + tid; m < mb; m += kFixThreads) y[m] = (TO)ys[m - bs];
 }
 
+// k_rs_fixup: the same for the periodic resampler ALONE (k_resample_periodic, no filter behind it).  Its compute waves list the
+// (tile, group)s whose accumulators held a non-finite value (RsPeriodic::nf); ONE workgroup -- the list is empty in a launch
+// over finite data: it reads a word and returns -- recomputes every listed group's rows x 16 outputs from each output's own
+// taps (the reference's dot product: src/filters.jl:252-255 -> DSP.jl's polyphase kernels, 0 * NaN included) and stores
+// them, finite or not: the group's NaNs that were only the window's become the reference's values.  It leaves the list empty
+// for the next launch.  (Before k_resample_fix: the outputs DSP.jl's accumulator places differently keep their own taps.)
+constexpr int kRsFixRows = 32, kRsFixKw = 160;
+template <typename TO>
+__global__ __launch_bounds__(kFixThreads) void k_rs_fixup(RsPerFixup fx) {
+    const RsPeriodic& g = fx.g;
+    const uint32_t count = g.nf[0];
+    if (count == 0) return;
+    __shared__ double win[kRsFixRows][kRsFixKw + 2];
+    const int tid = threadIdx.x;
+    const int rows = g.rows, kw = g.kw, taps = fx.taps;
+    const int ptmask = g.pt - 1, ptshift = g.ptshift;
+    const int ncar = fx.gsrc.ctl->ncar;
+    const uint32_t n = count < kRsNfCap ? count : kRsNfCap;
+    if (rows <= kRsFixRows && kw <= kRsFixKw) {
+        for (uint32_t e = 0; e < n; ++e) {
+            const uint32_t* en = g.nf + 4 + 4 * (size_t)e;
+            const int64_t P0 = (int64_t)(((uint64_t)en[1] << 32) | en[0]);
+            const int c0 = (int)en[2], gi = (int)en[3];
+            const int je = fx.jend[gi];
+            // ---- every row's window of the group: source frames [P M + je - (kw - 1), P M + je], two per call ----
+            __syncthreads();
+            for (int t = tid; t < rows * (kw / 2); t += kFixThreads) {
+                const int rho = t / (kw / 2), h = t - rho * (kw / 2);
+                const int64_t P = P0 + (rho & ptmask);
+                stage_generic_impl<double, 1>(g.n_in, 0, fx.gsrc.car, ncar, fx.gsrc.ops, fx.gsrc.leaves, P * g.M + je - (kw - 1) + 2 * h, h, 0,
+                                              c0 + (rho >> ptshift), &win[rho][0]);
+            }
+            __syncthreads();
+            // ---- outputs ----
+            for (int t = tid; t < rows * 16; t += kFixThreads) {
+                const int rho = t >> 4, n16 = t & 15;
+                const int64_t P = P0 + (rho & ptmask), r = (int64_t)gi * 16 + n16, m = P * g.L + r;
+                const int ch = c0 + (rho >> ptshift);
+                if (P >= g.nperiods || r >= g.L || m >= g.n_out || ch >= g.nch) continue;
+                const int jr = fx.jrel[r];
+                double acc = 0.0;
+                for (int a = taps - 1; a >= 0; --a) {
+                    const int kk = kw - 1 + jr - a;
+                    if (kk < 0 || kk >= kw) continue;  // (a tap the table does not hold: zero, and outside the staged window)
+                    acc = fma(fx.tab[((size_t)gi * kw + kk) * 16 + n16], win[rho][kk], acc);
+                }
+                ((TO*)fx.y)[(int64_t)ch * g.out_pitch + m] = (TO)acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) g.nf[0] = 0;
+}
+
+int launch_rs_fixup(const RsPerFixup& fx, hipStream_t st) {
+    if (fx.g.nf == nullptr) return 0;
+    if (fx.out_f32) hipLaunchKernelGGL((k_rs_fixup<float>), dim3(1), dim3(kFixThreads), 0, st, fx);
+    else hipLaunchKernelGGL((k_rs_fixup<double>), dim3(1), dim3(kFixThreads), 0, st, fx);
+    return 1;
+}
+
 int launch_rsos_fixup(const RsFixup& fx, hipStream_t st) {
     if (fx.g.bad == nullptr || fx.g.nranges < 1) return 0;
     const dim3 grid(32, (unsigned)fx.g.nch);

@@ -256,6 +256,25 @@ __global__ __launch_bounds__(1024) void k_resample_rows(const T* __restrict__ x,
                 }
             }
             const int r = gi * 16 + n16;
+            // A non-finite accumulator: the group's window -- wider than any single output's, padded with zero taps -- held a
+            // non-finite sample (0 * NaN is NaN).  The reference multiplies each output's own taps only (src/filters.jl:252-255
+            // -> DSP.jl's polyphase kernels): the unit's outputs once more, output by output from the combined-tap table the
+            // scalar path below uses -- the tile is still in LDS.  (Rounds 4 - 5 stated the superset instead.)
+            {
+                const bool bad = !(isfinite(acc[0]) && isfinite(acc[1]) && isfinite(acc[2]) && isfinite(acc[3]));
+                if (__builtin_amdgcn_ballot_w64(bad) != 0 && r < (int)g.L && !(g.debug & 8)) {
+                    const double* __restrict__ tp = ctab + (size_t)r * g.taps;
+                    const int jn = jr[r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rho = 16 * q + kq + 4 * i;
+                        const T* __restrict__ xp = lds + (rho >> g.pbshift) * g.pitch + (rho & pbmask) * (int)g.M - g.jlo + jn;
+                        double e = 0.0;
+                        for (int k = 0; k < g.taps; ++k) e = fma(tp[k], (double)xp[-k], e);
+                        acc[i] = e;
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rho = 16 * q + kq + 4 * i;  // D: row = (lane>>4) + 4*reg
@@ -1132,6 +1151,26 @@ __global__ __launch_bounds__(G >= 3 ? 512 : 1024) void k_resample_periodic(
                     }
                 }
                 const int r = gi * 16 + n16;  // output index inside the period
+                // A non-finite accumulator: the group's window -- wider than any single output's, and padded with zero taps --
+                // held a non-finite sample (0 * NaN is NaN).  The reference multiplies each output's own taps only: the tile
+                // and group go onto a list, and the launch behind this one recomputes them output by output (k_rs_fixup).
+                if (g.nf != nullptr) {
+                    bool bad = false;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bad |= !isfinite(acc[q][i]);
+                    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) {
+                        const uint32_t idx = atomicAdd(g.nf, 1u);
+                        if (idx < kRsNfCap) {
+                            uint32_t* e = g.nf + 4 + 4 * (size_t)idx;
+                            e[0] = (uint32_t)(uint64_t)P0;
+                            e[1] = (uint32_t)((uint64_t)P0 >> 32);
+                            e[2] = (uint32_t)c0;
+                            e[3] = (uint32_t)gi;
+                        }
+                    }
+                }
                 if (g.pad & 4) continue;
                 if (interior && gi * 16 + 16 <= g.L) {
 #pragma unroll

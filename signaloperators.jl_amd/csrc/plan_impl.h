@@ -152,6 +152,8 @@ struct Stage {
     int rsos_tab_buf = -1, rsos_jend_buf = -1;
     // ... for the exact recomputation behind a non-finite sample (k_rsos_fixup): newest input of every output of the period
     // relative to its group's window end, and the taps per output the REFERENCE multiplies (its own zero padding included)
+    std::vector<int> rs_jrel_host;  // the periodic resampler's own (k_rs_fixup): as rsos_jrel_host, from per_j and jend_host
+    int rs_jrel_buf = -1, rs_nf_buf = -1;
     std::vector<int> rsos_jrel_host;
     int rsos_jrel_buf = -1, rsos_taps = 0;
     bool arbk = false;   // ... its persistent form (k_resample_arb), geometry in ra

@@ -342,8 +342,23 @@ struct RsPeriodic {
     double* vper;
     int64_t in_pitch, out_pitch;
     long long* trace;   // SIGOPS_RS_TRACE: [16 waves][kRsTraceIters][kRsTraceStamps] cycle stamps of workgroup 0, or null
+    // (tile, group)s whose accumulators held a non-finite value: nf[0] counts them, entries of four words from nf[4] on (first
+    // period of the tile, low and high word; first channel; group) -- what k_rs_fixup recomputes output by output.  null: off.
+    uint32_t* nf;
 };
 constexpr int kRsTraceIters = 48, kRsTraceStamps = 8;
+constexpr uint32_t kRsNfCap = 2047;  // (a launch that lists more keeps its own, wider set for the rest)
+
+// k_rs_fixup (k_exact.hip): the launch behind k_resample_periodic that makes its set of non-finite outputs the REFERENCE's
+struct RsPerFixup {
+    RsPeriodic g;       // the launch's geometry (nf, rows, pt, ct, L, M, kw, ngroups, out_pitch, n_in, n_out as launched)
+    const double* tab;  // [ngroups][kw][16]
+    const int* jend;    // [ngroups]
+    const int* jrel;    // [L] newest input of output r, relative to its group's window end
+    int32_t taps, out_f32;
+    RsGlobalTables gsrc;
+    void* y;
+};
 constexpr int kRsTwoBases = 128;                          // share bases per tile (tiles of up to 8192 frames)
 constexpr int kRsTwoDoubles = 128 + 2 * 2 * kRsTwoBases;  // per-lane (sin,cos) of the lane's phase offset + two buffers of share bases
 

@@ -646,6 +646,13 @@ void Plan::process_stage(int sid) {
                 stages[sid].jend_host = jend;
                 stages[sid].tab_buf = raw_buf(tab.size() * 8);
                 stages[sid].jend_buf = raw_buf(jend.size() * 4);
+                // what k_rs_fixup needs to recompute the groups a non-finite sample reached output by output
+                if (!std::getenv("SIGOPS_RS_NO_FIXUP")) {
+                    stages[sid].rs_jrel_host.resize((size_t)Ls);
+                    for (int64_t r = 0; r < Ls; ++r) stages[sid].rs_jrel_host[(size_t)r] = (int)(jr[r] - jend[r / RM]);
+                    stages[sid].rs_jrel_buf = raw_buf((size_t)Ls * 4);
+                    stages[sid].rs_nf_buf = raw_buf((size_t)(4 + 4 * (kRsNfCap + 1)) * 4);
+                }
             }
         }
         }
