@@ -291,7 +291,13 @@ __device__ __forceinline__ void rsos_widen(uint32_t slot, uint32_t row_bytes, in
     }
 }
 
-constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlags = 56;
+constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlagXh = 49, kRsosFlags = 56;
+// Helper geometry (RsSos::help; 12 waves, taps in registers): the y waves of residues kRsosHres[0..2] -- one on each of SIMDs 1 .. 3 --
+// hand the y wave that shares the chain's SIMD (residue kRsosHelper) their X block instead of computing D . X themselves:
+// 68 / 68 / 68 / 66 MFMAs per round of ten blocks on the four SIMDs instead of 72 / 72 / 72 / 54.  (Not the chain wave: its
+// steps are the kernel's serial dependency.  Not the back parts -- state-dependent, needed at once: round 5 moved those and
+// made that wave the pace of everybody --: D . X of a block is needed ~8 blocks after its X exists.)
+constexpr int kRsosHres0 = 1, kRsosHres1 = 5, kRsosHres2 = 7, kRsosHelper = 6, kRsosHslots = 3;  // (SIMDs 2, 3, 1)
 constexpr int kRsosMaxGroups = 256;
 
 // What the three roles share besides the dynamic LDS (taps, ring, exchange slots): a copy of the kernel's arguments
@@ -352,6 +358,7 @@ __device__ __forceinline__ void rsos_count_out(long long* trace, int wave, int r
 struct RsosLds {
     SO_LDS double *taps, *ring, *gtab;
     volatile SO_LDS double *xs, *ss;  // what the waves hand each other
+    volatile SO_LDS double* xh;       // helper geometry: the fourth register of an X block ([3 waves][kRsosHslots][64]; 0..2 go to its xs slot)
 };
 // The roles are called with generic pointers (in vector registers, as the calling convention has it): made wave-uniform
 // 32-bit LDS pointers again here, so that every access below is a ds_ instruction with a scalar base.
@@ -378,6 +385,7 @@ __device__ __forceinline__ RsosLds rsos_carve(double* dyn_, int tapd, int rpitch
     l.xs = l.ring + (size_t)16 * rpitch;
     l.ss = l.xs + (size_t)nx * 192;
     l.gtab = (SO_LDS double*)l.ss + (size_t)ns * 192;
+    l.xh = l.gtab + 16 * 16 * 2;
     return l;
 }
 
@@ -1000,6 +1008,55 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     }
 }
 
+// =========================== helper wave ===========================
+// (16-wave geometry with RsSos::help: wave 12, the fourth wave of the chain's SIMD.)  D . X of the blocks whose y waves
+// hand over X itself -- residues kRsosHres0/1/2 of every round of NY blocks, in block order: four MFMAs that depend on
+// nothing but X, on the SIMD whose matrix pipe the chain's dependent steps leave idle two thirds of the time.  The result
+// replaces X in the block's exchange slot and the slot's counter tells the chain: what the y wave would have done itself.
+template <int NY>
+__device__ __attribute__((noinline)) void rsos_helper(RsosShared* sh_, double* dyn) {
+    constexpr int NX = 2 * NY + 1;
+    const int lane = threadIdx.x & 63;
+    SO_LDS RsosShared* const sh = (SO_LDS RsosShared*)rsos_lds_ptr(sh_);
+    const SO_LDS RsSos& g = sh->g;
+    const RsosLds l = rsos_carve(dyn, 0, uni(g.rpitch), NX, rsos_nss(NY));
+    const int NB = (uni(g.wp) + (int)rfl64(g.pr)) * uni(g.ngroups);
+    const double SO_GLB* mats = (const double SO_GLB*)rfl64((int64_t)(uintptr_t)g.mats);
+    const uint32_t fl_base = (uint32_t)(uintptr_t)sh->flags;
+    const int debug = uni(g.debug);
+    const bool f32m = uni(g.f32m) != 0 && uni(g.out_f32) != 0;
+    double Dk[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Dk[v] = f32m ? mats[(lane >> 4) * 64 + v * 16 + (lane & 15)] : mats[v * 64 + lane];
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int res[3] = {kRsosHres0, kRsosHres1, kRsosHres2};
+    int hslot[3] = {kRsosHres0 % NX, kRsosHres1 % NX, kRsosHres2 % NX}, hring = 0;
+    for (int b0 = 0; b0 < NB; b0 += NY) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int bh = b0 + res[j];
+            if (bh < NB) {
+                int spins = 0;
+                while (uni(flag_ld(fl_base + 4 * (kRsosFlagXh + j))) < bh + 1 && !(debug & 16)) SO_SPIN_PAUSE(spins, 2, 1 << 22);
+                double xr[4];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) xr[v] = l.xs[hslot[j] * 192 + v * 64 + lane];
+                xr[3] = l.xh[(j * kRsosHslots + hring) * 64 + lane];
+                v4d dh = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dh = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], xr[v], dh, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) l.xs[hslot[j] * 192 + v * 64 + lane] = dh[v];
+                flag_st(fl_base + 4 * (kRsosFlagXseq + hslot[j]), bh + 1);
+            }
+            hslot[j] += NY;
+            if (hslot[j] >= NX) hslot[j] -= NX;
+        }
+        hring = hring + 1 == kRsosHslots ? 0 : hring + 1;
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // =========================== y waves ===========================
 // CYC > 0: the wave's blocks cycle through CYC phase groups of the period (yi, yi + NY, ... modulo ngroups) and their
 // taps stay in registers for the whole kernel; CYC == 0: taps of any phase from the LDS table.
@@ -1009,7 +1066,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
 // row = 4 (lane >> 4) + reg where the Float64 instruction's is (lane >> 4) + 4 reg: register v of X, widened, is still k-step v of
 // the products that follow (D . X, X^T T^T: all Float64, like the cascade) -- with the k index of THEIR other operand
 // permuted the same way (Dk, Tk below are read from the matrices' table in that order).
-template <int KS, int NY, int NL, typename TO, int CYC, bool F32M = false>
+template <int KS, int NY, int NL, typename TO, int CYC, bool F32M = false, bool HW = false>
 __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dyn, int64_t G_, int yi_) {
     static_assert(!F32M || (sizeof(TO) == 4 && CYC > 0), "the Float32 MFMA form: Float32 results, taps in registers");
     constexpr int NX = 2 * NY + 1;
@@ -1118,6 +1175,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
         nb0_any = uni(m);
     }
+    // helper geometry: this wave hands its X blocks over (hj: which of the three), or is the one that takes them
+    constexpr bool HELPABLE = HW && NY == 10 && CYC == 1;  // (its own instantiation: the 12-wave kernel's block is what it was)
+    const bool help_on = HELPABLE && uni(g.help) != 0;
+    const int hj = !help_on ? -1 : yi == kRsosHres0 ? 0 : yi == kRsosHres1 ? 1 : yi == kRsosHres2 ? 2 : -1;
+    int hr = 0;  // (owner: this block's slot of the fourth-register ring; helper: per owner, below)
     int pi = 0, gi = yi;
     while (gi >= ngroups) {
         gi -= ngroups;
@@ -1347,9 +1409,12 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         }
         rsos_stamp(trace, wave, b / NY, 2, 40);
         // ---- D . X for the chain wave (its share of the recurrence that does not depend on the state) ----
+        // (helper geometry, a wave of the three: X itself goes to the exchange slot below, the helper wave forms D . X)
         v4d dx = v4d{0.0, 0.0, 0.0, 0.0};
+        if (!HELPABLE || hj < 0) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], ax[v], dx, 0, 0, 0);
+            for (int v = 0; v < 4; ++v) dx = __builtin_amdgcn_mfma_f64_16x16x4f64(Dk[v], ax[v], dx, 0, 0, 0);
+        }
         // ---- X^T T^T of this block (kept for the next round) ----
         // (also for a warm-up block, whose result is not stored: 7 % of the blocks; skipping the four products there makes
         //  the set a conditional value, and the register allocator pays for that with four copies behind an MFMA-result
@@ -1357,9 +1422,17 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
         pout = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0], Tk[0], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
         for (int v = 1; v < 4; ++v) pout = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[v], Tk[v], pout, 0, 0, 0);
+        if (!HELPABLE || hj < 0) {
 #pragma unroll
-        for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
-        flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
+            for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = dx[v];
+            flag_st(fl_base + 4 * (kRsosFlagXseq + slot), b + 1);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) l.xs[slot * 192 + v * 64 + lane] = ax[v];
+            l.xh[(hj * kRsosHslots + hr) * 64 + lane] = ax[3];
+            flag_st(fl_base + 4 * (kRsosFlagXh + hj), b + 1);
+            hr = hr + 1 == kRsosHslots ? 0 : hr + 1;
+        }
         // ---- the previous block's result ----
         if (early) back_store(ay_early, false);
         else if (pb_ >= 0) back(sq, sv, pin);
@@ -1436,10 +1509,16 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 }
 
 
+// NW: 8 / 12 / 16 waves, or 17 = the HELPER geometry: 16 waves of 128 registers with ONE loader (wave 4), ten y waves (1 - 3,
+// 5 - 7, 8 - 11: wave 8 shares the chain's SIMD) and wave 12 -- the chain's SIMD again -- forming D . X for three of them
+// (rsos_helper): what VERDICT round 5 asked for, a second wave on SIMD 0 that uses the matrix cycles the chain leaves.
+constexpr int rsos_nthreads(int nw) { return (nw == 17 ? 16 : nw) * 64; }
 template <int KS, int NW, typename TO, int CYC>
-__global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
+__global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
                                                   TO* __restrict__ y, RsGlobalTables gsrc) {
-    constexpr int NY = NW == 16 ? 10 : NW - 2, NL = NW == 16 ? 2 : 1, NX = 2 * NY + 1;
+    constexpr bool HW = NW == 17;
+    constexpr int NT = rsos_nthreads(NW);
+    constexpr int NY = NW >= 16 ? 10 : NW - 2, NL = NW == 16 ? 2 : 1, NX = 2 * NY + 1;
     // wave 0: chain; wave 4 (and 8 at 16 waves): loaders; the others: y waves (at 16 waves: ten of them -- one more on the
     // chain's SIMD, three on each of the others --, waves 13..15 have nothing to do)
     extern __shared__ double lds_raw[];
@@ -1457,12 +1536,12 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
         }
     }
     if constexpr (CYC == 0)
-        for (int i = threadIdx.x; i < g.ngroups * KS * 64; i += NW * 64) lds_raw[i] = tab[i];
-    for (int i = threadIdx.x; i < g.ngroups; i += NW * 64) sh.jend[i] = jend_g[i];
+        for (int i = threadIdx.x; i < g.ngroups * KS * 64; i += NT) lds_raw[i] = tab[i];
+    for (int i = threadIdx.x; i < g.ngroups; i += NT) sh.jend[i] = jend_g[i];
     {
         const int* src = reinterpret_cast<const int*>(gsrc.ctl);
         int* dst = reinterpret_cast<int*>(&sh.ctl);
-        for (int i = threadIdx.x; i < (int)(sizeof(RsCtl) / 4); i += NW * 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(RsCtl) / 4); i += NT) dst[i] = src[i];
     }
     const int64_t ncg = g.nch / g.ct;
     const int64_t ngrp = ncg * ((g.nranges + g.rgs - 1) / g.rgs);
@@ -1504,17 +1583,22 @@ __global__ __launch_bounds__(NW * 64) void k_rsos(const double* __restrict__ tab
                 else rsos_loader<NY, NL, 1, false>(&sh, lds_raw, G, q);
                 break;
             }
+        } else if (HW && wave == 12) {
+            if (g.help && !(g.debug & 128)) rsos_helper<NY>(&sh, lds_raw);
         } else if (!(g.debug & 128))
             {
-            if (NW == 16 && wave > 12) continue;
+            if (NW >= 16 && wave > 12) continue;
+            // (12 waves, and the helper geometry's sixteen: wave w sits on SIMD w % 4 and consecutive blocks go to consecutive
+            //  SIMDs -- residues 0 3 7 | 1 4 8 | 2 5 9 on SIMDs 1 | 2 | 3, 6 next to the chain.  Three consecutive residues on one
+            //  SIMD, tried for the helper geometry, cost the plain 12-wave form 4 %: the chain takes the blocks in order.)
             const int yi = NW == 16 ? (wave < 4 ? wave - 1 : wave < 8 ? wave - 2 : wave < 12 ? wave - 3 : 9) : wave - (wave > 4 ? 2 : 1);
             if constexpr (sizeof(TO) == 4 && CYC > 0) {
                 if (g.f32m) {
-                    rsos_ywave<KS, NY, NL, TO, CYC, true>(&sh, lds_raw, G, yi);
+                    rsos_ywave<KS, NY, NL, TO, CYC, true, HW>(&sh, lds_raw, G, yi);
                     continue;
                 }
             }
-            rsos_ywave<KS, NY, NL, TO, CYC>(&sh, lds_raw, G, yi);
+            rsos_ywave<KS, NY, NL, TO, CYC, false, HW>(&sh, lds_raw, G, yi);
         }
     }
 }
@@ -1528,7 +1612,7 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
     static bool seen[64];
     if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)k_rsos<KS, NW, TO, CYC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsos_lds_budget());
-    hipLaunchKernelGGL((k_rsos<KS, NW, TO, CYC>), dim3((unsigned)grid), dim3(NW * 64), lds, st, tab, jend, g, (TO*)y, gsrc);
+    hipLaunchKernelGGL((k_rsos<KS, NW, TO, CYC>), dim3((unsigned)grid), dim3(rsos_nthreads(NW)), lds, st, tab, jend, g, (TO*)y, gsrc);
 }
 
 // returns 0 when launched, -1 if no instantiation fits
@@ -1552,6 +1636,11 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
     if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 16) if (g.nwaves == 16) {
         if (g.cyc != 1) return -1;
         launch_rsos_k<KS, 16, TO, 1>(tab, jend, g, y, gsrc, grid, st);
+        return 0;
+    }
+    if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 17) if (g.nwaves == 17) {
+        if (g.cyc != 1) return -1;
+        launch_rsos_k<KS, 17, TO, 1>(tab, jend, g, y, gsrc, grid, st);
         return 0;
     }
     if constexpr (SO_RSOS_ONLY_NW == 0 || SO_RSOS_ONLY_NW == 8) if (g.nwaves == 8) {
@@ -1598,15 +1687,17 @@ int SO_RSOS_CAT(SO_RSOS_CAT(SO_RSOS_CAT(launch_rsos_ks, SO_RSOS_ONLY_KS), SO_RSO
 #else
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
-    const int ny = nwaves == 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
-    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)rsos_nss(ny) * 192 + 16 * 16 * 2) * 8;
+    const int ny = nwaves >= 16 ? 10 : nwaves - 2, nx = 2 * ny + 1;
+    return ((cyc > 0 ? 0 : (size_t)ngroups * ks * 64) + (size_t)16 * rpitch + (size_t)nx * 192 + (size_t)rsos_nss(ny) * 192 + 16 * 16 * 2 +
+            (nwaves == 17 ? 3 * kRsosHslots * 64 : 0)) * 8;
 }
 size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 
 #if SO_RSOS_ONLY_KS == 0
 #define SO_RS(KS_) \
     int launch_rsos_ks##KS_##d12(SO_RSOS_ARGS); int launch_rsos_ks##KS_##d16(SO_RSOS_ARGS); int launch_rsos_ks##KS_##d8(SO_RSOS_ARGS); \
-    int launch_rsos_ks##KS_##f12(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f16(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f8(SO_RSOS_ARGS);
+    int launch_rsos_ks##KS_##f12(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f16(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f8(SO_RSOS_ARGS); \
+    int launch_rsos_ks##KS_##d17(SO_RSOS_ARGS); int launch_rsos_ks##KS_##f17(SO_RSOS_ARGS);
 SO_RS(4) SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
 #undef SO_RS
 #endif
@@ -1619,6 +1710,7 @@ int launch_rsos(SO_RSOS_ARGS) {
         if (g.nwaves == 12) return g.out_f32 ? launch_rsos_ks##KS_##f12(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d12(tab, jend, g, y, gsrc, grid, st); \
         if (g.nwaves == 16) return g.out_f32 ? launch_rsos_ks##KS_##f16(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d16(tab, jend, g, y, gsrc, grid, st); \
         if (g.nwaves == 8) return g.out_f32 ? launch_rsos_ks##KS_##f8(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d8(tab, jend, g, y, gsrc, grid, st);    \
+        if (g.nwaves == 17) return g.out_f32 ? launch_rsos_ks##KS_##f17(tab, jend, g, y, gsrc, grid, st) : launch_rsos_ks##KS_##d17(tab, jend, g, y, gsrc, grid, st); \
         return -1;                                                                                                                 \
     }
 #else

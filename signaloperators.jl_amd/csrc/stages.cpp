@@ -1906,7 +1906,7 @@ void Plan::fuse_resample_sos() {
         // the phase groups its blocks cycle through in registers where they fit (10 y waves and the 10 groups of
         // 44.1 -> 48 kHz: one group each); otherwise the tap table goes to LDS and the input ring shrinks
         {
-            auto cyc_of = [&](int nw) { return g.ngroups / std::__gcd(nw == 16 ? 10 : nw - 2, g.ngroups); };
+            auto cyc_of = [&](int nw) { return g.ngroups / std::__gcd(nw >= 16 ? 10 : nw - 2, g.ngroups); };
             auto fits = [&](int nw) {
                 const int c = cyc_of(nw);
                 return nw == 12 ? ((c == 1 || c == 2) && c * ks <= 32) : ((c == 1 || c == 2 || c == 3 || c == 5) && c * ks <= 80);
@@ -1920,19 +1920,23 @@ void Plan::fuse_resample_sos() {
             //  the second loader wave still pays, 1.46 against 1.72)
             const bool stepped = was_ga || (!plain_src && !S3.carriers.empty() && S3.carriers[0].nsteps > 0);
             if (ct == 2 && stepped && nw == 12 && cyc_of(16) == 1 && ks <= 16) nw = 16;
-            if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : std::atoi(ev) == 16 && cyc_of(16) == 1 && ks <= 16 ? 16 : 12;
+            // (the helper geometry: sixteen waves of 128 registers, ONE loader, and a wave on the chain's SIMD that forms D . X for
+            //  three of the y waves -- k_rsos.hip, NW = 17: 68 / 68 / 68 / 66 MFMAs per round on the four SIMDs instead of 72 / 72 / 72 / 54)
+            // MEASURED (round 6) AND NOT THE DEFAULT: 0.978 ms against 0.978 for the plain pipeline, 1.08 against 1.00 with the fused
+            // Mix (the loader at 128 registers; four waves on the chain's SIMD) -- SIGOPS_RSOS_NWAVES=17 selects it
+            if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : (std::atoi(ev) == 16 || std::atoi(ev) == 17) && cyc_of(16) == 1 && ks <= 16 ? std::atoi(ev) : 12;
             g.nwaves = nw;
-            g.cyc = (nw == 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
+            g.cyc = (nw >= 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
             // (waves, groups per wave, window) as launch_rsos_t instantiates them -- a combination it has not (the 16-wave
             //  geometry with its taps in LDS, SIGOPS_RSOS_LDSTAPS) keeps the two kernels HERE instead of failing the execute
             const bool inst = nw == 12 ? (g.cyc == 0 || g.cyc == 1 || (g.cyc == 2 && ks <= 16))
-                            : nw == 16 ? g.cyc == 1
+                            : nw >= 16 ? g.cyc == 1
                                        : (g.cyc == 0 || g.cyc == 1 || g.cyc == 2 || (g.cyc == 3 && ks <= 20) || (g.cyc == 5 && ks <= 16));
             if (!inst) continue;
         }
         // input ring: as large as fits next to the tap table (if any) and the exchange slots
         {
-            const int ny = g.nwaves == 16 ? 10 : g.nwaves - 2;
+            const int ny = g.nwaves >= 16 ? 10 : g.nwaves - 2;
             // (a y wave's front part runs up to one of its own blocks ahead: the windows in use span 2 ny - 1 blocks)
             const int64_t span = (int64_t)(2 * ny - 1) * ((16 * Mp + L - 1) / L + 1) + kwp + 16 + 2 * g.chunk;
             int ring = 4096;  // (a multiple of 128: whole chunks, and rows of ring + 2 doubles fall on different banks)
@@ -1993,6 +1997,7 @@ void Plan::fuse_resample_sos() {
         // a Float64 signal made of a Float32 array and a Float64 generator it is that signal rounded to Float32 on its way INTO
         // the resampler instead of on its way into the Float32 result: inside the 1e-6 contract (tools/soak_rsos_f32m.py,
         // profiles/r06/relerr_maxima_rsos_f32m.json: worst 1.5e-7; gate 3e-7), SIGOPS_RSOS_NO_F32MFMA=1 keeps the Float64 products.
+        g.help = g.nwaves == 17 ? 1 : 0;
         g.f32m = g.src32 && g.fuse >= -1 && g.cyc > 0 && !std::getenv("SIGOPS_RSOS_NO_F32MFMA") && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;
         S2.rs = g;
         S2.rsos_src = i3;
@@ -2150,6 +2155,7 @@ void Plan::fuse_plain_sos() {
             g.ring = ring;
             g.rpitch = ring + 2;
         }
+        g.help = 0;  // (this form's pace is the chain wave's step: nothing more onto its SIMD)
         g.src32 = pure32 ? 1 : 0;
         g.x32 = pure32 ? 1 : 0;
         g.ring32 = pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;
