@@ -117,6 +117,25 @@ def pmc_traffic(stage_name):
     return None, None
 
 
+def pmc_traffic_sink(tag):
+    """HBM bytes per execute of a WHOLE sink (every stage of workload `tag` in the newest profiles/rNN/bench_pmc_hbm.json added up):
+    for the lines whose roofline is the sink's, not one kernel's (config 4, config 5).  Same rules as pmc_traffic."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "bench_pmc_hbm.json")), reverse=True)
+    if not paths:
+        return None, None
+    rel = os.path.relpath(paths[0], ROOT)
+    with open(paths[0]) as f:
+        d = json.load(f)
+    if d.get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, "%s is from other kernel sources (%s, now %s): not quoted" % (rel, d.get("kernel_sources_sha16"), kernel_sources_sha16())
+    vals = [v.get("corrected_bytes_per_execute") for k, v in d.get("stages", {}).items() if k.startswith(tag + ":")]
+    if not vals:
+        return None, None
+    return float(sum(vals)), rel + " (all stages of this workload, rocprofv3 --pmc passes on these kernel sources; not this run)"
+
+
 def kernel_sources_sha16():
     """hash of the device code's sources (what the PMC numbers depend on; the .so itself differs from build to build)"""
     import glob

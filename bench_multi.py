@@ -14,6 +14,22 @@ config5  x[10 000 000 x 128 per GPU] |> Filt(Lowpass 4 kHz) |> ToFramerate(16 kH
 import json
 import time
 
+
+def _sink_traffic(workload, world):
+    """PMC bytes per execute of the whole sink on ONE GPU (the PMC passes are single-GPU runs of the full workload: quoted for the
+    1-GPU line only)"""
+    if world != 1:
+        return None, "the PMC passes are of the 1-GPU run"
+    import bench
+
+    return bench.pmc_traffic_sink(workload)
+
+
+def _kernel_traffic(name):
+    import bench
+
+    return bench.pmc_traffic(name)
+
 import numpy as np
 
 
@@ -202,7 +218,8 @@ def run(args, so, torch, dist, rank, local_rank, world, dev, emit=True):
                 "dtype": args.dtype, "data": "synthetic", "config": cfg,
                 "algorithmic_bytes_per_step": algo,
                 "roofline": {"bound": "hbm", "achieved": algo / (ms_c * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": algo / (ms_c * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                             "frac": algo / (ms_c * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
+                             "traffic": _sink_traffic(args.workload, world)[0], "traffic_source": _sink_traffic(args.workload, world)[1],
                              "kernel": "whole sink per GPU, compute only (timed loop)"},
                 "rccl_ranks": dist.get_world_size() if dist is not None and dist.get_backend() == "nccl" else None,
                 "parity_gate": gate, "cpu_baseline": None})
@@ -247,8 +264,10 @@ def run(args, so, torch, dist, rank, local_rank, world, dev, emit=True):
                 "algorithmic_bytes_per_step": algo, "stages": stages,
                 "roofline": {"bound": "hbm", "achieved": dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None, "kernel": dom["name"], "kernel_ms": dom["ms"]},
+                             "traffic": _kernel_traffic("config5:" + dom["name"])[0], "traffic_source": _kernel_traffic("config5:" + dom["name"])[1],
+                             "kernel": dom["name"], "kernel_ms": dom["ms"]},
                 "roofline_sink": {"achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": _sink_traffic("config5", 1)[0], "traffic_source": _sink_traffic("config5", 1)[1],
                                   "from": "timed loop, per GPU"},
                 "cpu_baseline": None}), flush=True)
         plan.close()
