@@ -655,6 +655,7 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                         rs.out_f32 = g.out_dtype == SO_F32 || N.dtype == SO_F32;
                         if (rs.f32m && rs.out_f32) rs.ring32 = 1;  // (a Float32 result: Float32 samples in the ring, the Float32 MFMA)
                         else rs.f32m = 0;
+                        rs.sring = rs.f32m && (rs.fuse == 1 || rs.fuse == 2) && !std::getenv("SIGOPS_RSOS_NO_SRING") ? 1 : 0;
                         // the kernel's output m is frame m - store_lo of this stage's buffer (a window: the resampler's warm
                         // start lies store_lo frames before the cascade's); the sink's own skipped frames come on top
                         char* const yk = (char*)ob.d - (size_t)S.rs.store_lo * (rs.out_f32 ? 4 : 8);

@@ -625,6 +625,8 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     const char* const base0 = (const char*)rfl64((int64_t)(uintptr_t)C0.base);
     const int fuse = uni(g.fuse), fuse_sine = uni(g.fuse_sine), debug = uni(g.debug);
     const bool ring32 = SRC32 && uni(g.ring32) != 0;  // (the chunks stay Float32, at four bytes a frame: the y waves widen their operands)
+    const bool sring = ring32 && uni(g.sring) != 0;   // (... and the fused v + m / v - m is added by the y waves: the summand ring)
+    const uint32_t half_bytes = (uint32_t)uni(g.rpitch) * 4u;
     constexpr bool src32 = SRC32;  // (a Float32 array: 4-byte elements, 128 of them per chunk and LDS-DMA instruction; its own
                                    //  instantiation: the Float64 loader's per-chunk path stays what it was)
     constexpr int esh = src32 ? 2 : 3;
@@ -884,7 +886,12 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         }
         if (gain && !gain_done) {
             for (int j = 0; j < MU; ++j) {
-                if (!(k >= u_klo(j) && k < u_khi(j))) continue;
+                if (!(k >= u_klo(j) && k < u_khi(j))) {
+                    // (the summand ring -- see below -- of a chunk the general path staged with the step applied, or of zeros: zero)
+                    if (SRC32 && sring && lane < lanes)
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(u_lds(j) + half_bytes + (uint32_t)rho0 * 4u + (uint32_t)lane * 8u), "v"(float2{0.f, 0.f}) : "memory");
+                    continue;
+                }
                 const int u = q + j * NL;
                 v2d gn;
                 if (fuse_sine) {
@@ -893,7 +900,16 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                     gn[1] = fma(bs.x, d1.y, bs.y * d1.x);
                 } else
                     gn[0] = gn[1] = gconst;
-                if (src32 && ring32) {  // (the step on the Float32 samples where they lie: RsSos::f32m)
+                if (src32 && ring32 && sring) {
+                    // The summand ring (RsSos::sring: v + m / v - m on a ring of Float32 samples): the operand's two frames of this
+                    // lane go into the FREE half of the unit's first ring row (Float32 samples fill half a row), and the y waves
+                    // add them to their window operands -- one LDS write per unit here instead of a read, an add and a write per
+                    // row and lane next to the chain wave's MFMAs (the step in place cost 0.16 ms of the Float32 headline's 0.97).
+                    if (lane < lanes) {
+                        const float g0 = fuse == 2 ? -(float)gn[0] : (float)gn[0], g1 = fuse == 2 ? -(float)gn[1] : (float)gn[1];
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(u_lds(j) + half_bytes + (uint32_t)rho0 * 4u + (uint32_t)lane * 8u), "v"(float2{g0, g1}) : "memory");
+                    }
+                } else if (src32 && ring32) {  // (the step on the Float32 samples where they lie: RsSos::f32m)
                     if (lane < lanes) {
                         const uint32_t la = u_lds(j) + (uint32_t)rho0 * 4u + (uint32_t)lane * 8u;
                         const float g0 = (float)gn[0], g1 = (float)gn[1];
@@ -1094,6 +1110,8 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const bool x32 = sizeof(TO) == 4 && uni(g.x32) != 0;
     // (the ring keeps Float32 samples, four bytes a frame: RsSos::ring32 -- Float32-result instantiations only)
     [[maybe_unused]] const bool ring32 = sizeof(TO) == 4 && uni(g.ring32) != 0;
+    [[maybe_unused]] const bool sring = F32M && uni(g.sring) != 0;
+    [[maybe_unused]] const int srow = ((lane & 15) / (ct < 8 ? ct : 8)) * (ct < 8 ? ct : 8);  // (first ring row of this lane's unit)
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && uni(g.fuse) >= -1 &&
                         (!src32 || uni(g.chunk) == 128);
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
@@ -1320,6 +1338,23 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
                     const int p_ = pos + 4 * s;
                     bf32[s] = *(const SO_LDS float*)(ringc + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 4u);
                 }
+            }
+            if (sring) {  // (the fused v + m: the loader left m -- Float32, per range -- in the free half of the unit's first row)
+                float sn[KS];
+                const SO_LDS char* const sbase = (const SO_LDS char*)l.ring + (uint32_t)srow * (uint32_t)rpitch * 8u + (uint32_t)rpitch * 4u;
+                if (wbm + 20 + kw <= RING) {
+                    const SO_LDS float* p0 = (const SO_LDS float*)(sbase + (uint32_t)pos * 4u);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) sn[s] = p0[4 * s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const int p_ = pos + 4 * s;
+                        sn[s] = *(const SO_LDS float*)(sbase + (uint32_t)(p_ >= RING ? p_ - RING : p_) * 4u);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) bf32[s] += sn[s];
             }
             have_bx = true;
         } else if constexpr (sizeof(TO) == 4) {
