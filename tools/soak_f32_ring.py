@@ -87,6 +87,9 @@ for case in range(ncases):
     e = float(relerr(a, w)) if a.size else 0.0
     ec = float(relerr(a, c)) if a.size else 0.0
     worst = max(worst, e)
-    if a.dtype != np.float32 or not np.array_equal(a, b) or not (e <= 1e-6) or not (ec <= 3e-7):
+    # (round 6: resampled Float32 signals run the Float32 MFMA inside the fused kernel -- another rounding than the widening loader's
+    #  Float64 products; bit-equality with it holds, and is checked, under SIGOPS_RSOS_NO_F32MFMA=1: profiles/r06/soak_r06_others.txt)
+    same = np.array_equal(a, b) if os.environ.get("SIGOPS_RSOS_NO_F32MFMA") else float(relerr(a, b)) <= 3e-7
+    if a.dtype != np.float32 or not same or not (e <= 1e-6) or not (ec <= 3e-7):
         bad.append({"case": case, "fi": fi, "nch": nch, "n": n, "names": names, "relerr": e, "vs_unfused": ec, "equal": bool(np.array_equal(a, b))})
 print(json.dumps({"cases": ncases, "seed": seed, "with_k_rsos": int(ring), "worst_relerr": worst, "bad": bad[:8], "n_bad": len(bad)}))
