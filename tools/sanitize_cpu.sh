@@ -21,7 +21,7 @@ for f in planner stages accumulator executor design capi comm rtc; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize \
       -fno-omit-frame-pointer -x hip -c $C/$f.cpp -o $T/$f.o 2>&1 | grep -v "warning\|^ \|^$" | head -5
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $T/libsigops.so $T/planner.o $T/stages.o $T/accumulator.o $T/executor.o $T/design.o $T/capi.o $T/comm.o $T/rtc.o $C/k_pointwise.o $C/k_sos.o $C/k_small.o $C/k_resample_u*.o $C/k_rsos_ks*.o $C/k_resample_arb.o $C/kernels2.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $T/libsigops.so $T/planner.o $T/stages.o $T/accumulator.o $T/executor.o $T/design.o $T/capi.o $T/comm.o $T/rtc.o $C/k_pointwise.o $C/k_sos.o $C/k_small.o $C/k_exact.o $C/k_resample_u*.o $C/k_rsos_ks*.o $C/k_resample_arb.o $C/kernels2.o -ldl
 RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$RT SIGOPS_LIB=$T/libsigops.so \
 python -m pytest tests/test_design.py tests/test_host_api.py tests/test_resample_positions.py tests/test_oracle_dsp.py tests/test_randn_lowering.py \
