@@ -291,7 +291,7 @@ __device__ __forceinline__ void rsos_widen(uint32_t slot, uint32_t row_bytes, in
     }
 }
 
-constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlagXh = 49, kRsosFlags = 56;
+constexpr int kRsosFlagLdp = 0, kRsosFlagYrd = 4, kRsosFlagXseq = 16, kRsosFlagSseq = 48, kRsosFlagXh = 49, kRsosFlagLnd = 52, kRsosFlags = 56;
 // Helper geometry (RsSos::help; 12 waves, taps in registers): the y waves of residues kRsosHres[0..2] -- one on each of SIMDs 1 .. 3 --
 // hand the y wave that shares the chain's SIMD (residue kRsosHelper) their X block instead of computing D . X themselves:
 // 68 / 68 / 68 / 66 MFMAs per round of ten blocks on the four SIMDs instead of 72 / 72 / 72 / 54.  (Not the chain wave: its
@@ -592,7 +592,12 @@ __device__ __forceinline__ int vmcnt_now() {
     return (int)((v & 0xfu) | ((v >> 18) & 0x30u));
 }
 
-template <int NY, int NL, int RU, bool SRC32, int RB = 0>
+// MODE (RsSos::gsplit: the 16-wave geometry of two-channel groups with a fused step): 0 the whole loader; 1 the loader without
+// the step -- it issues, waits for a chunk to land and says so (kRsosFlagLnd) --; 2 the STEP wave (one of the otherwise idle
+// waves 13 / 14, on SIMDs 1 / 2) that applies the step to a landed chunk and publishes it.  Issue and step of a stereo chunk
+// are ~2 600 - 3 100 and ~2 000 - 2 500 cycles of ONE wave's time (every vector instruction next to fp64 MFMAs waits for a
+// gap between them) against a chunk period of ~6 000 at the plain pipeline's pace: as two stages of a pipeline they fit.
+template <int NY, int NL, int RU, bool SRC32, int RB = 0, int MODE = 0>
 __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
@@ -788,6 +793,12 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
     };
     auto retire = [&](int k, int rho0, int allowed) __attribute__((always_inline)) {
         rsos_stamp(trace, wave, k, 2, 40);
+        if constexpr (MODE == 1) {  // (the step wave takes it from here)
+            wait_vmcnt_le60(allowed);
+            flag_st(fl_base + 4 * (kRsosFlagLnd + q), k + 1);
+            rsos_stamp(trace, wave, k, 4, 40);
+            return;
+        }
         const bool gain = (fuse >= 0 || (src32 && !ring32)) && !(debug & 2);
         // what does not depend on the chunk's samples comes BEFORE the wait for them: the share bases of the next sixteen
         // chunks (every sixteenth chunk) and this chunk's own, read back from LDS
@@ -820,7 +831,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
             bs0 = double2{l.gtab[(u0 * 16 + (k & 15)) * 2], l.gtab[(u0 * 16 + (k & 15)) * 2 + 1]};
             if (MU > 1) bs1 = double2{l.gtab[(u1 * 16 + (k & 15)) * 2], l.gtab[(u1 * 16 + (k & 15)) * 2 + 1]};
         }
-        wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
+        if constexpr (MODE == 0) wait_vmcnt_le60(allowed);  // chunk k's DMA has landed
         rsos_stamp(trace, wave, k, 3, 40);
         bool gain_done = false;
         if constexpr (RU < 8 && !SRC32) {
@@ -958,6 +969,17 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         flag_st(fl_base + 4 * (kRsosFlagLdp + q), (k + 1) * CH);
         rsos_stamp(trace, wave, k, 4, 40);
     };
+    if constexpr (MODE == 2) {  // the step wave: chunk after chunk as the loader reports them landed
+        int rho = 0, spins2 = 0;
+        for (int k = 0; k < NK; ++k) {
+            spins2 = 0;
+            while (uni(flag_ld(fl_base + 4 * (kRsosFlagLnd + q))) < k + 1 && !(debug & 32)) SO_SPIN_PAUSE(spins2, 2, 1 << 22);
+            retire(k, rho, 0);
+            rho = rho + CH == RING ? 0 : rho + CH;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return;
+    }
     int issued = 0, retired = 0;
     int rho_i = 0, rho_r = 0;       // ring positions of the next chunk to issue / to retire
     int c0n = 0, c1n = 0, c2n = 0;  // DMA instructions of the youngest, second and third youngest chunk in flight
@@ -1589,9 +1611,34 @@ __global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __rest
         __syncthreads();
         if (wave == 0) {
             if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw, G);
+        } else if (NW == 16 && (wave == 13 || wave == 14)) {
+            // (the step waves of two-channel / four-channel groups: RsSos::gsplit)
+            if (!g.gsplit || (g.debug & 256) || g.src32) continue;
+            const int q = wave - 13;
+            if (ru == 2) {
+                if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8, 2>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 642) rsos_loader<NY, NL, 2, false, 642 * 8, 2>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 2, false, 0, 2>(&sh, lds_raw, G, q);
+            } else if (ru == 4) {
+                if (g.rpitch == 770) rsos_loader<NY, NL, 4, false, 770 * 8, 2>(&sh, lds_raw, G, q);
+                else if (g.rpitch == 642) rsos_loader<NY, NL, 4, false, 642 * 8, 2>(&sh, lds_raw, G, q);
+                else rsos_loader<NY, NL, 4, false, 0, 2>(&sh, lds_raw, G, q);
+            }
         } else if (wave == 4 || (NW == 16 && wave == 8)) {
             const int q = wave == 4 ? 0 : 1;
             if (g.debug & 256) continue;
+            if (NW == 16 && g.gsplit && !g.src32 && (ru == 2 || ru == 4)) {
+                if (ru == 2) {
+                    if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8, 1>(&sh, lds_raw, G, q);
+                    else if (g.rpitch == 642) rsos_loader<NY, NL, 2, false, 642 * 8, 1>(&sh, lds_raw, G, q);
+                    else rsos_loader<NY, NL, 2, false, 0, 1>(&sh, lds_raw, G, q);
+                } else {
+                    if (g.rpitch == 770) rsos_loader<NY, NL, 4, false, 770 * 8, 1>(&sh, lds_raw, G, q);
+                    else if (g.rpitch == 642) rsos_loader<NY, NL, 4, false, 642 * 8, 1>(&sh, lds_raw, G, q);
+                    else rsos_loader<NY, NL, 4, false, 0, 1>(&sh, lds_raw, G, q);
+                }
+                continue;
+            }
             switch (ru) {
             case 8:
                 if (g.src32 && g.rpitch == 770) rsos_loader<NY, NL, 8, true, 770 * 8>(&sh, lds_raw, G, q);

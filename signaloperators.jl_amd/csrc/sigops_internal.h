@@ -403,6 +403,7 @@ struct RsSos {
                           // MFMA (taps rounded once, Float32 accumulators; the cascade stays Float64) and the step on the Float32 samples
     int32_t sring;        // f32m with the fast path's step v + m / v - m: the loader writes m (Float32, once per unit and chunk) into the
                           // free half of the unit's first ring row and the y waves add it to their window operands
+    int32_t gsplit;       // 16 waves, groups of 2 / 4 channels with a fused step: the step is applied by waves 13 / 14 (k_rsos.hip, MODE)
     int32_t help;         // 12 waves, taps in registers: three y waves hand their X blocks to the y wave on the chain's SIMD, which
                           // forms D . X for them (k_rsos.hip, kRsosHres*: the SIMDs' MFMA counts evened out)
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space

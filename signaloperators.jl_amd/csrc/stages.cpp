@@ -1875,7 +1875,9 @@ void Plan::fuse_resample_sos() {
             //  lane-table reads next to the chain wave's MFMAs: the loader sets the pace there -- 1e8 samples: 0.65 ms
             //  for 8 channels per group, 0.78 / 1.01 / 2.07 for 4 / 2 (two loader waves) / 1 (tools/channel_matrix.py, tools/rsos_ct_abl.sh;
             //  an affine, table-free addressing of unaligned rows was built and is slower still) -- two kernels: 1.0)
-            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.2 : ct == 2 ? 1.55 : 3.2;  // (ct == 2: with its second loader wave)
+            // (round 6, measured with the step waves and without the spilled store offsets: 4 ch 1.04 / 0.98 with / without a fused
+            //  step against 0.95 for 8 ch; 2 ch 1.06 / 1.06)
+            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.1 : ct == 2 ? 1.15 : 3.2;
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.30 * unit_cost * (ks + 14) / 28.0 + 15.0;
             const double t_two = 8.0e-6 * (double)need * nch + 95.0;
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
@@ -1918,8 +1920,13 @@ void Plan::fuse_resample_sos() {
             //  reload and a wait for the previous store: 0.3 ms of a stereo signal's 1.34, k_rsos.hip `ystep`.  Without the spills
             //  12 waves win where the loader has no step to apply (2 ch x 2400 s: 1.07 against 1.10 ms); with the fused step
             //  the second loader wave still pays, 1.46 against 1.72)
+            //  ... and since the step has waves of its own (k_rsos.hip, MODE: the two loaders issue and wait, waves 13 / 14 apply the
+            //  step and publish -- two stages of a pipeline instead of one wave's serial time per chunk) sixteen waves carry groups of
+            //  two AND four channels with a fused step at the plain pipeline's pace: 2 ch 1.42 -> 1.06 ms, 4 ch 1.24 -> 1.04
             const bool stepped = was_ga || (!plain_src && !S3.carriers.empty() && S3.carriers[0].nsteps > 0);
-            if (ct == 2 && stepped && nw == 12 && cyc_of(16) == 1 && ks <= 16) nw = 16;
+            if ((ct == 2 || (ct == 4 && !was_ga && nodes[S2.node].dtype == SO_F64 && !std::getenv("SIGOPS_RSOS_NOGSPLIT"))) && stepped && nw == 12 &&
+                cyc_of(16) == 1 && ks <= 16)
+                nw = 16;
             // (the helper geometry: sixteen waves of 128 registers, ONE loader, and a wave on the chain's SIMD that forms D . X for
             //  three of the y waves -- k_rsos.hip, NW = 17: 68 / 68 / 68 / 66 MFMAs per round on the four SIMDs instead of 72 / 72 / 72 / 54)
             // MEASURED (round 6) AND NOT THE DEFAULT: 0.978 ms against 0.978 for the plain pipeline, 1.08 against 1.00 with the fused
@@ -1989,6 +1996,7 @@ void Plan::fuse_resample_sos() {
             } else if (c0.nsteps > 0)
                 g.fuse = -2;  // (every chunk takes the general staging path)
         }
+        g.gsplit = g.nwaves == 16 && !g.src32 && g.fuse >= 0 && (ct == 2 || ct == 4) && !std::getenv("SIGOPS_RSOS_NOGSPLIT") ? 1 : 0;
         g.ring32 = g.src32 && g.fuse == -1 && pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;  // (no step: the ring keeps the Float32 samples)
         // A Float32 array -- with or without the fast path's one step -- into a Float32 RESULT (known at execute time: the stage
         // may turn out to write the sink's Float32 buffer itself, Plan::alias_narrow): the ring keeps Float32 samples, the step is
@@ -2103,6 +2111,8 @@ void Plan::fuse_plain_sos() {
         nranges = (nperiods + pr - 1) / pr;
         const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
         if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * L >= ((int64_t)1 << 30)) continue;
+        const bool stepped_few = (ct == 2 || ct == 4) && !pure32 && c0.nsteps == 1 && !std::getenv("SIGOPS_RSOS_NOGSPLIT");
+        const int plain_nw = env_int("SIGOPS_PLAIN_NWAVES", stepped_few ? 16 : 12) == 16 ? 16 : 12;
         if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
             if (ngrp < std::atoll(ev)) continue;
         } else {
@@ -2113,12 +2123,15 @@ void Plan::fuse_plain_sos() {
             // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
             // (unit costs re-measured with the loader's vectorised unit scan: 25 M x 4 0.417 against 0.444, 50 M x 2 0.452 / 0.465)
             // (50 M x 2: the three passes read 0.406 - 0.465 by box, this form 0.452 - 0.458: 1.4 keeps the three passes there)
-            const double unit_cost = ct >= 8 ? 1.0 : ct == 4 ? 1.19 : ct == 2 ? 1.4 : 3.4;
+            // (with the step waves -- a fused step on groups of two / four channels, sixteen waves --: 50 M x 2 0.440, 25 M x 4 0.419)
+            const double unit_cost = stepped_few && plain_nw == 16 ? (ct == 4 ? 1.16 : 1.22) : ct >= 8 ? 1.0 : ct == 4 ? 1.19 : ct == 2 ? 1.4 : 3.4;
             const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
             const double nsamp = (double)need * nch;
             // (re-measured at the round's end: 12.5 M x 8 0.452 ms, 28.8 M x 8 0.891; Float32 signals: the three passes move half
             //  the bytes and take 0.9 of the time -- 0.40 / 0.82 --, this kernel's pace is the chain's: 0.335 / 0.72)
-            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (pure32 ? 0.9 : 1.0);
+            // (a sine formed in K2's own loads costs it ~10 %: Mix(sine, x) |> Filt(Bandstop) of 50 M x 2 0.509 ms against 0.440 for
+            //  this form with its step waves, 25 M x 4 0.512 against 0.419 -- tools/iir_mix_probe.py)
+            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (pure32 ? 0.9 : 1.0) * (c0.nsteps > 0 ? 1.1 : 1.0);
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
                              (long long)ngrp, (long long)pr, (long long)wp, t_three);
@@ -2143,7 +2156,9 @@ void Plan::fuse_plain_sos() {
         g.depth = std::max(1, std::min(4, env_int("SIGOPS_RSOS_DEPTH", 4)));
         g.nsec = cf.nsec;
         g.debug = env_int("SIGOPS_RSOS_DEBUG", 0);
-        g.nwaves = 12;
+        // (groups of two / four channels with a fused step: sixteen waves -- two loaders that issue, two step waves -- as in the
+        //  fused resampler + IIR form; SIGOPS_PLAIN_NWAVES: measurements)
+        g.nwaves = plain_nw;
         g.cyc = 1;
         {
             const int ny = 10;
@@ -2159,6 +2174,7 @@ void Plan::fuse_plain_sos() {
         g.src32 = pure32 ? 1 : 0;
         g.x32 = pure32 ? 1 : 0;
         g.ring32 = pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;
+        g.gsplit = 0;
         g.fuse = -1;
         if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 && (c0.op[0] == OP_MUL || c0.op[0] == OP_ADD || c0.op[0] == OP_SUB)) {
             g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);
@@ -2169,6 +2185,7 @@ void Plan::fuse_plain_sos() {
             else g.fuse = -2;
         } else if (c0.nsteps > 0)
             g.fuse = -2;
+        g.gsplit = g.nwaves == 16 && !g.src32 && g.fuse >= 0 && (ct == 2 || ct == 4) && !std::getenv("SIGOPS_RSOS_NOGSPLIT") ? 1 : 0;
         // identity taps: block gi of the period reads inputs [16 gi, 16 gi + 16)
         S2.rsos_tab_host.assign((size_t)ngp * kw * 16, 0.0);
         S2.rsos_jend_host.assign((size_t)ngp, 0);
