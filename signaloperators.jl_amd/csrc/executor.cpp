@@ -230,6 +230,7 @@ void Plan::finalize() {
         if (stages[i].need > 0) order.push_back((int)i);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return stages[a].node < stages[b].node; });
     std::vector<char> batch_pushed(batches.size(), 0);
+    std::vector<char> rsb_pushed(rsbatches.size(), 0);
     for (int sid : order) {
         Stage& S = stages[sid];
         if (S.batch >= 0) {  // one step for the whole batch, where its first member stood (members wait for nothing)
@@ -238,6 +239,18 @@ void Plan::finalize() {
             Step st{2, S.batch, "k_sos_batch", 0};
             for (int m : batches[S.batch].members)
                 st.bytes += 2 * (stages[m].need - stages[m].base) * stages[m].sg.nch * (int64_t)dsize(nodes[stages[m].node].dtype);
+            steps.push_back(st);
+            continue;
+        }
+        if (S.rsb >= 0) {  // ... and one for the plain filters that go through k_rsos together
+            if (rsb_pushed[S.rsb]) continue;
+            rsb_pushed[S.rsb] = 1;
+            Step st{3, S.rsb, "k_rsos_batch", 0};
+            for (int m : rsbatches[S.rsb].members) {
+                const Stage& M = stages[m];
+                const int64_t esz = (int64_t)dsize(nodes[M.node].dtype);
+                st.bytes += (M.rs.n_in * (int64_t)dsize(M.carriers[0].dtype) + M.rs.n_out * esz) * M.rs.nch;
+            }
             steps.push_back(st);
             continue;
         }
@@ -294,6 +307,17 @@ void Plan::plan_lanes() {
             }
         }
     };
+    auto carrier_reads = [&](const std::vector<DCarrier>& cs, std::set<int>& out) {
+        for (auto& c : cs) {
+            if (c.buf >= 0) out.insert(c.buf);
+            for (int k = 0; k < c.frame_len; ++k) {
+                const DOp& o = ops[c.frame_pc + k];
+                if ((o.code == OP_LOAD || o.code == OP_SCALAR) && leaves[o.arg].buf >= 0) out.insert(leaves[o.arg].buf);
+            }
+            for (int k = 0; k < c.nslots; ++k)
+                if (leaves[c.slot_leaf[k]].buf >= 0) out.insert(leaves[c.slot_leaf[k]].buf);
+        }
+    };
     for (int i = 0; i < n; ++i) {
         const Step& st = steps[i];
         if (st.kind == 0) {
@@ -311,18 +335,17 @@ void Plan::plan_lanes() {
                 if (S.win_off >= 0) wr[i].insert(-100 - m);
                 else wr[i].insert(m == alias_stage ? kFinal : S.out_buf);
             }
+        } else if (st.kind == 3) {  // every member reads through its carriers and writes its window or buffer
+            for (int m : rsbatches[st.idx].members) {
+                const Stage& S = stages[m];
+                carrier_reads(S.carriers, rd[i]);
+                if (S.win_off >= 0) wr[i].insert(-100 - m);
+                else wr[i].insert(m == alias_stage ? kFinal : S.out_buf);
+            }
         } else {
             const Stage& S = stages[st.idx];
             if (S.in_buf >= 0 && S.rsos_src < 0) rd[i].insert(S.in_buf);
-            for (auto& c : (S.rsos_src >= 0 ? stages[S.rsos_src].carriers : S.carriers)) {
-                if (c.buf >= 0) rd[i].insert(c.buf);
-                for (int k = 0; k < c.frame_len; ++k) {
-                    const DOp& o = ops[c.frame_pc + k];
-                    if ((o.code == OP_LOAD || o.code == OP_SCALAR) && leaves[o.arg].buf >= 0) rd[i].insert(leaves[o.arg].buf);
-                }
-                for (int k = 0; k < c.nslots; ++k)
-                    if (leaves[c.slot_leaf[k]].buf >= 0) rd[i].insert(leaves[c.slot_leaf[k]].buf);
-            }
+            carrier_reads(S.rsos_src >= 0 ? stages[S.rsos_src].carriers : S.carriers, rd[i]);
             if (S.win_off >= 0) wr[i].insert(-100 - st.idx);  // its own window of the result
             else wr[i].insert(st.idx == alias_stage ? kFinal : S.out_buf);
             if (S.kind == ST_NORM) {  // reads its own output buffer, writes the rms scalar
@@ -594,6 +617,69 @@ static int plan_execute_direct(Plan* P, void* outp, void* stream, std::string& e
                 if (poison) HIPCHECK((hipError_t)launch_fill_u32(P->bufs[B.bad_buf].d, P->bufs[B.bad_buf].bytes / 4, 0x7f7f7f7fu, st));  // "no non-finite chunk yet"
                 int nl = launch_sos_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.nsec, B.dtype, B.total, st);
                 if (poison) nl += launch_sos_poison_batch((const SosDesc*)P->bufs[B.desc_buf].d, (int)nm, B.dtype, st);
+                s.launches = nl;
+                launches += nl;
+            } else if (s.kind == 3) {
+                // plain filters, one pass each, ONE launch (k_rsos_batch): per member what the single launch below sets up
+                RsBatch& B = P->rsbatches[s.idx];
+                const size_t nm = B.members.size();
+                std::vector<RsosItem> items(nm);
+                std::vector<RsFixup> fix(nm);
+                const bool poison = B.bad_buf >= 0 && !std::getenv("SIGOPS_SOS_NOPOISON");
+                int maxch = 1, out_f32 = 0;
+                for (size_t m = 0; m < nm; ++m) {
+                    const int sid = B.members[m];
+                    const Stage& S = P->stages[sid];
+                    const Node& N = P->nodes[S.node];
+                    const size_t esz = dsize(N.dtype);
+                    Buf ob = P->bufs[S.out_buf];
+                    if (S.win_off >= 0) {  // its window of the result
+                        const Buf& ab = P->bufs[P->out_alias_buf];
+                        ob.d = (char*)(P->out.is_device ? outp : ab.d) + (size_t)S.win_off * esz;
+                        ob.pitch = ab.pitch;
+                    }
+                    RsosItem& I = items[m];
+                    std::memset(&I, 0, sizeof I);
+                    RsSos rs = S.rs;
+                    rs.out_pitch = ob.pitch;
+                    rs.out_f32 = N.dtype == SO_F32;
+                    rs.f32m = 0;
+                    rs.sring = 0;
+                    rs.mats = (const double*)P->bufs[S.rsos_mats_buf].d;
+                    rs.bad = poison ? (int32_t*)P->bufs[B.bad_buf].d + B.bad_off[m] : nullptr;
+                    rs.err = kernel_error_word(P);
+                    I.g = rs;
+                    I.tab = (const double*)P->bufs[S.rsos_tab_buf].d;
+                    I.jend = (const int*)P->bufs[S.rsos_jend_buf].d;
+                    I.y = (char*)ob.d - (size_t)S.rs.store_lo * (rs.out_f32 ? 4 : 8);
+                    I.gsrc = RsGlobalTables{(const RsCtl*)P->bufs[S.ctl_buf].d, (const DCarrier*)P->bufs[S.car_buf].d, P->d_ops, P->d_leaves};
+                    RsFixup& F = fix[m];
+                    std::memset(&F, 0, sizeof F);
+                    F.g = rs;
+                    F.tab = I.tab;
+                    F.jend = I.jend;
+                    F.jrel = (const int*)P->bufs[S.rsos_jrel_buf].d;
+                    F.taps = S.rsos_taps;
+                    F.cf = S.groups[0];
+                    F.gsrc = I.gsrc;
+                    F.y = I.y;
+                    maxch = std::max(maxch, (int)rs.nch);
+                    out_f32 = rs.out_f32;
+                }
+                if (B.host.size() != nm || std::memcmp(B.host.data(), items.data(), nm * sizeof(RsosItem)) != 0 ||
+                    std::memcmp(B.fhost.data(), fix.data(), nm * sizeof(RsFixup)) != 0) {
+                    // (as the three-pass batch's descriptors: the tables change only when the result or an array moves -- never
+                    //  between the direct execute for a result pointer and the capture that follows it)
+                    B.host = items;
+                    B.fhost = fix;
+                    HIPCHECK(hipMemcpyAsync(P->bufs[B.items_buf].d, B.host.data(), nm * sizeof(RsosItem), hipMemcpyHostToDevice, st));
+                    HIPCHECK(hipMemcpyAsync(P->bufs[B.fix_buf].d, B.fhost.data(), nm * sizeof(RsFixup), hipMemcpyHostToDevice, st));
+                }
+                if (poison) HIPCHECK((hipError_t)launch_fill_u32(P->bufs[B.bad_buf].d, P->bufs[B.bad_buf].bytes / 4, 0x7f7f7f7fu, st));  // "no non-finite range yet"
+                if (launch_rsos_batch((const RsosItem*)P->bufs[B.items_buf].d, (int)nm, B.gpm, items[0].g, st) != 0)
+                    fail(SO_ERR_RUNTIME, "internal: no batched one-pass IIR instantiation for this geometry");
+                int nl = 1;
+                if (poison) nl += launch_rsos_fixup_batch((const RsFixup*)P->bufs[B.fix_buf].d, (int)nm, maxch, out_f32, st);
                 s.launches = nl;
                 launches += nl;
             } else {

@@ -26,9 +26,10 @@ constexpr int kFixIn = 6144;    // input frames staged per segment (a segment is
 constexpr int kFixAhead = 64;   // outputs behind the block's first that are looked at
 
 template <typename TO>
-__global__ __launch_bounds__(kFixThreads) void k_rsos_fixup(RsFixup fx) {
+__device__ __forceinline__ void rsos_fixup_body(const RsFixup& fx) {
     const RsSos& g = fx.g;
     const int ch = blockIdx.y;
+    if (ch >= g.nch) return;
     const int r = g.bad[ch];
     if (r < 0 || r >= g.nranges) return;  // (the usual case: the large initial value)
     TO* const y = (TO*)fx.y + (int64_t)ch * g.out_pitch;
@@ -134,6 +135,22 @@ __global__ __launch_bounds__(kFixThreads) void k_rsos_fixup(RsFixup fx) {
     for (int64_t m = max(bs, lo) + tid; m < mb; m += kFixThreads) y[m] = (TO)ys[m - bs];
 }
 
+template <typename TO>
+__global__ __launch_bounds__(kFixThreads) void k_rsos_fixup(RsFixup fx) {
+    rsos_fixup_body<TO>(fx);
+}
+// ... behind a batched launch: blockIdx.z = the member (its own words say whether there is anything to do)
+template <typename TO>
+__global__ __launch_bounds__(kFixThreads) void k_rsos_fixup_batch(const RsFixup* __restrict__ items) {
+    const RsFixup* fx = items + blockIdx.z;
+    const int ch = blockIdx.y;
+    if (ch >= fx->g.nch) return;
+    const int r = fx->g.bad[ch];
+    if (r < 0 || r >= fx->g.nranges) return;  // (the usual case: nothing is copied from the table)
+    const RsFixup F = *fx;
+    rsos_fixup_body<TO>(F);
+}
+
 // k_rs_fixup: the same for the periodic resampler ALONE (k_resample_periodic, no filter behind it).  Its compute waves list the
 // (tile, group)s whose accumulators held a non-finite value (RsPeriodic::nf); ONE workgroup -- the list is empty in a launch
 // over finite data: it reads a word and returns -- recomputes every listed group's rows x 16 outputs from each output's own
@@ -192,6 +209,14 @@ int launch_rs_fixup(const RsPerFixup& fx, hipStream_t st) {
     if (fx.g.nf == nullptr) return 0;
     if (fx.out_f32) hipLaunchKernelGGL((k_rs_fixup<float>), dim3(1), dim3(kFixThreads), 0, st, fx);
     else hipLaunchKernelGGL((k_rs_fixup<double>), dim3(1), dim3(kFixThreads), 0, st, fx);
+    return 1;
+}
+
+int launch_rsos_fixup_batch(const RsFixup* items, int nitems, int nch, int out_f32, hipStream_t st) {
+    if (nitems <= 0) return 0;
+    const dim3 grid(32, (unsigned)nch, (unsigned)nitems);
+    if (out_f32) hipLaunchKernelGGL((k_rsos_fixup_batch<float>), grid, dim3(kFixThreads), 0, st, items);
+    else hipLaunchKernelGGL((k_rsos_fixup_batch<double>), grid, dim3(kFixThreads), 0, st, items);
     return 1;
 }
 

@@ -1570,9 +1570,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
 // 5 - 7, 8 - 11: wave 8 shares the chain's SIMD) and wave 12 -- the chain's SIMD again -- forming D . X for three of them
 // (rsos_helper): what VERDICT round 5 asked for, a second wave on SIMD 0 that uses the matrix cycles the chain leaves.
 constexpr int rsos_nthreads(int nw) { return (nw == 17 ? 16 : nw) * 64; }
+// (the kernel's body: sequence groups G0, G0 + Gstep, ... of ONE filter -- the whole grid's for k_rsos, a share of it for a member
+//  of k_rsos_batch)
 template <int KS, int NW, typename TO, int CYC>
-__global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
-                                                  TO* __restrict__ y, RsGlobalTables gsrc) {
+__device__ __forceinline__ void rsos_body(const double* __restrict__ tab, const int* __restrict__ jend_g, const RsSos& g, TO* __restrict__ y,
+                                          const RsGlobalTables& gsrc, int64_t G0, int64_t Gstep) {
     constexpr bool HW = NW == 17;
     constexpr int NT = rsos_nthreads(NW);
     constexpr int NY = NW >= 16 ? 10 : NW - 2, NL = NW == 16 ? 2 : 1, NX = 2 * NY + 1;
@@ -1604,7 +1606,7 @@ __global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __rest
     const int64_t ngrp = ncg * ((g.nranges + g.rgs - 1) / g.rgs);
     double* const ss = lds_raw + (CYC > 0 ? 0 : (size_t)g.ngroups * KS * 64) + (size_t)16 * g.rpitch + (size_t)NX * 192;  // (state slot 0)
     const int ru = g.ct < 8 ? g.ct : 8;
-    for (int64_t G = blockIdx.x; G < ngrp; G += gridDim.x) {
+    for (int64_t G = G0; G < ngrp; G += Gstep) {
         __syncthreads();  // (the previous group's LDS traffic is over; the first time: the tables are in place)
         if (threadIdx.x < kRsosFlags) sh.flags[threadIdx.x] = 0;
         if (threadIdx.x < 192) ss[threadIdx.x] = 0.0;  // s_0 = 0
@@ -1685,6 +1687,22 @@ __global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __rest
     }
 }
 
+template <int KS, int NW, typename TO, int CYC>
+__global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos(const double* __restrict__ tab, const int* __restrict__ jend_g, RsSos g,
+                                                  TO* __restrict__ y, RsGlobalTables gsrc) {
+    rsos_body<KS, NW, TO, CYC>(tab, jend_g, g, y, gsrc, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
+// Several filters in ONE launch (config 4: the 64 scenes of an Append, two channels each -- as launches of their own every one
+// of them would fill a tenth of the chip): workgroup b walks the groups b % gpm, b % gpm + gpm, ... of member b / gpm.  The
+// members' geometries, sources and results come from a table in global memory; everything else is k_rsos.
+template <int KS, int NW, typename TO, int CYC>
+__global__ __launch_bounds__(rsos_nthreads(NW)) void k_rsos_batch(const RsosItem* __restrict__ items, int gpm) {
+    const int it = (int)(blockIdx.x / (unsigned)gpm);
+    const RsosItem I = items[it];
+    rsos_body<KS, NW, TO, CYC>(I.tab, I.jend, I.g, (TO*)I.y, I.gsrc, (int64_t)(blockIdx.x % (unsigned)gpm), (int64_t)gpm);
+}
+
 constexpr size_t kRsosStaticLds = sizeof(RsosShared) + 64;
 
 #if SO_RSOS_ONLY_KS != 0
@@ -1695,6 +1713,15 @@ static void launch_rsos_k(const double* tab, const int* jend, const RsSos& g, vo
     if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)k_rsos<KS, NW, TO, CYC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsos_lds_budget());
     hipLaunchKernelGGL((k_rsos<KS, NW, TO, CYC>), dim3((unsigned)grid), dim3(rsos_nthreads(NW)), lds, st, tab, jend, g, (TO*)y, gsrc);
+}
+
+template <int KS, int NW, typename TO>
+static void launch_rsos_batch_k(const RsosItem* items, int nitems, int gpm, const RsSos& g0, hipStream_t st) {
+    const size_t lds = rsos_lds_bytes(g0.ngroups, KS, g0.rpitch, NW, 1);
+    static bool seen[64];
+    if (first_use_on_device(seen))
+        (void)hipFuncSetAttribute((const void*)k_rsos_batch<KS, NW, TO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsos_lds_budget());
+    hipLaunchKernelGGL((k_rsos_batch<KS, NW, TO, 1>), dim3((unsigned)(nitems * gpm)), dim3(rsos_nthreads(NW)), lds, st, items, gpm);
 }
 
 // returns 0 when launched, -1 if no instantiation fits
@@ -1766,6 +1793,13 @@ static int launch_rsos_t(const double* tab, const int* jend, const RsSos& g, voi
 int SO_RSOS_CAT(SO_RSOS_CAT(SO_RSOS_CAT(launch_rsos_ks, SO_RSOS_ONLY_KS), SO_RSOS_TAG), SO_RSOS_ONLY_NW)(SO_RSOS_ARGS) {
     return launch_rsos_t<SO_RSOS_ONLY_KS, SO_RSOS_TO>(tab, jend, g, y, gsrc, grid, st);
 }
+#if SO_RSOS_ONLY_KS == 4 && (SO_RSOS_ONLY_NW == 12 || SO_RSOS_ONLY_NW == 16)
+// (the batched launch exists for the plain filter's identity window: 12 waves, or 16 with the step waves)
+int SO_RSOS_CAT(SO_RSOS_CAT(launch_rsos_batch4, SO_RSOS_TAG), SO_RSOS_ONLY_NW)(const RsosItem* items, int nitems, int gpm, const RsSos& g0, hipStream_t st) {
+    launch_rsos_batch_k<4, SO_RSOS_ONLY_NW, SO_RSOS_TO>(items, nitems, gpm, g0, st);
+    return 0;
+}
+#endif
 #else
 // LDS the kernel needs besides its static block (the planner sizes the ring with this); cyc > 0: no tap table
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc) {
@@ -1783,6 +1817,31 @@ size_t rsos_lds_budget() { return 160 * 1024 - kRsosStaticLds; }
 SO_RS(4) SO_RS(12) SO_RS(13) SO_RS(14) SO_RS(16) SO_RS(20)
 #undef SO_RS
 #endif
+#if SO_RSOS_ONLY_KS == 0
+int launch_rsos_batch4d12(const RsosItem*, int, int, const RsSos&, hipStream_t);
+int launch_rsos_batch4f12(const RsosItem*, int, int, const RsSos&, hipStream_t);
+int launch_rsos_batch4d16(const RsosItem*, int, int, const RsSos&, hipStream_t);
+int launch_rsos_batch4f16(const RsosItem*, int, int, const RsSos&, hipStream_t);
+#endif
+// the members of a batch share window length, waves, ring and result type (g0: any member's geometry); 0 when launched
+int launch_rsos_batch(const RsosItem* items, int nitems, int gpm, const RsSos& g0, hipStream_t st) {
+    if (nitems <= 0 || gpm <= 0) return 0;
+    if (g0.ks != 4 || g0.cyc != 1 || (g0.nwaves != 12 && g0.nwaves != 16)) return -1;
+#if SO_RSOS_ONLY_KS == 0
+    if (g0.nwaves == 12) return g0.out_f32 ? launch_rsos_batch4f12(items, nitems, gpm, g0, st) : launch_rsos_batch4d12(items, nitems, gpm, g0, st);
+    return g0.out_f32 ? launch_rsos_batch4f16(items, nitems, gpm, g0, st) : launch_rsos_batch4d16(items, nitems, gpm, g0, st);
+#else
+    if (g0.nwaves == 12) {
+        if (g0.out_f32) launch_rsos_batch_k<4, 12, float>(items, nitems, gpm, g0, st);
+        else launch_rsos_batch_k<4, 12, double>(items, nitems, gpm, g0, st);
+    } else {
+        if (g0.out_f32) launch_rsos_batch_k<4, 16, float>(items, nitems, gpm, g0, st);
+        else launch_rsos_batch_k<4, 16, double>(items, nitems, gpm, g0, st);
+    }
+    return 0;
+#endif
+}
+
 int launch_rsos(SO_RSOS_ARGS) {
     if (g.n_out <= 0) return 0;
     if (g.ngroups > kRsosMaxGroups) return -1;

@@ -49,6 +49,8 @@ void launch_resample_fix(const RsFixArgs& a, hipStream_t st);
 // fused periodic resampler -> SOS IIR (k_rsos.hip): 0 when launched, -1 when no instantiation fits
 int launch_rsos_fixup(const RsFixup& fx, hipStream_t st);  // k_exact.hip
 int launch_rs_fixup(const RsPerFixup& fx, hipStream_t st);   // k_exact.hip
+int launch_rsos_batch(const RsosItem* items, int nitems, int gpm, const RsSos& g0, hipStream_t st);
+int launch_rsos_fixup_batch(const RsFixup* items, int nitems, int nch, int out_f32, hipStream_t st);  // k_exact.hip
 int launch_rsos(const double* tab, const int* jend, const RsSos& g, void* y, const RsGlobalTables& gsrc, int grid, hipStream_t st);
 size_t rsos_lds_bytes(int ngroups, int ks, int rpitch, int nwaves, int cyc);
 size_t rsos_lds_budget();

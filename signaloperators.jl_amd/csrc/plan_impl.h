@@ -152,6 +152,7 @@ struct Stage {
     int rsos_tab_buf = -1, rsos_jend_buf = -1;
     // ... for the exact recomputation behind a non-finite sample (k_rsos_fixup): newest input of every output of the period
     // relative to its group's window end, and the taps per output the REFERENCE multiplies (its own zero padding included)
+    int rsb = -1;  // member of Plan::rsbatches[rsb]: launched with the others (k_rsos_batch), not on its own
     std::vector<int> rs_jrel_host;  // the periodic resampler's own (k_rs_fixup): as rsos_jrel_host, from per_j and jend_host
     int rs_jrel_buf = -1, rs_nf_buf = -1;
     std::vector<int> rsos_jrel_host;
@@ -211,7 +212,7 @@ struct PwStep {
 };
 
 struct Step {
-    int kind;  // 0 pointwise, 1 stage kernel, 2 batch of IIR stages (idx into Plan::batches)
+    int kind;  // 0 pointwise, 1 stage kernel, 2 batch of IIR stages (idx into Plan::batches), 3 batch of one-pass IIR stages (Plan::rsbatches)
     int idx;
     std::string name;
     int64_t bytes = 0;
@@ -228,6 +229,18 @@ struct SosBatch {
     std::vector<int> bad_off;    // member m's first channel in it
     std::vector<SosDesc> host;   // the descriptors as last uploaded
     int64_t total[3] = {0, 0, 0};
+};
+
+// Several plain filters -- the scenes of an Append -- through the one-pass kernel in ONE launch (k_rsos_batch): every member has
+// its own geometry (Stage::rs), source and result; they share window length, waves, ring and result type, and every member
+// gets `gpm` sequence groups of the grid.
+struct RsBatch {
+    std::vector<int> members;  // stage ids in step order
+    int gpm = 1;               // workgroups (sequence groups) per member
+    int items_buf = -1, fix_buf = -1, bad_buf = -1;
+    std::vector<int> bad_off;           // member m's first channel in bad_buf
+    std::vector<RsosItem> host;         // the launch table as last uploaded
+    std::vector<RsFixup> fhost;         // ... and the fix-up launch's
 };
 
 constexpr int kProfExecs = 256;  // executes a deferred-profiling plan keeps events for
@@ -252,6 +265,7 @@ struct Plan {
     std::vector<PwStep> pw;
     std::vector<Step> steps;
     std::vector<SosBatch> batches;
+    std::vector<RsBatch> rsbatches;  // plain filters through k_rsos_batch (fuse_plain_sos)
     std::vector<DPiece> pieces;
     std::vector<DOp> ops;
     std::vector<DLeaf> leaves;

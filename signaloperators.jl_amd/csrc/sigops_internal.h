@@ -419,6 +419,15 @@ struct RsSos {
 };
 constexpr int kRsosTraceIters = 96;
 
+// One member of a batched k_rsos launch (k_rsos_batch): what launch_rsos would have been given for it
+struct RsosItem {
+    RsSos g;
+    const double* tab;
+    const int* jend;
+    void* y;
+    RsGlobalTables gsrc;
+};
+
 // k_rsos_fixup (k_exact.hip): the launch behind k_rsos that makes a channel's non-finite outputs the REFERENCE's set
 struct RsFixup {
     RsSos g;            // the fused launch's geometry (bad, store_lo, out_pitch, out_f32, x32 as launched)

@@ -1125,7 +1125,7 @@ void Plan::process_stage(int sid) {
     // read if the fused form is not taken.
     if (direct && S.kind == ST_SOS && S.groups.size() == 1 && S.groups[0].nsec <= 6 && !S.sg.exact && !S.onepass && !S.under_norm &&
         S.base == 0 && in_base == 0 && in_frames == need && (N.dtype == SO_F64 || (N.dtype == SO_F32 && !std::getenv("SIGOPS_RSOS_NO32"))) &&
-        need * N.nch >= (std::getenv("SIGOPS_RSOS_MINGROUPS") ? (int64_t)4096 : ((int64_t)1 << 22)) && !std::getenv("SIGOPS_NO_RSOS") && !std::getenv("SIGOPS_NO_PLAIN_RSOS")) {
+        need * N.nch >= (std::getenv("SIGOPS_RSOS_MINGROUPS") || (std::getenv("SIGOPS_RSOS_BATCH") && std::atoi(std::getenv("SIGOPS_RSOS_BATCH")) == 1) ? (int64_t)4096 : ((int64_t)1 << 22)) && !std::getenv("SIGOPS_NO_RSOS") && !std::getenv("SIGOPS_NO_PLAIN_RSOS")) {
         std::vector<DCarrier> cs;
         // (a Float32 signal: a plain Float32 array or buffer only -- the kernel's ring then keeps the Float32 samples)
         if (build_carriers(ps, N.nch, cs, false) && cs.size() == 1 && (N.dtype == SO_F64 || (cs[0].nsteps == 0 && cs[0].dtype == SO_F32))) S.carriers = cs;
@@ -2055,24 +2055,18 @@ void Plan::fuse_plain_sos() {
         const char* ev = std::getenv(name);
         return ev ? std::atoi(ev) : dflt;
     };
-    // Several filters of this kind in one plan (config 4's 64 scenes) are ONE batched launch per pass of the three-pass form
-    // (batch_sos_stages, 26 us per scene); as launches of their own of this kernel they would be 42 us each.  Small ones stay
-    // for the batch.
-    int candidates = 0;
-    for (auto& S : stages)
-        if (S.kind == ST_SOS && S.rsos_src < 0 && S.carriers.size() == 1 && S.need > 0) ++candidates;
-    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+    const int cus = env_int("SIGOPS_RSOS_GRID", 256);
+    // One filter's geometry for this kernel.  gpm == 0: a launch of its own (ranges to fill the chip, the estimate against the
+    // three passes decides); gpm > 0: as a member of a batched launch with gpm workgroups of its own (the caller decides for
+    // the batch as a whole; cost: the microseconds one of its workgroups works).
+    auto fit = [&](size_t i2, int gpm, RsSos& g, double& cost) -> bool {
         Stage& S2 = stages[i2];
-        if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || S2.xscan ||
-            S2.under_norm || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
-            continue;
-        if (candidates > 1 && (int64_t)S2.need * nodes[S2.node].nch < ((int64_t)1 << 26) && !std::getenv("SIGOPS_RSOS_MINGROUPS")) continue;
         const int dt = nodes[S2.node].dtype;
-        if (dt != SO_F64 && dt != SO_F32) continue;
+        if (dt != SO_F64 && dt != SO_F32) return false;
         const DCarrier& c0 = S2.carriers[0];
         const bool pure32 = dt == SO_F32;  // (a plain Float32 source: the ring keeps its samples, RsSos::ring32)
-        if (pure32 && (c0.nsteps != 0 || c0.dtype != SO_F32)) continue;
-        if (!pure32 && c0.dtype != SO_F64) continue;
+        if (pure32 && (c0.nsteps != 0 || c0.dtype != SO_F32)) return false;
+        if (!pure32 && c0.dtype != SO_F64) return false;
         const SosCoefs& cf = S2.groups[0];
         const int D = 2 * cf.nsec;
         const int nch = nodes[S2.node].nch;
@@ -2091,7 +2085,7 @@ void Plan::fuse_plain_sos() {
                 cur = matmul(cur, P, D);
                 ++wp;
             }
-            if (!(maxabs(cur) < tol)) continue;
+            if (!(maxabs(cur) < tol)) return false;
         }
         int ct = 1;
         for (int c : {16, 8, 4, 2})
@@ -2101,31 +2095,35 @@ void Plan::fuse_plain_sos() {
             }
         const int rgs = 16 / ct;
         const int64_t ncg = nch / ct;
-        const int cus = env_int("SIGOPS_RSOS_GRID", 256);
-        int64_t rgroups = std::max<int64_t>(1, cus / ncg);
+        if (gpm > 0 && ncg > gpm) return false;
+        int64_t rgroups = gpm > 0 ? gpm / ncg : std::max<int64_t>(1, cus / ncg);
         int64_t nranges = rgroups * rgs;
         const int64_t min_pr = std::max<int64_t>(1, 4 * wp);  // (a range at least four warm-ups long: <= 25 % of the blocks)
         if (nperiods / nranges < min_pr) nranges = std::max<int64_t>(rgs, nperiods / min_pr / rgs * rgs);
-        if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES")) nranges = std::max<int64_t>(1, std::atoll(ev));
+        if (const char* ev = std::getenv("SIGOPS_RSOS_RANGES"))
+            if (gpm == 0) nranges = std::max<int64_t>(1, std::atoll(ev));
         const int64_t pr = (nperiods + nranges - 1) / nranges;
         nranges = (nperiods + pr - 1) / pr;
         const int64_t ngrp = ncg * ((nranges + rgs - 1) / rgs);
-        if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * L >= ((int64_t)1 << 30)) continue;
+        if ((pr + wp) * ngp >= (1 << 30) || (pr + wp) * L >= ((int64_t)1 << 30)) return false;
         const bool stepped_few = (ct == 2 || ct == 4) && !pure32 && c0.nsteps == 1 && !std::getenv("SIGOPS_RSOS_NOGSPLIT");
         const int plain_nw = env_int("SIGOPS_PLAIN_NWAVES", stepped_few ? 16 : 12) == 16 ? 16 : 12;
-        if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
-            if (ngrp < std::atoll(ev)) continue;
+        // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
+        // channels, eight loader units per chunk: 1.3 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
+        // 3.4 ps + 110 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
+        // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals: widened chunk by chunk by the one
+        // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
+        // (unit costs re-measured with the loader's vectorised unit scan: 25 M x 4 0.417 against 0.444, 50 M x 2 0.452 / 0.465)
+        // (50 M x 2: the three passes read 0.406 - 0.465 by box, this form 0.452 - 0.458: 1.4 keeps the three passes there)
+        // (with the step waves -- a fused step on groups of two / four channels, sixteen waves --: 50 M x 2 0.440, 25 M x 4 0.419)
+        const double unit_cost = stepped_few && plain_nw == 16 ? (ct == 4 ? 1.16 : 1.22) : ct >= 8 ? 1.0 : ct == 4 ? 1.19 : ct == 2 ? 1.4 : 3.4;
+        cost = (double)((pr + wp) * ngp) * 0.197 * unit_cost;
+        if (gpm > 0) {
+            cost *= (double)((ngrp + gpm - 1) / gpm);
+        } else if (const char* ev = std::getenv("SIGOPS_RSOS_MINGROUPS")) {
+            if (ngrp < std::atoll(ev)) return false;
         } else {
-            // a block of this form: 0.197 us on its workgroup (15 + 3 MFMAs; the chain wave's step sets the pace; groups of two
-            // channels, eight loader units per chunk: 1.3 x); the three passes: 4.4 ps per sample + 25 us up to 1e8 samples,
-            // 3.4 ps + 110 us beyond (tools/iir_one_pass_probe.py, Float64 Lowpass: 12.5 M x 8 0.344 against 0.442 ms, 28.8 M x 8
-            // 0.735 / 0.763, 50 M x 2 0.574 / 0.464, 2.6 M x 2 0.055 / 0.048).  Float32 signals: widened chunk by chunk by the one
-            // loader wave this form took 0.47 against 0.39 ms (12.5 M x 8); their samples stay Float32 in the ring now (ring32).
-            // (unit costs re-measured with the loader's vectorised unit scan: 25 M x 4 0.417 against 0.444, 50 M x 2 0.452 / 0.465)
-            // (50 M x 2: the three passes read 0.406 - 0.465 by box, this form 0.452 - 0.458: 1.4 keeps the three passes there)
-            // (with the step waves -- a fused step on groups of two / four channels, sixteen waves --: 50 M x 2 0.440, 25 M x 4 0.419)
-            const double unit_cost = stepped_few && plain_nw == 16 ? (ct == 4 ? 1.16 : 1.22) : ct >= 8 ? 1.0 : ct == 4 ? 1.19 : ct == 2 ? 1.4 : 3.4;
-            const double t_fused = (double)((ngrp + cus - 1) / cus) * (double)((pr + wp) * ngp) * 0.197 * unit_cost + 15.0;
+            const double t_fused = (double)((ngrp + cus - 1) / cus) * cost + 15.0;
             const double nsamp = (double)need * nch;
             // (re-measured at the round's end: 12.5 M x 8 0.452 ms, 28.8 M x 8 0.891; Float32 signals: the three passes move half
             //  the bytes and take 0.9 of the time -- 0.40 / 0.82 --, this kernel's pace is the chain's: 0.335 / 0.72)
@@ -2135,9 +2133,9 @@ void Plan::fuse_plain_sos() {
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
                              (long long)ngrp, (long long)pr, (long long)wp, t_three);
-            if (t_fused > t_three) continue;
+            if (t_fused > t_three) return false;
         }
-        RsSos g{};
+        g = RsSos{};
         g.n_in = S2.in_frames;
         g.n_out = need;
         g.store_lo = 0;
@@ -2166,7 +2164,7 @@ void Plan::fuse_plain_sos() {
             int ring = 4096;
             while (ring >= 128 && rsos_lds_bytes(g.ngroups, ks, ring + 2, g.nwaves, g.cyc) > rsos_lds_budget()) ring -= 128;
             if (const char* ev = std::getenv("SIGOPS_RSOS_RING")) ring = std::min(ring, std::max(128, std::atoi(ev) / 128 * 128));
-            if (ring < 128 || ring < span) continue;
+            if (ring < 128 || ring < span) return false;
             g.ring = ring;
             g.rpitch = ring + 2;
         }
@@ -2186,7 +2184,13 @@ void Plan::fuse_plain_sos() {
         } else if (c0.nsteps > 0)
             g.fuse = -2;
         g.gsplit = g.nwaves == 16 && !g.src32 && g.fuse >= 0 && (ct == 2 || ct == 4) && !std::getenv("SIGOPS_RSOS_NOGSPLIT") ? 1 : 0;
-        // identity taps: block gi of the period reads inputs [16 gi, 16 gi + 16)
+        return true;
+    };
+    // identity taps: block gi of the period reads inputs [16 gi, 16 gi + 16)
+    auto commit = [&](size_t i2, const RsSos& g) {
+        Stage& S2 = stages[i2];
+        const int ngp = g.ngroups, kw = 16;
+        const int64_t L = g.L;
         S2.rsos_tab_host.assign((size_t)ngp * kw * 16, 0.0);
         S2.rsos_jend_host.assign((size_t)ngp, 0);
         for (int gi = 0; gi < ngp; ++gi) {
@@ -2201,13 +2205,90 @@ void Plan::fuse_plain_sos() {
         S2.rsos_taps = 1;
         S2.rs = g;
         S2.rsos_src = (int)i2;  // (its own carriers, control block and tables)
+        const int64_t ngrp = (int64_t)(g.nch / g.ct) * ((g.nranges + g.rgs - 1) / g.rgs);
         S2.rsos_grid = (int)std::min<int64_t>(ngrp, cus);
-        rsos_block_matrices(cf, S2.rsos_mats_host);
+        rsos_block_matrices(S2.groups[0], S2.rsos_mats_host);
         S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);
-        if (S2.bad_buf < 0) S2.bad_buf = raw_buf((size_t)nch * 4);
         if (std::getenv("SIGOPS_DEBUG_PLAN"))
-            std::fprintf(stderr, "[sigops] IIR in one pass (k_rsos, identity resampler): %lld ranges of %lld periods (+%lld warm-up), %lld groups of %d ch x %d ranges, ring=%d fuse=%d/%d\n",
-                         (long long)nranges, (long long)pr, (long long)wp, (long long)ngrp, ct, rgs, g.ring, g.fuse, g.fuse_sine);
+            std::fprintf(stderr, "[sigops] IIR in one pass (k_rsos, identity resampler%s): %lld ranges of %lld periods (+%d warm-up), %lld groups of %d ch x %d ranges, ring=%d fuse=%d/%d\n",
+                         S2.rsb >= 0 ? ", batched" : "", (long long)g.nranges, (long long)g.pr, g.wp, (long long)ngrp, g.ct, g.rgs, g.ring, g.fuse, g.fuse_sine);
+    };
+    // Several filters of this kind in one plan (config 4's 64 scenes) are ONE batched launch per pass of the three-pass form
+    // (batch_sos_stages, 26 us per scene); as launches of their own of this kernel they would be 42 us each.  Small ones go
+    // through this kernel TOGETHER (k_rsos_batch) where that wins, and stay for the three-pass batch otherwise.
+    int candidates = 0;
+    for (auto& S : stages)
+        if (S.kind == ST_SOS && S.rsos_src < 0 && S.carriers.size() == 1 && S.need > 0) ++candidates;
+    std::vector<size_t> small;
+    for (size_t i2 = 0; i2 < stages.size(); ++i2) {
+        Stage& S2 = stages[i2];
+        if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || S2.xscan ||
+            S2.under_norm || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
+            continue;
+        if (candidates > 1 && (int64_t)S2.need * nodes[S2.node].nch < ((int64_t)1 << 26) && !std::getenv("SIGOPS_RSOS_MINGROUPS")) {
+            small.push_back(i2);
+            continue;
+        }
+        RsSos g{};
+        double cost = 0.0;
+        if (!fit(i2, 0, g, cost)) continue;
+        commit(i2, g);
+        if (S2.bad_buf < 0) S2.bad_buf = raw_buf((size_t)g.nch * 4);
+    }
+    // ---- the small ones, together: members that share the kernel's instantiation (waves; the result's type) ----
+    const char* const want_s = std::getenv("SIGOPS_RSOS_BATCH");  // 0: never, 1: whenever it fits (tests, measurements), default: by the estimate
+    const int want = want_s && *want_s ? std::atoi(want_s) : -1;
+    if (small.size() < 2 || want == 0) return;
+    std::map<std::pair<int, int>, std::vector<size_t>> kinds;
+    for (size_t i2 : small) {
+        if ((int)i2 == alias_stage) continue;
+        RsSos g{};
+        double cost = 0.0;
+        if (!fit(i2, 1 << 20, g, cost)) continue;  // (which instantiation it would take)
+        kinds[{nodes[stages[i2].node].dtype == SO_F32 ? 1 : 0, g.nwaves}].push_back(i2);
+    }
+    for (auto& kv : kinds) {
+        const std::vector<size_t>& cand = kv.second;
+        if (cand.size() < 2) continue;
+        const int gpm = (int)std::max<int64_t>(1, cus / (int64_t)cand.size());
+        RsBatch B;
+        B.gpm = gpm;
+        std::vector<RsSos> gs;
+        double worst = 0.0, nsamp = 0.0;
+        bool stepped = false;
+        for (size_t i2 : cand) {
+            RsSos g{};
+            double cost = 0.0;
+            if (!fit(i2, gpm, g, cost) || g.nwaves != kv.first.second) continue;
+            if (!gs.empty() && (g.ring != gs[0].ring || g.ngroups != gs[0].ngroups)) continue;
+            B.members.push_back((int)i2);
+            gs.push_back(g);
+            worst = std::max(worst, cost);
+            nsamp += (double)stages[i2].need * g.nch;
+            stepped = stepped || stages[i2].carriers[0].nsteps > 0;
+        }
+        if (B.members.size() < 2) continue;
+        // the batch as a whole: its workgroups in rounds of the chip's 256, the slowest member's pace; the three-pass batch: as
+        // one filter over all the members' samples (bench.py --workload config4: 64 scenes of 2.6 M x 2 with a sine mixed in,
+        // 1.55 ms in three passes)
+        const double t_batch = (double)(((int64_t)B.members.size() * gpm + cus - 1) / cus) * worst + 15.0;
+        const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (kv.first.first ? 0.9 : 1.0) * (stepped ? 1.2 : 1.0);
+        if (std::getenv("SIGOPS_DEBUG_PLAN"))
+            std::fprintf(stderr, "[sigops] batched single-pass IIR estimate: %zu members x %d groups, %.0f us; three passes %.0f us\n", B.members.size(), gpm,
+                         t_batch, t_three);
+        if (want != 1 && t_batch > t_three) continue;
+        const int bi = (int)rsbatches.size();
+        int off = 0;
+        for (size_t m = 0; m < B.members.size(); ++m) {
+            stages[B.members[m]].rsb = bi;
+            commit((size_t)B.members[m], gs[m]);
+            B.bad_off.push_back(off);
+            off += gs[m].nch;
+        }
+        B.bad_buf = raw_buf((size_t)std::max(off, 1) * 4);
+        B.items_buf = raw_buf(B.members.size() * sizeof(RsosItem));
+        B.fix_buf = raw_buf(B.members.size() * sizeof(RsFixup));
+        rsbatches.push_back(std::move(B));
     }
 }
 
