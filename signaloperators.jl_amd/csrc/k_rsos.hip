@@ -422,7 +422,9 @@ __device__ __forceinline__ RsosGroup rsos_group(const SO_LDS RsosShared* sh, int
 }
 
 // =========================== chain wave ===========================
-template <int NY>
+// NK: k-steps of the state, 4 states each (a cascade of 1 - 2 sections: 1, 3 - 4: 2, 5 - 6: 3) -- the MFMAs of this wave's
+// recurrence, 64 cycles each; the y waves' S^T C^T takes as many
+template <int NY, int NK>
 __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dyn, int64_t G_) {
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
@@ -467,12 +469,12 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     // state do not exist: the fourth pair is never read back and may hold anything -- it is never written either)
     v4d dA = v4d{0.0, 0.0, 0.0, 0.0}, dB = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int v = 0; v < 3; ++v) dA[v] = l.xs[v * 64 + lane];
+    for (int v = 0; v < NK; ++v) dA[v] = l.xs[v * 64 + lane];
     if (NB > 1) {
         spins = 0;
         while (uni(flag_ld(fl_base + 4 * (kRsosFlagXseq + 1))) < 2 && !(debug & 4)) SO_SPIN_PAUSE(spins, 1, 1 << 22);
 #pragma unroll
-        for (int v = 0; v < 3; ++v) dB[v] = l.xs[192 + v * 64 + lane];
+        for (int v = 0; v < NK; ++v) dB[v] = l.xs[192 + v * 64 + lane];
     }
     const uint32_t xs0 = (uint32_t)(uintptr_t)l.xs + (uint32_t)lane * 8u, ss0 = (uint32_t)(uintptr_t)l.ss + (uint32_t)lane * 8u;
     int fA = NB > 2 ? flag_ld(fl_base + 4 * (kRsosFlagXseq + 2 % NX)) : 0x7fffffff;  // counters of blocks 2 and 3
@@ -502,7 +504,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
         auto put_state = [&]() __attribute__((always_inline)) {
             if (!(debug & 1024)) {
 #pragma unroll
-                for (int v = 0; v < 3; ++v) *(volatile SO_LDS double*)(uintptr_t)(as + (uint32_t)v * 512u) = sin[v];
+                for (int v = 0; v < NK; ++v) *(volatile SO_LDS double*)(uintptr_t)(as + (uint32_t)v * 512u) = sin[v];
                 *(volatile SO_LDS int*)(uintptr_t)ag = bv;
             }
         };
@@ -521,13 +523,27 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
         auto get_dx = [&]() __attribute__((always_inline)) {
             if (more) {
 #pragma unroll
-                for (int v = 0; v < 3; ++v) din[v] = *(volatile SO_LDS double*)(uintptr_t)(ax + (uint32_t)v * 512u);
+                for (int v = 0; v < NK; ++v) din[v] = *(volatile SO_LDS double*)(uintptr_t)(ax + (uint32_t)v * 512u);
             }
         };
         auto get_flag = [&]() __attribute__((always_inline)) {
             if (more && b + 4 < NB) fpend = *(volatile SO_LDS int*)(uintptr_t)af;
         };
-        if constexpr (SO_CHAIN_ORDER == 0) {
+        if constexpr (NK == 1) {
+            // (one MFMA: the LDS traffic behind it -- the requests are out before its 64 cycles are)
+            put_state();
+            wait_dx();
+            get_dx();
+            get_flag();
+        } else if constexpr (NK == 2) {
+            // (two: everything under the first -- five LDS instructions --, nothing under the last, as below)
+            put_state();
+            wait_dx();
+            get_dx();
+            get_flag();
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[1], sin[1], acc, 0, 0, 0);
+        } else if constexpr (SO_CHAIN_ORDER == 0) {
             wait_dx();
             get_dx();
             get_flag();
@@ -572,7 +588,7 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     int32_t* bad = (int32_t*)rfl64((int64_t)(uintptr_t)g.bad);
     if (bad != nullptr) {
         const v4d sE = (NB & 1) ? sB : sA;  // the state the last block left
-        const bool nf = !(isfinite(sE[0]) && isfinite(sE[1]) && isfinite(sE[2]));
+        const bool nf = !(isfinite(sE[0]) && (NK < 2 || isfinite(sE[1])) && (NK < 3 || isfinite(sE[2])));
         const uint64_t m = __ballot(nf);
         const uint32_t rows = (uint32_t)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu);  // row = lane & 15
         if (rows != 0 && lane < 16 && ((rows >> lane) & 1u)) {
@@ -1139,6 +1155,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
     const int gq = lane >> 4, n16 = lane & 15;
     double Dk[4], Tk[4], Ck[3];
+    const int nkc = (uni(g.debug) & 131072) ? 3 : (2 * uni(g.nsec) + 3) / 4;  // k-steps of the state (rsos_chain's NK)
     // (k-step v, lane (gq, n16) holds index 4 v + gq of the contracted dimension; F32M: 4 gq + v -- see above)
 #pragma unroll
     for (int v = 0; v < 4; ++v) Dk[v] = F32M ? mats[(lane >> 4) * 64 + v * 16 + (lane & 15)] : mats[v * 64 + lane];
@@ -1270,9 +1287,11 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
             for (int v = 0; v < 3; ++v) sv[v] = l.ss[pslot_ * 192 + v * 64 + lane];
         }
     };
+    // (as many k-steps as the cascade has states / 4: the chain wave writes no more of a state slot -- RsosChain's NK)
     auto back_mfma = [&](const double (&sv)[3], v4d ay) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < 3; ++v) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[v], Ck[v], ay, 0, 0, 0);
+        ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[0], Ck[0], ay, 0, 0, 0);
+        if (nkc > 1) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[1], Ck[1], ay, 0, 0, 0);
+        if (nkc > 2) ay = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[2], Ck[2], ay, 0, 0, 0);
         return ay;
     };
     // (fresh: the MFMAs that wrote ay are the last instructions in front of this -- the 18 wait states a Float64 store needs
@@ -1612,7 +1631,12 @@ __device__ __forceinline__ void rsos_body(const double* __restrict__ tab, const 
         if (threadIdx.x < 192) ss[threadIdx.x] = 0.0;  // s_0 = 0
         __syncthreads();
         if (wave == 0) {
-            if (!(g.debug & 64)) rsos_chain<NY>(&sh, lds_raw, G);
+            if (!(g.debug & 64)) {
+                const int nk = (g.debug & 131072) ? 3 : (2 * g.nsec + 3) / 4;
+                if (nk <= 1) rsos_chain<NY, 1>(&sh, lds_raw, G);
+                else if (nk == 2) rsos_chain<NY, 2>(&sh, lds_raw, G);
+                else rsos_chain<NY, 3>(&sh, lds_raw, G);
+            }
         } else if (NW == 16 && (wave == 13 || wave == 14)) {
             // (the step waves of two-channel / four-channel groups: RsSos::gsplit)
             if (!g.gsplit || (g.debug & 256) || g.src32) continue;
