@@ -84,7 +84,7 @@ __device__ __forceinline__ void rsos_fixup_body(const RsFixup& fx) {
         if (nin > kFixIn) return;  // (one output's own window does not fit: not a geometry k_rsos runs)
         // ---- the source's frames [jlo, jlo + nin): two per call, zero outside the signal ----
         for (int t = tid; 2 * t < nin; t += kFixThreads)
-            stage_generic_impl<double, 1>(g.n_in, 0, fx.gsrc.car, ncar, fx.gsrc.ops, fx.gsrc.leaves, jlo + 2 * t, t, 0, ch, xin);
+            stage_generic_impl<double, 1, true>(g.n_in, 0, fx.gsrc.car, ncar, fx.gsrc.ops, fx.gsrc.leaves, jlo + 2 * t, t, 0, ch, xin);
         __syncthreads();
         // ---- resample: each output from its own taps (oldest first, one accumulator: the reference's dot product) ----
         for (int64_t m = seg + tid; m < se; m += kFixThreads) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kFixThreads) void k_rs_fixup(RsPerFixup fx) {
             for (int t = tid; t < rows * (kw / 2); t += kFixThreads) {
                 const int rho = t / (kw / 2), h = t - rho * (kw / 2);
                 const int64_t P = P0 + (rho & ptmask);
-                stage_generic_impl<double, 1>(g.n_in, 0, fx.gsrc.car, ncar, fx.gsrc.ops, fx.gsrc.leaves, P * g.M + je - (kw - 1) + 2 * h, h, 0,
+                stage_generic_impl<double, 1, true>(g.n_in, 0, fx.gsrc.car, ncar, fx.gsrc.ops, fx.gsrc.leaves, P * g.M + je - (kw - 1) + 2 * h, h, 0,
                                               c0 + (rho >> ptshift), &win[rho][0]);
             }
             __syncthreads();

@@ -120,7 +120,7 @@ template <int RU>
 __device__ __attribute__((noinline)) void rsos_stage_slow(int64_t n_in, int rpitch, const DCarrier* gcar, int ncar, const DOp* gops,
                                                           const DLeaf* gleaves, int64_t n0, int lanes, int ch0, double* buf) {
     const int lane = threadIdx.x & 63;
-    if (lane < lanes) stage_generic_impl<double, RU>(n_in, rpitch, gcar, ncar, gops, gleaves, n0 + 2 * lane, lane, 0, ch0, buf);
+    if (lane < lanes) stage_generic_impl<double, RU, true>(n_in, rpitch, gcar, ncar, gops, gleaves, n0 + 2 * lane, lane, 0, ch0, buf);  // (true: a second array's step too)
 }
 // ... into a ring that keeps Float32 samples (RsSos::ring32): four frames per lane, rows 2 rpitch floats apart
 template <int RU>
@@ -601,6 +601,15 @@ __device__ __attribute__((noinline)) void rsos_chain(RsosShared* sh_, double* dy
     }
 }
 
+// Two arrays (RsSos::arr2): the second one's rows can be read 16 bytes per lane at the frames the first one's 128-byte lines
+// start at -- both arrays' rows equally aligned.  Loaders, step waves and y waves agree on it (it is part of `single`).
+__device__ __forceinline__ bool rsos_two_ok(const SO_LDS DCarrier& C0, int chunk) {
+    const uint64_t b0 = (uint64_t)rfl64((int64_t)(uintptr_t)C0.base), b2 = (uint64_t)rfl64((int64_t)(uintptr_t)C0.base2);
+    const int64_t df0 = rfl64(C0.df), df2 = rfl64(C0.df2), cs0 = rfl64(C0.cstride), cs2 = rfl64(C0.cstride2);
+    return uni((int)(C0.base2 != nullptr && C0.vec_ok2 && C0.dtype2 == SO_F64)) && chunk == 128 && !((((b2 >> 3) + (uint64_t)df2) ^ ((b0 >> 3) + (uint64_t)df0)) & 1) &&
+           !((cs2 ^ cs0) & 1);
+}
+
 // =========================== loader waves ===========================
 // vmcnt of this wave, read without waiting (HW_REG_IB_STS: VM_CNT in bits 3:0 and 23:22)
 __device__ __forceinline__ int vmcnt_now() {
@@ -613,8 +622,17 @@ __device__ __forceinline__ int vmcnt_now() {
 // waves 13 / 14, on SIMDs 1 / 2) that applies the step to a landed chunk and publishes it.  Issue and step of a stereo chunk
 // are ~2 600 - 3 100 and ~2 000 - 2 500 cycles of ONE wave's time (every vector instruction next to fp64 MFMAs waits for a
 // gap between them) against a chunk period of ~6 000 at the plain pipeline's pace: as two stages of a pipeline they fit.
-template <int NY, int NL, int RU, bool SRC32, int RB = 0, int MODE = 0>
+// A2 (RsSos::arr2; sixteen waves, groups of eight channels): carrier 0's one step takes a SECOND Float64 array as its operand --
+// `Mix(x, y)` / `Amplify(x, y)` of two arrays in front of the resampler (reference: src/mapsignal.jl:54-57 evaluated block by
+// block inside the resampler's pull, src/filters.jl:240-244).  The first array goes into the ring by LDS-DMA as ever (the two
+// loader waves, MODE 1: issue, wait, report); the second one's samples go through the REGISTERS of the two step waves (MODE 2,
+// one unit of eight rows each): 16 bytes per lane and row, THREE chunks in flight per wave (96 registers: 48 KB per workgroup --
+// under load a global load takes ~5 us to return; one chunk in flight next to the loader's own DMA made the second array's
+// 0.8 GB take 0.95 ms), applied to the landed chunk by the LDS's own adder like the sine of the fused `Mix(sine, x)`.  No
+// staging buffer (none fits next to the ring), no vector instruction per row.
+template <int NY, int NL, int RU, bool SRC32, int RB = 0, int MODE = 0, bool A2 = false>
 __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
+    static_assert(!A2 || (RU == 8 && !SRC32 && MODE == 2 && NL == 2), "the second array's waves: groups of eight channels, sixteen waves");
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
@@ -652,7 +670,7 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
                                    //  instantiation: the Float64 loader's per-chunk path stays what it was)
     constexpr int esh = src32 ? 2 : 3;
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && fuse >= -1 &&
-                        (!src32 || CH == 128);
+                        (!src32 || CH == 128) && (!uni(g.arr2) || rsos_two_ok(C0, CH));
     const int64_t lo_ok = a0 > 0 ? a0 : 0, hi_ok = b0 < n_in ? b0 : n_in;
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)((uintptr_t)base0 >> esh), cs0, df0);
     // the fused step's gain: a constant, or a sine generator evaluated in two levels (share bases per chunk in gtab,
@@ -985,6 +1003,76 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         flag_st(fl_base + 4 * (kRsosFlagLdp + q), (k + 1) * CH);
         rsos_stamp(trace, wave, k, 4, 40);
     };
+    if constexpr (MODE == 2 && A2) {
+        // the second array's wave of unit q: three register sets, each a chunk of the unit (8 rows x 16 bytes per lane), loaded
+        // three chunks ahead; a set is applied to its chunk once the loader has reported the chunk landed and no more of this
+        // wave's loads are outstanding than were issued behind the set's
+        const char* const base2 = (const char*)rfl64((int64_t)(uintptr_t)C0.base2);
+        const int64_t cs2 = rfl64(C0.cstride2), df2 = rfl64(C0.df2);
+        const char* const row0 = base2 + (((int64_t)ch0_s0 * cs2 + df2 + Au_s0) << 3);
+        v2d b0[8], b1[8], b2[8];
+        auto ld = [&](int k, v2d (&b)[8]) __attribute__((always_inline)) -> int {
+            if (!(k < NK && k >= klo_s0 && k < khi_s0)) return 0;
+            const char* row = row0 + ((int64_t)k << 10);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                // (the row's address complete in its scalar pair BEFORE the load: seen without this, the high half's add-with-carry
+                //  scheduled behind the load that reads the pair)
+                uint64_t rc = (uint64_t)(uintptr_t)(row + (int64_t)c * cs2 * 8);
+                asm volatile("" : "+s"(rc));
+                asm volatile("global_load_dwordx4 %0, %1, %2" SO_LD_NT : "=v"(b[c]) : "v"(lane16), "s"(rc) : "memory");
+            }
+            return 8;
+        };
+        auto ap = [&](int k, int rho0, v2d (&b)[8], int nself, int younger) __attribute__((always_inline)) {
+            int sp = 0;
+            while (uni(flag_ld(fl_base + 4 * (kRsosFlagLnd + q))) < k + 1 && !(debug & 32)) SO_SPIN_PAUSE(sp, 2, 1 << 22);
+            if (nself && !(debug & 2)) {
+                wait_vmcnt_le60(younger);
+                const uint32_t la = lds_s0 + (uint32_t)rho0 * 8u + lane16;
+                if (fuse == 1) {  // v + m
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(b[c][0]), "v"(b[c][1]) : "memory");
+                } else if (fuse == 2) {  // v - m
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(-b[c][0]), "v"(-b[c][1]) : "memory");
+                } else {  // v * m, m - v: read, one operation, written back
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t a = la + (uint32_t)c * row_bytes;
+                        v2d vv[1] = {lds_ld16(a)};
+                        lds_wait(vv);
+                        vv[0] = fuse == 0 ? vv[0] * b[c] : b[c] - vv[0];
+                        lds_pin(vv);
+                        lds_st16(a, vv[0]);
+                    }
+                }
+            }
+            flag_st(fl_base + 4 * (kRsosFlagLdp + q), (k + 1) * CH);
+        };
+        int n0 = ld(0, b0), n1 = ld(1, b1), n2 = ld(2, b2);
+        int rho = 0;
+        for (int k = 0; k < NK; k += 3) {
+            ap(k, rho, b0, n0, n1 + n2);
+            n0 = ld(k + 3, b0);
+            rho = rho + CH == RING ? 0 : rho + CH;
+            if (k + 1 < NK) {
+                ap(k + 1, rho, b1, n1, n2 + n0);
+                n1 = ld(k + 4, b1);
+                rho = rho + CH == RING ? 0 : rho + CH;
+            }
+            if (k + 2 < NK) {
+                ap(k + 2, rho, b2, n2, n0 + n1);
+                n2 = ld(k + 5, b2);
+                rho = rho + CH == RING ? 0 : rho + CH;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of this wave in flight when it leaves: the registers are the next group's)
+        __builtin_amdgcn_s_setprio(0);
+        return;
+    }
     if constexpr (MODE == 2) {  // the step wave: chunk after chunk as the loader reports them landed
         int rho = 0, spins2 = 0;
         for (int k = 0; k < NK; ++k) {
@@ -1151,7 +1239,7 @@ __device__ __attribute__((noinline)) void rsos_ywave(RsosShared* sh_, double* dy
     [[maybe_unused]] const bool sring = F32M && uni(g.sring) != 0;
     [[maybe_unused]] const int srow = ((lane & 15) / (ct < 8 ? ct : 8)) * (ct < 8 ? ct : 8);  // (first ring row of this lane's unit)
     const bool single = uni((int)(C0.base != nullptr && C0.vec_ok && C0.dtype == (src32 ? SO_F32 : SO_F64))) && !(df0 & 1) && uni(g.fuse) >= -1 &&
-                        (!src32 || uni(g.chunk) == 128);
+                        (!src32 || uni(g.chunk) == 128) && (!uni(g.arr2) || rsos_two_ok(C0, uni(g.chunk)));
     const RsosGroup grp = rsos_group(sh, G, single, (int64_t)(rfl64((int64_t)(uintptr_t)C0.base) >> (src32 ? 2 : 3)), cs0, df0);
     const int gq = lane >> 4, n16 = lane & 15;
     double Dk[4], Tk[4], Ck[3];
@@ -1641,7 +1729,11 @@ __device__ __forceinline__ void rsos_body(const double* __restrict__ tab, const 
             // (the step waves of two-channel / four-channel groups: RsSos::gsplit)
             if (!g.gsplit || (g.debug & 256) || g.src32) continue;
             const int q = wave - 13;
-            if (ru == 2) {
+            if (ru == 8) {
+                if constexpr (NL == 2) {
+                    if (g.arr2) rsos_loader<NY, NL, 8, false, 0, 2, true>(&sh, lds_raw, G, q);
+                }
+            } else if (ru == 2) {
                 if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8, 2>(&sh, lds_raw, G, q);
                 else if (g.rpitch == 642) rsos_loader<NY, NL, 2, false, 642 * 8, 2>(&sh, lds_raw, G, q);
                 else rsos_loader<NY, NL, 2, false, 0, 2>(&sh, lds_raw, G, q);
@@ -1653,6 +1745,10 @@ __device__ __forceinline__ void rsos_body(const double* __restrict__ tab, const 
         } else if (wave == 4 || (NW == 16 && wave == 8)) {
             const int q = wave == 4 ? 0 : 1;
             if (g.debug & 256) continue;
+            if (NW == 16 && g.gsplit && !g.src32 && ru == 8 && g.arr2) {
+                rsos_loader<NY, NL, 8, false, 0, 1>(&sh, lds_raw, G, q);
+                continue;
+            }
             if (NW == 16 && g.gsplit && !g.src32 && (ru == 2 || ru == 4)) {
                 if (ru == 2) {
                     if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8, 1>(&sh, lds_raw, G, q);

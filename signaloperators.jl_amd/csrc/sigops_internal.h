@@ -408,6 +408,8 @@ struct RsSos {
                           // forms D . X for them (k_rsos.hip, kRsosHres*: the SIMDs' MFMA counts evened out)
     int32_t debug;        // ablation bits (SIGOPS_RSOS_DEBUG): 1 no stores, 2 no gain, 4 chain does not wait for x, 8 y waves not for states, 16 nor for input, 32 loader not for ring space
     int32_t cyc;          // > 0: a y wave's blocks cycle through cyc phase groups whose taps it keeps in registers; 0: tap table in LDS
+    int32_t arr2;         // the fast path's step takes a SECOND array as its operand (DCarrier::base2): the loader's A2 instantiation
+    int32_t pad_;
     int64_t out_pitch;
     int64_t store_lo;     // outputs below this one are not stored (a window's warm-up: the kernel's output 0 is where the
                           // resampler stage's warm start begins, the result where the window does)

@@ -1674,8 +1674,20 @@ void Plan::fuse_resample_sos() {
         // kernel's coordinates are the resampler stage's: its output 0 is frame S3.base, the cascade starts from rest
         // there (earlier than the cascade stage alone would: a longer warm-up), and nothing below S2.base is stored.
         if (S3.base > S2.base) continue;
-        if (rp.nstate || rp.arr2 || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
-            continue;  // (arr2: a source of two arrays is K3's A2 instantiation's; this kernel's loader takes one)
+        if (rp.nstate || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
+            continue;
+        // (arr2: a source of two arrays -- K3's A2 instantiation's alone; this kernel's loader takes the second one for groups of
+        //  eight channels, Float64, ONE carrier whose one step is `v (op) y`: k_rsos.hip, rsos_loader's A2)
+        bool two_arrays = false;
+        if (rp.arr2) {
+            const bool ok = !pure32 && nodes[S2.node].dtype == SO_F64 && S3.carriers.size() == 1 && S3.carriers[0].nsteps == 1 &&
+                            (S3.carriers[0].arg[0] & kCarArr2) && !(S3.carriers[0].arg[0] & 0x200) && S3.carriers[0].dtype == SO_F64 &&
+                            S3.carriers[0].dtype2 == SO_F64 && nodes[S2.node].nch % 8 == 0 &&
+                            (S3.carriers[0].op[0] == OP_ADD || S3.carriers[0].op[0] == OP_SUB || S3.carriers[0].op[0] == OP_MUL) &&
+                            !std::getenv("SIGOPS_RSOS_NO_ARR2");
+            if (!ok) continue;
+            two_arrays = true;
+        }
         if (pure32) {
             bool plain = nodes[nodes[S3.node].kids[0]].dtype == SO_F32 && rp.ga == 0;
             for (auto& c : S3.carriers)
@@ -1932,6 +1944,11 @@ void Plan::fuse_resample_sos() {
             // MEASURED (round 6) AND NOT THE DEFAULT: 0.978 ms against 0.978 for the plain pipeline, 1.08 against 1.00 with the fused
             // Mix (the loader at 128 registers; four waves on the chain's SIMD) -- SIGOPS_RSOS_NWAVES=17 selects it
             if (const char* ev = std::getenv("SIGOPS_RSOS_NWAVES")) nw = std::atoi(ev) == 8 ? 8 : (std::atoi(ev) == 16 || std::atoi(ev) == 17) && cyc_of(16) == 1 && ks <= 16 ? std::atoi(ev) : 12;
+            // (a source of two arrays: the second one goes through the registers of the sixteen-wave geometry's two step waves)
+            if (two_arrays) {
+                if (!(cyc_of(16) == 1 && ks <= 16)) continue;
+                nw = 16;
+            }
             g.nwaves = nw;
             g.cyc = (nw >= 16 || fits(nw)) && !std::getenv("SIGOPS_RSOS_LDSTAPS") ? cyc_of(nw) : 0;
             // (waves, groups per wave, window) as launch_rsos_t instantiates them -- a combination it has not (the 16-wave
@@ -1985,7 +2002,11 @@ void Plan::fuse_resample_sos() {
         {
             const DCarrier& c0 = S3.carriers[0];
             g.fuse = -1;
-            if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 &&
+            if (two_arrays) {
+                g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);
+                g.fuse_sine = 0;
+                g.arr2 = 1;
+            } else if (c0.nsteps == 1 && (c0.arg[0] & 0x2ff) == 0 && c0.nslots >= 1 &&
                 (c0.op[0] == OP_MUL || c0.op[0] == OP_ADD || c0.op[0] == OP_SUB)) {
                 g.fuse = c0.op[0] == OP_MUL ? 0 : c0.op[0] == OP_ADD ? 1 : ((c0.arg[0] & 0x100) ? 3 : 2);
                 const DLeaf& L0 = leaves[c0.slot_leaf[0]];
@@ -1996,7 +2017,7 @@ void Plan::fuse_resample_sos() {
             } else if (c0.nsteps > 0)
                 g.fuse = -2;  // (every chunk takes the general staging path)
         }
-        g.gsplit = g.nwaves == 16 && !g.src32 && g.fuse >= 0 && (ct == 2 || ct == 4) && !std::getenv("SIGOPS_RSOS_NOGSPLIT") ? 1 : 0;
+        g.gsplit = g.nwaves == 16 && !g.src32 && g.fuse >= 0 && (g.arr2 || ((ct == 2 || ct == 4) && !std::getenv("SIGOPS_RSOS_NOGSPLIT"))) ? 1 : 0;
         g.ring32 = g.src32 && g.fuse == -1 && pure32 && !std::getenv("SIGOPS_RSOS_NO_RING32") ? 1 : 0;  // (no step: the ring keeps the Float32 samples)
         // A Float32 array -- with or without the fast path's one step -- into a Float32 RESULT (known at execute time: the stage
         // may turn out to write the sink's Float32 buffer itself, Plan::alias_narrow): the ring keeps Float32 samples, the step is

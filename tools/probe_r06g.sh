@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {
 for as in "" 0/2 0/4 0/8; do
-  for b in "" 1 0; do
+  for b in -1 1 0; do
     echo "== shard '${as}' SIGOPS_RSOS_BATCH='${b}'"
     SIGOPS_BENCH_AS=$as SIGOPS_RSOS_BATCH=$b SIGOPS_DEBUG_PLAN=1 python3 bench.py --workload config4 --steps 100 --warmup 20 --no-one-shot 2>&1 | \
       python3 -c "
