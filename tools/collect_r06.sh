@@ -45,6 +45,7 @@ python3 tools/iir_one_pass_probe.py 2>/dev/null > $S/iir_one_pass.jsonl
 python3 tools/nk_probe.py 2>/dev/null | grep '^{' > $S/nk_probe.txt
 bash tools/probe_r06g.sh > /dev/null 2>&1; cp gpurun_out/probe_r06g.txt $S/config4_batch_shards.txt
 python3 tools/iir_mix_probe.py 2>/dev/null > $S/iir_mix_probe.txt
+python3 tools/arr2_probe.py 2>/dev/null | grep '^{' > $S/arr2_probe.txt
 python3 tools/headline_parity_loop.py 100 2>/dev/null > $S/headline_parity_loop.txt
 python3 tools/soak_rsos_f32m.py 0 > $S/relerr_maxima_rsos_f32m.json 2> $S/relerr_maxima_rsos_f32m.err
 for d in 344 72 388 164 224 60 1; do echo "debug=$d $(SIGOPS_RSOS_DEBUG=$d python3 tools/rsos_probe.py --seconds 600 --only-fused --oracle 0 --warm 40 --reps 100 2>/dev/null | grep -o '"fused_ms": [0-9.]*')"; done > $S/rsos_ablation.txt
