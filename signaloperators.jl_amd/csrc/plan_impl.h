@@ -110,6 +110,7 @@ struct Stage {
     bool norm_alias = false;  // Normpower whose `vals` is its child stage's output buffer (no copy)
     bool norm_direct = false; // Normpower of a plain array leaf: the rms is taken over the array where it lies, readers divide its loads
     bool under_norm = false;  // a Normpower consumes this stage (directly or through further stages)
+    int64_t norm_df = 0;      // ... the largest frame offset it is read at on such a path (0: every Normpower's region starts at this stage's first frame)
     int out_buf = -1, in_buf = -1, aux_buf = -1;
     int64_t win_off = -1;  // >= 0: the stage writes the RESULT's frames [win_off, win_off + need) itself (window aliasing)
     // input source (after processing): either a materialised buffer or a direct view

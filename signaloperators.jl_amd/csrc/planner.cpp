@@ -595,7 +595,10 @@ std::vector<Piece> Plan::lower(int ni, Rect r, Map m) {
             return out;
         }
         int sid = stage_for(ni, kind);
-        if (in_norm > 0) stages[sid].under_norm = true;
+        if (in_norm > 0) {
+            stages[sid].under_norm = true;
+            stages[sid].norm_df = std::max(stages[sid].norm_df, m.sf == 1 ? m.df : (int64_t)1 << 60);
+        }
         if (kind == ST_NORM) {
             if (isinf_(N.len))
                 fail(SO_ERR_LENGTH, "Cannot normalize an infinite-length signal. Please use `Until` to take a prefix of the signal");

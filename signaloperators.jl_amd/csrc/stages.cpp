@@ -1123,7 +1123,11 @@ void Plan::process_stage(int sid) {
     // block-state-space kernel (Plan::fuse_plain_sos: k_rsos with an identity resampler) instead of the three-pass chunked
     // scan: its source as a carrier, like a periodic resampler's.  The direct view above stays -- what the three passes
     // read if the fused form is not taken.
-    if (direct && S.kind == ST_SOS && S.groups.size() == 1 && S.groups[0].nsec <= 6 && !S.sg.exact && !S.onepass && !S.under_norm &&
+    // (below a Normpower: where every Normpower's region starts at this filter's first frame -- Stage::norm_df == 0.  What the
+    //  one-pass form's warm starts cut, 2^-70 of what lay a decay time earlier, is then 2^-70 of something INSIDE the region
+    //  the rms is taken over; a Normpower of a decayed tail alone -- `Filt |> After |> Normpower` -- keeps the exact scan.)
+    if (direct && S.kind == ST_SOS && S.groups.size() == 1 && S.groups[0].nsec <= 6 && !S.sg.exact && !S.onepass &&
+        (!S.under_norm || (S.norm_df == 0 && !std::getenv("SIGOPS_NORM_EXACT_FILT"))) &&
         S.base == 0 && in_base == 0 && in_frames == need && (N.dtype == SO_F64 || (N.dtype == SO_F32 && !std::getenv("SIGOPS_RSOS_NO32"))) &&
         need * N.nch >= (std::getenv("SIGOPS_RSOS_MINGROUPS") || (std::getenv("SIGOPS_RSOS_BATCH") && std::atoi(std::getenv("SIGOPS_RSOS_BATCH")) == 1) ? (int64_t)4096 : ((int64_t)1 << 22)) && !std::getenv("SIGOPS_NO_RSOS") && !std::getenv("SIGOPS_NO_PLAIN_RSOS")) {
         std::vector<DCarrier> cs;
@@ -2150,7 +2154,9 @@ void Plan::fuse_plain_sos() {
             //  the bytes and take 0.9 of the time -- 0.40 / 0.82 --, this kernel's pace is the chain's: 0.335 / 0.72)
             // (a sine formed in K2's own loads costs it ~10 %: Mix(sine, x) |> Filt(Bandstop) of 50 M x 2 0.509 ms against 0.440 for
             //  this form with its step waves, 25 M x 4 0.512 against 0.419 -- tools/iir_mix_probe.py)
-            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (pure32 ? 0.9 : 1.0) * (c0.nsteps > 0 ? 1.1 : 1.0);
+            // (below a Normpower the three passes scan exactly -- launch_sos_xscan: 0.76 ms for 12.5 M x 8 where the cut scan takes 0.47)
+            const double t_three = (nsamp < 1e8 ? 4.4e-6 * nsamp + 25.0 : 3.4e-6 * nsamp + 110.0) * (pure32 ? 0.9 : 1.0) * (c0.nsteps > 0 ? 1.1 : 1.0) *
+                                   (S2.under_norm ? 1.6 : 1.0);
             if (std::getenv("SIGOPS_DEBUG_PLAN"))
                 std::fprintf(stderr, "[sigops] single-pass IIR estimate: %.0f us (%lld groups, %lld + %lld periods), three passes %.0f us\n", t_fused,
                              (long long)ngrp, (long long)pr, (long long)wp, t_three);
@@ -2243,8 +2249,9 @@ void Plan::fuse_plain_sos() {
     std::vector<size_t> small;
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {
         Stage& S2 = stages[i2];
-        if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || S2.xscan ||
-            S2.under_norm || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
+        // (xscan: the exact scan the three-pass form takes below a Normpower -- a property of that form)
+        if (S2.kind != ST_SOS || S2.rsos_src >= 0 || S2.carriers.size() != 1 || S2.need <= 0 || S2.onepass || S2.sg.exact || (S2.xscan && !S2.under_norm) ||
+            (S2.under_norm && S2.norm_df != 0) || S2.batch >= 0 || S2.pre_stage >= 0 || S2.base != 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 || S2.pw_step >= 0)
             continue;
         if (candidates > 1 && (int64_t)S2.need * nodes[S2.node].nch < ((int64_t)1 << 26) && !std::getenv("SIGOPS_RSOS_MINGROUPS")) {
             small.push_back(i2);

@@ -215,3 +215,28 @@ def test_loud_then_quiet_with_a_local_tolerance():
         for got in (a, b):
             e = np.linalg.norm(got[: nb * 1024].reshape(nb, 1024, -1) - w, axis=(1, 2)) / np.linalg.norm(w, axis=(1, 2))
             assert e.max() < 1e-9, (float(e.max()), int(e.argmax()))
+
+
+def test_below_a_normpower_whose_region_starts_at_the_filters_first_frame():
+    """`Filt |> Normpower` (reference src/filters.jl:296-309: vals filled from the child, one rms, every sample divided): the
+    filter takes the one-pass form when every Normpower above it reads it from its first frame on (Stage::norm_df == 0) -- what
+    the warm starts cut is 2^-70 of something inside the region the rms is taken over; 12.5 M x 8: 1.25 -> 0.87 ms.  A
+    Normpower of a window behind an `After` -- possibly a decayed tail alone (tests/test_gpu_fences.py) -- keeps the exact scan."""
+    rng = np.random.default_rng(15)
+    n = 700_000
+    d = rng.standard_normal((n, 8))
+    d[100_000:] *= 1e-4  # (a loud start, then 80 dB down)
+    x = so.Signal(F(d), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz)
+    for tree, one_pass in ((x | so.Normpower, True),
+                           (x | so.Until(500_000 * so.frames) | so.Normpower | so.Amplify(-20 * so.dB), True),
+                           (x | so.After(300_000 * so.frames) | so.Normpower, False),
+                           (so.Mix(x | so.Normpower, x | so.After(1000 * so.frames) | so.Normpower | so.Pad(so.zero) | so.Until(n * so.frames)), False)):
+        with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_PLAIN_RSOS=None, SIGOPS_NO_RSOS=None):  # (the estimate aside: short signals)
+            names = steps_of(tree)
+            got = so.sink(tree)[0]
+        assert ("k_rsos" in names) == one_pass and ("k_sos" in names) == (not one_pass), names
+        want = oracle_sink(tree)
+        assert relerr(got, want) < 1e-9
+        with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NORM_EXACT_FILT=1):
+            assert "k_rsos" not in steps_of(tree)
+            assert relerr(so.sink(tree)[0], want) < 1e-9
