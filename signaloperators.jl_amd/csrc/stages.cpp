@@ -1657,10 +1657,10 @@ void Plan::fuse_resample_sos() {
     for (size_t i2 = 0; i2 < stages.size(); ++i2) {
         Stage& S2 = stages[i2];
         if (S2.kind != ST_SOS || S2.onepass || S2.need <= 0 || S2.groups.size() != 1 || S2.groups[0].nsec > 6 ||
-            S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != S2.base || S2.pw_step >= 0 || S2.sg.exact || S2.xscan ||
-            S2.under_norm || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 ||
+            S2.in_buf < 0 || S2.in_array_node >= 0 || S2.in_offset != S2.base || S2.pw_step >= 0 || S2.sg.exact || (S2.xscan && !S2.under_norm) ||
+            (S2.under_norm && (S2.norm_df != 0 || S2.base != 0 || std::getenv("SIGOPS_NORM_EXACT_FILT"))) || S2.src_op || S2.batch >= 0 || S2.pre_stage >= 0 ||
             (nodes[S2.node].dtype != SO_F64 && nodes[S2.node].dtype != SO_F32) || S2.in_frames != S2.need - S2.base)
-            continue;
+            continue;  // (below a Normpower: only where its region starts at the filter's first frame -- fuse_plain_sos, Stage::norm_df)
         // A Float32 signal all the way (Float32 source, resampler and filter stages): the kernel rounds the resampled values to
         // Float32 where the reference's resampler stores them (RsSos::x32) and stores a Float32 result; its sources are plain
         // Float32 arrays or buffers (a Float32 x Float32 step rounds too: K1 materialises it)
@@ -1841,7 +1841,7 @@ void Plan::fuse_resample_sos() {
         // all blocks.  SIGOPS_RSOS_WTOL: another exponent.)
         int64_t wp = 1;
         {
-            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", 56)));
+            const double tol = std::ldexp(1.0, -std::abs(env_int("SIGOPS_RSOS_WTOL", S2.under_norm ? 70 : 56)));  // (below a Normpower: the plain form's cut)
             const Mat P = matpow(sos_state_matrix(cf), L, D);
             Mat cur = P;
             while (!(maxabs(cur) < tol) && wp < 1000000 && std::isfinite(maxabs(cur))) {

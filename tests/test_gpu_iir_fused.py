@@ -240,3 +240,19 @@ def test_below_a_normpower_whose_region_starts_at_the_filters_first_frame():
         with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NORM_EXACT_FILT=1):
             assert "k_rsos" not in steps_of(tree)
             assert relerr(so.sink(tree)[0], want) < 1e-9
+
+
+def test_resampler_and_filter_in_one_launch_below_a_whole_signal_normpower():
+    """`Filt |> ToFramerate |> Normpower` (the reference resamples, then filters: src/filters.jl:143-148): the fused kernel below a
+    Normpower whose region starts at the filter's first frame, its warm-up cut at 2^-70 there; behind an `After` resampler and
+    exact scan stay apart"""
+    rng = np.random.default_rng(16)
+    d = rng.standard_normal((600_000, 8))
+    d[50_000:] *= 1e-3
+    x = so.Signal(F(d), 44.1 * so.kHz) | so.Filt(so.Bandstop, 0.5 * so.kHz, 2 * so.kHz) | so.ToFramerate(48 * so.kHz)
+    for tree, fused in ((x | so.Normpower, True), (x | so.After(2 * so.s) | so.Normpower, False)):
+        with env(SIGOPS_RSOS_MINGROUPS=1, SIGOPS_NO_RSOS=None):
+            names = steps_of(tree)
+            got = so.sink(tree)[0]
+        assert (names[0] == "k_rsos") == fused, names
+        assert relerr(got, oracle_sink(tree)) < 1e-9
