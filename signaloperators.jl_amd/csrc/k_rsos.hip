@@ -632,7 +632,7 @@ __device__ __forceinline__ int vmcnt_now() {
 // staging buffer (none fits next to the ring), no vector instruction per row.
 template <int NY, int NL, int RU, bool SRC32, int RB = 0, int MODE = 0, bool A2 = false>
 __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* dyn, int64_t G_, int q_) {
-    static_assert(!A2 || (RU == 8 && !SRC32 && MODE == 2 && NL == 2), "the second array's waves: groups of eight channels, sixteen waves");
+    static_assert(!A2 || ((RU == 8 || RU == 4 || RU == 2) && !SRC32 && MODE == 2 && NL == 2), "the second array's waves: groups of two, four or eight channels, sixteen waves");
     constexpr int NX = 2 * NY + 1;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
@@ -1004,49 +1004,60 @@ __device__ __attribute__((noinline)) void rsos_loader(RsosShared* sh_, double* d
         rsos_stamp(trace, wave, k, 4, 40);
     };
     if constexpr (MODE == 2 && A2) {
-        // the second array's wave of unit q: three register sets, each a chunk of the unit (8 rows x 16 bytes per lane), loaded
-        // three chunks ahead; a set is applied to its chunk once the loader has reported the chunk landed and no more of this
-        // wave's loads are outstanding than were issued behind the set's
+        // the second array's wave of the units q, q + 2, ... (eight rows in all: one unit of eight channels, two of four, four of
+        // two): three register sets, each a chunk of those rows (16 bytes per lane and row), loaded three chunks ahead; a set is
+        // applied to its chunk once the loader has reported the chunk landed and no more of this wave's loads are outstanding
+        // than were issued behind the set's
+        constexpr int MUA = (16 / RU) / NL;
         const char* const base2 = (const char*)rfl64((int64_t)(uintptr_t)C0.base2);
         const int64_t cs2 = rfl64(C0.cstride2), df2 = rfl64(C0.df2);
-        const char* const row0 = base2 + (((int64_t)ch0_s0 * cs2 + df2 + Au_s0) << 3);
         v2d b0[8], b1[8], b2[8];
         auto ld = [&](int k, v2d (&b)[8]) __attribute__((always_inline)) -> int {
-            if (!(k < NK && k >= klo_s0 && k < khi_s0)) return 0;
-            const char* row = row0 + ((int64_t)k << 10);
+            int n = 0;
+            if (k >= NK) return 0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                // (the row's address complete in its scalar pair BEFORE the load: seen without this, the high half's add-with-carry
-                //  scheduled behind the load that reads the pair)
-                uint64_t rc = (uint64_t)(uintptr_t)(row + (int64_t)c * cs2 * 8);
-                asm volatile("" : "+s"(rc));
-                asm volatile("global_load_dwordx4 %0, %1, %2" SO_LD_NT : "=v"(b[c]) : "v"(lane16), "s"(rc) : "memory");
+            for (int j = 0; j < MUA; ++j) {
+                if (!(k >= u_klo(j) && k < u_khi(j))) continue;
+                const char* row = base2 + ((((int64_t)u_ch0(j) * cs2 + df2 + u_Au(j)) << 3) + ((int64_t)k << 10));
+#pragma unroll
+                for (int c = 0; c < RU; ++c) {
+                    // (the row's address complete in its scalar pair BEFORE the load: seen without this, the high half's
+                    //  add-with-carry scheduled behind the load that reads the pair)
+                    uint64_t rc = (uint64_t)(uintptr_t)(row + (int64_t)c * cs2 * 8);
+                    asm volatile("" : "+s"(rc));
+                    asm volatile("global_load_dwordx4 %0, %1, %2" SO_LD_NT : "=v"(b[j * RU + c]) : "v"(lane16), "s"(rc) : "memory");
+                }
+                n += RU;
             }
-            return 8;
+            return n;
         };
         auto ap = [&](int k, int rho0, v2d (&b)[8], int nself, int younger) __attribute__((always_inline)) {
             int sp = 0;
             while (uni(flag_ld(fl_base + 4 * (kRsosFlagLnd + q))) < k + 1 && !(debug & 32)) SO_SPIN_PAUSE(sp, 2, 1 << 22);
             if (nself && !(debug & 2)) {
                 wait_vmcnt_le60(younger);
-                const uint32_t la = lds_s0 + (uint32_t)rho0 * 8u + lane16;
-                if (fuse == 1) {  // v + m
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(b[c][0]), "v"(b[c][1]) : "memory");
-                } else if (fuse == 2) {  // v - m
+                for (int j = 0; j < MUA; ++j) {
+                    if (!(k >= u_klo(j) && k < u_khi(j))) continue;  // (staged by the general path, the step applied)
+                    const uint32_t la = u_lds(j) + (uint32_t)rho0 * 8u + lane16;
+                    if (fuse == 1) {  // v + m
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(-b[c][0]), "v"(-b[c][1]) : "memory");
-                } else {  // v * m, m - v: read, one operation, written back
+                        for (int c = 0; c < RU; ++c)
+                            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(b[j * RU + c][0]), "v"(b[j * RU + c][1]) : "memory");
+                    } else if (fuse == 2) {  // v - m
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const uint32_t a = la + (uint32_t)c * row_bytes;
-                        v2d vv[1] = {lds_ld16(a)};
-                        lds_wait(vv);
-                        vv[0] = fuse == 0 ? vv[0] * b[c] : b[c] - vv[0];
-                        lds_pin(vv);
-                        lds_st16(a, vv[0]);
+                        for (int c = 0; c < RU; ++c)
+                            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(la + (uint32_t)c * row_bytes), "v"(-b[j * RU + c][0]), "v"(-b[j * RU + c][1]) : "memory");
+                    } else {  // v * m, m - v: read, one operation, written back
+#pragma unroll
+                        for (int c = 0; c < RU; ++c) {
+                            const uint32_t a = la + (uint32_t)c * row_bytes;
+                            v2d vv[1] = {lds_ld16(a)};
+                            lds_wait(vv);
+                            vv[0] = fuse == 0 ? vv[0] * b[j * RU + c] : b[j * RU + c] - vv[0];
+                            lds_pin(vv);
+                            lds_st16(a, vv[0]);
+                        }
                     }
                 }
             }
@@ -1729,9 +1740,11 @@ __device__ __forceinline__ void rsos_body(const double* __restrict__ tab, const 
             // (the step waves of two-channel / four-channel groups: RsSos::gsplit)
             if (!g.gsplit || (g.debug & 256) || g.src32) continue;
             const int q = wave - 13;
-            if (ru == 8) {
+            if (g.arr2) {  // (the second array's waves)
                 if constexpr (NL == 2) {
-                    if (g.arr2) rsos_loader<NY, NL, 8, false, 0, 2, true>(&sh, lds_raw, G, q);
+                    if (ru == 8) rsos_loader<NY, NL, 8, false, 0, 2, true>(&sh, lds_raw, G, q);
+                    else if (ru == 4) rsos_loader<NY, NL, 4, false, 0, 2, true>(&sh, lds_raw, G, q);
+                    else if (ru == 2) rsos_loader<NY, NL, 2, false, 0, 2, true>(&sh, lds_raw, G, q);
                 }
             } else if (ru == 2) {
                 if (g.rpitch == 770) rsos_loader<NY, NL, 2, false, 770 * 8, 2>(&sh, lds_raw, G, q);

@@ -1681,12 +1681,12 @@ void Plan::fuse_resample_sos() {
         if (rp.nstate || nodes[S3.node].dtype != nodes[S2.node].dtype || !S3.fix_host.empty() || S3.need < S2.need || (int)S3.carriers.size() > kCtlCar)
             continue;
         // (arr2: a source of two arrays -- K3's A2 instantiation's alone; this kernel's loader takes the second one for groups of
-        //  eight channels, Float64, ONE carrier whose one step is `v (op) y`: k_rsos.hip, rsos_loader's A2)
+        //  two, four or eight channels, Float64, ONE carrier whose one step is `v (op) y`: k_rsos.hip, rsos_loader's A2)
         bool two_arrays = false;
         if (rp.arr2) {
             const bool ok = !pure32 && nodes[S2.node].dtype == SO_F64 && S3.carriers.size() == 1 && S3.carriers[0].nsteps == 1 &&
                             (S3.carriers[0].arg[0] & kCarArr2) && !(S3.carriers[0].arg[0] & 0x200) && S3.carriers[0].dtype == SO_F64 &&
-                            S3.carriers[0].dtype2 == SO_F64 && nodes[S2.node].nch % 8 == 0 &&
+                            S3.carriers[0].dtype2 == SO_F64 && nodes[S2.node].nch % 2 == 0 &&
                             (S3.carriers[0].op[0] == OP_ADD || S3.carriers[0].op[0] == OP_SUB || S3.carriers[0].op[0] == OP_MUL) &&
                             !std::getenv("SIGOPS_RSOS_NO_ARR2");
             if (!ok) continue;
