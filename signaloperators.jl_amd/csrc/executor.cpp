@@ -268,7 +268,7 @@ void Plan::finalize() {
             const std::vector<int>& kids = nodes[R.node].kids;
             return !kids.empty() && kids[0] >= 0 ? (int64_t)dsize(nodes[kids[0]].dtype) : esz;
         };
-        if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in * src_esz(stages[S.rsos_src]) + S.rs.n_out * osz) * S.rs.nch;
+        if (S.kind == ST_SOS && S.rsos_src >= 0) st.bytes = (S.rs.n_in * src_esz(stages[S.rsos_src]) * (S.rs.arr2 ? 2 : 1) + S.rs.n_out * osz) * S.rs.nch;  // (arr2: a second array read)
         else if (S.kind == ST_SOS) st.bytes = (S.need - S.base) * S.sg.nch * (esz + osz);
         else if (S.kind == ST_RESAMPLE) st.bytes = (S.rg.n_in * (src_esz(S) + (S.rp.arr2 ? src_esz(S) : 0)) + S.rg.n_out * osz) * S.rg.nch;  // (arr2: a second array of the source's type read)
         else st.bytes = (S.need - S.base) * nodes[S.node].nch * esz;

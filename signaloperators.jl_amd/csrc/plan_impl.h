@@ -154,6 +154,8 @@ struct Stage {
     // ... for the exact recomputation behind a non-finite sample (k_rsos_fixup): newest input of every output of the period
     // relative to its group's window end, and the taps per output the REFERENCE multiplies (its own zero padding included)
     int rsb = -1;  // member of Plan::rsbatches[rsb]: launched with the others (k_rsos_batch), not on its own
+    std::vector<DCarrier> alt_carriers;  // a resampler whose input K1 materialises as `x (op) y` of two arrays: that map as ONE two-array
+                                         // carrier -- what the fused resampler + IIR kernel reads instead, if it takes the stage (fuse_resample_sos)
     std::vector<int> rs_jrel_host;  // the periodic resampler's own (k_rs_fixup): as rsos_jrel_host, from per_j and jend_host
     int rs_jrel_buf = -1, rs_nf_buf = -1;
     std::vector<int> rsos_jrel_host;

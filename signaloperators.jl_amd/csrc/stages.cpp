@@ -1230,6 +1230,14 @@ void Plan::process_stage(int sid) {
             }
         }
     } else if (!direct) {
+        // (a periodic resampler over `x (op) y` of two Float64 arrays in a shape its own two-array form does not take -- two
+        //  channels --: K1 materialises the map, but the fused resampler + IIR kernel could read both arrays itself; keep the
+        //  map as a two-array carrier for fuse_resample_sos to swap in IF it takes the stage)
+        if (S.kind == ST_RESAMPLE && S.periodic && N.dtype == SO_F64 && in_dtype == SO_F64 && N.nch % 2 == 0 && !std::getenv("SIGOPS_RSOS_NO_ARR2") &&
+            !std::getenv("SIGOPS_NO_ARR2")) {
+            std::vector<DCarrier> alt;
+            if (build_carriers(ps, N.nch, alt, false, true) && alt.size() == 1 && alt[0].nsteps == 1 && car_has_arr2(alt[0])) S.alt_carriers = alt;
+        }
         S.in_buf = new_buf(in_frames, N.nch, in_dtype);
         S.in_pitch = -1;
         S.in_array_node = -1;
@@ -1682,8 +1690,27 @@ void Plan::fuse_resample_sos() {
             continue;
         // (arr2: a source of two arrays -- K3's A2 instantiation's alone; this kernel's loader takes the second one for groups of
         //  two, four or eight channels, Float64, ONE carrier whose one step is `v (op) y`: k_rsos.hip, rsos_loader's A2)
+        // ... also where K1 materialises the map for K3 (Stage::alt_carriers): tried with the two-array carrier in place of the
+        // materialised buffer's; whatever makes this stage `continue` below puts K1's step and the buffer's carrier back
+        struct AltGuard {
+            Stage& S;
+            std::vector<DCarrier> car;
+            int pw;
+            bool armed;
+            ~AltGuard() {
+                if (armed) {
+                    S.carriers = car;
+                    S.pw_step = pw;
+                }
+            }
+        } alt{S3, S3.carriers, S3.pw_step, false};
+        if (!rp.arr2 && !S3.alt_carriers.empty() && S3.pw_step >= 0 && S3.in_buf >= 0 && !std::getenv("SIGOPS_RSOS_NO_ARR2")) {
+            S3.carriers = S3.alt_carriers;
+            S3.pw_step = -1;
+            alt.armed = true;
+        }
         bool two_arrays = false;
-        if (rp.arr2) {
+        if (rp.arr2 || alt.armed) {
             const bool ok = !pure32 && nodes[S2.node].dtype == SO_F64 && S3.carriers.size() == 1 && S3.carriers[0].nsteps == 1 &&
                             (S3.carriers[0].arg[0] & kCarArr2) && !(S3.carriers[0].arg[0] & 0x200) && S3.carriers[0].dtype == SO_F64 &&
                             S3.carriers[0].dtype2 == SO_F64 && nodes[S2.node].nch % 2 == 0 &&
@@ -2057,6 +2084,10 @@ void Plan::fuse_resample_sos() {
         S2.rsos_mats_buf = raw_buf(S2.rsos_mats_host.size() * 8);
         if (S2.bad_buf < 0) S2.bad_buf = raw_buf((size_t)nch * 4);  // first range per channel that ended in a non-finite state
         S3.fused_away = true;
+        if (alt.armed) {  // (K1's copy of `x (op) y` is never made: its step is not in the plan, its buffer holds nothing)
+            alt.armed = false;
+            bufs[S3.in_buf].bytes = 0;
+        }
         if (std::getenv("SIGOPS_DEBUG_PLAN"))
             std::fprintf(stderr,
                          "[sigops] resampler + IIR fused (k_rsos): %lld ranges of %lld periods (+%lld warm-up), %lld groups of %d ch x %d ranges, "

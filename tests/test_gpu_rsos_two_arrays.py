@@ -33,7 +33,7 @@ def three(tree):
     return a, b, c, names, names1, names2
 
 
-@pytest.mark.parametrize("nch", [8, 16, 24, 4, 12])
+@pytest.mark.parametrize("nch", [8, 16, 24, 4, 12, 2, 6])
 @pytest.mark.parametrize("op", sorted(OPS))
 def test_one_launch_bit_equal_to_the_materialised_sum(op, nch):
     n = 400_003
@@ -42,7 +42,8 @@ def test_one_launch_bit_equal_to_the_materialised_sum(op, nch):
     a, b, c, names, names1, names2 = three(tree)
     assert names == ["k_rsos"], names
     assert len(names1) == 2 and names1[0].startswith("k_pointwise") and names1[1] == "k_rsos", names1
-    assert "k_resample_periodic" in names2 and "k_rsos" not in names2[:1], names2
+    # (two channels: the resampler alone has no two-array form -- K1's sum, then resampler and filter)
+    assert "k_rsos" not in names2[:1] and ("k_resample_periodic" in names2 or nch % 4 != 0), names2
     assert np.array_equal(a, b), float(np.abs(a - b).max())
     want = oracle_sink(tree)
     assert relerr(a, want) <= 1e-9 and relerr(c, want) <= 1e-9
@@ -86,10 +87,10 @@ def test_operands_of_different_lengths():
     assert relerr(got, oracle_sink(tree)) <= 1e-9
 
 
-def test_two_channels_and_float32_keep_the_earlier_forms():
-    """(two channels: the resampler stage has no two-array carriers -- K3's own two-array form starts at four channels --, the sum
-    is materialised; Float32: K3's Float32 two-array form + the filter)"""
-    x, y = arrays(300_000, 2, 26)
+def test_odd_channel_counts_and_float32_keep_the_earlier_forms():
+    """(three channels: groups of one channel have sixteen units, which the step waves do not take; Float32: K3's Float32
+    two-array form + the filter)"""
+    x, y = arrays(300_000, 3, 26)
     tree = so.Mix(so.Signal(x, 44.1 * so.kHz), so.Signal(y, 44.1 * so.kHz)) | FILT() | so.ToFramerate(48 * so.kHz)
     with env(SIGOPS_RSOS_MINGROUPS=1):
         names = steps_of(tree)

@@ -25,7 +25,7 @@ def run(n, nch, env, op="Mix"):
     ms = e0.elapsed_time(e1) / 60
     names = [s["name"] for s in plan.steps()]; plan.close()
     return {"n": n, "nch": nch, "op": op, "env": env, "ms": round(ms, 4), "steps": names}
-for n, nch in ((12_500_000, 8), (6_250_000, 16), (26_460_000, 8), (25_000_000, 4)):
+for n, nch in ((12_500_000, 8), (6_250_000, 16), (26_460_000, 8), (25_000_000, 4), (50_000_000, 2)):
     for env in ({}, {"SIGOPS_RSOS_NO_ARR2": "1"}, {"SIGOPS_NO_ARR2": "1"}, {"SIGOPS_NO_RSOS": "1"}):
         print(json.dumps(run(n, nch, env)), flush=True)
 print(json.dumps(run(12_500_000, 8, {}, "Amplify")), flush=True)

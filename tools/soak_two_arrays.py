@@ -38,7 +38,7 @@ for case in range(ncases):
     fi, fo = rng.choice(RATES, 2, replace=False)
     if rng.random() < 0.6:  # (the 14-k-step family the instantiation takes, up-sampling: the lazy map is resampled as a whole)
         fi, fo = [(44.1, 48.0), (22.05, 24.0), (32.0, 48.0), (8.0, 11.025), (11.025, 16.0)][int(rng.integers(0, 5))]
-    nch = int(rng.choice([8, 16, 24, 8, 4, 3]) if FILT else rng.choice([1, 2, 3, 4, 8, 16]))
+    nch = int(rng.choice([8, 16, 24, 2, 4, 3, 6, 2]) if FILT else rng.choice([1, 2, 3, 4, 8, 16]))
     nx = int(rng.integers(1, 60000)) if not FILT else int(rng.integers(20000, 300000))
     ny = nx if rng.random() < (0.85 if FILT else 0.5) else int(rng.integers(1, 60000))
     dt = np.float32 if rng.random() < (0.1 if FILT else 0.35) else np.float64  # (both operands: a Float32 signal all the way, or Float64)
