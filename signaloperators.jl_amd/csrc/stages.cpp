@@ -1162,7 +1162,11 @@ void Plan::process_stage(int sid) {
                build_carriers(ps, N.nch, S.carriers, ga_fits(S, N.dtype),
                               // (the A2 instantiations: Float64 -- or Float32 all the way --, 32-row tiles of 4 or 8 channels, 14 k-steps, one group per compute wave)
                               // ... and two tile slots + the loader waves' staging rows of the second array fit LDS)
-                              (N.dtype == SO_F64 || (N.dtype == SO_F32 && S.rp.f32m)) && S.rp.rows == 32 && (S.rp.ct == 8 || S.rp.ct == 4) && S.rp.kw == 56 &&
+                              // (Float64 groups of FOUR channels: measured 1.81 ms for two 25 M x 4 arrays where K1's sum + the one-array
+                              //  kernel take 0.87 -- round 6, tools/operator_matrix.py NCH=4; left to K1 unless SIGOPS_RS_ARR2_CT4.  With a
+                              //  filter behind, the fused kernel takes both arrays itself: Stage::alt_carriers below)
+                              (N.dtype == SO_F64 || (N.dtype == SO_F32 && S.rp.f32m)) && S.rp.rows == 32 &&
+                                  (S.rp.ct == 8 || (S.rp.ct == 4 && (N.dtype == SO_F32 || std::getenv("SIGOPS_RS_ARR2_CT4")))) && S.rp.kw == 56 &&
                                   (S.rp.ngroups + S.rp.ncompute - 1) / S.rp.ncompute == 1 &&
                                   (size_t)2 * S.rp.ct * S.rp.lds_pitch * dsize(N.dtype) + (size_t)(S.rp.nwaves - S.rp.ncompute) * S.rp.ct * 1024 <=
                                       160 * 1024 - sizeof(RsCtl) - 64)) {

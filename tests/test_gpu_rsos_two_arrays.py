@@ -42,8 +42,8 @@ def test_one_launch_bit_equal_to_the_materialised_sum(op, nch):
     a, b, c, names, names1, names2 = three(tree)
     assert names == ["k_rsos"], names
     assert len(names1) == 2 and names1[0].startswith("k_pointwise") and names1[1] == "k_rsos", names1
-    # (two channels: the resampler alone has no two-array form -- K1's sum, then resampler and filter)
-    assert "k_rsos" not in names2[:1] and ("k_resample_periodic" in names2 or nch % 4 != 0), names2
+    # (groups of two or four channels: the resampler alone takes no second Float64 array -- K1's sum, then the fused kernel)
+    assert "k_rsos" not in names2[:1] and ("k_resample_periodic" in names2 or nch % 8 != 0), names2
     assert np.array_equal(a, b), float(np.abs(a - b).max())
     want = oracle_sink(tree)
     assert relerr(a, want) <= 1e-9 and relerr(c, want) <= 1e-9
