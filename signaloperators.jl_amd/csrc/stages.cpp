@@ -2305,6 +2305,15 @@ void Plan::fuse_plain_sos() {
     std::map<std::pair<int, int>, std::vector<size_t>> kinds;
     for (size_t i2 : small) {
         if ((int)i2 == alias_stage) continue;
+        // (members wait for nothing: the batch's step stands where its first member stood -- a member that reads a stage's
+        //  buffer, or a scalar some launch writes, could run before its producer; such filters keep launches of their own)
+        {
+            const DCarrier& c0 = stages[i2].carriers[0];
+            bool plain = c0.array_node >= 0 && c0.buf < 0;
+            for (int k = 0; k < c0.nslots && plain; ++k)
+                if (leaves[c0.slot_leaf[k]].buf >= 0) plain = false;
+            if (!plain) continue;
+        }
         RsSos g{};
         double cost = 0.0;
         if (!fit(i2, 1 << 20, g, cost)) continue;  // (which instantiation it would take)

@@ -259,3 +259,25 @@ def test_config4_full_size():
         want = oracle_sink(bench.scene(so, host, k, n))
         got = a[:, k * n:(k + 1) * n].t().cpu().numpy()
         assert relerr(got, want) <= 1e-10, k
+
+
+def test_filters_that_read_a_stages_buffer_keep_launches_of_their_own():
+    """the batch's step stands where its first member stood and waits for nothing: a filter whose source is another stage's
+    buffer -- here a long-period resampler's (44.1 -> 16 kHz runs the row-tiled kernel, which the filter does not fuse with) --
+    could run before its producer, so it is not a member (found by running the whole suite with SIGOPS_RSOS_BATCH=1:
+    tests/test_gpu_fuzz.py's multirate trees returned NaN)"""
+    rng = np.random.default_rng(41)
+    kids = [so.Signal(_noise(rng, 60000 + 17 * k, 2), 44.1 * so.kHz) | so.ToFramerate(16 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) for k in range(3)]
+    kids += [so.Signal(_noise(rng, 30000 + k, 2), 16 * so.kHz) | so.Filt(so.Lowpass, 3 * so.kHz) for k in range(3)]
+    tree = so.Append(*kids)
+    with env(SIGOPS_RSOS_BATCH=1):
+        names = [n for n, _ in _steps(tree, 2)]
+        got = so.sink(tree, so.Array)
+    want = np.concatenate([oracle_sink(k) for k in kids])
+    assert np.isfinite(got).all() and relerr(got, want) <= 1e-9
+    # (the three filters over arrays are one batch; the three behind resamplers are not in it)
+    assert names.count("k_rsos_batch") == 1, names
+    i_batch = names.index("k_rsos_batch")
+    assert any(n.startswith("k_resample") for n in names), names
+    assert sum(1 for n in names if n in ("k_sos", "k_rsos", "k_sos_batch")) >= 1, names
+    del i_batch
